@@ -1,0 +1,79 @@
+"""ctypes loader for libbdm_hip.so (the C ABI declared in include/bdm_hip.h).
+
+There is NO CPU fallback: if the shared object is missing, or a call is made with tensors
+that do not live on a HIP device, an exception is raised.  PyTorch is used for device
+memory and streams only; every kernel on the denoiser path lives in the library.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libbdm_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+_lib = None
+
+
+class BdmHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, jobs: int = 4) -> str:
+    """Compile csrc/*.hip for gfx950 into bdm_amd/libbdm_hip.so (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", CSRC, f"-j{jobs}"]
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(args)
+    return SO_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise BdmHipError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C bdm_amd/csrc`). There is no CPU fallback for the HIP path.")
+        _lib = ctypes.CDLL(SO_PATH)
+        _lib.bdm_last_error.restype = ctypes.c_char_p
+        _lib.bdm_voxelize_workspace_bytes.restype = ctypes.c_size_t
+        for name in ("bdm_workspace_bytes_conv3d",):
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = ctypes.c_size_t
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().bdm_last_error()
+        raise BdmHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: no CPU path."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise BdmHipError("bdm_amd operators run on a HIP device only; got a CPU tensor (no CPU fallback)")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32(t):
+    if t.dtype != torch.float32:
+        raise BdmHipError(f"expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def i32(t):
+    return (t if t.dtype == torch.int32 else t.int()).contiguous()
+
+
+c_float = ctypes.c_float
+c_int = ctypes.c_int
+c_ll = ctypes.c_longlong

@@ -1,0 +1,68 @@
+// Shared helpers for the gfx950 kernels of libbdm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BDM_OK 0
+#define BDM_ERR_ARG 1
+#define BDM_ERR_LAUNCH 2
+#define BDM_ERR_UNSUPPORTED 3
+
+namespace bdm {
+
+// Records a message retrievable through bdm_last_error(); never exits the process
+// (the reference's CUDA_CHECK_ERRORS calls exit(-1), cuda_utils.cuh:28-37).
+void set_error(const char *fmt, ...);
+
+inline int launch_status(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return BDM_ERR_LAUNCH;
+  }
+  return BDM_OK;
+}
+
+#define BDM_REQUIRE(cond, ...)      \
+  do {                              \
+    if (!(cond)) {                  \
+      bdm::set_error(__VA_ARGS__);  \
+      return BDM_ERR_ARG;           \
+    }                               \
+  } while (0)
+
+// Raise a kernel's dynamic-LDS ceiling (up to the CU's 160 KiB); not a stream operation.
+#define BDM_ALLOW_LDS(kernel, bytes)                                                              \
+  do {                                                                                            \
+    if ((bytes) > 48 * 1024)                                                                      \
+      (void)hipFuncSetAttribute((const void *)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)(bytes));                                                    \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
+
+// Unfused IEEE multiply/add: the distance arithmetic shared with the oracle is defined
+// without FMA contraction (oracle/pvcnn_ops_ref.c header).
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace bdm

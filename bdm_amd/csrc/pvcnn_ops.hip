@@ -1,0 +1,501 @@
+// pvcnn_ops.hip -- gfx950 kernels for the seven forward operators of the reference plugin
+// `_pvcnn_backend` (reference: experiments/model/pvcnn/modules/functional/src/**).
+//
+// The reference launches grid = B blocks for every one of these (e.g. ball_query.cu:55),
+// i.e. < 7 % of a 256-CU part at B = 16.  Here every operator is tiled over
+// (batch x centres/points/voxels x channel chunks) so that a B = 16 call fills the chip, the
+// neighbour scans are wave-cooperative (64 candidates per step, ballot-ordered appends), and
+// the iterative sampler keeps its state in registers with one barrier per round.
+//
+// Index-producing arithmetic is written with explicit unfused IEEE ops (common.h: sqdist3)
+// so that indices are bit-identical to the CPU oracle on identical inputs.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/bdm_hip.h"
+#include "common.h"
+
+// The whole file is compiled without multiply-add contraction (also -ffp-contract=off in the
+// Makefile): __fmul_rn/__fadd_rn are plain '*' and '+' in ROCm's headers and would otherwise
+// be fused, breaking bit-equality of indices with the oracle.
+#pragma clang fp contract(off)
+
+namespace bdm {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace bdm
+
+extern "C" const char *bdm_last_error(void) { return bdm::g_err; }
+extern "C" int bdm_abi_version(void) { return 1; }
+
+using namespace bdm;
+
+// =====================================================================================
+// Furthest point sampling
+// =====================================================================================
+// One workgroup per shape (the M-1 rounds are strictly sequential).  Each thread owns PPT
+// points (coordinates + running min-distance in registers).  A round is: distance update,
+// per-thread best, 64-lane shuffle reduction, one LDS slot per wave, ONE barrier (slots are
+// double-buffered by round parity), redundant final reduction in every wave.
+//
+// Ordering key: (distance bits, ~rank) with rank(k) = (k mod 512) * Q + k / 512,
+// Q = ceil(n / 512): the lexicographic (k mod 512, k) preference of the reference's
+// 512-thread scan + tree (sampling.cu:120-160) as a single u64 max.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long w = __shfl_xor(v, o, 64);
+    v = w > v ? w : v;
+  }
+  return v;
+}
+
+template <int PPT>
+__global__ void fps_kernel(int n, int m, const float *__restrict__ coords, int *__restrict__ indices,
+                           float *__restrict__ centers_out, int use_lds) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+  const float *cx = coords + (size_t)blockIdx.x * 3 * n, *cy = cx + n, *cz = cy + n;
+  int *out = indices + (size_t)blockIdx.x * m;
+  float *cen = centers_out ? centers_out + (size_t)blockIdx.x * 3 * m : nullptr;
+
+  unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_raw);  // [2][16]
+  float *sx = reinterpret_cast<float *>(smem_raw + 2 * 16 * sizeof(unsigned long long));
+  float *sy = sx + n, *sz = sy + n;
+
+  const unsigned Q = (unsigned)((n + 511) / 512);
+  float px[PPT], py[PPT], pz[PPT], dist[PPT];
+  unsigned inv_rank[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid + i * T;
+    if (k < n) {
+      px[i] = cx[k]; py[i] = cy[k]; pz[i] = cz[k];
+      if (use_lds) { sx[k] = px[i]; sy[k] = py[i]; sz[k] = pz[i]; }
+      inv_rank[i] = 0xFFFFFFFFu - ((unsigned)(k & 511) * Q + (unsigned)(k >> 9));
+    } else {
+      px[i] = py[i] = pz[i] = 0.f;
+      inv_rank[i] = 0u;  // key 0 never wins
+    }
+    dist[i] = 1e38f;  // sampling.cpp:53-54
+  }
+  if (tid == 0) {
+    out[0] = 0;
+    if (cen) { cen[0] = cx[0]; cen[m] = cy[0]; cen[2 * m] = cz[0]; }
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int j = 1; j < m; ++j) {
+    float x1, y1, z1;
+    if (use_lds) { x1 = sx[cur]; y1 = sy[cur]; z1 = sz[cur]; }
+    else { x1 = cx[cur]; y1 = cy[cur]; z1 = cz[cur]; }
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float d = sqdist3(px[i], py[i], pz[i], x1, y1, z1);
+      const float d2 = fminf(d, dist[i]);
+      dist[i] = d2;
+      const unsigned long long key =
+          inv_rank[i] ? (((unsigned long long)__float_as_uint(d2) << 32) | inv_rank[i]) : 0ull;
+      best = key > best ? key : best;
+    }
+    best = wave_max_u64(best);
+    unsigned long long *slot = slots + (j & 1) * 16;
+    if (nwaves > 1) {
+      if (lane == 0) slot[wave] = best;
+      __syncthreads();
+      best = lane < nwaves ? slot[lane] : 0ull;
+      best = wave_max_u64(best);
+    }
+    const unsigned rank = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
+    cur = (int)((rank % Q) * 512u + rank / Q);
+    if (tid == 0) {
+      out[j] = cur;
+      if (cen) {
+        float ox, oy, oz;
+        if (use_lds) { ox = sx[cur]; oy = sy[cur]; oz = sz[cur]; }
+        else { ox = cx[cur]; oy = cy[cur]; oz = cz[cur]; }
+        cen[j] = ox; cen[m + j] = oy; cen[2 * m + j] = oz;
+      }
+    }
+  }
+}
+
+extern "C" int bdm_furthest_point_sampling(int b, int n, int m, const float *coords, int *indices,
+                                           float *centers_out, void *stream) {
+  BDM_REQUIRE(b >= 0 && n >= 1 && m >= 0, "fps: bad sizes b=%d n=%d m=%d", b, n, m);
+  BDM_REQUIRE(n <= 16384, "fps: n=%d exceeds the 16384-point limit of the register-resident sampler", n);
+  if (b == 0 || m == 0) return BDM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int ppt = 1;
+  if (n >= 256) ppt = 4;
+  while ((n + ppt - 1) / ppt > 1024) ppt *= 2;
+  int T = ((n + ppt - 1) / ppt + 63) / 64 * 64;
+  const int use_lds = n <= 12288;
+  const size_t smem = 2 * 16 * sizeof(unsigned long long) + (use_lds ? (size_t)3 * n * sizeof(float) : 0);
+#define FPS_LAUNCH(P)                                                                                   \
+  do {                                                                                                  \
+    BDM_ALLOW_LDS(fps_kernel<P>, smem);                                                                 \
+    hipLaunchKernelGGL(fps_kernel<P>, dim3(b), dim3(T), smem, s, n, m, coords, indices, centers_out,    \
+                       use_lds);                                                                        \
+  } while (0)
+  switch (ppt) {
+    case 1: FPS_LAUNCH(1); break;
+    case 4: FPS_LAUNCH(4); break;
+    case 8: FPS_LAUNCH(8); break;
+    case 16: FPS_LAUNCH(16); break;
+    default: set_error("fps: unsupported points-per-thread %d", ppt); return BDM_ERR_UNSUPPORTED;
+  }
+#undef FPS_LAUNCH
+  return launch_status("fps");
+}
+
+// =====================================================================================
+// Gather
+// =====================================================================================
+__global__ void gather_kernel(int c, int n, int m, const float *__restrict__ feat,
+                              const int *__restrict__ idx, float *__restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (j >= m) return;
+  const int src = idx[(size_t)bi * m + j];
+  for (int ci = blockIdx.y; ci < c; ci += gridDim.y)
+    out[((size_t)bi * c + ci) * m + j] = feat[((size_t)bi * c + ci) * n + src];
+}
+
+extern "C" int bdm_gather_features_forward(int b, int c, int n, int m, const float *features,
+                                           const int *indices, float *out, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 0 && n >= 1 && m >= 0, "gather: bad sizes");
+  if (b == 0 || c == 0 || m == 0) return BDM_OK;
+  dim3 grid(cdiv(m, 256), c < 64 ? c : 64, b);
+  hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, m, features, indices, out);
+  return launch_status("gather");
+}
+
+// =====================================================================================
+// Ball query: one wave per centre, 64 candidates per step, ballot-ordered append
+// =====================================================================================
+__global__ void ball_query_kernel(int n, int m, float r2, int u, const float *__restrict__ centers,
+                                  const float *__restrict__ points, int *__restrict__ neighbors) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int bi = blockIdx.y;
+  if (j >= m) return;  // whole wave exits together
+  const float *px = points + (size_t)bi * 3 * n, *py = px + n, *pz = py + n;
+  const float *cb = centers + (size_t)bi * 3 * m;
+  const float cx = cb[j], cy = cb[m + j], cz = cb[2 * m + j];
+  int *nb = neighbors + ((size_t)bi * m + j) * u;
+
+  int cnt = 0, first = 0;
+  for (int k0 = 0; k0 < n && cnt < u; k0 += 64) {
+    const int k = k0 + lane;
+    bool hit = false;
+    if (k < n) hit = sqdist3(cx, cy, cz, px[k], py[k], pz[k]) < r2;
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+      const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      if (hit && pos < u) nb[pos] = k;
+      if (cnt == 0) first = k0 + (__ffsll((long long)mask) - 1);
+      cnt += __popcll(mask);
+    }
+  }
+  // slots never reached: first hit (ball_query.cu:40-44), or 0 when there was none
+  // (the reference's output tensor is torch::zeros, ball_query.cpp:20-22)
+  const int fill = cnt > 0 ? first : 0;
+  for (int s = lane; s < u; s += 64)
+    if (s >= cnt) nb[s] = fill;
+}
+
+extern "C" int bdm_ball_query(int b, int n, int m, float radius, int u, const float *centers,
+                              const float *points, int *neighbors, void *stream) {
+  BDM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && u >= 1, "ball_query: bad sizes");
+  if (b == 0 || m == 0) return BDM_OK;
+  const float r2 = radius * radius;  // ball_query.cpp:24
+  dim3 grid(cdiv(m, 4), b);
+  hipLaunchKernelGGL(ball_query_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, r2, u, centers,
+                     points, neighbors);
+  return launch_status("ball_query");
+}
+
+// =====================================================================================
+// Grouping
+// =====================================================================================
+__global__ void grouping_kernel(int c, int n, int mu, const float *__restrict__ feat,
+                                const int *__restrict__ idx, float *__restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (e >= mu) return;
+  const int src = idx[(size_t)bi * mu + e];
+  for (int ci = blockIdx.y; ci < c; ci += gridDim.y)
+    out[((size_t)bi * c + ci) * mu + e] = feat[((size_t)bi * c + ci) * n + src];
+}
+
+extern "C" int bdm_grouping_forward(int b, int c, int n, int m, int u, const float *features,
+                                    const int *indices, float *out, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 0 && n >= 1 && m >= 0 && u >= 0, "grouping: bad sizes");
+  if (b == 0 || c == 0 || m * u == 0) return BDM_OK;
+  dim3 grid(cdiv(m * u, 256), c < 32 ? c : 32, b);
+  hipLaunchKernelGGL(grouping_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, m * u, features,
+                     indices, out);
+  return launch_status("grouping");
+}
+
+// =====================================================================================
+// Three nearest neighbours + inverse-squared-distance interpolation
+// =====================================================================================
+__global__ void three_nn_search_kernel(int m, int n, const float *__restrict__ points,
+                                       const float *__restrict__ centers, int *__restrict__ indices,
+                                       float *__restrict__ weights) {
+  extern __shared__ float sc[];  // centres, staged in chunks
+  const int bi = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const float *cb = centers + (size_t)bi * 3 * m;
+  const float *pb = points + (size_t)bi * 3 * n;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (j < n) { ux = pb[j]; uy = pb[n + j]; uz = pb[2 * n + j]; }
+  // running bests hold float values (the reference keeps them in doubles, :37)
+  float b0 = INFINITY, b1 = INFINITY, b2 = INFINITY;
+  int i0 = 0, i1 = 0, i2 = 0;
+  const int CH = 1024;
+  for (int base = 0; base < m; base += CH) {
+    const int len = min(CH, m - base);
+    __syncthreads();
+    for (int t = threadIdx.x; t < len; t += blockDim.x) {
+      sc[t] = cb[base + t]; sc[CH + t] = cb[m + base + t]; sc[2 * CH + t] = cb[2 * m + base + t];
+    }
+    __syncthreads();
+    for (int k = 0; k < len; ++k) {
+      const float d = sqdist3(ux, uy, uz, sc[k], sc[CH + k], sc[2 * CH + k]);
+      if (d < b2) {
+        b2 = d; i2 = base + k;
+        if (d < b1) {
+          b2 = b1; i2 = i1; b1 = d; i1 = base + k;
+          if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = base + k; }
+        }
+      }
+    }
+  }
+  if (j >= n) return;
+  b0 = fmaxf(fminf(1e10f, b0), 1e-10f);
+  b1 = fmaxf(fminf(1e10f, b1), 1e-10f);
+  b2 = fmaxf(fminf(1e10f, b2), 1e-10f);
+  const float d0d1 = __fmul_rn(b0, b1), d0d2 = __fmul_rn(b0, b2), d1d2 = __fmul_rn(b1, b2);
+  const float inv = __fdiv_rn(1.0f, __fadd_rn(__fadd_rn(d0d1, d0d2), d1d2));
+  float *w = weights + (size_t)bi * 3 * n;
+  int *id = indices + (size_t)bi * 3 * n;
+  w[j] = __fmul_rn(d1d2, inv);         id[j] = i0;
+  w[n + j] = __fmul_rn(d0d2, inv);     id[n + j] = i1;
+  w[2 * n + j] = __fmul_rn(d0d1, inv); id[2 * n + j] = i2;
+}
+
+__global__ void three_nn_apply_kernel(int c, int m, int n, const float *__restrict__ feat, long long bs_f,
+                                      int ld_f, const int *__restrict__ indices,
+                                      const float *__restrict__ weights, float *__restrict__ out,
+                                      long long bs_o, int ld_o) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (j >= n) return;
+  const int *id = indices + (size_t)bi * 3 * n;
+  const float *w = weights + (size_t)bi * 3 * n;
+  const int i0 = id[j], i1 = id[n + j], i2 = id[2 * n + j];
+  const float w0 = w[j], w1 = w[n + j], w2 = w[2 * n + j];
+  const float *f = feat + (size_t)bi * bs_f;
+  float *o = out + (size_t)bi * bs_o;
+  for (int ci = blockIdx.y; ci < c; ci += gridDim.y) {
+    const float *fr = f + (size_t)ci * ld_f;
+    o[(size_t)ci * ld_o + j] =
+        __fadd_rn(__fadd_rn(__fmul_rn(fr[i0], w0), __fmul_rn(fr[i1], w1)), __fmul_rn(fr[i2], w2));
+  }
+}
+
+extern "C" int bdm_three_nn_search(int b, int m, int n, const float *points, const float *centers,
+                                   int *indices, float *weights, void *stream) {
+  BDM_REQUIRE(b >= 0 && m >= 1 && n >= 0, "three_nn_search: bad sizes");
+  if (b == 0 || n == 0) return BDM_OK;
+  dim3 grid(cdiv(n, 256), b);
+  hipLaunchKernelGGL(three_nn_search_kernel, grid, dim3(256), 3 * 1024 * sizeof(float), (hipStream_t)stream,
+                     m, n, points, centers, indices, weights);
+  return launch_status("three_nn_search");
+}
+
+extern "C" int bdm_three_nn_apply(int b, int c, int m, int n, const float *features, long long bs_f, int ld_f,
+                                  const int *indices, const float *weights, float *out, long long bs_o,
+                                  int ld_o, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 0 && m >= 1 && n >= 0, "three_nn_apply: bad sizes");
+  if (b == 0 || c == 0 || n == 0) return BDM_OK;
+  dim3 grid(cdiv(n, 256), c < 64 ? c : 64, b);
+  hipLaunchKernelGGL(three_nn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, m, n, features, bs_f,
+                     ld_f, indices, weights, out, bs_o, ld_o);
+  return launch_status("three_nn_apply");
+}
+
+extern "C" int bdm_three_nn_interpolate_forward(int b, int c, int m, int n, const float *points,
+                                                const float *centers, const float *features, float *out,
+                                                int *indices, float *weights, void *stream) {
+  int rc = bdm_three_nn_search(b, m, n, points, centers, indices, weights, stream);
+  if (rc) return rc;
+  return bdm_three_nn_apply(b, c, m, n, features, (long long)c * m, m, indices, weights, out,
+                            (long long)c * n, n, stream);
+}
+
+// =====================================================================================
+// Average voxelisation, deterministic
+// =====================================================================================
+// Plan kernel (one workgroup per shape, LDS histogram of r^3 counters):
+//   ind[i], cnt[v]  ->  start[v] (exclusive scan)  ->  per-voxel point lists, each list in
+//   ascending point index (unordered atomic fill, then rank-within-list placement).
+// Reduce kernel: out[c][v] = sum over list(v), in list order, of feat[c][p] * (1/cnt[v]).
+struct VoxWs {
+  int *start;   // [b][r3]
+  int *tmp;     // [b][n]
+  int *sorted;  // [b][n]
+};
+static inline VoxWs vox_ws(void *ws, int b, int n, int r3) {
+  VoxWs w;
+  w.start = (int *)ws;
+  w.tmp = w.start + (size_t)b * r3;
+  w.sorted = w.tmp + (size_t)b * n;
+  return w;
+}
+extern "C" size_t bdm_voxelize_workspace_bytes(int b, int n, int r) {
+  return sizeof(int) * ((size_t)b * r * r * r + 2 * (size_t)b * n);
+}
+
+__global__ void vox_plan_kernel(int n, int r, const int *__restrict__ coords, int *__restrict__ ind,
+                                int *__restrict__ cnt, int *__restrict__ start, int *__restrict__ tmp,
+                                int *__restrict__ sorted) {
+  extern __shared__ int lcnt[];  // [r3] counters, then cursors
+  __shared__ int wave_tot[16];
+  const int r2 = r * r, r3 = r2 * r;
+  const int bi = blockIdx.x, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int *vx = coords + (size_t)bi * 3 * n, *vy = vx + n, *vz = vy + n;
+  int *id = ind + (size_t)bi * n;
+  int *gc = cnt + (size_t)bi * r3;
+  int *gs = start + (size_t)bi * r3;
+  int *tp = tmp + (size_t)bi * n;
+  int *so = sorted + (size_t)bi * n;
+
+  for (int v = tid; v < r3; v += T) lcnt[v] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += T) {
+    const int v = vx[i] * r2 + vy[i] * r + vz[i];
+    id[i] = v;
+    atomicAdd(&lcnt[v], 1);
+  }
+  __syncthreads();
+  // exclusive scan over r3 counters: each thread owns a contiguous run
+  const int per = (r3 + T - 1) / T;
+  const int lo = min(tid * per, r3), hi = min(lo + per, r3);
+  int local = 0;
+  for (int v = lo; v < hi; ++v) { const int cv = lcnt[v]; gc[v] = cv; local += cv; }
+  int incl = local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+  int run = wave_off + incl - local;
+  for (int v = lo; v < hi; ++v) { const int cv = lcnt[v]; gs[v] = run; lcnt[v] = run; run += cv; }
+  __syncthreads();
+  for (int i = tid; i < n; i += T) tp[atomicAdd(&lcnt[id[i]], 1)] = i;
+  __syncthreads();
+  for (int i = tid; i < n; i += T) {
+    const int v = id[i];
+    const int s = gs[v], cv = gc[v];
+    int rank = 0;
+    for (int q = 0; q < cv; ++q) rank += tp[s + q] < i;
+    so[s + rank] = i;
+  }
+}
+
+__global__ void vox_reduce_kernel(int c, int n, int r3, const float *__restrict__ feat,
+                                  const int *__restrict__ cnt, const int *__restrict__ start,
+                                  const int *__restrict__ sorted, float *__restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (v >= r3) return;
+  const int cv = cnt[(size_t)bi * r3 + v];
+  const int s = start[(size_t)bi * r3 + v];
+  const int *so = sorted + (size_t)bi * n + s;
+  const float inv = cv > 0 ? (float)(1.0 / (double)(float)cv) : 0.f;  // vox.cu:66
+  for (int ci = blockIdx.y; ci < c; ci += gridDim.y) {
+    const float *f = feat + ((size_t)bi * c + ci) * n;
+    float acc = 0.f;
+    for (int q = 0; q < cv; ++q) acc = __fadd_rn(acc, __fmul_rn(f[so[q]], inv));
+    out[((size_t)bi * c + ci) * r3 + v] = acc;
+  }
+}
+
+extern "C" int bdm_avg_voxelize_forward(int b, int c, int n, int r, const float *features, const int *coords,
+                                        float *out, int *ind, int *cnt, void *workspace, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 0 && n >= 1 && r >= 1 && r <= 32, "avg_voxelize: bad sizes (r<=32 supported)");
+  BDM_REQUIRE(workspace != nullptr, "avg_voxelize: workspace is NULL");
+  if (b == 0) return BDM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int r3 = r * r * r;
+  VoxWs w = vox_ws(workspace, b, n, r3);
+  const size_t smem = (size_t)r3 * sizeof(int);
+  BDM_ALLOW_LDS(vox_plan_kernel, smem);
+  hipLaunchKernelGGL(vox_plan_kernel, dim3(b), dim3(1024), smem, s, n, r, coords, ind, cnt, w.start, w.tmp,
+                     w.sorted);
+  int rc = launch_status("vox_plan");
+  if (rc || c == 0) return rc;
+  dim3 grid(cdiv(r3, 256), c < 64 ? c : 64, b);
+  hipLaunchKernelGGL(vox_reduce_kernel, grid, dim3(256), 0, s, c, n, r3, features, cnt, w.start, w.sorted, out);
+  return launch_status("vox_reduce");
+}
+
+// =====================================================================================
+// Trilinear devoxelisation (inference form)
+// =====================================================================================
+__global__ void devox_kernel(int c, int n, int r, const float *__restrict__ coords,
+                             const float *__restrict__ grid, float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (i >= n) return;
+  const int r2 = r * r, r3 = r2 * r;
+  const float *pc = coords + (size_t)bi * 3 * n;
+  const float x = pc[i], y = pc[n + i], z = pc[2 * n + i];
+  const float xl = floorf(x), yl = floorf(y), zl = floorf(z);
+  const float x1 = x - xl, y1 = y - yl, z1 = z - zl;
+  const float x0 = 1.0f - x1, y0 = 1.0f - y1, z0 = 1.0f - z1;
+  const float x0y0 = __fmul_rn(x0, y0), x0y1 = __fmul_rn(x0, y1), x1y0 = __fmul_rn(x1, y0), x1y1 = __fmul_rn(x1, y1);
+  const float w000 = __fmul_rn(x0y0, z0), w001 = __fmul_rn(x0y0, z1), w010 = __fmul_rn(x0y1, z0),
+              w011 = __fmul_rn(x0y1, z1), w100 = __fmul_rn(x1y0, z0), w101 = __fmul_rn(x1y0, z1),
+              w110 = __fmul_rn(x1y1, z0), w111 = __fmul_rn(x1y1, z1);
+  const int sx = x1 > 0 ? r2 : 0, sy = y1 > 0 ? r : 0, sz = z1 > 0 ? 1 : 0;
+  const int i000 = (int)xl * r2 + (int)yl * r + (int)zl;
+  const int i001 = i000 + sz, i010 = i000 + sy, i011 = i010 + sz;
+  const int i100 = i000 + sx, i101 = i100 + sz, i110 = i100 + sy, i111 = i110 + sz;
+  for (int ci = blockIdx.y; ci < c; ci += gridDim.y) {
+    const float *g = grid + ((size_t)bi * c + ci) * r3;
+    float acc = __fmul_rn(w000, g[i000]);
+    acc = __fadd_rn(acc, __fmul_rn(w001, g[i001]));
+    acc = __fadd_rn(acc, __fmul_rn(w010, g[i010]));
+    acc = __fadd_rn(acc, __fmul_rn(w011, g[i011]));
+    acc = __fadd_rn(acc, __fmul_rn(w100, g[i100]));
+    acc = __fadd_rn(acc, __fmul_rn(w101, g[i101]));
+    acc = __fadd_rn(acc, __fmul_rn(w110, g[i110]));
+    acc = __fadd_rn(acc, __fmul_rn(w111, g[i111]));
+    out[((size_t)bi * c + ci) * n + i] = acc;
+  }
+}
+
+extern "C" int bdm_trilinear_devoxelize_forward(int b, int c, int n, int r, const float *coords,
+                                                const float *grid, float *out, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 0 && n >= 0 && r >= 1, "devoxelize: bad sizes");
+  if (b == 0 || c == 0 || n == 0) return BDM_OK;
+  dim3 g(cdiv(n, 256), c < 64 ? c : 64, b);
+  hipLaunchKernelGGL(devox_kernel, g, dim3(256), 0, (hipStream_t)stream, c, n, r, coords, grid, out);
+  return launch_status("devoxelize");
+}

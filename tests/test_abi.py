@@ -1,0 +1,49 @@
+"""The C-ABI shared library loads on a CPU-only box and exports every symbol include/bdm_hip.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bdm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bdm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from bdm_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    names = declared_symbols()
+    assert len(names) >= 10
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in bdm_hip.h but not exported: {missing}"
+    lib.bdm_abi_version.restype = ctypes.c_int
+    assert lib.bdm_abi_version() >= 1
+
+
+def test_no_cpu_fallback():
+    """Host tensors are refused: the product path must not silently run on the CPU."""
+    import pytest
+    import torch
+    from bdm_amd import _lib
+    with pytest.raises(_lib.BdmHipError):
+        _lib.ptr(torch.zeros(3))
+    from bdm_amd.functional import _backend
+    with pytest.raises(RuntimeError):
+        _backend.ball_query(torch.zeros(1, 3, 4), torch.zeros(1, 3, 8), 0.1, 4)
+
+
+def test_product_does_not_import_oracle():
+    """Nothing under bdm_amd/ may import, link or execute the oracle."""
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "bdm_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|from\s+\.\.?oracle|liboracle", src, flags=re.M):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

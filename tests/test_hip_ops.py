@@ -1,0 +1,114 @@
+"""GPU parity: the `_pvcnn_backend`-compatible HIP operators vs the CPU oracle, through the C ABI.
+Bit-exact for every index output; float outputs are bit-exact too because the HIP kernels
+use the oracle's unfused operation order (tolerance written per test)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def cloud(B, N, seed, scale=0.4):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(B, 3, N, generator=g) * scale).contiguous()
+
+
+LEVELS = [(4096, 1024, 0.1), (1024, 256, 0.2), (256, 64, 0.4), (64, 16, 0.8)]
+
+
+@pytest.mark.parametrize("n,m", [(4096, 1024), (1024, 256), (256, 64), (64, 16), (1100, 77), (8192, 1024),
+                                 (16384, 64), (3, 5), (1, 1)])
+def test_fps_bit_exact(hip, oracle_ops, n, m):
+    B = 3
+    pts = cloud(B, n, seed=n + m)
+    if n >= 1024:  # force exact distance ties across lanes and within a lane (sampling.cu:120-160)
+        pts[0, :, 90] = pts[0, :, 600] * 1.0
+        pts[1, :, 5] = pts[1, :, 517]
+    ref = oracle_ops.furthest_point_sampling(pts, m)
+    got = hip.furthest_point_sampling(pts.cuda(), m).cpu()
+    assert torch.equal(ref, got)
+
+
+def test_fps_tie_rule_known_answer(hip):
+    n = 1024
+    c = torch.zeros(1, 3, n)
+    c[0, 0, 90] = 1.0
+    c[0, 0, 600] = -1.0
+    assert hip.furthest_point_sampling(c.cuda(), 3).cpu()[0].tolist() == [0, 600, 90]
+
+
+@pytest.mark.parametrize("n,m,radius", LEVELS + [(1100, 300, 0.15), (16384, 1024, 0.1), (50, 7, 1e-4)])
+def test_ball_query_bit_exact(hip, oracle_ops, n, m, radius):
+    B, U = 2, 32
+    pts = cloud(B, n, seed=7 * n)
+    idx = oracle_ops.furthest_point_sampling(pts, m)
+    ctr = oracle_ops.gather_features_forward(pts, idx)
+    if radius < 1e-3:
+        ctr = ctr + 5.0  # no hits at all -> all-zero rows
+    ref = oracle_ops.ball_query(ctr, pts, radius, U)
+    got = hip.ball_query(ctr.cuda(), pts.cuda(), radius, U).cpu()
+    assert torch.equal(ref, got)
+
+
+def test_gather_grouping_exact(hip, oracle_ops):
+    B, C, N, M, U = 2, 35, 1000, 130, 32
+    g = torch.Generator().manual_seed(1)
+    f = torch.randn(B, C, N, generator=g)
+    idx = torch.randint(0, N, (B, M), generator=g, dtype=torch.int32)
+    nb = torch.randint(0, N, (B, M, U), generator=g, dtype=torch.int32)
+    assert torch.equal(oracle_ops.gather_features_forward(f, idx), hip.gather_features_forward(f.cuda(), idx.cuda()).cpu())
+    assert torch.equal(oracle_ops.grouping_forward(f, nb), hip.grouping_forward(f.cuda(), nb.cuda()).cpu())
+
+
+@pytest.mark.parametrize("n,m,c", [(64, 16, 576), (256, 64, 320), (1024, 256, 320), (4096, 1024, 192), (1100, 3, 7),
+                                   (500, 2, 4), (16384, 1024, 8)])
+def test_three_nn_bit_exact(hip, oracle_ops, n, m, c):
+    B = 2
+    pts = cloud(B, n, seed=n)
+    ctr = pts[:, :, torch.randperm(n, generator=torch.Generator().manual_seed(3))[:m]].contiguous()
+    f = torch.randn(B, c, m, generator=torch.Generator().manual_seed(4))
+    ro, ri, rw = oracle_ops.three_nearest_neighbors_interpolate_forward(pts, ctr, f)
+    go, gi, gw = hip.three_nearest_neighbors_interpolate_forward(pts.cuda(), ctr.cuda(), f.cuda())
+    assert torch.equal(ri, gi.cpu())
+    assert torch.equal(rw, gw.cpu())  # tolerance: 0 (same unfused op order, IEEE division)
+    assert torch.equal(ro, go.cpu())
+
+
+@pytest.mark.parametrize("n,r,c", [(4096, 32, 35), (1024, 16, 128), (256, 8, 192), (64, 8, 256), (1100, 32, 3),
+                                   (16384, 32, 4), (5000, 2, 3)])
+def test_avg_voxelize_bit_exact(hip, oracle_ops, n, r, c):
+    B = 2
+    g = torch.Generator().manual_seed(n + r)
+    # gaussian-concentrated voxel coordinates: many points per voxel near the centre
+    vc = (torch.randn(B, 3, n, generator=g) * r / 8 + r / 2).round().clamp(0, r - 1).to(torch.int32)
+    f = torch.randn(B, c, n, generator=g) * 100
+    ro, ri, rc = oracle_ops.avg_voxelize_forward(f, vc, r)
+    go, gi, gc = hip.avg_voxelize_forward(f.cuda(), vc.cuda(), r)
+    assert torch.equal(ri, gi.cpu()) and torch.equal(rc, gc.cpu())
+    assert torch.equal(ro, go.cpu())  # tolerance: 0 -- ascending-point-index accumulation on both sides
+    # and run-to-run deterministic (the reference's float atomics are not)
+    go2 = hip.avg_voxelize_forward(f.cuda(), vc.cuda(), r)[0]
+    assert torch.equal(go, go2)
+
+
+@pytest.mark.parametrize("n,r,c", [(4096, 32, 64), (1024, 16, 128), (64, 8, 256), (1100, 32, 5)])
+def test_devoxelize_bit_exact(hip, oracle_ops, n, r, c):
+    B = 2
+    g = torch.Generator().manual_seed(n * r)
+    coords = (torch.rand(B, 3, n, generator=g) * (r - 1)).contiguous()
+    coords[:, :, :8] = coords[:, :, :8].round()  # integer coordinates incl. the upper face
+    coords[0, :, 0] = r - 1
+    grid = torch.randn(B, c, r ** 3, generator=g)
+    ro = oracle_ops.trilinear_devoxelize_forward(r, False, coords, grid)[0]
+    go = hip.trilinear_devoxelize_forward(r, False, coords.cuda(), grid.cuda())[0]
+    assert torch.equal(ro, go.cpu())  # tolerance: 0
+
+
+def test_argument_errors_raise_not_exit(hip):
+    with pytest.raises(RuntimeError):
+        hip.ball_query(torch.zeros(1, 3, 4), torch.zeros(1, 3, 8).cuda(), 0.1, 4)  # host tensor
+    with pytest.raises(RuntimeError):
+        hip.grouping_forward(torch.zeros(1, 3, 8).cuda(), torch.zeros(1, 2, 2).cuda())  # float indices
+    from bdm_amd import _lib
+    with pytest.raises(_lib.BdmHipError):
+        hip.furthest_point_sampling(torch.zeros(1, 3, 20000).cuda(), 4)  # beyond the sampler's limit
