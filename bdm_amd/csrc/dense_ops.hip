@@ -1,0 +1,710 @@
+// dense_ops.hip -- gfx950 kernels for the dense per-point / per-voxel operators the reference
+// runs as stock PyTorch modules around its plugin inside one denoiser forward:
+//   Conv1d/Conv2d k=1 (SharedMLP, attention projections, zero-conv projections, classifier)
+//       -> f32-input MFMA GEMM  (modules/shared_mlp.py:25-30, pvconv.py:21-31, pvcnn_fuse.py:111-123)
+//   GroupNorm(8) [+ residual] [+ Swish]      (shared_mlp.py:27-29, pvconv.py:80-86,61)
+//   max over neighbours                      (pointnet.py:86)
+//   SE3d gate                                (se.py:8-19)
+//   timestep embedding + embedf              (pvcnn_utils.py:171-185, pvcnn.py:72-76)
+//   Voxelization.forward coordinate maths    (modules/voxelization.py:16-25)
+//   trilinear devoxelise * SE gate + point branch  (pvconv.py:95-96)
+//   attention cores                          (pvconv.py:40-63)
+// All arithmetic is fp32; contractions use v_mfma_f32_32x32x2_f32 (exact fp32 products, k-ordered
+// fp32 accumulation -- the 1e-3 end-to-end criterion after 1000 steps rules out bf16 here).
+#include "../../include/bdm_hip.h"
+#include "common.h"
+
+using namespace bdm;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// =====================================================================================
+// Pointwise convolution = batched GEMM  Y[b] = W (M x K) * X[b] (K x N) + bias
+// =====================================================================================
+// Channel-first operands put the point index on the MFMA lane: B-operand rows are
+// contiguous point runs (coalesced 16-B loads, conflict-free ds_read_b32), the weight tile is
+// stored k-major in LDS so A-operand reads are conflict-free too.
+// Tile: (32*MI) x (128*NI) per 256-thread workgroup, K chunk 16, 4 waves side by side along N.
+#define PW_BK 16
+template <int MI, int NI>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const float *__restrict__ W, int ldw,
+                                                      const float *__restrict__ X, long long bsx, int ldx,
+                                                      const float *__restrict__ bias,
+                                                      const float *__restrict__ bbias, int ldbb,
+                                                      const float *__restrict__ R, long long bsr, int ldr,
+                                                      float *__restrict__ Y, long long bsy, int ldy, int act,
+                                                      float slope) {
+  constexpr int BM = 32 * MI, BN = 128 * NI, LDA = BM + 4;
+  __shared__ float As[PW_BK * LDA];
+  __shared__ __align__(16) float Bs[PW_BK * BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, bi = blockIdx.z;
+  const float *Xb = X + (size_t)bi * bsx;
+  float *Yb = Y + (size_t)bi * bsy;
+  const bool vec_ok = ((ldx & 3) == 0) && ((((uintptr_t)Xb) & 15) == 0);
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int c = 0; c < NI; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+  for (int k0 = 0; k0 < K; k0 += PW_BK) {
+    // ---- stage W tile (BM x 16), transposed to k-major
+#pragma unroll
+    for (int i = 0; i < (BM * PW_BK) / 256; ++i) {
+      const int e = tid + i * 256, m = e >> 4, k = e & 15;
+      float v = 0.f;
+      if (m0 + m < M && k0 + k < K) v = W[(size_t)(m0 + m) * ldw + k0 + k];
+      As[k * LDA + m] = v;
+    }
+    // ---- stage X tile (16 x BN)
+#pragma unroll
+    for (int i = 0; i < (PW_BK * BN / 4) / 256; ++i) {
+      const int e = tid + i * 256, k = e / (BN / 4), c4 = (e % (BN / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + k < K) {
+        const float *src = Xb + (size_t)(k0 + k) * ldx + n0 + c4;
+        if (vec_ok && n0 + c4 + 3 < N) {
+          v = *reinterpret_cast<const float4 *>(src);
+        } else {
+          if (n0 + c4 + 0 < N) v.x = src[0];
+          if (n0 + c4 + 1 < N) v.y = src[1];
+          if (n0 + c4 + 2 < N) v.z = src[2];
+          if (n0 + c4 + 3 < N) v.w = src[3];
+        }
+      }
+      *reinterpret_cast<float4 *>(&Bs[k * BN + c4]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < PW_BK / 2; ++kk) {
+      float a[MI], b[NI];
+#pragma unroll
+      for (int x = 0; x < MI; ++x) a[x] = As[(2 * kk + lh) * LDA + x * 32 + li];
+#pragma unroll
+      for (int y = 0; y < NI; ++y) b[y] = Bs[(2 * kk + lh) * BN + (wave * NI + y) * 32 + li];
+#pragma unroll
+      for (int x = 0; x < MI; ++x)
+#pragma unroll
+        for (int y = 0; y < NI; ++y)
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: C/D map  row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+#pragma unroll
+  for (int x = 0; x < MI; ++x)
+#pragma unroll
+    for (int y = 0; y < NI; ++y) {
+      const int n = n0 + (wave * NI + y) * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && n < N) {
+          float v = acc[x][y][r];
+          if (bias) v += bias[m];
+          if (bbias) v += bbias[(size_t)bi * ldbb + m];
+          if (act == 2) v = v > 0.f ? v : v * slope;
+          if (R) v += R[(size_t)bi * bsr + (size_t)m * ldr + n];
+          Yb[(size_t)m * ldy + n] = v;
+        }
+      }
+    }
+}
+
+extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, int ldw, const float *x,
+                                  long long bs_x, int ld_x, const float *bias, const float *batch_bias,
+                                  int ld_bb, const float *residual, long long bs_r, int ld_r, float *y,
+                                  long long bs_y, int ld_y, int act, float slope, void *stream) {
+  BDM_REQUIRE(b >= 0 && m >= 1 && k >= 1 && n >= 0, "pointwise_conv: bad sizes m=%d k=%d n=%d", m, k, n);
+  BDM_REQUIRE(act == 0 || act == 2, "pointwise_conv: act must be 0 (none) or 2 (leaky relu)");
+  if (b == 0 || n == 0) return BDM_OK;
+  hipStream_t s = (hipStream_t)stream;
+#define PW_LAUNCH(MI, NI)                                                                                   \
+  hipLaunchKernelGGL((pw_gemm_kernel<MI, NI>), dim3(cdiv(n, 128 * NI), cdiv(m, 32 * MI), b), dim3(256), 0, s, \
+                     m, k, n, w, ldw, x, bs_x, ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r, y, bs_y, ld_y, act, slope)
+  if (m <= 32) {
+    if (n <= 128) PW_LAUNCH(1, 1); else PW_LAUNCH(1, 2);
+  } else {
+    if (n <= 128) PW_LAUNCH(2, 1); else PW_LAUNCH(2, 2);
+  }
+#undef PW_LAUNCH
+  return launch_status("pointwise_conv");
+}
+
+// =====================================================================================
+// GroupNorm(G) [+ residual] [+ Swish] over (B, C, L) with row stride ld
+// =====================================================================================
+// Two launches: slice-partial (sum, sumsq) in fp64, then normalise; the second kernel re-reduces
+// the S partials in a fixed order, so results are run-to-run deterministic.
+#define GN_MAX_SLICES 64
+__device__ __forceinline__ float swishf(float x) { return x / (1.0f + expf(-x)); }
+
+__global__ void gn_stats_kernel(int cg, int L, const float *__restrict__ x, long long bs, int ld,
+                                const float *__restrict__ res, long long bs_r, int ld_r, int G,
+                                double *__restrict__ partial) {
+  const int S = gridDim.x, s = blockIdx.x, bg = blockIdx.y, bi = bg / G, g = bg % G;
+  const float *xb = x + (size_t)bi * bs + (size_t)g * cg * ld;
+  const float *rb = res ? res + (size_t)bi * bs_r + (size_t)g * cg * ld_r : nullptr;
+  const long long total = (long long)cg * L;
+  const long long per = (total + S - 1) / S;
+  const long long lo = (long long)s * per, hi = lo + per < total ? lo + per : total;
+  double sum = 0.0, sq = 0.0;
+  for (long long e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+    const int row = (int)(e / L), col = (int)(e % L);
+    float v = xb[(size_t)row * ld + col];
+    if (rb) v += rb[(size_t)row * ld_r + col];
+    sum += v;
+    sq += (double)v * v;
+  }
+  __shared__ double sh[2][16];
+  sum = wave_sum(sum);
+  sq = wave_sum(sq);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sh[0][wave] = sum; sh[1][wave] = sq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, q = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += sh[0][w]; q += sh[1][w]; }
+    partial[((size_t)bg * S + s) * 2 + 0] = a;
+    partial[((size_t)bg * S + s) * 2 + 1] = q;
+  }
+}
+
+__global__ void gn_apply_kernel(int cg, int L, const float *__restrict__ x, long long bs, int ld,
+                                const float *__restrict__ res, long long bs_r, int ld_r, int G, int S,
+                                const double *__restrict__ partial, const float *__restrict__ gamma,
+                                const float *__restrict__ beta, float eps, int act, float *__restrict__ y,
+                                long long bs_y, int ld_y) {
+  const int bg = blockIdx.y, bi = bg / G, g = bg % G;
+  double a = 0.0, q = 0.0;
+  for (int s = 0; s < S; ++s) { a += partial[((size_t)bg * S + s) * 2]; q += partial[((size_t)bg * S + s) * 2 + 1]; }
+  const double cnt = (double)cg * L;
+  const double mean_d = a / cnt;
+  double var = q / cnt - mean_d * mean_d;
+  if (var < 0) var = 0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float *xb = x + (size_t)bi * bs + (size_t)g * cg * ld;
+  const float *rb = res ? res + (size_t)bi * bs_r + (size_t)g * cg * ld_r : nullptr;
+  float *yb = y + (size_t)bi * bs_y + (size_t)g * cg * ld_y;
+  const long long total = (long long)cg * L;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(e / L), col = (int)(e % L);
+    float v = xb[(size_t)row * ld + col];
+    if (rb) v += rb[(size_t)row * ld_r + col];
+    const int ch = g * cg + row;
+    v = (v - mean) * rstd * gamma[ch] + beta[ch];
+    if (act == 1) v = swishf(v);
+    yb[(size_t)row * ld_y + col] = v;
+  }
+}
+
+extern "C" size_t bdm_group_norm_workspace_bytes(int b, int groups) {
+  return sizeof(double) * 2 * (size_t)b * groups * GN_MAX_SLICES;
+}
+
+extern "C" int bdm_group_norm(int b, int c, int l, int groups, const float *x, long long bs_x, int ld_x,
+                              const float *residual, long long bs_r, int ld_r, const float *gamma,
+                              const float *beta, float eps, int act, float *y, long long bs_y, int ld_y,
+                              void *workspace, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && l >= 1 && groups >= 1 && c % groups == 0, "group_norm: bad sizes c=%d groups=%d", c, groups);
+  BDM_REQUIRE(workspace != nullptr, "group_norm: workspace is NULL");
+  BDM_REQUIRE(act == 0 || act == 1, "group_norm: act must be 0 (none) or 1 (swish)");
+  if (b == 0) return BDM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int cg = c / groups;
+  const long long total = (long long)cg * l;
+  int S = (int)((total + 8191) / 8192);
+  if (S < 1) S = 1;
+  if (S > GN_MAX_SLICES) S = GN_MAX_SLICES;
+  double *partial = (double *)workspace;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(S, b * groups), dim3(256), 0, s, cg, l, x, bs_x, ld_x, residual, bs_r,
+                     ld_r, groups, partial);
+  int rc = launch_status("gn_stats");
+  if (rc) return rc;
+  int gx = (int)((total + 1023) / 1024);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, b * groups), dim3(256), 0, s, cg, l, x, bs_x, ld_x, residual, bs_r,
+                     ld_r, groups, S, partial, gamma, beta, eps, act, y, bs_y, ld_y);
+  return launch_status("gn_apply");
+}
+
+// =====================================================================================
+// max over the neighbour axis: (B, C, M, U) -> (B, C, M)
+// =====================================================================================
+__global__ void max_u_kernel(int c, int m, int u, const float *__restrict__ x, float *__restrict__ y,
+                             long long bs_y, int ld_y) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (j >= m) return;
+  for (int ci = blockIdx.y; ci < c; ci += gridDim.y) {
+    const float *row = x + (((size_t)bi * c + ci) * m + j) * u;
+    float v = row[0];
+    if ((u & 3) == 0) {
+      const float4 *r4 = reinterpret_cast<const float4 *>(row);
+      for (int q = 0; q < u / 4; ++q) {
+        const float4 t = r4[q];
+        v = fmaxf(v, fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)));
+      }
+    } else {
+      for (int q = 1; q < u; ++q) v = fmaxf(v, row[q]);
+    }
+    y[(size_t)bi * bs_y + (size_t)ci * ld_y + j] = v;
+  }
+}
+
+extern "C" int bdm_max_over_neighbors(int b, int c, int m, int u, const float *x, float *y, long long bs_y,
+                                      int ld_y, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && m >= 1 && u >= 1, "max_over_neighbors: bad sizes");
+  if (b == 0) return BDM_OK;
+  dim3 grid(cdiv(m, 64), c < 256 ? c : 256, b);
+  hipLaunchKernelGGL(max_u_kernel, grid, dim3(64), 0, (hipStream_t)stream, c, m, u, x, y, bs_y, ld_y);
+  return launch_status("max_over_neighbors");
+}
+
+// =====================================================================================
+// Grouped SA input: out[b] = cat[ group(coords) - centre , group(features) ]   (ball_query.py:16-30)
+// =====================================================================================
+__global__ void sa_group_kernel(int c, int n, int m, int u, const float *__restrict__ coords,
+                                const float *__restrict__ centers, const float *__restrict__ feat, long long bs_f,
+                                int ld_f, const int *__restrict__ idx, float *__restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z, mu = m * u;
+  if (e >= mu) return;
+  const int src = idx[(size_t)bi * mu + e];
+  float *ob = out + (size_t)bi * (c + 3) * mu;
+  if (blockIdx.y == 0) {
+    const int j = e / u;
+    const float *pc = coords + (size_t)bi * 3 * n;
+    const float *cc = centers + (size_t)bi * 3 * m;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) ob[(size_t)d * mu + e] = pc[(size_t)d * n + src] - cc[(size_t)d * m + j];
+  }
+  const float *fb = feat + (size_t)bi * bs_f;
+  for (int ci = blockIdx.y; ci < c; ci += gridDim.y) ob[(size_t)(3 + ci) * mu + e] = fb[(size_t)ci * ld_f + src];
+}
+
+extern "C" int bdm_sa_group(int b, int c, int n, int m, int u, const float *coords, const float *centers,
+                            const float *features, long long bs_f, int ld_f, const int *indices, float *out,
+                            void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 0 && n >= 1 && m >= 1 && u >= 1, "sa_group: bad sizes");
+  if (b == 0) return BDM_OK;
+  int gy = c < 32 ? (c < 1 ? 1 : c) : 32;
+  hipLaunchKernelGGL(sa_group_kernel, dim3(cdiv(m * u, 256), gy, b), dim3(256), 0, (hipStream_t)stream, c, n, m, u,
+                     coords, centers, features, bs_f, ld_f, indices, out);
+  return launch_status("sa_group");
+}
+
+// =====================================================================================
+// Small helpers: broadcast a per-shape vector along points; strided copy; axpby-free add
+// =====================================================================================
+__global__ void bcast_rows_kernel(int c, int l, const float *__restrict__ v, int ld_v, float *__restrict__ y,
+                                  long long bs_y, int ld_y) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (col >= l) return;
+  for (int ci = blockIdx.y; ci < c; ci += gridDim.y)
+    y[(size_t)bi * bs_y + (size_t)ci * ld_y + col] = v[(size_t)bi * ld_v + ci];
+}
+extern "C" int bdm_broadcast_rows(int b, int c, int l, const float *v, int ld_v, float *y, long long bs_y,
+                                  int ld_y, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && l >= 1, "broadcast_rows: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(bcast_rows_kernel, dim3(cdiv(l, 256), c < 64 ? c : 64, b), dim3(256), 0, (hipStream_t)stream, c,
+                     l, v, ld_v, y, bs_y, ld_y);
+  return launch_status("broadcast_rows");
+}
+
+__global__ void copy_rows_kernel(int c, int l, const float *__restrict__ x, long long bs_x, int ld_x,
+                                 float *__restrict__ y, long long bs_y, int ld_y) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (col >= l) return;
+  for (int ci = blockIdx.y; ci < c; ci += gridDim.y)
+    y[(size_t)bi * bs_y + (size_t)ci * ld_y + col] = x[(size_t)bi * bs_x + (size_t)ci * ld_x + col];
+}
+extern "C" int bdm_copy_rows(int b, int c, int l, const float *x, long long bs_x, int ld_x, float *y,
+                             long long bs_y, int ld_y, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 0 && l >= 1, "copy_rows: bad sizes");
+  if (b == 0 || c == 0) return BDM_OK;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(l, 256), c < 64 ? c : 64, b), dim3(256), 0, (hipStream_t)stream, c,
+                     l, x, bs_x, ld_x, y, bs_y, ld_y);
+  return launch_status("copy_rows");
+}
+
+// (B, N, C) point-major  ->  (B, C, N) channel-first  (point_cloud_model.py:65 `inputs.transpose(1, 2)`)
+__global__ void transpose_kernel(int rows, int cols, const float *__restrict__ x, float *__restrict__ y) {
+  __shared__ float tile[32][33];
+  const int bi = blockIdx.z;
+  const float *xb = x + (size_t)bi * rows * cols;
+  float *yb = y + (size_t)bi * rows * cols;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[i][threadIdx.x] = xb[(size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) yb[(size_t)c * rows + r] = tile[threadIdx.x][i];
+  }
+}
+extern "C" int bdm_transpose(int b, int rows, int cols, const float *x, float *y, void *stream) {
+  BDM_REQUIRE(b >= 0 && rows >= 1 && cols >= 1, "transpose: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32), b), dim3(32, 8), 0, (hipStream_t)stream,
+                     rows, cols, x, y);
+  return launch_status("transpose");
+}
+
+// =====================================================================================
+// Timestep embedding + embedf   (pvcnn_utils.py:171-185, pvcnn.py:72-76,87-88)
+// =====================================================================================
+__global__ void time_embed_kernel(int dim, const float *__restrict__ t, const float *__restrict__ w0,
+                                  const float *__restrict__ b0, const float *__restrict__ w2,
+                                  const float *__restrict__ b2, float *__restrict__ out) {
+  extern __shared__ float sh[];  // emb[dim], hid[dim]
+  float *emb = sh, *hid = sh + dim;
+  const int bi = blockIdx.x, i = threadIdx.x, half = dim / 2;
+  if (i < dim) {
+    const int fi = i < half ? i : i - half;
+    // numpy float64 exp, then .float()
+    const float freq = (float)exp(-(double)fi * (log(10000.0) / (double)(half - 1)));
+    const float arg = t[bi] * freq;
+    emb[i] = i < half ? sinf(arg) : cosf(arg);
+  }
+  __syncthreads();
+  if (i < dim) {
+    float a = b0[i];
+    for (int k = 0; k < dim; ++k) a += w0[i * dim + k] * emb[k];
+    hid[i] = a > 0.f ? a : 0.1f * a;
+  }
+  __syncthreads();
+  if (i < dim) {
+    float a = b2[i];
+    for (int k = 0; k < dim; ++k) a += w2[i * dim + k] * hid[k];
+    out[(size_t)bi * dim + i] = a;
+  }
+}
+extern "C" int bdm_time_embedding(int b, int dim, const float *t, const float *w0, const float *b0,
+                                  const float *w2, const float *b2, float *out, void *stream) {
+  BDM_REQUIRE(b >= 0 && dim >= 4 && dim % 2 == 0 && dim <= 1024, "time_embedding: bad dim %d", dim);
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(time_embed_kernel, dim3(b), dim3((dim + 63) / 64 * 64), 2 * dim * sizeof(float),
+                     (hipStream_t)stream, dim, t, w0, b0, w2, b2, out);
+  return launch_status("time_embedding");
+}
+
+// =====================================================================================
+// Voxelization.forward coordinate maths  (modules/voxelization.py:16-25, normalize=True)
+// =====================================================================================
+// One workgroup per shape: mean over points, max point norm, then
+//   nc = clamp(((p - mean) / (2*maxnorm + eps) + 0.5) * r, 0, r-1);  vox = round-half-even(nc).
+__global__ void voxel_coords_kernel(int n, int r, float eps, const float *__restrict__ coords,
+                                    float *__restrict__ norm_coords, int *__restrict__ vox_coords) {
+  __shared__ double shd[3][16];
+  __shared__ float shf[16];
+  __shared__ float s_mean[3], s_max;
+  const int bi = blockIdx.x, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+  const float *p = coords + (size_t)bi * 3 * n;
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int i = tid; i < n; i += T) { s[0] += p[i]; s[1] += p[n + i]; s[2] += p[2 * n + i]; }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    s[d] = wave_sum(s[d]);
+    if (lane == 0) shd[d][wave] = s[d];
+  }
+  __syncthreads();
+  if (tid < 3) {
+    double a = 0.0;
+    for (int w = 0; w < nw; ++w) a += shd[tid][w];
+    s_mean[tid] = (float)(a / (double)n);
+  }
+  __syncthreads();
+  const float mx = s_mean[0], my = s_mean[1], mz = s_mean[2];
+  float best = 0.f;
+  for (int i = tid; i < n; i += T) {
+    const float x = p[i] - mx, y = p[n + i] - my, z = p[2 * n + i] - mz;
+    best = fmaxf(best, sqrtf(x * x + y * y + z * z));
+  }
+  best = wave_max(best);
+  if (lane == 0) shf[wave] = best;
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f;
+    for (int w = 0; w < nw; ++w) a = fmaxf(a, shf[w]);
+    s_max = a;
+  }
+  __syncthreads();
+  const float denom = s_max * 2.0f + eps;
+  float *nc = norm_coords + (size_t)bi * 3 * n;
+  int *vc = vox_coords + (size_t)bi * 3 * n;
+  const float hi = (float)(r - 1);
+  for (int i = tid; i < n; i += T) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float v = (p[(size_t)d * n + i] - s_mean[d]) / denom + 0.5f;
+      v = fminf(fmaxf(v * (float)r, 0.f), hi);
+      nc[(size_t)d * n + i] = v;
+      vc[(size_t)d * n + i] = (int)rintf(v);
+    }
+  }
+}
+extern "C" int bdm_voxel_coords(int b, int n, int r, float eps, const float *coords, float *norm_coords,
+                                int *vox_coords, void *stream) {
+  BDM_REQUIRE(b >= 0 && n >= 1 && r >= 1, "voxel_coords: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(voxel_coords_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, n, r, eps, coords,
+                     norm_coords, vox_coords);
+  return launch_status("voxel_coords");
+}
+
+// =====================================================================================
+// SE3d gate: s = sigmoid(W2 relu(W1 mean_grid(v)))   (se.py:8-19, with_se_relu=True)
+// =====================================================================================
+__global__ void row_mean_kernel(int l, const float *__restrict__ x, float *__restrict__ mean) {
+  const int row = blockIdx.x;
+  const float *xr = x + (size_t)row * l;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < l; i += blockDim.x) s += xr[i];
+  __shared__ double sh[16];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += sh[w];
+    mean[row] = (float)(a / (double)l);
+  }
+}
+__global__ void se_fc_kernel(int c, int h, const float *__restrict__ mean, const float *__restrict__ w1,
+                             const float *__restrict__ w2, float *__restrict__ gate) {
+  extern __shared__ float sh[];  // s[c], hid[h]
+  float *s = sh, *hid = sh + c;
+  const int bi = blockIdx.x;
+  for (int i = threadIdx.x; i < c; i += blockDim.x) s[i] = mean[(size_t)bi * c + i];
+  __syncthreads();
+  for (int j = threadIdx.x; j < h; j += blockDim.x) {
+    float a = 0.f;
+    for (int k = 0; k < c; ++k) a += w1[(size_t)j * c + k] * s[k];
+    hid[j] = fmaxf(a, 0.f);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    float a = 0.f;
+    for (int k = 0; k < h; ++k) a += w2[(size_t)i * h + k] * hid[k];
+    gate[(size_t)bi * c + i] = 1.0f / (1.0f + expf(-a));
+  }
+}
+extern "C" int bdm_se_gate(int b, int c, int hidden, int l, const float *x, const float *w1, const float *w2,
+                           float *mean_ws, float *gate, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && hidden >= 1 && l >= 1, "se_gate: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(row_mean_kernel, dim3(b * c), dim3(256), 0, s, l, x, mean_ws);
+  int rc = launch_status("se_row_mean");
+  if (rc) return rc;
+  hipLaunchKernelGGL(se_fc_kernel, dim3(b), dim3(256), (c + hidden) * sizeof(float), s, c, hidden, mean_ws, w1, w2,
+                     gate);
+  return launch_status("se_fc");
+}
+
+// =====================================================================================
+// PVConv tail: out = trilinear_devoxelize(grid * gate) + point_branch   (pvconv.py:95-96)
+// =====================================================================================
+__global__ void devox_fused_kernel(int c, int n, int r, const float *__restrict__ coords,
+                                   const float *__restrict__ grid, const float *__restrict__ gate,
+                                   const float *__restrict__ add, long long bs_a, int ld_a, float *__restrict__ out,
+                                   long long bs_o, int ld_o) {
+#pragma clang fp contract(off)  // same unfused order as the stand-alone operator and the oracle
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (i >= n) return;
+  const int r2 = r * r, r3 = r2 * r;
+  const float *pc = coords + (size_t)bi * 3 * n;
+  const float x = pc[i], y = pc[n + i], z = pc[2 * n + i];
+  const float xl = floorf(x), yl = floorf(y), zl = floorf(z);
+  const float x1 = x - xl, y1 = y - yl, z1 = z - zl;
+  const float x0 = 1.0f - x1, y0 = 1.0f - y1, z0 = 1.0f - z1;
+  const float w000 = x0 * y0 * z0, w001 = x0 * y0 * z1, w010 = x0 * y1 * z0, w011 = x0 * y1 * z1,
+              w100 = x1 * y0 * z0, w101 = x1 * y0 * z1, w110 = x1 * y1 * z0, w111 = x1 * y1 * z1;
+  const int sx = x1 > 0 ? r2 : 0, sy = y1 > 0 ? r : 0, sz = z1 > 0 ? 1 : 0;
+  const int i000 = (int)xl * r2 + (int)yl * r + (int)zl;
+  const int i001 = i000 + sz, i010 = i000 + sy, i011 = i010 + sz;
+  const int i100 = i000 + sx, i101 = i100 + sz, i110 = i100 + sy, i111 = i110 + sz;
+  for (int ci = blockIdx.y; ci < c; ci += gridDim.y) {
+    const float *g = grid + ((size_t)bi * c + ci) * r3;
+    const float s = gate ? gate[(size_t)bi * c + ci] : 1.0f;
+    float acc = w000 * (g[i000] * s);
+    acc += w001 * (g[i001] * s);
+    acc += w010 * (g[i010] * s);
+    acc += w011 * (g[i011] * s);
+    acc += w100 * (g[i100] * s);
+    acc += w101 * (g[i101] * s);
+    acc += w110 * (g[i110] * s);
+    acc += w111 * (g[i111] * s);
+    if (add) acc += add[(size_t)bi * bs_a + (size_t)ci * ld_a + i];
+    out[(size_t)bi * bs_o + (size_t)ci * ld_o + i] = acc;
+  }
+}
+extern "C" int bdm_devoxelize_gate_add(int b, int c, int n, int r, const float *coords, const float *grid,
+                                       const float *gate, const float *add, long long bs_a, int ld_a,
+                                       float *out, long long bs_o, int ld_o, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && n >= 1 && r >= 1, "devoxelize_gate_add: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(devox_fused_kernel, dim3(cdiv(n, 256), c < 64 ? c : 64, b), dim3(256), 0, (hipStream_t)stream, c,
+                     n, r, coords, grid, gate, add, bs_a, ld_a, out, bs_o, ld_o);
+  return launch_status("devoxelize_gate_add");
+}
+
+// =====================================================================================
+// Attention cores  (pvconv.py:40-63):  h = v * softmax(q^T k)^T, no 1/sqrt(C) scale
+// =====================================================================================
+// (a) flash-style kernel for the 16^3 = 4096-token voxel attention inside sa_layers.1.0.
+//     S^T tile = K^T Q is computed with the KEY on the accumulator rows and the QUERY on the MFMA
+//     lane, so (i) the softmax over keys is a register + one-partner-lane reduction and (ii) the
+//     probability tile is already the B operand of the P*V product (no LDS round trip): step s of
+//     that product consumes accumulator register s, whose key index is
+//     4*(lane>>5) + (s&3) + 8*(s>>2); the V operand is read from LDS with the same key order.
+//     One wave = 32 queries; 4 waves share the K/V tiles of a 32-key step.
+template <int CB>  // channel blocks of 32 (C <= 32*CB)
+__global__ __launch_bounds__(256) void attn_flash_kernel(int C, int L, const float *__restrict__ q,
+                                                         const float *__restrict__ k, const float *__restrict__ v,
+                                                         long long bs, int ld, float *__restrict__ out,
+                                                         long long bs_o, int ld_o) {
+  constexpr int CP = 32 * CB;
+  __shared__ float Ks[CP][32 + 1];  // [c][key]
+  __shared__ float Vs[CP][32 + 1];  // [c][key]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int bi = blockIdx.y;
+  const int i0 = (blockIdx.x * 4 + wave) * 32;  // this wave's first query
+  const float *qb = q + (size_t)bi * bs, *kb = k + (size_t)bi * bs, *vb = v + (size_t)bi * bs;
+
+  // Q as B operand: lane holds q[c = 2s+lh][i0+li], s = 0..CP/2-1
+  float qreg[CP / 2];
+#pragma unroll
+  for (int s = 0; s < CP / 2; ++s) {
+    const int c = 2 * s + lh;
+    qreg[s] = (c < C && i0 + li < L) ? qb[(size_t)c * ld + i0 + li] : 0.f;
+  }
+  f32x16 o[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
+  float run_max = -INFINITY, run_sum = 0.f;
+
+  for (int j0 = 0; j0 < L; j0 += 32) {
+    __syncthreads();
+    for (int e = tid; e < CP * 32; e += 256) {
+      const int c = e >> 5, j = e & 31;
+      const bool ok = c < C && j0 + j < L;
+      Ks[c][j] = ok ? kb[(size_t)c * ld + j0 + j] : 0.f;
+      Vs[c][j] = ok ? vb[(size_t)c * ld + j0 + j] : 0.f;
+    }
+    __syncthreads();
+    // S^T[j][i] = sum_c k[c][j] q[c][i] : A[row=j][kk=c] = Ks[c][j]
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < CP / 2; ++s)
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[2 * s + lh][li], qreg[s], st, 0, 0, 0);
+    // keys beyond L do not exist
+    float tile_max = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (j >= L) st[r] = -INFINITY;
+      tile_max = fmaxf(tile_max, st[r]);
+    }
+    tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 32, 64));
+    const float new_max = fmaxf(run_max, tile_max);
+    const float corr = expf(run_max - new_max);  // exp(-inf) = 0 on the first tile
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] = expf(st[r] - new_max);
+      psum += st[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    run_sum = run_sum * corr + psum;
+    run_max = new_max;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[cb][r] *= corr;
+      // O^T[c][i] += sum_j v[c][j] P[j][i] : A[row=c][kk] = Vs[c][key(s,lh)], B = st[s]
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        o[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[cb * 32 + li][(s & 3) + 8 * (s >> 2) + 4 * lh], st[s], o[cb],
+                                                     0, 0, 0);
+    }
+  }
+  const float inv = 1.0f / run_sum;
+  float *ob = out + (size_t)bi * bs_o;
+  if (i0 + li < L) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (c < C) ob[(size_t)c * ld_o + i0 + li] = o[cb][r] * inv;
+      }
+  }
+}
+
+// (b) small-sequence kernel (global attention: 16 tokens x 512 channels): one workgroup per shape
+__global__ void attn_small_kernel(int C, int L, const float *__restrict__ q, const float *__restrict__ k,
+                                  const float *__restrict__ v, long long bs, int ld, float *__restrict__ out,
+                                  long long bs_o, int ld_o) {
+  extern __shared__ float S[];  // [L][L]
+  const int bi = blockIdx.x;
+  const float *qb = q + (size_t)bi * bs, *kb = k + (size_t)bi * bs, *vb = v + (size_t)bi * bs;
+  for (int e = threadIdx.x; e < L * L; e += blockDim.x) {
+    const int i = e / L, j = e % L;
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += qb[(size_t)c * ld + i] * kb[(size_t)c * ld + j];
+    S[e] = a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+    float mx = -INFINITY;
+    for (int j = 0; j < L; ++j) mx = fmaxf(mx, S[i * L + j]);
+    float sum = 0.f;
+    for (int j = 0; j < L; ++j) { const float e = expf(S[i * L + j] - mx); S[i * L + j] = e; sum += e; }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < L; ++j) S[i * L + j] *= inv;
+  }
+  __syncthreads();
+  float *ob = out + (size_t)bi * bs_o;
+  for (int e = threadIdx.x; e < C * L; e += blockDim.x) {
+    const int c = e / L, i = e % L;
+    float a = 0.f;
+    for (int j = 0; j < L; ++j) a += vb[(size_t)c * ld + j] * S[i * L + j];
+    ob[(size_t)c * ld_o + i] = a;
+  }
+}
+
+extern "C" int bdm_attention_core(int b, int c, int l, const float *q, const float *k, const float *v,
+                                  long long bs_qkv, int ld_qkv, float *out, long long bs_o, int ld_o,
+                                  void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && l >= 1, "attention_core: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (l <= 64) {
+    hipLaunchKernelGGL(attn_small_kernel, dim3(b), dim3(256), (size_t)l * l * sizeof(float), s, c, l, q, k, v, bs_qkv,
+                       ld_qkv, out, bs_o, ld_o);
+    return launch_status("attention_small");
+  }
+  BDM_REQUIRE(c <= 64, "attention_core: the flash kernel supports at most 64 channels at %d tokens (got %d)", l, c);
+  dim3 grid(cdiv(l, 128), b);
+  if (c <= 32)
+    hipLaunchKernelGGL(attn_flash_kernel<1>, grid, dim3(256), 0, s, c, l, q, k, v, bs_qkv, ld_qkv, out, bs_o, ld_o);
+  else
+    hipLaunchKernelGGL(attn_flash_kernel<2>, grid, dim3(256), 0, s, c, l, q, k, v, bs_qkv, ld_qkv, out, bs_o, ld_o);
+  return launch_status("attention_flash");
+}

@@ -1,0 +1,295 @@
+"""Point-voxel building blocks with the reference's class names, constructor signatures,
+tuple-in / tuple-out forward protocol and state-dict keys
+(experiments/model/pvcnn/modules/{pvconv,pointnet,ball_query,shared_mlp,se,voxelization}.py;
+identical copy under experiments/pvd/modules/), so published checkpoints load unchanged.
+
+The torch.nn layers held inside (nn.Conv1d, nn.Conv3d, nn.GroupNorm, nn.Linear) are PARAMETER
+CONTAINERS only: their forward is never called.  Every forward below runs hand-written gfx950
+kernels through the C ABI (bdm_amd/ops.py, bdm_amd/functional).  Inference only.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from . import ops
+
+__all__ = ["Swish", "SharedMLP", "SE3d", "Voxelization", "Attention", "PVConv", "BallQuery",
+           "PointNetSAModule", "PointNetFPModule"]
+
+
+class Swish(nn.Module):
+    """pvconv.py:12-14.  Placeholder inside nn.Sequential containers (keeps layer indices = key names);
+    the activation itself is fused into the GroupNorm kernel."""
+
+    def forward(self, x):  # pragma: no cover - never on the HIP path
+        raise RuntimeError("Swish is fused into bdm_group_norm on the HIP path")
+
+
+class SharedMLP(nn.Module):
+    """shared_mlp.py:11-37: [Conv k=1 -> GroupNorm(8) -> Swish] per output width."""
+
+    def __init__(self, in_channels, out_channels, dim=1):
+        super().__init__()
+        if dim == 1:
+            conv = nn.Conv1d
+        elif dim == 2:
+            conv = nn.Conv2d
+        else:
+            raise ValueError
+        if not isinstance(out_channels, (list, tuple)):
+            out_channels = [out_channels]
+        layers = []
+        for oc in out_channels:
+            layers.extend([conv(in_channels, oc, 1), nn.GroupNorm(8, oc), Swish()])
+            in_channels = oc
+        self.layers = nn.Sequential(*layers)
+
+    def run(self, x, out_last=None):
+        n = len(self.layers) // 3
+        for i in range(n):
+            conv, gn = self.layers[3 * i], self.layers[3 * i + 1]
+            dst = out_last if (i == n - 1) else None
+            x = ops.pointwise_conv(x, conv.weight, conv.bias, out=dst)
+            ops.group_norm_(x, gn.weight, gn.bias, gn.num_groups, gn.eps, swish=True)
+        return x
+
+    def forward(self, inputs):
+        if isinstance(inputs, (list, tuple)):
+            return (self.run(inputs[0]), *inputs[1:])
+        return self.run(inputs)
+
+
+class SE3d(nn.Module):
+    """se.py:8-19.  forward returns the per-(shape, channel) gate; the multiplication is fused
+    into the devoxelisation gather (PVConv.forward)."""
+
+    def __init__(self, channel, reduction=8, use_relu=False):
+        super().__init__()
+        if not use_relu:
+            raise NotImplementedError("the denoisers are built with with_se_relu=True (pvcnn_utils.py:93)")
+        self.fc = nn.Sequential(nn.Linear(channel, channel // reduction, bias=False), nn.ReLU(True),
+                                nn.Linear(channel // reduction, channel, bias=False), nn.Sigmoid())
+
+    def gate(self, grid):
+        return ops.se_gate(grid, self.fc[0].weight, self.fc[2].weight)
+
+
+class Voxelization(nn.Module):
+    """voxelization.py:10-25."""
+
+    def __init__(self, resolution, normalize=True, eps=0):
+        super().__init__()
+        self.r = int(resolution)
+        self.normalize = normalize
+        self.eps = eps
+        if not normalize:
+            raise NotImplementedError("normalize=False is not used by the denoisers")
+
+    def forward(self, features, coords):
+        norm_coords, vox_coords = ops.voxel_coords(coords, self.r, self.eps)
+        return ops.avg_voxelize(features, vox_coords, self.r), norm_coords
+
+
+class Attention(nn.Module):
+    """pvconv.py:17-63 (D=3 voxel attention / D=1 global attention); no 1/sqrt(C) scale."""
+
+    def __init__(self, in_ch, num_groups, D=3):
+        super().__init__()
+        assert in_ch % num_groups == 0
+        conv = nn.Conv3d if D == 3 else nn.Conv1d
+        self.q = conv(in_ch, in_ch, 1)
+        self.k = conv(in_ch, in_ch, 1)
+        self.v = conv(in_ch, in_ch, 1)
+        self.out = conv(in_ch, in_ch, 1)
+        self.norm = nn.GroupNorm(num_groups, in_ch)
+        self.nonlin = Swish()
+        self._qkv = None
+
+    def _qkv_params(self):
+        """q, k, v projections as ONE (3C x C) GEMM (cached; rebuilt when a weight changes)."""
+        ver = tuple(p._version for p in (self.q.weight, self.k.weight, self.v.weight, self.q.bias, self.k.bias, self.v.bias))
+        ptr = self.q.weight.data_ptr()
+        if self._qkv is None or self._qkv[0] != (ver, ptr):
+            C = self.q.weight.shape[0]
+            w = torch.cat([self.q.weight.reshape(C, C), self.k.weight.reshape(C, C), self.v.weight.reshape(C, C)], 0).contiguous()
+            b = torch.cat([self.q.bias, self.k.bias, self.v.bias], 0).contiguous()
+            self._qkv = ((ver, ptr), w, b)
+        return self._qkv[1], self._qkv[2]
+
+    def forward(self, x):
+        B, C = x.shape[:2]
+        flat = x.reshape(B, C, -1)
+        w, b = self._qkv_params()
+        qkv = ops.pointwise_conv(flat, w, b)
+        h = ops.attention_core(qkv, C)
+        h = ops.pointwise_conv(h, self.out.weight, self.out.bias)
+        ops.group_norm_(h, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, swish=True,
+                        residual=flat)
+        return h.reshape(x.shape)
+
+
+class PVConv(nn.Module):
+    """pvconv.py:65-97."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, resolution, attention=False,
+                 dropout=0.1, with_se=False, with_se_relu=False, normalize=True, eps=0):
+        super().__init__()
+        assert kernel_size == 3, "the denoisers use 3x3x3 voxel convolutions only"
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.resolution = resolution
+        self.voxelization = Voxelization(resolution, normalize=normalize, eps=eps)
+        voxel_layers = [nn.Conv3d(in_channels, out_channels, kernel_size, stride=1, padding=kernel_size // 2),
+                        nn.GroupNorm(num_groups=8, num_channels=out_channels), Swish()]
+        voxel_layers += [nn.Dropout(dropout)] if dropout is not None else []
+        voxel_layers += [nn.Conv3d(out_channels, out_channels, kernel_size, stride=1, padding=kernel_size // 2),
+                         nn.GroupNorm(num_groups=8, num_channels=out_channels),
+                         Attention(out_channels, 8) if attention else Swish()]
+        if with_se:
+            voxel_layers.append(SE3d(out_channels, use_relu=with_se_relu))
+        self.voxel_layers = nn.Sequential(*voxel_layers)
+        self.point_features = SharedMLP(in_channels, out_channels)
+        self._packed = {}
+
+    def _packed_weight(self, conv):
+        key = id(conv)
+        sig = (conv.weight._version, conv.weight.data_ptr())
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != sig:
+            hit = (sig, ops.conv3d_pack(conv.weight.detach()))
+            self._packed[key] = hit
+        return hit[1]
+
+    def forward(self, inputs):
+        features, coords, temb = inputs
+        r = self.resolution
+        layers = list(self.voxel_layers)
+        conv1, gn1 = layers[0], layers[1]
+        rest = [m for m in layers[2:] if isinstance(m, (nn.Conv3d, nn.GroupNorm, Attention, SE3d))]
+        conv2, gn2 = rest[0], rest[1]
+        att = next((m for m in rest if isinstance(m, Attention)), None)
+        se = next((m for m in rest if isinstance(m, SE3d)), None)
+
+        features = ops.materialize(features)
+        vox, norm_coords = self.voxelization(features, coords)
+        v = ops.conv3d(vox, self._packed_weight(conv1), conv1.bias, r)
+        ops.group_norm_(v, gn1.weight, gn1.bias, 8, gn1.eps, swish=True)
+        v = ops.conv3d(v, self._packed_weight(conv2), conv2.bias, r)
+        ops.group_norm_(v, gn2.weight, gn2.bias, 8, gn2.eps, swish=(att is None))
+        if att is not None:
+            v = att(v)
+        gate = se.gate(v) if se is not None else None
+        pf = self.point_features.run(features)
+        fused = ops.devoxelize_gate_add(norm_coords, v, r, gate=gate, add=pf)
+        return fused, coords, temb
+
+
+class BallQuery(nn.Module):
+    """ball_query.py:9-35."""
+
+    def __init__(self, radius, num_neighbors, include_coordinates=True):
+        super().__init__()
+        self.radius = radius
+        self.num_neighbors = num_neighbors
+        self.include_coordinates = include_coordinates
+
+    def forward(self, points_coords, centers_coords, temb, points_features=None):
+        points_coords = points_coords.contiguous()
+        centers_coords = centers_coords.contiguous()
+        idx = F.ball_query(centers_coords, points_coords, self.radius, self.num_neighbors)
+        if points_features is None:
+            assert self.include_coordinates, "No Features For Grouping"
+            points_features = points_coords[:, :0]
+        assert self.include_coordinates
+        grouped = ops.sa_group(points_coords, centers_coords, points_features, idx)
+        if ops.is_point_invariant(temb):
+            # grouping a point-invariant tensor is the identity on its values (exact)
+            g_t = temb[:, :, :1, None].expand(-1, -1, idx.shape[1], idx.shape[2])
+        else:
+            g_t = F.grouping(temb, idx)
+        return grouped, g_t
+
+
+class PointNetSAModule(nn.Module):
+    """pointnet.py:49-94 (single-radius form used by the denoisers)."""
+
+    def __init__(self, num_centers, radius, num_neighbors, in_channels, out_channels, include_coordinates=True):
+        super().__init__()
+        if not isinstance(radius, (list, tuple)):
+            radius = [radius]
+        if not isinstance(num_neighbors, (list, tuple)):
+            num_neighbors = [num_neighbors] * len(radius)
+        assert len(radius) == len(num_neighbors)
+        if not isinstance(out_channels, (list, tuple)):
+            out_channels = [[out_channels]] * len(radius)
+        elif not isinstance(out_channels[0], (list, tuple)):
+            out_channels = [out_channels] * len(radius)
+        assert len(radius) == len(out_channels)
+        groupers, mlps = [], []
+        total_out_channels = 0
+        for _radius, _out_channels, _num_neighbors in zip(radius, out_channels, num_neighbors):
+            groupers.append(BallQuery(radius=_radius, num_neighbors=_num_neighbors, include_coordinates=include_coordinates))
+            mlps.append(SharedMLP(in_channels=in_channels + (3 if include_coordinates else 0),
+                                  out_channels=_out_channels, dim=2))
+            total_out_channels += _out_channels[-1]
+        self.num_centers = num_centers
+        self.out_channels = total_out_channels
+        self.groupers = nn.ModuleList(groupers)
+        self.mlps = nn.ModuleList(mlps)
+
+    def forward(self, inputs):
+        features, coords, temb = inputs
+        coords = coords.contiguous()
+        centers_coords = F.furthest_point_sample(coords, self.num_centers)
+        assert len(self.groupers) == 1, "multi-radius grouping is not used by the denoisers"
+        grouped, g_t = self.groupers[0](coords, centers_coords, temb, features)
+        h = self.mlps[0].run(grouped)
+        out = ops.max_over_neighbors(h)
+        if g_t.stride(2) == 0 and g_t.stride(3) == 0:
+            temb_out = g_t[:, :, 0, 0][:, :, None].expand(-1, -1, self.num_centers)
+        else:
+            temb_out = ops.max_over_neighbors(g_t.contiguous())
+        return out, centers_coords, temb_out
+
+
+class PointNetFPModule(nn.Module):
+    """pointnet.py:96-113."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.mlp = SharedMLP(in_channels=in_channels, out_channels=out_channels, dim=1)
+
+    def forward(self, inputs):
+        if len(inputs) == 3:
+            points_coords, centers_coords, centers_features, temb = inputs
+            points_features = None
+        else:
+            points_coords, centers_coords, centers_features, points_features, temb = inputs
+        from . import _lib as L
+        pc, cc = points_coords.contiguous(), centers_coords.contiguous()
+        B, _, n = pc.shape
+        m = cc.shape[2]
+        dev = pc.device
+        idx = torch.empty(B, 3, n, dtype=torch.int32, device=dev)
+        w = torch.empty(B, 3, n, dtype=torch.float32, device=dev)
+        # one search serves both tensors (the reference searches twice, pointnet.py:107-108: same result)
+        L.check(L.lib().bdm_three_nn_search(B, m, n, L.ptr(pc), L.ptr(cc), L.ptr(idx), L.ptr(w), L.stream()), "three_nn_search")
+
+        def apply(src, dst):
+            s, _, C, _, bs_f, ld_f = ops._bcl(src)
+            _, _, _, _, bs_o, ld_o = ops._bcl(dst)
+            L.check(L.lib().bdm_three_nn_apply(B, C, m, n, L.ptr(s), L.c_ll(bs_f), ld_f, L.ptr(idx), L.ptr(w), L.ptr(dst),
+                                               L.c_ll(bs_o), ld_o, L.stream()), "three_nn_apply")
+
+        cf = ops.materialize(centers_features)
+        c_int = cf.shape[1]
+        c_skip = 0 if points_features is None else points_features.shape[1]
+        buf = torch.empty(B, c_int + c_skip, n, dtype=torch.float32, device=dev)
+        apply(cf, buf[:, :c_int])
+        if c_skip:
+            ops.copy_rows(points_features, buf[:, c_int:])
+        t_src = ops.materialize(temb)
+        interpolated_temb = torch.empty(B, t_src.shape[1], n, dtype=torch.float32, device=dev)
+        apply(t_src, interpolated_temb)
+        return self.mlp.run(buf), points_coords, interpolated_temb

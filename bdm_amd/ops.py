@@ -1,0 +1,255 @@
+"""Torch-tensor front end of the dense C-ABI operators (include/bdm_hip.h, section 2).
+
+Tensors are (B, C, L) or (B, C, M, U) fp32 on a HIP device; any view whose innermost dims
+are contiguous (e.g. a channel slice of a concat buffer) is passed by (batch stride,
+row stride) without a copy.  Torch supplies memory and the current stream only.
+"""
+import torch
+
+from . import _lib as L
+
+
+def _bcl(t):
+    """(tensor, B, C, L, batch_stride, row_stride) of a (B, C, *rest) tensor.
+
+    Views whose trailing dims are densely packed (channel slices of a concat buffer) pass
+    through untouched; anything else (expanded / permuted views) is made contiguous first."""
+    if t.dtype != torch.float32:
+        raise L.BdmHipError(f"expected float32, got {t.dtype}")
+    B, C = t.shape[0], t.shape[1]
+    l = 1
+    for s in t.shape[2:]:
+        l *= s
+    dense, exp = True, 1
+    for d in range(t.dim() - 1, 1, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            dense = False
+        exp *= t.shape[d]
+    if dense and C > 1 and t.stride(1) < l:
+        dense = False
+    if not dense:
+        t = t.contiguous()
+    ld = t.stride(1) if C > 1 else l
+    bs = t.stride(0) if B > 1 else C * ld
+    return t, B, C, l, bs, ld
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="ws"):
+    key = (tag, str(device))
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def pointwise_conv(x, weight, bias=None, out=None, batch_bias=None, act=0, slope=0.0, residual=None):
+    """y = W x + b  over the channel axis; weight (M,K[,1[,1]]) as in nn.Conv1d/Conv2d(k=1)/nn.Linear."""
+    x, B, K, n, bs_x, ld_x = _bcl(x)
+    M = weight.shape[0]
+    w = weight.reshape(M, -1)
+    assert w.shape[1] == K, f"weight expects {w.shape[1]} channels, input has {K}"
+    w = w if w.is_contiguous() else w.contiguous()
+    if out is None:
+        out = torch.empty((B, M) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    o, Bo, Mo, no, bs_y, ld_y = _bcl(out)
+    assert o.data_ptr() == out.data_ptr() and (Bo, Mo, no) == (B, M, n), "out must be a dense-row view of matching shape"
+    if residual is not None:
+        rr, _, _, _, bs_r, ld_r = _bcl(residual)
+        assert rr.data_ptr() == residual.data_ptr() and residual.shape[1] == M
+    else:
+        bs_r, ld_r = 0, 0
+    L.check(L.lib().bdm_pointwise_conv(B, M, K, n, L.ptr(w), K, L.ptr(x), L.c_ll(bs_x), ld_x, L.ptr(bias),
+                                       L.ptr(batch_bias), M, L.ptr(residual), L.c_ll(bs_r), ld_r, L.ptr(out),
+                                       L.c_ll(bs_y), ld_y, int(act), L.c_float(slope), L.stream()), "pointwise_conv")
+    return out
+
+
+def group_norm_(x, gamma, beta, groups=8, eps=1e-5, swish=False, residual=None, out=None):
+    """GroupNorm(groups) [+residual first] [+Swish]; in place unless `out` is given."""
+    xx, B, C, l, bs_x, ld_x = _bcl(x)
+    assert xx.data_ptr() == x.data_ptr(), "group_norm_ needs a dense-row view"
+    if out is None:
+        out = x
+    _, _, _, _, bs_y, ld_y = _bcl(out)
+    if residual is not None:
+        rr, _, _, _, bs_r, ld_r = _bcl(residual)
+        assert rr.data_ptr() == residual.data_ptr()
+    else:
+        bs_r, ld_r = 0, 0
+    ws = workspace(L.lib().bdm_group_norm_workspace_bytes(B, groups), x.device, "gn")
+    L.check(L.lib().bdm_group_norm(B, C, l, groups, L.ptr(x), L.c_ll(bs_x), ld_x, L.ptr(residual), L.c_ll(bs_r), ld_r,
+                                   L.ptr(gamma), L.ptr(beta), L.c_float(eps), 1 if swish else 0, L.ptr(out),
+                                   L.c_ll(bs_y), ld_y, L.ptr(ws), L.stream()), "group_norm")
+    return out
+
+
+def max_over_neighbors(x, out=None):
+    B, C, M, U = x.shape
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty(B, C, M, dtype=torch.float32, device=x.device)
+    _, _, _, _, bs_y, ld_y = _bcl(out)
+    L.check(L.lib().bdm_max_over_neighbors(B, C, M, U, L.ptr(x), L.ptr(out), L.c_ll(bs_y), ld_y, L.stream()),
+            "max_over_neighbors")
+    return out
+
+
+def sa_group(coords, centers, features, indices):
+    """cat[grouping(coords) - centers, grouping(features)] -> (B, 3+C, M, U)."""
+    B, _, n = coords.shape
+    m, u = indices.shape[1], indices.shape[2]
+    f, _, C, _, bs_f, ld_f = _bcl(features)
+    out = torch.empty(B, 3 + C, m, u, dtype=torch.float32, device=coords.device)
+    L.check(L.lib().bdm_sa_group(B, C, n, m, u, L.ptr(coords), L.ptr(centers), L.ptr(f), L.c_ll(bs_f), ld_f,
+                                 L.ptr(indices), L.ptr(out), L.stream()), "sa_group")
+    return out
+
+
+def broadcast_rows(v, l, out=None):
+    """v (B,C) -> (B,C,l) materialised (or written into the view `out`)."""
+    B, C = v.shape
+    v = v.contiguous()
+    if out is None:
+        out = torch.empty(B, C, l, dtype=torch.float32, device=v.device)
+    _, _, _, _, bs_y, ld_y = _bcl(out)
+    L.check(L.lib().bdm_broadcast_rows(B, C, l, L.ptr(v), C, L.ptr(out), L.c_ll(bs_y), ld_y, L.stream()),
+            "broadcast_rows")
+    return out
+
+
+def copy_rows(x, out):
+    xx, B, C, l, bs_x, ld_x = _bcl(x)
+    _, _, _, _, bs_y, ld_y = _bcl(out)
+    L.check(L.lib().bdm_copy_rows(B, C, l, L.ptr(xx), L.c_ll(bs_x), ld_x, L.ptr(out), L.c_ll(bs_y), ld_y, L.stream()),
+            "copy_rows")
+    return out
+
+
+def is_point_invariant(t):
+    """True for `v[:, :, None].expand(-1, -1, N)` views (the time embedding, pvcnn.py:88)."""
+    return t.dim() == 3 and t.stride(2) == 0
+
+
+def materialize(t):
+    if is_point_invariant(t):
+        return broadcast_rows(t[:, :, 0], t.shape[2])
+    return t
+
+
+def cat_channels(parts):
+    """torch.cat(parts, dim=1) for (B, C_i, L) parts, built with copy/broadcast kernels."""
+    parts = [p for p in parts if p.shape[1] > 0]
+    B, l = parts[0].shape[0], parts[0].shape[2]
+    out = torch.empty(B, sum(p.shape[1] for p in parts), l, dtype=torch.float32, device=parts[0].device)
+    c0 = 0
+    for p in parts:
+        dst = out[:, c0:c0 + p.shape[1], :]
+        if is_point_invariant(p):
+            broadcast_rows(p[:, :, 0], l, out=dst)
+        else:
+            copy_rows(p, dst)
+        c0 += p.shape[1]
+    return out
+
+
+def transpose12(x):
+    """(B, R, C) -> (B, C, R) contiguous."""
+    x = x.contiguous()
+    B, R, C = x.shape
+    out = torch.empty(B, C, R, dtype=torch.float32, device=x.device)
+    L.check(L.lib().bdm_transpose(B, R, C, L.ptr(x), L.ptr(out), L.stream()), "transpose")
+    return out
+
+
+def time_embedding(t, w0, b0, w2, b2):
+    B, dim = t.shape[0], w0.shape[0]
+    tf = t.to(torch.float32).contiguous()
+    out = torch.empty(B, dim, dtype=torch.float32, device=t.device)
+    L.check(L.lib().bdm_time_embedding(B, dim, L.ptr(tf), L.ptr(w0), L.ptr(b0), L.ptr(w2), L.ptr(b2), L.ptr(out),
+                                       L.stream()), "time_embedding")
+    return out
+
+
+def voxel_coords(coords, r, eps=0.0):
+    B, _, n = coords.shape
+    coords = coords.contiguous()
+    nc = torch.empty(B, 3, n, dtype=torch.float32, device=coords.device)
+    vc = torch.empty(B, 3, n, dtype=torch.int32, device=coords.device)
+    L.check(L.lib().bdm_voxel_coords(B, n, int(r), L.c_float(eps), L.ptr(coords), L.ptr(nc), L.ptr(vc), L.stream()),
+            "voxel_coords")
+    return nc, vc
+
+
+def avg_voxelize(features, vox_coords, r):
+    f = features.contiguous()
+    B, C, n = f.shape
+    dev = f.device
+    out = torch.empty(B, C, r ** 3, dtype=torch.float32, device=dev)
+    ind = torch.empty(B, n, dtype=torch.int32, device=dev)
+    cnt = torch.empty(B, r ** 3, dtype=torch.int32, device=dev)
+    ws = workspace(L.lib().bdm_voxelize_workspace_bytes(B, n, r), dev, "vox")
+    L.check(L.lib().bdm_avg_voxelize_forward(B, C, n, r, L.ptr(f), L.ptr(vox_coords), L.ptr(out), L.ptr(ind), L.ptr(cnt),
+                                             L.ptr(ws), L.stream()), "avg_voxelize")
+    return out
+
+
+def se_gate(x, w1, w2):
+    B, C = x.shape[:2]
+    x = x.contiguous()
+    l = x.numel() // (B * C)
+    mean = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    gate = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    L.check(L.lib().bdm_se_gate(B, C, w1.shape[0], l, L.ptr(x), L.ptr(w1), L.ptr(w2), L.ptr(mean), L.ptr(gate),
+                                L.stream()), "se_gate")
+    return gate
+
+
+def devoxelize_gate_add(norm_coords, grid, r, gate=None, add=None, out=None):
+    B, C = grid.shape[:2]
+    n = norm_coords.shape[2]
+    grid = grid.contiguous()
+    if out is None:
+        out = torch.empty(B, C, n, dtype=torch.float32, device=grid.device)
+    _, _, _, _, bs_o, ld_o = _bcl(out)
+    if add is not None:
+        aa, _, _, _, bs_a, ld_a = _bcl(add)
+        assert aa.data_ptr() == add.data_ptr()
+    else:
+        bs_a, ld_a = 0, 0
+    L.check(L.lib().bdm_devoxelize_gate_add(B, C, n, int(r), L.ptr(norm_coords), L.ptr(grid), L.ptr(gate), L.ptr(add),
+                                            L.c_ll(bs_a), ld_a, L.ptr(out), L.c_ll(bs_o), ld_o, L.stream()),
+            "devoxelize_gate_add")
+    return out
+
+
+def attention_core(qkv, C):
+    """qkv (B, 3C, L): rows [0,C) = q, [C,2C) = k, [2C,3C) = v  ->  (B, C, L)."""
+    B, _, l = qkv.shape
+    out = torch.empty(B, C, l, dtype=torch.float32, device=qkv.device)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    L.check(L.lib().bdm_attention_core(B, C, l, L.ptr(q), L.ptr(k), L.ptr(v), L.c_ll(qkv.stride(0)), qkv.stride(1),
+                                       L.ptr(out), L.c_ll(C * l), l, L.stream()), "attention_core")
+    return out
+
+
+def conv3d_pack(weight):
+    cout, cin = weight.shape[:2]
+    w = weight.contiguous()
+    packed = torch.empty(27, cin, cout, dtype=torch.float32, device=w.device)
+    L.check(L.lib().bdm_conv3d_pack_weights(cout, cin, L.ptr(w), L.ptr(packed), L.stream()), "conv3d_pack_weights")
+    return packed
+
+
+def conv3d(x, packed_w, bias, r):
+    """x (B, Cin, r^3) contiguous -> (B, Cout, r^3)."""
+    x = x.contiguous()
+    B, cin = x.shape[:2]
+    cout = packed_w.shape[2]
+    y = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=x.device)
+    L.check(L.lib().bdm_conv3d_3x3x3(B, cin, cout, int(r), L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(y), L.stream()),
+            "conv3d")
+    return y

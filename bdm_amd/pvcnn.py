@@ -1,0 +1,265 @@
+"""The point-voxel denoisers of BDM on the HIP path, state-dict compatible with the reference:
+
+  PVCNN2_PC2   experiments/model/pvcnn/pvcnn.py:10-150          (reconstruction denoiser, 390 input channels)
+  PVCNN2_PVD   experiments/pvd/model/pvcnn_generation.py:172-245 + experiments/pvd/__init__.py:299-333 (prior)
+  PVCNN_fuse   experiments/model/pvcnn/pvcnn_fuse.py:14-276      (BDM-Merging network)
+
+Topology quirks reproduced on purpose: set-abstraction levels 1-2 hold ONE PVConv
+although their tables say 3 (pvcnn_utils.py:98-101); voxel attention exists only in sa_layers.1.0;
+feature-propagation PVConvs never get attention (pvcnn_utils.py:139,150).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .modules import Attention, PointNetFPModule, PointNetSAModule, PVConv, SharedMLP
+
+SA_BLOCKS = [
+    ((32, 2, 32), (1024, 0.1, 32, (32, 64))),
+    ((64, 3, 16), (256, 0.2, 32, (64, 128))),
+    ((128, 3, 8), (64, 0.4, 32, (128, 256))),
+    (None, (16, 0.8, 32, (256, 256, 512))),
+]
+FP_BLOCKS = [
+    ((256, 256), (256, 3, 8)),
+    ((256, 256), (256, 3, 8)),
+    ((256, 128), (128, 2, 16)),
+    ((128, 128, 64), (64, 2, 32)),
+]
+
+
+def create_pointnet2_sa_components(sa_blocks, extra_feature_channels, embed_dim=64, use_att=False, dropout=0.1,
+                                   with_se=False, normalize=True, eps=0, width_multiplier=1,
+                                   voxel_resolution_multiplier=1):
+    """pvcnn_utils.py:71-127."""
+    r, vr = width_multiplier, voxel_resolution_multiplier
+    in_channels = extra_feature_channels + 3
+    sa_layers, sa_in_channels = [], []
+    num_centers = None
+    for c, (conv_configs, sa_configs) in enumerate(sa_blocks):
+        k = 0
+        sa_in_channels.append(in_channels)
+        blocks = []
+        if conv_configs is not None:
+            out_channels, num_blocks, voxel_resolution = conv_configs
+            out_channels = int(r * out_channels)
+            for p in range(num_blocks):
+                attention = (c + 1) % 2 == 0 and use_att and p == 0
+                if c == 0 or k == 0:  # levels > 0 keep only their first block (pvcnn_utils.py:98-101)
+                    blocks.append(PVConv(in_channels if c == 0 else in_channels + embed_dim, out_channels,
+                                         kernel_size=3, resolution=int(vr * voxel_resolution), attention=attention,
+                                         dropout=dropout, with_se=with_se, with_se_relu=True, normalize=normalize, eps=eps))
+                in_channels = out_channels
+                k += 1
+            extra_feature_channels = in_channels
+        num_centers, radius, num_neighbors, out_channels = sa_configs
+        out_channels = [int(r * oc) for oc in out_channels]
+        blocks.append(PointNetSAModule(num_centers=num_centers, radius=radius, num_neighbors=num_neighbors,
+                                       in_channels=extra_feature_channels + (embed_dim if k == 0 else 0),
+                                       out_channels=out_channels, include_coordinates=True))
+        in_channels = extra_feature_channels = blocks[-1].out_channels
+        sa_layers.append(blocks[0] if len(blocks) == 1 else nn.Sequential(*blocks))
+    return sa_layers, sa_in_channels, in_channels, 1 if num_centers is None else num_centers
+
+
+def create_pointnet2_fp_modules(fp_blocks, in_channels, sa_in_channels, embed_dim=64, use_att=False, dropout=0.1,
+                                with_se=False, normalize=True, eps=0, width_multiplier=1,
+                                voxel_resolution_multiplier=1):
+    """pvcnn_utils.py:130-168 (attention is never enabled here: shadowed variable in the reference)."""
+    r, vr = width_multiplier, voxel_resolution_multiplier
+    fp_layers = []
+    for fp_idx, (fp_configs, conv_configs) in enumerate(fp_blocks):
+        blocks = []
+        out_channels = tuple(int(r * oc) for oc in fp_configs)
+        blocks.append(PointNetFPModule(in_channels=in_channels + sa_in_channels[-1 - fp_idx] + embed_dim,
+                                       out_channels=out_channels))
+        in_channels = out_channels[-1]
+        if conv_configs is not None:
+            out_channels, num_blocks, voxel_resolution = conv_configs
+            out_channels = int(r * out_channels)
+            for _ in range(num_blocks):
+                blocks.append(PVConv(in_channels, out_channels, kernel_size=3, resolution=int(vr * voxel_resolution),
+                                     attention=False, dropout=dropout, with_se=with_se, with_se_relu=True,
+                                     normalize=normalize, eps=eps))
+                in_channels = out_channels
+        fp_layers.append(blocks[0] if len(blocks) == 1 else nn.Sequential(*blocks))
+    return fp_layers, in_channels
+
+
+def create_classifier(in_channels, dropout, num_classes, width_multiplier=1):
+    """create_mlp_components(in, [128, dropout, num_classes], classifier=True, dim=2) (pvcnn_utils.py:13-44)."""
+    hidden = int(width_multiplier * 128)
+    return nn.Sequential(SharedMLP(in_channels, hidden), nn.Dropout(dropout), nn.Conv1d(hidden, num_classes, 1))
+
+
+def run_blocks(blocks, inputs):
+    """nn.Sequential protocol of the reference: every block maps a tuple to a tuple."""
+    if isinstance(blocks, nn.Sequential):
+        for blk in blocks:
+            inputs = blk(inputs)
+        return inputs
+    return blocks(inputs)
+
+
+def run_classifier(classifier, features):
+    h = classifier[0].run(features)
+    last = classifier[-1]
+    return ops.pointwise_conv(h, last.weight, last.bias)
+
+
+def embed_time(embedf, t, embed_dim, n):
+    """get_timestep_embedding + embedf, as a point-invariant (B, D, n) view (pvcnn.py:87-88)."""
+    te = ops.time_embedding(t, embedf[0].weight, embedf[0].bias, embedf[2].weight, embedf[2].bias)
+    return te[:, :, None].expand(-1, -1, n)
+
+
+def encode(sa_layers, global_att, inputs, t_emb):
+    """Down path (pvcnn.py:90-110)."""
+    coords = inputs[:, :3, :].contiguous()
+    features = inputs
+    coords_list, in_features_list = [], []
+    for i, sa_blocks in enumerate(sa_layers):
+        in_features_list.append(features)
+        coords_list.append(coords)
+        if i == 0:
+            features, coords, t_emb = run_blocks(sa_blocks, (features, coords, t_emb))
+        else:
+            features, coords, t_emb = run_blocks(sa_blocks, (ops.cat_channels([features, t_emb]), coords, t_emb))
+    if global_att is not None:
+        features = global_att(features)
+    return features, coords, t_emb, coords_list, in_features_list
+
+
+def decode(fp_layers, classifier, features, coords, t_emb, coords_list, in_features_list):
+    """Up path + head (pvcnn.py:112-127)."""
+    for fp_idx, fp_blocks in enumerate(fp_layers):
+        features, coords, t_emb = run_blocks(
+            fp_blocks, (coords_list[-1 - fp_idx], coords, ops.cat_channels([features, t_emb]),
+                        in_features_list[-1 - fp_idx], t_emb))
+    return run_classifier(classifier, features)
+
+
+class PVCNN2Base(nn.Module):
+    """Shared body of PVCNN2Base_PC2 (pvcnn.py:10-127) and PVCNN2Base_PVD (pvcnn_generation.py:172-245)."""
+    sa_blocks = SA_BLOCKS
+    fp_blocks = FP_BLOCKS
+
+    def __init__(self, num_classes, embed_dim, use_att=True, dropout=0.1, extra_feature_channels=3,
+                 width_multiplier=1, voxel_resolution_multiplier=1):
+        super().__init__()
+        assert extra_feature_channels >= 0
+        self.embed_dim = embed_dim
+        self.dropout = dropout
+        self.width_multiplier = width_multiplier
+        self.in_channels = extra_feature_channels + 3
+        sa_layers, sa_in_channels, channels_sa_features, _ = create_pointnet2_sa_components(
+            sa_blocks=self.sa_blocks, extra_feature_channels=extra_feature_channels, with_se=True, embed_dim=embed_dim,
+            use_att=use_att, dropout=dropout, width_multiplier=width_multiplier,
+            voxel_resolution_multiplier=voxel_resolution_multiplier)
+        self.sa_layers = nn.ModuleList(sa_layers)
+        self.global_att = None if not use_att else Attention(channels_sa_features, 8, D=1)
+        sa_in_channels[0] = extra_feature_channels  # only the last FP module sees the extra features
+        fp_layers, channels_fp_features = create_pointnet2_fp_modules(
+            fp_blocks=self.fp_blocks, in_channels=channels_sa_features, sa_in_channels=sa_in_channels, with_se=True,
+            embed_dim=embed_dim, use_att=use_att, dropout=dropout, width_multiplier=width_multiplier,
+            voxel_resolution_multiplier=voxel_resolution_multiplier)
+        self.fp_layers = nn.ModuleList(fp_layers)
+        self.channels_fp_features = channels_fp_features
+        self.classifier = create_classifier(channels_fp_features, dropout, num_classes, width_multiplier)
+        self.embedf = nn.Sequential(nn.Linear(embed_dim, embed_dim), nn.LeakyReLU(0.1, inplace=True),
+                                    nn.Linear(embed_dim, embed_dim))
+
+    @torch.no_grad()
+    def forward(self, inputs, t):
+        """inputs (B, 3+S, N) channel-first fp32 on the GPU; t (B,).  Returns (B, num_classes, N)."""
+        inputs = inputs.contiguous()
+        t_emb = embed_time(self.embedf, t, self.embed_dim, inputs.shape[-1])
+        features, coords, t_emb, coords_list, in_features_list = encode(self.sa_layers, self.global_att, inputs, t_emb)
+        in_features_list[0] = inputs[:, 3:, :]
+        return decode(self.fp_layers, self.classifier, features, coords, t_emb, coords_list, in_features_list)
+
+
+class PVCNN2_PC2(PVCNN2Base):
+    """pvcnn.py:130-150."""
+
+
+class PVCNN2_PVD(PVCNN2Base):
+    """pvd/__init__.py:299-333."""
+
+
+class PVCNN_fuse(nn.Module):
+    """pvcnn_fuse.py:14-276: PC2 encoder + PVD encoder + zero-conv projections + fine-tuned PC2 decoder copy.
+
+    Defined semantic for the reference's out-of-bounds t_emb gather (pvcnn_fuse.py:163-165 -> 184-186,
+    grouping.cu:33): the PVD encoder receives the time embedding
+    re-broadcast to its own N points."""
+    sa_blocks = SA_BLOCKS
+    fp_blocks = FP_BLOCKS
+
+    def __init__(self, pvd_model, pc2_model, num_classes, embed_dim, use_att=True, dropout=0.1,
+                 extra_feature_channels=3, width_multiplier=1, voxel_resolution_multiplier=1):
+        super().__init__()
+        assert extra_feature_channels >= 0
+        self.pvd_model_sa_layers = pvd_model.model.module.sa_layers
+        self.pvd_model_global_att = pvd_model.model.module.global_att
+        pc2 = pc2_model.point_cloud_model.model
+        self.pc2_model_sa_layers = pc2.sa_layers
+        self.pc2_model_global_att = pc2.global_att
+        self.pc2_model_fp_layers = pc2.fp_layers
+        self.pc2_model_classiifier = pc2.classifier  # (sic) the reference's attribute name is a state-dict key
+        self.pc2_model_embedf = pc2.embedf
+        self.embed_dim = embed_dim
+        self.dropout = dropout
+        self.width_multiplier = width_multiplier
+        self.in_channels = extra_feature_channels + 3
+        _, sa_in_channels, channels_sa_features, _ = create_pointnet2_sa_components(
+            sa_blocks=self.sa_blocks, extra_feature_channels=extra_feature_channels, with_se=True, embed_dim=embed_dim,
+            use_att=use_att, dropout=dropout, width_multiplier=width_multiplier,
+            voxel_resolution_multiplier=voxel_resolution_multiplier)
+        sa_in_channels[0] = extra_feature_channels
+        fp_layers, channels_fp_features = create_pointnet2_fp_modules(
+            fp_blocks=self.fp_blocks, in_channels=channels_sa_features, sa_in_channels=sa_in_channels, with_se=True,
+            embed_dim=embed_dim, use_att=use_att, dropout=dropout, width_multiplier=width_multiplier,
+            voxel_resolution_multiplier=voxel_resolution_multiplier)
+        self.fusion_decoder_fp_layers = nn.ModuleList(fp_layers)
+        self.channels_fp_features = channels_fp_features
+        self.classifier = create_classifier(channels_fp_features, dropout, num_classes, width_multiplier)
+        self.embedf = nn.Sequential(nn.Linear(embed_dim, embed_dim), nn.LeakyReLU(0.1, inplace=True),
+                                    nn.Linear(embed_dim, embed_dim))
+        # initialise the trainable copies from the PC2 weights (pvcnn_fuse.py:100-107)
+        self.embedf.load_state_dict(self.pc2_model_embedf.state_dict())
+        self.fusion_decoder_fp_layers.load_state_dict(self.pc2_model_fp_layers.state_dict())
+        self.classifier.load_state_dict(self.pc2_model_classiifier.state_dict())
+        projs = []
+        for dim in [64, 128, 256, 512]:  # hard-coded in the reference (pvcnn_fuse.py:111-123)
+            conv1, conv2, zero_conv = nn.Conv1d(dim, dim, 1), nn.Conv1d(dim, dim, 1), nn.Conv1d(dim, dim, 1)
+            for p in (conv1, conv2):
+                nn.init.normal_(p.weight, mean=0.0, std=(2 / dim) ** 0.5)
+                nn.init.constant_(p.bias, 0)
+            for p in zero_conv.parameters():
+                p.detach().zero_()
+            projs.append(nn.Sequential(conv1, nn.LeakyReLU(0.02, inplace=True), conv2, zero_conv))
+        self.projs = nn.ModuleList(projs)
+
+    @staticmethod
+    def _proj(seq, x, add):
+        h = ops.pointwise_conv(x, seq[0].weight, seq[0].bias, act=2, slope=0.02)
+        h = ops.pointwise_conv(h, seq[2].weight, seq[2].bias)
+        return ops.pointwise_conv(h, seq[3].weight, seq[3].bias, residual=add)
+
+    @torch.no_grad()
+    def forward(self, recon_inputs_with_cond, input_from_prior, t, mode="fusion_nstep"):
+        x = recon_inputs_with_cond.contiguous()
+        n = x.shape[-1]
+        te = ops.time_embedding(t, self.embedf[0].weight, self.embedf[0].bias, self.embedf[2].weight, self.embedf[2].bias)
+        t_emb = te[:, :, None].expand(-1, -1, n)
+        f_pc2, c_pc2, _, coords_pc2_list, skips_pc2 = encode(self.pc2_model_sa_layers, self.pc2_model_global_att, x, t_emb)
+        skips_pc2[0] = x[:, 3:, :]
+        pvd_in = (input_from_prior if mode == "fusion_nstep" else x[:, :3, :]).contiguous()
+        t_emb_pvd = te[:, :, None].expand(-1, -1, pvd_in.shape[-1])
+        f_pvd, _, t_emb_out, _, skips_pvd = encode(self.pvd_model_sa_layers, self.pvd_model_global_att, pvd_in, t_emb_pvd)
+        features = self._proj(self.projs[-1], f_pvd, f_pc2)
+        fused = [skips_pc2[0]]
+        for i in range(3):
+            fused.append(self._proj(self.projs[i], skips_pvd[i + 1], skips_pc2[i + 1]))
+        return decode(self.fusion_decoder_fp_layers, self.classifier, features, c_pc2, t_emb_out, coords_pc2_list, fused)

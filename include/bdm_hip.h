@@ -93,6 +93,87 @@ int bdm_avg_voxelize_forward(int b, int c, int n, int r, const float *features, 
 int bdm_trilinear_devoxelize_forward(int b, int c, int n, int r, const float *coords,
                                      const float *grid, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * 2. Dense per-point / per-voxel operators of one denoiser forward
+ *    (stock nn.Modules in the reference; hand-written gfx950 kernels here)
+ *    Strided operands: a (B, C, L) tensor is addressed as base + b*bs + c*ld + l (elements),
+ *    so callers can read from / write into channel slices of concat buffers
+ *    (torch.cat in pvcnn.py:104,120 and pointnet.py:110) without copies.
+ * ---------------------------------------------------------------------------------- */
+
+/* Conv1d / Conv2d with kernel 1 (+ bias [+ per-shape bias] [+ LeakyReLU]):
+ *   y[b] (m x n) = act(w (m x k, row stride ldw) * x[b] (k x n) + bias[m] + batch_bias[b][m]) + residual[b]
+ * Replaces nn.Conv1d/nn.Conv2d(k=1) in modules/shared_mlp.py:25-30, the q/k/v/out projections of
+ * modules/pvconv.py:21-31, pvcnn_fuse.py:111-123 and the classifier (pvcnn.py:62-69).
+ * act: 0 none, 2 LeakyReLU(slope); bias, batch_bias and residual may be NULL (residual: the
+ * `proj(x) + skip` additions of pvcnn_fuse.py:203-212).  f32-input MFMA, fp32 accumulate. */
+int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, int ldw, const float *x,
+                       long long bs_x, int ld_x, const float *bias, const float *batch_bias,
+                       int ld_bb, const float *residual, long long bs_r, int ld_r, float *y,
+                       long long bs_y, int ld_y, int act, float slope, void *stream);
+
+/* nn.GroupNorm(groups, c) over (b, c, l) with optional residual added first and optional Swish
+ * (shared_mlp.py:27-29; pvconv.py:78-86; Attention: norm(h + x) then Swish, pvconv.py:59-61).
+ * act: 0 none, 1 Swish.  In-place (y == x) is allowed.  Deterministic two-pass reduction. */
+size_t bdm_group_norm_workspace_bytes(int b, int groups);
+int bdm_group_norm(int b, int c, int l, int groups, const float *x, long long bs_x, int ld_x,
+                   const float *residual, long long bs_r, int ld_r, const float *gamma,
+                   const float *beta, float eps, int act, float *y, long long bs_y, int ld_y,
+                   void *workspace, void *stream);
+
+/* features.max(dim=-1) over the neighbour axis (pointnet.py:86): x (b,c,m,u) -> y (b,c,m) strided. */
+int bdm_max_over_neighbors(int b, int c, int m, int u, const float *x, float *y, long long bs_y,
+                           int ld_y, void *stream);
+
+/* BallQuery.forward's grouped tensor (modules/ball_query.py:16-30) in one launch:
+ * out (b, 3+c, m, u) = cat[ grouping(coords, idx) - centers[..., None], grouping(features, idx) ]. */
+int bdm_sa_group(int b, int c, int n, int m, int u, const float *coords, const float *centers,
+                 const float *features, long long bs_f, int ld_f, const int *indices, float *out,
+                 void *stream);
+
+/* y[b][ci][:] = v[b][ci]   -- t_emb[:, :, None].expand(-1, -1, N) (pvcnn.py:88) written into a concat slice. */
+int bdm_broadcast_rows(int b, int c, int l, const float *v, int ld_v, float *y, long long bs_y,
+                       int ld_y, void *stream);
+/* strided row copy (building torch.cat operands in place) */
+int bdm_copy_rows(int b, int c, int l, const float *x, long long bs_x, int ld_x, float *y,
+                  long long bs_y, int ld_y, void *stream);
+/* (b, rows, cols) -> (b, cols, rows): PointCloudModel.forward's transposes (point_cloud_model.py:65). */
+int bdm_transpose(int b, int rows, int cols, const float *x, float *y, void *stream);
+
+/* get_timestep_embedding + embedf (pvcnn_utils.py:171-185, pvcnn.py:72-76,87-88):
+ * t (b,) float -> out (b, dim) = Linear(LeakyReLU_0.1(Linear([sin, cos](t * freq)))). */
+int bdm_time_embedding(int b, int dim, const float *t, const float *w0, const float *b0,
+                       const float *w2, const float *b2, float *out, void *stream);
+
+/* Voxelization.forward's coordinate maths (modules/voxelization.py:16-25, normalize=True):
+ * coords (b,3,n) -> norm_coords (b,3,n) float in [0, r-1], vox_coords (b,3,n) int32 (round half even). */
+int bdm_voxel_coords(int b, int n, int r, float eps, const float *coords, float *norm_coords,
+                     int *vox_coords, void *stream);
+
+/* SE3d gate (modules/se.py:8-19, ReLU variant): gate (b,c) = sigmoid(w2 relu(w1 mean_l x)).
+ * x (b,c,l) contiguous; mean_ws (b,c) scratch. */
+int bdm_se_gate(int b, int c, int hidden, int l, const float *x, const float *w1, const float *w2,
+                float *mean_ws, float *gate, void *stream);
+
+/* PVConv tail (pvconv.py:95-96): out = trilinear_devoxelize(grid * gate[:, :, None]) + add.
+ * gate and add may be NULL. */
+int bdm_devoxelize_gate_add(int b, int c, int n, int r, const float *coords, const float *grid,
+                            const float *gate, const float *add, long long bs_a, int ld_a,
+                            float *out, long long bs_o, int ld_o, void *stream);
+
+/* Attention core (pvconv.py:46-55): out[c][i] = sum_j v[c][j] softmax_j(sum_c' q[c'][i] k[c'][j]),
+ * no 1/sqrt(c) scale.  q, k, v share strides.  l <= 64: one workgroup per shape (global attention);
+ * otherwise a flash-style MFMA kernel (c <= 64; the 16^3-token voxel attention). */
+int bdm_attention_core(int b, int c, int l, const float *q, const float *k, const float *v,
+                       long long bs_qkv, int ld_qkv, float *out, long long bs_o, int ld_o,
+                       void *stream);
+
+/* nn.Conv3d(cin, cout, 3, padding=1) on (b, cin, r, r, r), r in {8, 16, 32} (pvconv.py:75-85).
+ * packed_w = bdm_conv3d_pack_weights(w) : [27][cin][cout] from the module's (cout, cin, 3, 3, 3). */
+int bdm_conv3d_pack_weights(int cout, int cin, const float *w, float *packed, void *stream);
+int bdm_conv3d_3x3x3(int b, int cin, int cout, int r, const float *x, const float *packed_w,
+                     const float *bias, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,44 @@
+"""CPU: the oracle's denoiser restatement reproduces the golden vectors produced by the REFERENCE's own
+modules (oracle/gen_golden.py, run in the build container with /root/reference imported)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import point_cloud_inputs, rel_l2, seeded
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def state_dict_from(g, prefix=""):
+    from bdm_amd.utils.procedural import procedural_tensor
+    shapes = [eval(s) for s in g["shapes"]]
+    return {prefix + k: procedural_tensor(str(k), sh, int(g["weight_seed"])) for k, sh in zip(g["keys"], shapes)}
+
+
+@pytest.mark.parametrize("name", ["pc2_wm025_n1100.npz", "pvd_full_n1024.npz"])
+def test_oracle_matches_reference_golden(name, oracle_ops):
+    from oracle import ref_net
+    g = load(name)
+    B, S, N = int(g["B"]), int(g["S"]), int(g["N"])
+    x = point_cloud_inputs(B, 3 + S, N, int(g["input_seed"]))
+    y = ref_net.pvcnn_forward(state_dict_from(g), x, torch.from_numpy(g["t"]))
+    assert rel_l2(y, torch.from_numpy(g["out"])) < 2e-5  # same torch CPU kernels; only thread-order noise
+
+
+def test_pvd_gaussian_diffusion_golden():
+    from bdm_amd.pvd import GaussianDiffusion, get_betas
+    g = load("pvd_gaussian_diffusion.npz")
+    gd = GaussianDiffusion(get_betas("linear", 0.0001, 0.02, 1000), "mse", "eps", "fixedsmall")
+    for k in ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+              "posterior_mean_coef2", "posterior_log_variance_clipped"):
+        assert np.array_equal(getattr(gd, k).numpy(), g[k]), k  # tables: bit-exact
+    x, eps, z = seeded((2, 3, 64), int(g["x_seed"])), seeded((2, 3, 64), int(g["eps_seed"])), seeded((2, 3, 64), int(g["z_seed"]))
+    for i, tt in enumerate(g["ts"]):
+        out = gd.p_sample_host(x, eps, z, int(tt))
+        assert np.allclose(out.numpy(), g["out"][i], rtol=0, atol=1e-6), int(tt)

@@ -1,0 +1,163 @@
+"""GPU parity of the dense C-ABI operators vs plain PyTorch fp32 on the CPU (tolerances per test)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops(hip):
+    from bdm_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("B,M,K,N", [(2, 64, 35, 1024 * 32), (2, 32, 390, 4096), (1, 3, 128, 1100), (3, 512, 323, 16),
+                                     (2, 256, 832, 64), (1, 192, 64, 4096), (2, 8, 8, 33)])
+def test_pointwise_conv(ops, B, M, K, N):
+    g = torch.Generator().manual_seed(M * K)
+    x = torch.randn(B, K, N, generator=g)
+    w = torch.randn(M, K, 1, generator=g) / K ** 0.5
+    b = torch.randn(M, generator=g)
+    ref = TF.conv1d(x.double(), w.double(), b.double()).float()
+    got = ops.pointwise_conv(x.cuda(), w.cuda(), b.cuda()).cpu()
+    assert rel(got, ref) < 2e-6  # fp32 MFMA, k-ordered accumulation vs fp64 reference
+
+
+def test_pointwise_conv_views_residual_leaky(ops):
+    g = torch.Generator().manual_seed(5)
+    B, K, M, N = 2, 67, 40, 300
+    big = torch.randn(B, K + 9, N, generator=g).cuda()
+    x = big[:, 4:4 + K]
+    w = (torch.randn(M, K, generator=g) / 8).cuda()
+    bias = torch.randn(M, generator=g).cuda()
+    res = torch.randn(B, M, N, generator=g).cuda()
+    outbuf = torch.zeros(B, M + 5, N).cuda()
+    ops.pointwise_conv(x, w, bias, out=outbuf[:, 5:], act=2, slope=0.02, residual=res)
+    ref = TF.leaky_relu(TF.conv1d(x.cpu(), w.cpu()[:, :, None], bias.cpu()), 0.02) + res.cpu()
+    assert rel(outbuf[:, 5:].cpu(), ref) < 2e-6
+    assert float(outbuf[:, :5].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,C,L", [(2, 64, 32768), (3, 32, 1024 * 32), (2, 512, 16), (1, 8, 33), (2, 256, 512)])
+@pytest.mark.parametrize("swish", [False, True])
+def test_group_norm(ops, B, C, L, swish):
+    g = torch.Generator().manual_seed(C + L)
+    x = torch.randn(B, C, L, generator=g) * 3 + 1
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = TF.group_norm(x, 8, ga, be, 1e-5)
+    if swish:
+        ref = ref * torch.sigmoid(ref)
+    got = ops.group_norm_(x.cuda(), ga.cuda(), be.cuda(), 8, 1e-5, swish=swish).cpu()
+    assert rel(got, ref) < 3e-6
+
+
+def test_group_norm_residual(ops):
+    g = torch.Generator().manual_seed(3)
+    x, r = torch.randn(2, 64, 4096, generator=g), torch.randn(2, 64, 4096, generator=g)
+    ga, be = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    ref = TF.group_norm(x + r, 8, ga, be)
+    ref = ref * torch.sigmoid(ref)
+    got = ops.group_norm_(x.cuda(), ga.cuda(), be.cuda(), swish=True, residual=r.cuda()).cpu()
+    assert rel(got, ref) < 3e-6
+
+
+@pytest.mark.parametrize("cin,cout,r", [(35, 32, 32), (32, 32, 32), (64, 64, 32), (128, 64, 16), (128, 128, 16),
+                                        (192, 128, 8), (256, 256, 8), (7, 8, 8), (16, 40, 16)])
+def test_conv3d(ops, cin, cout, r):
+    B = 2
+    g = torch.Generator().manual_seed(cin * cout + r)
+    x = torch.randn(B, cin, r, r, r, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = TF.conv3d(x.double(), w.double(), b.double(), padding=1).float().reshape(B, cout, -1)
+    pw = ops.conv3d_pack(w.cuda())
+    got = ops.conv3d(x.cuda().reshape(B, cin, -1), pw, b.cuda(), r).cpu()
+    assert rel(got, ref) < 2e-6
+
+
+def test_conv3d_boundary_exact(ops):
+    """all-ones input and weights: interior = 27*cin, faces/edges/corners smaller (zero padding)."""
+    cin, cout, r = 8, 32, 8
+    x = torch.ones(1, cin, r ** 3).cuda()
+    w = torch.ones(cout, cin, 3, 3, 3).cuda()
+    y = ops.conv3d(x, ops.conv3d_pack(w), None, r).cpu().view(cout, r, r, r)
+    assert float(y[0, 3, 3, 3]) == 27 * cin and float(y[5, 0, 0, 0]) == 8 * cin
+    assert float(y[31, 0, 4, 4]) == 18 * cin and float(y[7, 0, 0, 4]) == 12 * cin
+
+
+@pytest.mark.parametrize("B,C,L", [(2, 64, 4096), (1, 16, 4096), (2, 512, 16), (1, 128, 16), (1, 64, 512), (1, 24, 200)])
+def test_attention_core(ops, B, C, L):
+    g = torch.Generator().manual_seed(C * L)
+    qkv = torch.randn(B, 3 * C, L, generator=g) * (0.5 if L > 64 else 0.2)
+    q, k, v = qkv[:, :C].double(), qkv[:, C:2 * C].double(), qkv[:, 2 * C:].double()
+    w = torch.softmax(torch.matmul(q.permute(0, 2, 1), k), -1)
+    ref = torch.matmul(v, w.permute(0, 2, 1)).float()
+    got = ops.attention_core(qkv.cuda(), C).cpu()
+    assert rel(got, ref) < 5e-6
+
+
+def test_small_ops(ops):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 70, 130, 32, generator=g)
+    assert torch.equal(ops.max_over_neighbors(x.cuda()).cpu(), x.max(-1).values)
+    # SE gate
+    C, r = 64, 16
+    v = torch.randn(2, C, r ** 3, generator=g)
+    w1, w2 = torch.randn(C // 8, C, generator=g) / 8, torch.randn(C, C // 8, generator=g) / 3
+    ref = torch.sigmoid(TF.linear(torch.relu(TF.linear(v.mean(-1), w1)), w2))
+    assert rel(ops.se_gate(v.cuda(), w1.cuda(), w2.cuda()).cpu(), ref) < 2e-6
+    # time embedding
+    from oracle import ref_net
+    sd = {"0.weight": torch.randn(64, 64, generator=g) / 8, "0.bias": torch.randn(64, generator=g),
+          "2.weight": torch.randn(64, 64, generator=g) / 8, "2.bias": torch.randn(64, generator=g)}
+    t = torch.tensor([0, 1, 17, 500, 999])
+    ref = ref_net.embedf(sd, "", t, 64)
+    got = ops.time_embedding(t.cuda(), *(sd[k].cuda() for k in ("0.weight", "0.bias", "2.weight", "2.bias"))).cpu()
+    assert rel(got, ref) < 2e-5  # sin/cos of arguments up to 999 rad: device vs host libm
+    # transpose, concat, broadcast
+    a = torch.randn(2, 100, 37, generator=g)
+    assert torch.equal(ops.transpose12(a.cuda()).cpu(), a.transpose(1, 2).contiguous())
+    te = torch.randn(2, 64, generator=g).cuda()
+    f = torch.randn(2, 10, 77, generator=g).cuda()
+    cat = ops.cat_channels([f, te[:, :, None].expand(-1, -1, 77), f[:, 2:5]])
+    assert torch.equal(cat.cpu(), torch.cat([f, te[:, :, None].expand(-1, -1, 77), f[:, 2:5]], 1).cpu())
+
+
+@pytest.mark.parametrize("n,r", [(4096, 32), (1024, 16), (64, 8), (1100, 32)])
+def test_voxel_coords(ops, n, r):
+    from oracle import ref_net
+    g = torch.Generator().manual_seed(n)
+    coords = torch.randn(2, 3, n, generator=g) * 0.4 + 0.1
+    ref_nc, ref_vc = ref_net.voxel_coords(coords, r)
+    nc, vc = ops.voxel_coords(coords.cuda(), r)
+    assert float((nc.cpu() - ref_nc).abs().max()) < 1e-4 * r  # reductions differ in the last ulp
+    # rounding may flip only where the coordinate sits within float noise of .5
+    flips = (vc.cpu() != ref_vc)
+    assert int(flips.sum()) <= 2
+    assert bool(((ref_nc - ref_nc.floor() - 0.5).abs()[flips] < 1e-3).all())
+
+
+def test_pvconv_tail_and_sa_group(ops, oracle_ops):
+    g = torch.Generator().manual_seed(2)
+    B, C, n, r = 2, 32, 1000, 16
+    nc = torch.rand(B, 3, n, generator=g) * (r - 1)
+    grid = torch.randn(B, C, r ** 3, generator=g)
+    gate = torch.rand(B, C, generator=g)
+    add = torch.randn(B, C, n, generator=g)
+    ref = oracle_ops.trilinear_devoxelize_forward(r, False, nc, (grid * gate[:, :, None]).contiguous())[0] + add
+    got = ops.devoxelize_gate_add(nc.cuda(), grid.cuda(), r, gate.cuda(), add.cuda()).cpu()
+    assert torch.equal(got, ref)  # tolerance 0: same unfused order
+    pts = torch.randn(B, 3, n, generator=g) * 0.3
+    idx = oracle_ops.furthest_point_sampling(pts, 50)
+    ctr = oracle_ops.gather_features_forward(pts, idx)
+    nb = oracle_ops.ball_query(ctr, pts, 0.2, 32)
+    f = torch.randn(B, 11, n, generator=g)
+    ref = torch.cat([oracle_ops.grouping_forward(pts, nb) - ctr.unsqueeze(-1), oracle_ops.grouping_forward(f, nb)], 1)
+    got = ops.sa_group(pts.cuda(), ctr.cuda(), f.cuda(), nb.cuda()).cpu()
+    assert torch.equal(got, ref)
