@@ -1,0 +1,241 @@
+// sampler_ops.hip -- the per-step glue of the coupled DDPM loop as gfx950 kernels:
+//   PC^2 scheduler step   (diffusers 0.21.0 DDPMScheduler.step; call sites model/model.py:193,286,563)
+//   PVD scheduler step    (pvd/__init__.py:136-224)
+//   mean-centring         (main_blending.py:229, model/model.py:530-531)
+//   BDM-Blending select   (main_blending.py:326-344)
+//   projection conditioning: point rasterisation + feature scatter
+//                         (model/projection_model.py:127-157,179-231; pytorch3d PointsRasterizer)
+// Elementwise arithmetic mirrors torch's op-by-op rounding (no FMA contraction in this file).
+#include "../../include/bdm_hip.h"
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+using namespace bdm;
+
+// x_{t-1} = c_x0 * ((x - sqrt(1-abar_t) * eps) / sqrt(abar_t)) + c_x * x  [+ sigma * z]
+__global__ void ddpm_step_kernel(long long n, const float *__restrict__ x, const float *__restrict__ eps,
+                                 const float *__restrict__ z, float sqrt_beta_prod, float sqrt_alpha_prod,
+                                 float c_x0, float c_x, float sigma, float *__restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float xi = x[i];
+    const float x0 = (xi - sqrt_beta_prod * eps[i]) / sqrt_alpha_prod;
+    float v = c_x0 * x0 + c_x * xi;
+    if (z) v = v + sigma * z[i];
+    out[i] = v;
+  }
+}
+extern "C" int bdm_ddpm_step(long long n, const float *x, const float *eps, const float *noise,
+                             float sqrt_beta_prod, float sqrt_alpha_prod, float coef_x0, float coef_x,
+                             float sigma, float *out, void *stream) {
+  BDM_REQUIRE(n >= 0, "ddpm_step: bad size");
+  if (n == 0) return BDM_OK;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, x, eps, noise,
+                     sqrt_beta_prod, sqrt_alpha_prod, coef_x0, coef_x, sigma, out);
+  return launch_status("ddpm_step");
+}
+
+// x0 = a*x - b*eps ; mean = c1*x0 + c2*x ; out = mean + sigma*z   (sigma = 0 at t == 0)
+__global__ void pvd_step_kernel(long long n, const float *__restrict__ x, const float *__restrict__ eps,
+                                const float *__restrict__ z, float a, float b, float c1, float c2, float sigma,
+                                float *__restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float xi = x[i];
+    const float x0 = a * xi - b * eps[i];
+    const float mean = c1 * x0 + c2 * xi;
+    out[i] = mean + sigma * z[i];
+  }
+}
+extern "C" int bdm_pvd_step(long long n, const float *x, const float *eps, const float *noise,
+                            float sqrt_recip_abar, float sqrt_recipm1_abar, float coef1, float coef2,
+                            float sigma, float *out, void *stream) {
+  BDM_REQUIRE(n >= 0 && noise != nullptr, "pvd_step: bad arguments");
+  if (n == 0) return BDM_OK;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(pvd_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, x, eps, noise,
+                     sqrt_recip_abar, sqrt_recipm1_abar, coef1, coef2, sigma, out);
+  return launch_status("pvd_step");
+}
+
+// x (B, N, 3) point-major: x -= mean over points (per shape, per axis), in place
+__global__ void center_points_kernel(int n, float *__restrict__ x) {
+  __shared__ double sh[3][16];
+  __shared__ float mean[3];
+  float *xb = x + (size_t)blockIdx.x * n * 3;
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { s[0] += xb[3 * i]; s[1] += xb[3 * i + 1]; s[2] += xb[3 * i + 2]; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    s[d] = wave_sum(s[d]);
+    if (lane == 0) sh[d][wave] = s[d];
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double a = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += sh[threadIdx.x][w];
+    mean[threadIdx.x] = (float)(a / (double)n);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) xb[i] = xb[i] - mean[i % 3];
+}
+extern "C" int bdm_center_points(int b, int n, float *x, void *stream) {
+  BDM_REQUIRE(b >= 0 && n >= 1, "center_points: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(center_points_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, n, x);
+  return launch_status("center_points");
+}
+
+// out[p] = mask[p] ? prior[p] : recon[p]   for every point p (3 floats each)
+__global__ void blend_kernel(long long npts, const float *__restrict__ recon, const float *__restrict__ prior,
+                             const long long *__restrict__ mask, float *__restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * npts;
+       i += (long long)gridDim.x * blockDim.x)
+    out[i] = mask[i / 3] ? prior[i] : recon[i];
+}
+extern "C" int bdm_blend_select(long long num_points, const float *recon, const float *prior,
+                                const long long *mask, float *out, void *stream) {
+  BDM_REQUIRE(num_points >= 0, "blend_select: bad size");
+  if (num_points == 0) return BDM_OK;
+  int grid = (int)((3 * num_points + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(blend_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, num_points, recon, prior, mask, out);
+  return launch_status("blend_select");
+}
+
+// -------------------------------------------------------------------------------------
+// Projection conditioning
+// -------------------------------------------------------------------------------------
+// Points are projected with a PerspectiveCameras model (row-vector convention:
+// X_view = X_world R + T; ndc = focal * X_view.xy / X_view.z + principal_point) and rasterised
+// with the naive PointsRasterizer rule: pixel (yi, xi) has its centre at
+// ndc (x, y) = (1 - (2 xi + 1)/W, 1 - (2 yi + 1)/H)  (+X left, +Y up); a point covers the pixel
+// when dx^2 + dy^2 < radius^2 and z >= 0; the pixel keeps the point with the smallest z
+// (earliest index on ties).  A point then takes the feature vector of the LAST pixel (row-major)
+// it owns -- the sequential semantics of the reference's duplicate-index assignment
+// (projection_model.py:152-153); points that own no pixel get zeros.
+struct Cam { float r[9]; float t[3]; float f[2]; float p[2]; };
+
+__device__ __forceinline__ void project(const Cam &c, float x, float y, float z, float &u, float &v, float &d) {
+  const float xv = x * c.r[0] + y * c.r[3] + z * c.r[6] + c.t[0];
+  const float yv = x * c.r[1] + y * c.r[4] + z * c.r[7] + c.t[1];
+  const float zv = x * c.r[2] + y * c.r[5] + z * c.r[8] + c.t[2];
+  u = c.f[0] * xv / zv + c.p[0];
+  v = c.f[1] * yv / zv + c.p[1];
+  d = zv;
+}
+__device__ __forceinline__ Cam load_cam(const float *cams, int bi) {
+  Cam c;
+  const float *p = cams + (size_t)bi * 16;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) c.r[i] = p[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) c.t[i] = p[9 + i];
+  c.f[0] = p[12]; c.f[1] = p[13]; c.p[0] = p[14]; c.p[1] = p[15];
+  return c;
+}
+#define RAST_WIN 2  // candidate window: pixels within +-2 of the nearest one (radius < 2 pixel pitches)
+
+__global__ void raster_clear_kernel(long long n, unsigned long long *zbuf) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    zbuf[i] = ~0ull;
+}
+
+__global__ void raster_splat_kernel(int n, int H, int W, float radius2, const float *__restrict__ pts,
+                                    const float *__restrict__ cams, unsigned long long *__restrict__ zbuf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.y;
+  if (i >= n) return;
+  const Cam c = load_cam(cams, bi);
+  const float *p = pts + ((size_t)bi * n + i) * 3;
+  float u, v, d;
+  project(c, p[0], p[1], p[2], u, v, d);
+  if (!(d >= 0.f)) return;  // behind the camera (or NaN)
+  // nearest pixel column/row:  u = 1 - (2 xi + 1)/W  ->  xi = ((1 - u) W - 1) / 2
+  const int xc = (int)rintf(((1.f - u) * W - 1.f) * 0.5f), yc = (int)rintf(((1.f - v) * H - 1.f) * 0.5f);
+  unsigned long long *zb = zbuf + (size_t)bi * H * W;
+  const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
+  for (int yi = yc - RAST_WIN; yi <= yc + RAST_WIN; ++yi) {
+    if (yi < 0 || yi >= H) continue;
+    const float yf = 1.f - (2.f * yi + 1.f) / H;
+    const float dy = yf - v;
+    for (int xi = xc - RAST_WIN; xi <= xc + RAST_WIN; ++xi) {
+      if (xi < 0 || xi >= W) continue;
+      const float xf = 1.f - (2.f * xi + 1.f) / W;
+      const float dx = xf - u;
+      if (dx * dx + dy * dy < radius2) atomicMin(&zb[(size_t)yi * W + xi], key);
+    }
+  }
+}
+
+__global__ void raster_owner_kernel(int n, int H, int W, float radius2, const float *__restrict__ pts,
+                                    const float *__restrict__ cams, const unsigned long long *__restrict__ zbuf,
+                                    int *__restrict__ pix_of_point) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.y;
+  if (i >= n) return;
+  const Cam c = load_cam(cams, bi);
+  const float *p = pts + ((size_t)bi * n + i) * 3;
+  float u, v, d;
+  project(c, p[0], p[1], p[2], u, v, d);
+  int owner = -1;
+  if (d >= 0.f) {
+    const int xc = (int)rintf(((1.f - u) * W - 1.f) * 0.5f), yc = (int)rintf(((1.f - v) * H - 1.f) * 0.5f);
+    const unsigned long long *zb = zbuf + (size_t)bi * H * W;
+    for (int yi = yc - RAST_WIN; yi <= yc + RAST_WIN; ++yi) {
+      if (yi < 0 || yi >= H) continue;
+      for (int xi = xc - RAST_WIN; xi <= xc + RAST_WIN; ++xi) {
+        if (xi < 0 || xi >= W) continue;
+        if ((unsigned)(zb[(size_t)yi * W + xi] & 0xFFFFFFFFull) == (unsigned)i &&
+            zb[(size_t)yi * W + xi] != ~0ull)
+          owner = yi * W + xi;  // row-major scan: the last owned pixel wins
+      }
+    }
+  }
+  pix_of_point[(size_t)bi * n + i] = owner;
+}
+
+extern "C" size_t bdm_rasterize_workspace_bytes(int b, int h, int w) { return sizeof(unsigned long long) * (size_t)b * h * w; }
+
+extern "C" int bdm_rasterize_points(int b, int n, int h, int w, float radius, const float *points,
+                                    const float *cameras, int *pix_of_point, void *workspace, void *stream) {
+  BDM_REQUIRE(b >= 0 && n >= 1 && h >= 1 && w >= 1, "rasterize_points: bad sizes");
+  BDM_REQUIRE(workspace != nullptr, "rasterize_points: workspace is NULL");
+  BDM_REQUIRE(radius * (h > w ? h : w) * 0.5f < (float)RAST_WIN, "rasterize_points: radius %g spans more than %d pixels", radius, RAST_WIN);
+  if (b == 0) return BDM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long *zbuf = (unsigned long long *)workspace;
+  hipLaunchKernelGGL(raster_clear_kernel, dim3(1024), dim3(256), 0, s, (long long)b * h * w, zbuf);
+  hipLaunchKernelGGL(raster_splat_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, h, w, radius * radius, points,
+                     cameras, zbuf);
+  hipLaunchKernelGGL(raster_owner_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, h, w, radius * radius, points,
+                     cameras, zbuf, pix_of_point);
+  return launch_status("rasterize_points");
+}
+
+// out (B, N, 3 + C) point-major = cat[x_t, feature_image[pix_of_point]]  (zeros when pix < 0);
+// feature image stored pixel-major (B, H*W, C): one contiguous C-vector per pixel.
+__global__ void condition_gather_kernel(int n, int C, int HW, const float *__restrict__ x_t,
+                                        const float *__restrict__ feat, const int *__restrict__ pix,
+                                        float *__restrict__ out) {
+  const int pt = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63, bi = blockIdx.y;
+  if (pt >= n) return;
+  const int px = pix[(size_t)bi * n + pt];
+  float *o = out + ((size_t)bi * n + pt) * (3 + C);
+  if (lane < 3) o[lane] = x_t[((size_t)bi * n + pt) * 3 + lane];
+  if (px >= 0) {
+    const float *f = feat + ((size_t)bi * HW + px) * C;
+    for (int c = lane; c < C; c += 64) o[3 + c] = f[c];
+  } else {
+    for (int c = lane; c < C; c += 64) o[3 + c] = 0.f;
+  }
+}
+extern "C" int bdm_condition_gather(int b, int n, int c, int hw, const float *x_t, const float *feature_image,
+                                    const int *pix_of_point, float *out, void *stream) {
+  BDM_REQUIRE(b >= 0 && n >= 1 && c >= 0 && hw >= 1, "condition_gather: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(condition_gather_kernel, dim3(cdiv(n, 4), b), dim3(256), 0, (hipStream_t)stream, n, c, hw, x_t,
+                     feature_image, pix_of_point, out);
+  return launch_status("condition_gather");
+}

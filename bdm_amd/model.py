@@ -1,0 +1,278 @@
+"""Diffusion-model API of the reference on the HIP path (experiments/model/{model,projection_model,
+point_cloud_model,__init__}.py): same class names, constructor arguments, attributes
+(`schedulers_map`, `scheduler`, `point_cloud_model`, `feature_model`, `fusion_model`), methods
+(`forward`, `forward_sample`, `interaction_sample`, `nstep_fuse`, `get_input_with_conditioning`)
+and state-dict keys (`point_cloud_model.model.*`, `feature_model.model.*`, `fusion_model.model.*`),
+so main_blending.py / main_merging.py drive it unchanged.  Sampling only.
+"""
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib as L
+from . import ops
+from .cameras import PerspectiveCameras, Pointclouds, join_cameras
+from .feature_model import FeatureModel
+from .pvcnn import PVCNN2_PC2, PVCNN_fuse
+from .schedulers import make_schedulers_map
+
+
+class _DeviceMixin:
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+
+class PointCloudModel(_DeviceMixin, nn.Module):
+    """point_cloud_model.py:14-65 (model_type 'pvcnn')."""
+
+    def __init__(self, model_type="pvcnn", in_channels=3, out_channels=3, embed_dim=64, dropout=0.1,
+                 width_multiplier=1, voxel_resolution_multiplier=1):
+        super().__init__()
+        if model_type != "pvcnn":
+            raise NotImplementedError("only the default 'pvcnn' denoiser (config/structured.py:110) is on the HIP path")
+        self.model_type = model_type
+        self.model = PVCNN2_PC2(embed_dim=embed_dim, num_classes=out_channels, extra_feature_channels=in_channels - 3,
+                                dropout=dropout, width_multiplier=width_multiplier,
+                                voxel_resolution_multiplier=voxel_resolution_multiplier)
+        self.model.classifier[-1].bias.data.normal_(0, 1e-6)
+        self.model.classifier[-1].weight.data.normal_(0, 1e-6)
+
+    @torch.no_grad()
+    def forward(self, inputs: Tensor, t: Tensor) -> Tensor:
+        """(B, N, in_channels) -> (B, N, out_channels)."""
+        return ops.transpose12(self.model(ops.transpose12(inputs), t))
+
+
+class PC2_PVDFusionModel(_DeviceMixin, nn.Module):
+    """point_cloud_model.py:68-100."""
+
+    def __init__(self, pvd_model, pc2_model, in_channels=3, out_channels=3, embed_dim=64, dropout=0.1,
+                 width_multiplier=1, voxel_resolution_multiplier=1):
+        super().__init__()
+        self.model = PVCNN_fuse(pvd_model=pvd_model, pc2_model=pc2_model, embed_dim=embed_dim, num_classes=out_channels,
+                                extra_feature_channels=in_channels - 3, dropout=dropout,
+                                width_multiplier=width_multiplier, voxel_resolution_multiplier=voxel_resolution_multiplier)
+
+    @torch.no_grad()
+    def forward(self, input_with_condition, pred_from_prior, t, mode="fusion_nstep"):
+        return ops.transpose12(self.model(ops.transpose12(input_with_condition), ops.transpose12(pred_from_prior), t, mode))
+
+
+class PointCloudProjectionModel(_DeviceMixin, nn.Module):
+    """projection_model.py:19-235.  The image encoder is hoisted out of the per-step loop: the pixel-major
+    conditioning image is cached per `image_rgb` tensor and only the x_t-dependent part (rasterise the current
+    points, copy each owned pixel's feature vector) runs at every step, in HIP."""
+
+    def __init__(self, image_size: int, image_feature_model: str, use_local_colors=True, use_local_features=True,
+                 use_global_features=False, use_mask=True, use_distance_transform=True, predict_shape=True,
+                 predict_color=False, process_color=False, image_color_channels=3, color_channels=3, colors_mean=0.5,
+                 colors_std=0.5, scale_factor=1.0, raster_point_radius=0.0075, raster_points_per_pixel=1, bin_size=0):
+        super().__init__()
+        self.image_size = image_size
+        self.scale_factor = scale_factor
+        self.use_local_colors, self.use_local_features = use_local_colors, use_local_features
+        self.use_global_features, self.use_mask = use_global_features, use_mask
+        self.use_distance_transform = use_distance_transform
+        self.predict_shape, self.predict_color, self.process_color = predict_shape, predict_color, process_color
+        self.image_color_channels, self.color_channels = image_color_channels, color_channels
+        self.colors_mean, self.colors_std = colors_mean, colors_std
+        if use_global_features or use_mask or use_distance_transform or predict_color or process_color:
+            raise NotImplementedError("the BDM configs use local colours + local features only (config/structured.py:80-84)")
+        if raster_points_per_pixel != 1:
+            raise NotImplementedError("one point per pixel (projection_model.py:41)")
+        self.use_local_conditioning = use_local_colors or use_local_features
+        self.use_global_conditioning = False
+        self.feature_model = FeatureModel(image_size, image_feature_model)
+        self.in_channels = 3 + (image_color_channels if use_local_colors else 0) + \
+            (self.feature_model.feature_dim if use_local_features else 0)
+        self.out_channels = 3
+        self.raster_point_radius = raster_point_radius
+        self._cond_cache = None
+
+    def normalize(self, x):
+        return (x - self.colors_mean) / self.colors_std
+
+    def denormalize(self, x, clamp=True):
+        x = x * self.colors_std + self.colors_mean
+        return torch.clamp(x, 0, 1) if clamp else x
+
+    def get_local_conditioning(self, image_rgb, mask=None):
+        """projection_model.py:110-125 -> (B, D_cond, H, W)."""
+        parts = []
+        if self.use_local_colors:
+            parts.append(self.normalize(image_rgb))
+        if self.use_local_features:
+            parts.append(self.feature_model(image_rgb))
+        return torch.cat(parts, dim=1)
+
+    def conditioning_image(self, image_rgb, mask=None):
+        """Pixel-major (B, H*W, D_cond) conditioning image, computed once per image batch (hoisted)."""
+        key = (image_rgb.data_ptr(), image_rgb._version, tuple(image_rgb.shape))
+        if self._cond_cache is None or self._cond_cache[0] != key:
+            lf = self.get_local_conditioning(image_rgb, mask)
+            B, C, H, W = lf.shape
+            self._cond_cache = (key, lf.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous(), (H, W))
+        return self._cond_cache[1], self._cond_cache[2]
+
+    def surface_projection_indices(self, points, camera, hw):
+        """Per-point owning pixel (or -1): rasterisation part of projection_model.py:127-157."""
+        B, N, _ = points.shape
+        H, W = hw
+        cam = join_cameras(camera).clone()
+        cam.T = cam.T * self.scale_factor
+        cams = cam.packed().to(points.device)
+        assert cams.shape[0] == B
+        points = points.contiguous()  # bound to a local: raw pointers must not outlive their tensor
+        pix = torch.empty(B, N, dtype=torch.int32, device=points.device)
+        ws = ops.workspace(L.lib().bdm_rasterize_workspace_bytes(B, H, W), points.device, "raster")
+        L.check(L.lib().bdm_rasterize_points(B, N, H, W, L.c_float(self.raster_point_radius), L.ptr(points),
+                                             L.ptr(cams), L.ptr(pix), L.ptr(ws), L.stream()), "rasterize_points")
+        return pix
+
+    def point_cloud_to_tensor(self, pc, normalize=False, scale=False):
+        if isinstance(pc, torch.Tensor):
+            return pc
+        return pc.points_padded() * (self.scale_factor if scale else 1)
+
+    def tensor_to_point_cloud(self, x, denormalize=False, unscale=False):
+        assert x.shape[2] == 3
+        return Pointclouds(points=x[:, :, :3] / (self.scale_factor if unscale else 1))
+
+    @torch.no_grad()
+    def get_input_with_conditioning(self, x_t, camera, image_rgb, mask, t):
+        """projection_model.py:179-231 -> (B, N, in_channels)."""
+        B, N = x_t.shape[:2]
+        x_t = x_t.contiguous()
+        if not self.use_local_conditioning:
+            return x_t
+        feat, hw = self.conditioning_image(image_rgb, mask)
+        if hw != tuple(image_rgb.shape[-2:]):
+            raise ValueError(f"{hw=} and {image_rgb.shape=}")
+        pix = self.surface_projection_indices(x_t[:, :, :3], camera, hw)
+        C = feat.shape[2]
+        out = torch.empty(B, N, 3 + C, dtype=torch.float32, device=x_t.device)
+        L.check(L.lib().bdm_condition_gather(B, N, C, hw[0] * hw[1], L.ptr(x_t), L.ptr(feat), L.ptr(pix), L.ptr(out),
+                                             L.stream()), "condition_gather")
+        return out
+
+
+def _timestep_list(scheduler, num_inference_steps, start_time, end_time):
+    scheduler.set_timesteps(num_inference_steps)
+    ts = scheduler.timesteps[num_inference_steps - start_time: num_inference_steps - end_time]
+    return [int(v) for v in ts]
+
+
+class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
+    """model.py:23-318."""
+
+    def __init__(self, beta_start: float, beta_end: float, beta_schedule: str, point_cloud_model: str,
+                 point_cloud_model_embed_dim: int, **kwargs):
+        super().__init__(**kwargs)
+        if not self.predict_shape:
+            raise NotImplementedError("Must predict shape if performing diffusion.")
+        if beta_schedule == "custom":
+            raise NotImplementedError("custom beta schedule is not used by the BDM recipes")
+        self.schedulers_map = make_schedulers_map(beta_start=beta_start, beta_end=beta_end, beta_schedule=beta_schedule)
+        self.scheduler = self.schedulers_map["ddpm"]
+        self.point_cloud_model = PointCloudModel(model_type=point_cloud_model, embed_dim=point_cloud_model_embed_dim,
+                                                 in_channels=self.in_channels, out_channels=self.out_channels)
+
+    def _denoise_loop(self, x_t, camera, image_rgb, mask, scheduler, timesteps, generator=None):
+        B = x_t.shape[0]
+        for t in timesteps:
+            tt = torch.full((B,), t, dtype=torch.int64, device=x_t.device)
+            x_in = self.get_input_with_conditioning(x_t, camera=camera, image_rgb=image_rgb, mask=mask, t=tt)
+            noise_pred = self.point_cloud_model(x_in, tt)
+            x_t = scheduler.step(noise_pred, t, x_t, generator=generator).prev_sample
+        return x_t
+
+    @torch.no_grad()
+    def forward_sample(self, num_points: int, camera, image_rgb: Optional[Tensor], mask: Optional[Tensor],
+                       scheduler: Optional[str] = "ddpm", num_inference_steps: Optional[int] = 1000, eta=0.0,
+                       return_sample_every_n_steps: int = -1, disable_tqdm: bool = False):
+        """model.py:123-214 (vanilla PC^2 sampling)."""
+        scheduler = self.scheduler if scheduler is None else self.schedulers_map[scheduler]
+        B = 1 if image_rgb is None else image_rgb.shape[0]
+        device = self.device if image_rgb is None else image_rgb.device
+        x_t = torch.randn(B, num_points, 3, device=device)
+        ts = _timestep_list(scheduler, num_inference_steps, num_inference_steps, 0)
+        all_outputs = []
+        if return_sample_every_n_steps > 0:
+            for i, t in enumerate(ts):
+                x_t = self._denoise_loop(x_t, camera, image_rgb, mask, scheduler, [t])
+                if i % return_sample_every_n_steps == 0 or i == len(ts) - 1:
+                    all_outputs.append(x_t)
+            return self.tensor_to_point_cloud(x_t, denormalize=True, unscale=True), \
+                [self.tensor_to_point_cloud(o, denormalize=True, unscale=True) for o in all_outputs]
+        x_t = self._denoise_loop(x_t, camera, image_rgb, mask, scheduler, ts)
+        return self.tensor_to_point_cloud(x_t, denormalize=True, unscale=True)
+
+    @torch.no_grad()
+    def interaction_sample(self, point_cloud: Tensor, camera, image_rgb: Tensor, mask: Optional[Tensor],
+                           scheduler: Optional[str] = "ddpm", num_inference_steps: Optional[int] = 1000, eta=0.0,
+                           return_sample_every_n_steps: int = -1, disable_tqdm: bool = False,
+                           start_time: int = 1000, end_time: int = 0):
+        """model.py:216-291: PC^2 steps t = start_time-1 ... end_time on `point_cloud` (B, N, 3)."""
+        scheduler = self.scheduler if scheduler is None else self.schedulers_map[scheduler]
+        ts = _timestep_list(scheduler, num_inference_steps, start_time, end_time)
+        return self._denoise_loop(point_cloud, camera, image_rgb, mask, scheduler, ts)
+
+    def forward(self, batch, mode: str = "train", **kwargs):
+        if isinstance(batch, dict):
+            from .data import FrameData
+            batch = FrameData(**batch)
+        if mode == "sample":
+            pc = batch.sequence_point_cloud
+            num_points = kwargs.pop("num_points", pc.points_padded().shape[1] if isinstance(pc, Pointclouds) else pc.shape[1])
+            return self.forward_sample(num_points=num_points, camera=batch.camera, image_rgb=batch.image_rgb,
+                                       mask=batch.fg_probability, **kwargs)
+        raise NotImplementedError("training is out of scope for the MI355X sampling path")
+
+
+class PointCloudFusionModel(PointCloudProjectionModel):
+    """model.py:320-600 (sampling half: nstep_fuse)."""
+
+    def __init__(self, pvd_model, pc2_model, beta_start: float, beta_end: float, beta_schedule: str,
+                 point_cloud_model: str, point_cloud_model_embed_dim: int, **kwargs):
+        super().__init__(**kwargs)
+        self.p_forget = 0.2
+        self.schedulers_map = make_schedulers_map(beta_start=beta_start, beta_end=beta_end, beta_schedule=beta_schedule)
+        self.scheduler = self.schedulers_map["ddpm"]
+        self.fusion_model = PC2_PVDFusionModel(pc2_model=pc2_model, pvd_model=pvd_model,
+                                               embed_dim=point_cloud_model_embed_dim, in_channels=self.in_channels,
+                                               out_channels=self.out_channels)
+
+    @torch.no_grad()
+    def nstep_fuse(self, pred_from_prior: Tensor, pred_from_recon: Tensor, camera, image_rgb: Tensor,
+                   mask: Optional[Tensor], scheduler: Optional[str] = "ddpm", num_inference_steps: Optional[int] = 1000,
+                   eta=0.0, return_sample_every_n_steps: int = -1, disable_tqdm: bool = False, timestep: int = 0):
+        """model.py:510-570: one fused denoising step at `timestep` on the recon cloud."""
+        scheduler = self.scheduler if scheduler is None else self.schedulers_map[scheduler]
+        B, N = pred_from_recon.shape[:2]
+        # in-place centring of BOTH inputs, as the reference does (model.py:530-531)
+        for x in (pred_from_prior, pred_from_recon):
+            assert x.is_contiguous()
+            L.check(L.lib().bdm_center_points(B, N, L.ptr(x), L.stream()), "center_points")
+        scheduler.set_timesteps(num_inference_steps)
+        t = int(timestep)
+        tt = torch.full((B,), t, dtype=torch.int64, device=pred_from_recon.device)
+        x_in = self.get_input_with_conditioning(pred_from_recon, camera=camera, image_rgb=image_rgb, mask=mask, t=tt)
+        noise_pred = self.fusion_model(x_in, pred_from_prior, tt, mode="fusion_nstep")
+        return scheduler.step(noise_pred, t, pred_from_recon).prev_sample
+
+
+def get_model(cfg):
+    """model/__init__.py:7-11."""
+    return ConditionalPointCloudDiffusionModel(**cfg.model.as_kwargs())
+
+
+def get_fusion_model(cfg, pvd_model, pc2_model):
+    """model/__init__.py:21-36."""
+    model = PointCloudFusionModel(pvd_model, pc2_model, **cfg.model.as_kwargs())
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return model

@@ -174,6 +174,49 @@ int bdm_conv3d_pack_weights(int cout, int cin, const float *w, float *packed, vo
 int bdm_conv3d_3x3x3(int b, int cin, int cout, int r, const float *x, const float *packed_w,
                      const float *bias, float *y, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * 3. Per-step glue of the coupled DDPM loop
+ * ---------------------------------------------------------------------------------- */
+
+/* PC^2 scheduler step: diffusers 0.21.0 DDPMScheduler.step (epsilon prediction, fixed_small
+ * variance, clip_sample=False), call sites experiments/model/model.py:193,286,563.
+ *   x0   = (x - sqrt_beta_prod * eps) / sqrt_alpha_prod
+ *   out  = coef_x0 * x0 + coef_x * x  [+ sigma * noise   when noise != NULL, i.e. t > 0]
+ * The five scalars are the scheduler's per-timestep float32 coefficients (host side). */
+int bdm_ddpm_step(long long n, const float *x, const float *eps, const float *noise,
+                  float sqrt_beta_prod, float sqrt_alpha_prod, float coef_x0, float coef_x,
+                  float sigma, float *out, void *stream);
+
+/* PVD scheduler step: GaussianDiffusion.p_sample (experiments/pvd/__init__.py:136-224):
+ *   x0 = sqrt_recip_abar * x - sqrt_recipm1_abar * eps;  mean = coef1 * x0 + coef2 * x;
+ *   out = mean + sigma * noise      (sigma = 0 at t == 0; noise is always drawn, as the reference does) */
+int bdm_pvd_step(long long n, const float *x, const float *eps, const float *noise,
+                 float sqrt_recip_abar, float sqrt_recipm1_abar, float coef1, float coef2,
+                 float sigma, float *out, void *stream);
+
+/* x (b, n, 3) point-major: subtract the per-shape mean over points, in place
+ * (main_blending.py:229; model/model.py:530-531). */
+int bdm_center_points(int b, int n, float *x, void *stream);
+
+/* BDM-Blending per-point select (main_blending.py:326-344):
+ * out[p] = mask[p] ? prior[p] : recon[p] for num_points = B*N points of 3 floats; mask int64. */
+int bdm_blend_select(long long num_points, const float *recon, const float *prior,
+                     const long long *mask, float *out, void *stream);
+
+/* Projection conditioning, per-step part (model/projection_model.py:127-157; pytorch3d
+ * PerspectiveCameras + naive PointsRasterizer, radius in NDC, one point per pixel).
+ * points (b,n,3) point-major world coordinates; cameras (b,16) = R row-major (9), T (3),
+ * focal (2), principal point (2).  pix_of_point (b,n): flat index h*W+w of the LAST pixel
+ * (row-major) owned by the point, or -1. */
+size_t bdm_rasterize_workspace_bytes(int b, int h, int w);
+int bdm_rasterize_points(int b, int n, int h, int w, float radius, const float *points,
+                         const float *cameras, int *pix_of_point, void *workspace, void *stream);
+/* get_input_with_conditioning's output (projection_model.py:179-231):
+ * out (b, n, 3+c) = cat[x_t, feature_image[pix_of_point]] with zeros for points owning no pixel;
+ * feature_image is stored pixel-major (b, h*w, c). */
+int bdm_condition_gather(int b, int n, int c, int hw, const float *x_t, const float *feature_image,
+                         const int *pix_of_point, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

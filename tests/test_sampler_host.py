@@ -1,0 +1,131 @@
+"""CPU tests of the host-side sampler logic (no GPU, no HIP calls)."""
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ddpm_scheduler_closed_form():
+    """step coefficients == the DDPM posterior q(x_{t-1} | x_t, x_0) in float64 (Ho et al. eq. 6-7)."""
+    from bdm_amd.schedulers import DDPMScheduler
+    s = DDPMScheduler(beta_start=1e-5, beta_end=8e-3, beta_schedule="linear", clip_sample=False)
+    s.set_timesteps(1000)
+    assert s.timesteps.tolist() == list(range(999, -1, -1))
+    betas = np.linspace(1e-5, 8e-3, 1000, dtype=np.float32).astype(np.float64)
+    abar = np.cumprod(1 - betas)
+    for t in (999, 500, 1, 0):
+        c = s.step_coefficients(t)
+        ab_prev = abar[t - 1] if t > 0 else 1.0
+        beta_t = 1 - abar[t] / ab_prev
+        # the scheduler works in float32 like diffusers: 1 - abar_t cancels badly at small t
+        tol = 2e-2 if t < 10 else 2e-4
+        assert math.isclose(c["coef_x0"], math.sqrt(ab_prev) * beta_t / (1 - abar[t]), rel_tol=tol, abs_tol=1e-9)
+        assert math.isclose(c["coef_x"], math.sqrt(1 - beta_t) * (1 - ab_prev) / (1 - abar[t]), rel_tol=tol, abs_tol=1e-9)
+        assert math.isclose(c["sigma"] ** 2, max((1 - ab_prev) / (1 - abar[t]) * beta_t, 1e-20), rel_tol=2 * tol, abs_tol=1e-18)
+        assert math.isclose(c["sqrt_alpha_prod"], math.sqrt(abar[t]), rel_tol=1e-5)
+    s.set_timesteps(100)  # config C1: 100 steps -> leading spacing, stride 10
+    assert s.timesteps.tolist()[:3] == [990, 980, 970] and s.previous_timestep(990) == 980
+
+
+def test_ddpm_host_coefficients_match_oracle_step():
+    from bdm_amd.schedulers import DDPMScheduler
+    from oracle.ref_sampler import RefDDPM
+    s, o = DDPMScheduler(beta_start=1e-5, beta_end=8e-3, clip_sample=False), RefDDPM()
+    s.set_timesteps(1000)
+    g = torch.Generator().manual_seed(0)
+    x, eps, z = (torch.randn(2, 50, 3, generator=g) for _ in range(3))
+    for t in (999, 321, 1, 0):
+        c = s.step_coefficients(t)
+        x0 = (x - c["sqrt_beta_prod"] * eps) / c["sqrt_alpha_prod"]
+        mine = c["coef_x0"] * x0 + c["coef_x"] * x + (c["sigma"] * z if t > 0 else 0)
+        assert torch.allclose(mine, o.step(eps, t, x, z), rtol=0, atol=1e-6)
+
+
+def test_schedule_segment_arithmetic():
+    from bdm_amd.sampling import count_forwards
+    assert count_forwards() == (1000, 80, 0)
+    assert count_forwards(merging=True) == (995, 75, 5)
+
+
+def test_config_overrides_reference_recipe():
+    from bdm_amd.config import parse_overrides
+    cfg = parse_overrides(["logging.wandb_project=bdm", "run.job=sample_bdm_blending", "run.save_dir=./outputs",
+                           "run.num_inference_steps=1000", "run.diffusion_scheduler=ddpm", "run.name=x", "dataset=shapenet_r2n2",
+                           "dataset.root=/data", "dataset.r2n2_dir=/r2n2", "dataset.image_size=224", "dataset.category=chair",
+                           "dataset.max_points=4096", "dataset.subset_ratio=0.1", "dataloader.batch_size=16",
+                           "dataloader.num_workers=8", "checkpoint.resume=ckpt.pth", "aux_run.roll_step=16",
+                           "aux_run.milestones=[1000,968,936,872,128,64,32,0]", "aux_run.prior_ckpt=p.pth", "aux_run.recon_ckpt=r.pth"])
+    assert cfg.dataset.type == "shapenet_r2n2" and cfg.dataset.max_points == 4096 and cfg.dataloader.batch_size == 16
+    assert cfg.aux_run.milestones == [1000, 968, 936, 872, 128, 64, 32, 0] and cfg.model.beta_end == 8e-3
+    with pytest.raises(KeyError):
+        parse_overrides(["run.no_such_key=1"])
+
+
+def test_model_state_dict_layout():
+    """checkpoint compatibility of the top-level model."""
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.model import get_model
+    m = get_model(ProjectConfig())
+    keys = list(m.state_dict().keys())
+    assert "feature_model.model.cls_token" in keys and "feature_model.model.blocks.11.mlp.fc2.bias" in keys
+    assert "point_cloud_model.model.sa_layers.1.0.voxel_layers.6.q.weight" in keys
+    assert "point_cloud_model.model.classifier.2.weight" in keys
+    assert m.in_channels == 390 and sum(1 for k in keys if k.startswith("point_cloud_model.model.")) == 298
+
+
+def test_rasterizer_oracle_geometry():
+    from bdm_amd.cameras import r2n2_camera
+    from oracle.ref_sampler import owner_pixels, project_points, rasterize_bruteforce
+    cam = r2n2_camera(30.0, 27.0, 1.5).packed()[0]
+    pts = torch.tensor([[0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [5.0, 5.0, 5.0]])
+    u, v, d = project_points(pts, cam)
+    assert abs(float(u[0])) < 1e-6 and abs(float(v[0])) < 1e-6 and abs(float(d[0]) - 1.5) < 1e-5  # camera looks at the origin
+    H = W = 32
+    idx = rasterize_bruteforce(pts, cam, H, W, 0.05)
+    own = owner_pixels(pts, cam, H, W, 0.05)
+    assert int((idx == 0).sum()) >= 1 and int((idx == 1).sum()) == 0  # equal depth: the EARLIER point wins
+    assert own[1].item() == -1 and own[0].item() == int(torch.nonzero(idx.reshape(-1) == 0).max())
+
+
+def test_shard_indices_cover_and_balance():
+    from bdm_amd.distributed import shard_indices
+    for n, w in [(128, 8), (16, 1), (10, 4), (3, 8)]:
+        parts = [shard_indices(n, r, w) for r in range(w)]
+        assert sum(parts, []) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_two_rank_gloo_sharding_equivalence(tmp_path):
+    """world_size 2 over gloo: per-shape noise streams and the result gather are rank-count invariant."""
+    script = tmp_path / "worker.py"
+    script.write_text(f"""
+import sys, torch
+sys.path.insert(0, {ROOT!r})
+from bdm_amd.data import SyntheticShapes, shape_generator
+from bdm_amd.distributed import init_from_env, shard_indices, gather_clouds, barrier, max_over_ranks
+rank, local_rank, world = init_from_env(backend="gloo")
+N, TOTAL = 64, 5
+idx = shard_indices(TOTAL, rank, world)
+# stand-in for a trajectory: a deterministic function of the per-shape streams only
+local = torch.stack([torch.randn(N, 3, generator=shape_generator(42, j)) for j in idx]) if idx else torch.zeros(0, N, 3)
+batches = list(SyntheticShapes(idx, 2, seed=42, image_size=8, num_points=N))
+assert sum(b.image_rgb.shape[0] for b in batches) == len(idx)
+barrier()
+full = gather_clouds(local, TOTAL, rank, world)
+ref = torch.stack([torch.randn(N, 3, generator=shape_generator(42, j)) for j in range(TOTAL)])
+assert torch.equal(full, ref), "gathered result differs from the single-rank result"
+assert max_over_ranks(float(rank), torch.device("cpu")) == world - 1
+print("OK", rank)
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("OK") == 2
