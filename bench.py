@@ -1,0 +1,241 @@
+"""bench.py -- sampled shapes/sec of the BDM coupled-diffusion sampling hot path on MI355X.
+
+Metric (BASELINE.json): sampled shapes/sec (4096 pts, 1000 DDPM steps).  One "step" = ONE COMPLETE
+BDM-Blending trajectory of a batch of 16 shapes per GPU (config C2: N = 4096, milestones
+[1000,968,936,872,128,64,32,0], roll_step 16 -> 1000 PC^2 denoiser steps with per-step projection
+conditioning + 80 PVD prior steps + 5 blends, plus the hoisted image encoder once per batch), on
+synthetic inputs and procedural random-init weights (no datasets / checkpoints offline).  Nothing is
+skipped inside the timed region.  N GPUs = N independent shards of 16 shapes (weak scaling, no
+collective on the data path; one barrier + MAX-over-ranks for timing).
+
+    python bench.py                          # 1 GPU, 1 trajectory (about a minute)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel (3x3x3 voxel convolution, f32 MFMA): algorithmic FLOPs of the launches
+                  timed with HIP events inside the timed region / their summed duration, vs the dense fp32
+                  matrix peak of MI355X_MICROARCH.md (157.3 TFLOP/s).
+  cpu_baseline -- the CPU oracle ("port": oracle/ref_net.py + oracle/pvcnn_ops_ref.c, the reference has no CPU
+                  path) timed on this box's host cores on a bounded sample and extrapolated to a trajectory.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+MILESTONES = [1000, 968, 936, 872, 128, 64, 32, 0]
+
+
+class ConvTimer:
+    """HIP-event timing of the launches of ONE kernel instantiation (conv3d_kernel<2,4>: Cout > 32 on the
+    32^3 / 16^3 grids) on the stream they are enqueued on (torch's current stream), sampled every `every`-th launch."""
+
+    def __init__(self, every=16):
+        self.every, self.count, self.pairs, self.flops = every, 0, [], 0.0
+
+    def wants(self, cout, r):
+        return cout > 32 and r in (16, 32)
+
+    def begin(self, b, cin, cout, r):
+        self.count += 1
+        if self.count % self.every:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (e0, e1, 2.0 * 27 * cin * cout * r ** 3 * b)
+
+    def end(self, tok):
+        if tok is not None:
+            tok[1].record()
+            self.pairs.append(tok)
+
+    def summary(self):
+        if not self.pairs:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.pairs)
+        fl = sum(f for _, _, f in self.pairs)
+        return dict(launches_timed=len(self.pairs), launches_total=self.count, avg_us=ms * 1e3 / len(self.pairs),
+                    tflops=fl / (ms * 1e-3) / 1e12)
+
+
+def install_conv_timer(timer):
+    from bdm_amd import ops
+    raw = ops.conv3d
+
+    def timed(x, packed_w, bias, r):
+        cout = packed_w.shape[2]
+        if timer is not None and timer.wants(cout, r):
+            tok = timer.begin(x.shape[0], x.shape[1], cout, r)
+            y = raw(x, packed_w, bias, r)
+            timer.end(tok)
+            return y
+        return raw(x, packed_w, bias, r)
+
+    ops.conv3d = timed
+    return raw
+
+
+def host_cores():
+    """CPUs this process may actually use: min(affinity mask, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(model, pvd_model, n_points, budget_s=25.0):
+    """Oracle ("port") timed on the host cores: PC^2 and PVD denoiser forwards + scheduler steps at B = 1."""
+    from oracle import ref_net, ref_sampler
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd_pc2 = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    sd_pvd = {k: v.detach().cpu() for k, v in pvd_model.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, n_points, 3, generator=g) * 0.5
+    feats = torch.randn(1, n_points, 387, generator=g)
+    x_in = torch.cat([x, feats], dim=2)
+    t = torch.tensor([500])
+    ddpm, gd = ref_sampler.RefDDPM(), ref_sampler.RefPVDDiffusion()
+
+    def pc2_step():
+        eps = ref_net.point_cloud_model_forward(sd_pc2, x_in, t, prefix="point_cloud_model.model.")
+        return ddpm.step(eps, 500, x, torch.zeros_like(x))
+
+    def pvd_step():
+        xp = x.permute(0, 2, 1).contiguous()
+        eps = ref_net.pvcnn_forward(sd_pvd, xp, t, prefix="model.module.")
+        return gd.step(eps, 500, xp, torch.zeros_like(xp))
+
+    def timed(fn, budget):
+        fn()  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget or n >= 20:
+                return el / n, n
+
+    s_pc2, n_pc2 = timed(pc2_step, budget_s * 0.6)
+    s_pvd, n_pvd = timed(pvd_step, budget_s * 0.3)
+    t_shape = 1000 * s_pc2 + 80 * s_pvd
+    return {"value": 1.0 / t_shape, "unit": "shapes/s", "cores": cores, "kind": "port",
+            "sample": f"{n_pc2} PC2 + {n_pvd} PVD denoiser steps at B=1, N={n_points} (denoiser forward + scheduler step; "
+                      f"projection conditioning excluded); {s_pc2:.3f} s / {s_pvd:.3f} s per step, EXTRAPOLATED to "
+                      f"1000 PC2 + 80 PVD steps per shape",
+            "s_per_pc2_step": s_pc2, "s_per_pvd_step": s_pvd}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1, help="timed trajectories (each = 1000 DDPM steps of a 16-shape batch)")
+    ap.add_argument("--warmup", type=int, default=0, help="untimed trajectories before the timed ones")
+    ap.add_argument("--batch", type=int, default=16, help="shapes per GPU (config C2)")
+    ap.add_argument("--points", type=int, default=4096)
+    ap.add_argument("--ddpm-steps", type=int, default=1000, help="ONLY for smoke runs; any value != 1000 marks the line invalid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from bdm_amd import _lib
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.distributed import barrier, init_from_env, max_over_ranks, shard_indices
+    from bdm_amd.model import get_model
+    from bdm_amd.pvd import prepare_pvd_model
+    from bdm_amd.sampling import bdm_blending, count_forwards
+    from bdm_amd.utils.procedural import fill_module_
+
+    rank, local_rank, world = init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    _lib.lib()  # fail loudly if the HIP extension is missing
+
+    cfg = ProjectConfig()
+    cfg.dataset.max_points = args.points
+    cfg.aux_run.roll_step = 16
+    if args.ddpm_steps == 1000:
+        cfg.aux_run.milestones = MILESTONES
+    else:  # smoke only: a short schedule with one coupling point (recon + prior branch + blend)
+        s = args.ddpm_steps
+        cfg.aux_run.milestones, cfg.aux_run.roll_step = [1000, 1000 - s // 3, 1000 - 2 * s // 3, 1000 - s], 1
+    torch.manual_seed(cfg.run.seed + rank)
+    model = fill_module_(get_model(cfg).eval(), seed=cfg.run.seed).to(device)
+    pvd_model = prepare_pvd_model({"model": None, "nc": 3, "embed_dim": 64, "attention": True, "dropout": 0.1}, device)
+    total_shapes = args.batch * world
+    batch = next(iter(SyntheticShapes(shard_indices(total_shapes, rank, world), args.batch, seed=cfg.run.seed,
+                                      image_size=224, num_points=args.points))).to(device)
+    gen = torch.Generator().manual_seed(cfg.run.seed + rank)
+
+    def trajectory():
+        model._cond_cache = None  # the hoisted image encoder runs once per trajectory, inside the timed region
+        return bdm_blending(None, batch, cfg, model, pvd_model, generator=gen).points_padded()
+
+    # prime allocator / code objects (not a "step": a 2-forward schedule)
+    prime_cfg = ProjectConfig()
+    prime_cfg.dataset.max_points = args.points
+    prime_cfg.aux_run.milestones, prime_cfg.aux_run.roll_step = [1000, 998, 996], 1
+    bdm_blending(None, batch, prime_cfg, model, pvd_model, generator=gen)
+    for _ in range(args.warmup):
+        trajectory()
+
+    timer = ConvTimer(every=16)
+    install_conv_timer(timer)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trajectory()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, device)
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        pc2_f, pvd_f, _ = count_forwards(cfg.aux_run.milestones, cfg.aux_run.roll_step)
+        value = total_shapes * args.steps / elapsed
+        conv = timer.summary()
+        line = {
+            "metric": "sampled shapes/sec (4096 pts, 1000 DDPM steps)", "value": value, "unit": "shapes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: BDM-Blending, N=4096 pts, 1000 DDPM steps, batch=16 per GPU, synthetic R2N2-style "
+                                   "inputs, procedural random-init PC2 + PVD weights",
+                       "shapes_per_gpu": args.batch, "points": args.points, "pc2_forwards": pc2_f, "pvd_forwards": pvd_f,
+                       "milestones": cfg.aux_run.milestones, "roll_step": cfg.aux_run.roll_step},
+        }
+        if args.ddpm_steps != 1000 or args.points != 4096:
+            line["invalid"] = "smoke configuration: not the metric's workload"
+        if conv:
+            line["roofline"] = {"bound": "mfma", "achieved": conv["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": conv["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                "kernel": "conv3d_kernel<2,4> (3x3x3 voxel conv, Cout>32, 32^3/16^3 grids)",
+                                "avg_launch_us": conv["avg_us"], "launches_timed": conv["launches_timed"],
+                                "launches_total": conv["launches_total"]}
+        # whole-path view: algorithmic FLOPs of SURVEY.md 8d per trajectory
+        tflop_per_shape = (pc2_f * 103.64 + pvd_f * 81.22) / 1e3 if args.points == 4096 else None
+        if tflop_per_shape:
+            line["path_tflops"] = value * tflop_per_shape
+            line["path_frac_of_fp32_mfma_peak"] = value * tflop_per_shape / (FP32_MFMA_PEAK_TFLOPS * world)
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(model, pvd_model, args.points)
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    barrier()
+
+
+if __name__ == "__main__":
+    main()
