@@ -38,36 +38,43 @@ extern "C" int bdm_conv3d_pack_weights(int cout, int cin, const float *w, float 
   return launch_status("conv3d_pack_weights");
 }
 
-template <int MI, int NI>
-__global__ __launch_bounds__(256) void conv3d_kernel(int Cin, int Cout, int r, int TX, int TY,
-                                                     const float *__restrict__ x, const float *__restrict__ wp,
-                                                     const float *__restrict__ bias, float *__restrict__ y) {
+// Staging is software-pipelined through registers: the global loads of chunk c+1 are issued before
+// the 27 x 4 MFMA steps of chunk c and written to LDS after them, so their latency hides under
+// ~14-55k cycles of matrix work even at one wave per SIMD.  Grid resolution R and the tile shape are
+// template constants so that every index split is a shift or a multiply-by-constant.
+template <int MI, int NI, int R, int TX, int TY>
+__global__ __launch_bounds__(256) void conv3d_kernel(int Cin, int Cout, const float *__restrict__ x,
+                                                     const float *__restrict__ wp, const float *__restrict__ bias,
+                                                     float *__restrict__ y) {
   extern __shared__ __align__(16) float smem[];
   constexpr int BM = 32 * MI;
-  const int RS = r + 8;                       // halo row stride (floats)
-  const int HALO = (TX + 2) * (TY + 2) * RS;  // floats per input channel
-  float *Xs = smem;                           // [C3_BKC][HALO]
-  float *Ws = smem + C3_BKC * HALO;           // [27][C3_BKC][BM]
+  constexpr int RS = R + 8;                  // halo row stride (floats)
+  constexpr int ROWS = (TX + 2) * (TY + 2);  // halo rows per channel
+  constexpr int HALO = ROWS * RS;            // floats per input channel
+  constexpr int R4 = R / 4, R2 = R * R, R3 = R2 * R;
+  constexpr int XV = C3_BKC * ROWS * R4, XI = (XV + 255) / 256;      // float4 pieces of the input tile
+  constexpr int WV = 27 * C3_BKC * (BM / 4), WI = (WV + 255) / 256;  // float4 pieces of the weight tile
+  float *Xs = smem;                          // [C3_BKC][HALO]
+  float *Ws = smem + C3_BKC * HALO;          // [27][C3_BKC][BM]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const int r2 = r * r, r3 = r2 * r;
-  const int tiles_y = r / TY;
+  constexpr int tiles_y = R / TY;
   const int X0 = (blockIdx.x / tiles_y) * TX, Y0 = (blockIdx.x % tiles_y) * TY;
   const int m0 = blockIdx.y * BM, bi = blockIdx.z;
-  const float *xb = x + (size_t)bi * Cin * r3;
-  float *yb = y + (size_t)bi * Cout * r3;
+  const float *xb = x + (size_t)bi * Cin * R3;
+  float *yb = y + (size_t)bi * Cout * R3;
 
   // per-lane voxel of each of this wave's NI column blocks
-  const int rpb = 32 / r;  // grid rows per 32-wide column block (1, 2 or 4)
-  const int dyl = li / r, zl = li % r;
-  const int blocks_per_plane = TY / rpb;
+  constexpr int rpb = 32 / R;  // grid rows per 32-wide column block (1, 2 or 4)
+  const int dyl = li / R, zl = li % R;
+  constexpr int blocks_per_plane = TY / rpb;
   int lbase[NI], gvox[NI];
 #pragma unroll
   for (int q = 0; q < NI; ++q) {
     const int nb = wave * NI + q;
     const int tx = nb / blocks_per_plane, ty = (nb % blocks_per_plane) * rpb + dyl;
     lbase[q] = ((tx + 1) * (TY + 2) + (ty + 1)) * RS + C3_ZOFF + zl;
-    gvox[q] = ((X0 + tx) * r + (Y0 + ty)) * r + zl;
+    gvox[q] = ((X0 + tx) * R + (Y0 + ty)) * R + zl;
   }
 
   f32x16 acc[MI][NI];
@@ -81,58 +88,85 @@ __global__ __launch_bounds__(256) void conv3d_kernel(int Cin, int Cout, int r, i
   // zero the halo tile once: z pads and out-of-grid rows are never written again
   for (int e = tid; e < C3_BKC * HALO; e += 256) Xs[e] = 0.f;
 
-  const int rows_per_ch = (TX + 2) * (TY + 2);
-  const int r4 = r / 4;  // float4 per row
+  // ---- per-thread staging descriptors (chunk independent)
+  int x_goff[XI], x_loff[XI];  // global offset within a chunk (-1: nothing to do), LDS offset
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int e = tid + i * 256;
+    const int z4 = (e % R4) * 4, row = (e / R4) % ROWS, ci = e / (R4 * ROWS);
+    const int hx = row / (TY + 2), hy = row % (TY + 2);
+    const int gx = X0 + hx - 1, gy = Y0 + hy - 1;
+    const bool ok = e < XV && gx >= 0 && gx < R && gy >= 0 && gy < R;
+    x_goff[i] = ok ? ci * R3 + (gx * R + gy) * R + z4 : -1;
+    x_loff[i] = ci * HALO + row * RS + C3_ZOFF + z4;
+  }
+  float4 xr[XI], wr[WI];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x_goff[i] >= 0 && c0 + (x_goff[i] / R3) < Cin)
+        xr[i] = *reinterpret_cast<const float4 *>(xb + (size_t)c0 * R3 + x_goff[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int e = tid + i * 256;
+      const int m4 = (e % (BM / 4)) * 4, ci = (e / (BM / 4)) % C3_BKC, tap = e / ((BM / 4) * C3_BKC);
+      wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < WV && c0 + ci < Cin && m0 + m4 < Cout)
+        wr[i] = *reinterpret_cast<const float4 *>(wp + ((size_t)tap * Cin + c0 + ci) * Cout + m0 + m4);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < XI; ++i)
+      if (x_goff[i] >= 0) *reinterpret_cast<float4 *>(&Xs[x_loff[i]]) = xr[i];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int e = tid + i * 256;
+      if (e < WV) *reinterpret_cast<float4 *>(&Ws[e * 4]) = wr[i];
+    }
+  };
+
+  load_chunk(0);
   for (int c0 = 0; c0 < Cin; c0 += C3_BKC) {
-    __syncthreads();  // previous chunk fully consumed (and the zero fill above is complete)
-    // ---- stage the input halo tile: interior cells of in-grid rows
-    for (int e = tid; e < C3_BKC * rows_per_ch * r4; e += 256) {
-      const int z4 = (e % r4) * 4;
-      const int row = (e / r4) % rows_per_ch;
-      const int ci = e / (r4 * rows_per_ch);
-      const int hx = row / (TY + 2), hy = row % (TY + 2);
-      const int gx = X0 + hx - 1, gy = Y0 + hy - 1;
-      if (gx >= 0 && gx < r && gy >= 0 && gy < r) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 + ci < Cin)
-          v = *reinterpret_cast<const float4 *>(xb + (size_t)(c0 + ci) * r3 + (gx * r + gy) * r + z4);
-        *reinterpret_cast<float4 *>(&Xs[ci * HALO + row * RS + C3_ZOFF + z4]) = v;
-      }
-    }
-    // ---- stage the weight tile [27][8][BM]
-    for (int e = tid; e < 27 * C3_BKC * BM; e += 256) {
-      const int m = e % BM;
-      const int ci = (e / BM) % C3_BKC;
-      const int tap = e / (BM * C3_BKC);
-      float v = 0.f;
-      if (c0 + ci < Cin && m0 + m < Cout) v = wp[((size_t)tap * Cin + c0 + ci) * Cout + m0 + m];
-      Ws[e] = v;
-    }
+    __syncthreads();  // previous chunk fully consumed (first pass: the zero fill is complete)
+    store_chunk();
     __syncthreads();
-    // ---- 27 taps x 4 k-steps
-    for (int dx = -1; dx <= 1; ++dx)
-      for (int dy = -1; dy <= 1; ++dy) {
+    if (c0 + C3_BKC < Cin) load_chunk(c0 + C3_BKC);  // in flight during the MFMA block below
+    // ---- 27 taps x 4 k-steps, operands of step s+1 fetched from LDS ahead of the MFMAs of step s
+    float a_cur[MI], b_cur[NI];
+    {
+      const int toff = (-(TY + 2) - 1) * RS - 1;
 #pragma unroll
-        for (int dz = -1; dz <= 1; ++dz) {
-          const int tap = (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1);
-          const int toff = (dx * (TY + 2) + dy) * RS + dz;
+      for (int p = 0; p < MI; ++p) a_cur[p] = Ws[lh * BM + li + p * 32];
 #pragma unroll
-          for (int kk = 0; kk < C3_BKC / 2; ++kk) {
-            float a[MI], b[NI];
-            const float *wrow = Ws + (tap * C3_BKC + 2 * kk + lh) * BM + li;
-            const float *xrow = Xs + (2 * kk + lh) * HALO + toff;
+      for (int q = 0; q < NI; ++q) b_cur[q] = Xs[lh * HALO + toff + lbase[q]];
+    }
 #pragma unroll
-            for (int p = 0; p < MI; ++p) a[p] = wrow[p * 32];
+    for (int s = 0; s < 27 * (C3_BKC / 2); ++s) {
+      float a_nxt[MI], b_nxt[NI];
+      if (s + 1 < 27 * (C3_BKC / 2)) {
+        const int tap = (s + 1) / (C3_BKC / 2), kk = (s + 1) % (C3_BKC / 2);
+        const int dx = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dz = tap % 3 - 1;
+        const int toff = (dx * (TY + 2) + dy) * RS + dz;
 #pragma unroll
-            for (int q = 0; q < NI; ++q) b[q] = xrow[lbase[q]];
+        for (int p = 0; p < MI; ++p) a_nxt[p] = Ws[(tap * C3_BKC + 2 * kk + lh) * BM + li + p * 32];
 #pragma unroll
-            for (int p = 0; p < MI; ++p)
-#pragma unroll
-              for (int q = 0; q < NI; ++q)
-                acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], b[q], acc[p][q], 0, 0, 0);
-          }
-        }
+        for (int q = 0; q < NI; ++q) b_nxt[q] = Xs[(2 * kk + lh) * HALO + toff + lbase[q]];
       }
+#pragma unroll
+      for (int p = 0; p < MI; ++p)
+#pragma unroll
+        for (int q = 0; q < NI; ++q)
+          acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[p], b_cur[q], acc[p][q], 0, 0, 0);
+      if (s + 1 < 27 * (C3_BKC / 2)) {
+#pragma unroll
+        for (int p = 0; p < MI; ++p) a_cur[p] = a_nxt[p];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) b_cur[q] = b_nxt[q];
+      }
+    }
   }
   // ---- epilogue
 #pragma unroll
@@ -142,7 +176,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(int Cin, int Cout, int r, i
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int m = m0 + p * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-        if (m < Cout) yb[(size_t)m * r3 + gvox[q]] = acc[p][q][i] + (bias ? bias[m] : 0.f);
+        if (m < Cout) yb[(size_t)m * R3 + gvox[q]] = acc[p][q][i] + (bias ? bias[m] : 0.f);
       }
 }
 
@@ -162,6 +196,7 @@ static size_t conv3d_smem(const C3Cfg &c, int r) {
 extern "C" int bdm_conv3d_3x3x3(int b, int cin, int cout, int r, const float *x, const float *packed_w,
                                 const float *bias, float *y, void *stream) {
   BDM_REQUIRE(b >= 0 && cin >= 1 && cout >= 1, "conv3d: bad sizes");
+  BDM_REQUIRE(cout % 4 == 0, "conv3d: cout must be a multiple of 4 (GroupNorm(8) widths are)");
   if (r != 8 && r != 16 && r != 32) {
     set_error("conv3d: resolution %d unsupported (8, 16, 32 are the grids of the PVCNN denoisers)", r);
     return BDM_ERR_UNSUPPORTED;
@@ -171,15 +206,15 @@ extern "C" int bdm_conv3d_3x3x3(int b, int cin, int cout, int r, const float *x,
   const size_t smem = conv3d_smem(c, r);
   dim3 grid((r / c.tx) * (r / c.ty), cdiv(cout, 32 * c.mi), b);
   hipStream_t s = (hipStream_t)stream;
-#define C3_LAUNCH(MI, NI)                                                                                       \
-  do {                                                                                                          \
-    BDM_ALLOW_LDS((conv3d_kernel<MI, NI>), smem);                                                               \
-    hipLaunchKernelGGL((conv3d_kernel<MI, NI>), grid, dim3(256), smem, s, cin, cout, r, c.tx, c.ty, x, packed_w, \
-                       bias, y);                                                                                \
+#define C3_LAUNCH(MI, NI, R, TX, TY)                                                                          \
+  do {                                                                                                        \
+    BDM_ALLOW_LDS((conv3d_kernel<MI, NI, R, TX, TY>), smem);                                                  \
+    hipLaunchKernelGGL((conv3d_kernel<MI, NI, R, TX, TY>), grid, dim3(256), smem, s, cin, cout, x, packed_w,  \
+                       bias, y);                                                                              \
   } while (0)
-  if (c.mi == 2 && c.ni == 4) C3_LAUNCH(2, 4);
-  else if (c.mi == 1 && c.ni == 4) C3_LAUNCH(1, 4);
-  else C3_LAUNCH(1, 2);
+  if (r == 32) { if (c.mi == 2) C3_LAUNCH(2, 4, 32, 2, 8); else C3_LAUNCH(1, 4, 32, 2, 8); }
+  else if (r == 16) { if (c.mi == 2) C3_LAUNCH(2, 4, 16, 2, 16); else C3_LAUNCH(1, 4, 16, 2, 16); }
+  else C3_LAUNCH(1, 2, 8, 4, 8);
 #undef C3_LAUNCH
   return launch_status("conv3d");
 }
