@@ -42,9 +42,16 @@ extern "C" int bdm_conv3d_pack_weights(int cout, int cin, const float *w, float 
 // the 27 x 4 MFMA steps of chunk c and written to LDS after them, so their latency hides under
 // ~14-55k cycles of matrix work even at one wave per SIMD.  Grid resolution R and the tile shape are
 // template constants so that every index split is a shift or a multiply-by-constant.
-template <int MI, int NI, int R, int TX, int TY>
+//
+// SPARSE variant (first convolution of a PVConv: its input is the freshly voxelised point cloud, at most
+// N of the r^3 cells are non-zero): `rowocc` (B, r*r) flags the (x, y) grid rows that hold at least one
+// point.  A 32-wide column block shifted by a tap (dx, dy, .) reads only rows whose flag is clear -> its
+// B operand is all zeros for every input channel -> the 3 x 4 x MI MFMAs of that (block, dx, dy) are
+// skipped (wave-uniform branch).  Exact up to the order of additions of zeros, i.e. bit-identical.
+template <int MI, int NI, int R, int TX, int TY, bool SPARSE>
 __global__ __launch_bounds__(256) void conv3d_kernel(int Cin, int Cout, const float *__restrict__ x,
                                                      const float *__restrict__ wp, const float *__restrict__ bias,
+                                                     const unsigned char *__restrict__ rowocc,
                                                      float *__restrict__ y) {
   extern __shared__ __align__(16) float smem[];
   constexpr int BM = 32 * MI;
@@ -59,7 +66,17 @@ __global__ __launch_bounds__(256) void conv3d_kernel(int Cin, int Cout, const fl
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   constexpr int tiles_y = R / TY;
-  const int X0 = (blockIdx.x / tiles_y) * TX, Y0 = (blockIdx.x % tiles_y) * TY;
+  // Workgroups are dealt to the 8 XCDs round-robin by linear id.  With occupancy-dependent work (SPARSE) the busy
+  // tiles of every shape would otherwise pile up on the same XCDs (same tile index modulo 8), so the tile index is
+  // rotated by the group number: each XCD sees every tile residue.  Pure speed; any placement is correct.
+  constexpr int NT = (R / TX) * tiles_y;
+  int tile = blockIdx.x;
+  if constexpr (SPARSE) {
+    const int k = blockIdx.y + gridDim.y * blockIdx.z;
+    if constexpr (NT % 8 == 0) tile = (tile & ~7) | ((tile + (tile >> 3) + k) & 7);
+    else tile = (tile + k) % NT;
+  }
+  const int X0 = (tile / tiles_y) * TX, Y0 = (tile % tiles_y) * TY;
   const int m0 = blockIdx.y * BM, bi = blockIdx.z;
   const float *xb = x + (size_t)bi * Cin * R3;
   float *yb = y + (size_t)bi * Cout * R3;
@@ -71,7 +88,7 @@ __global__ __launch_bounds__(256) void conv3d_kernel(int Cin, int Cout, const fl
   int lbase[NI], gvox[NI];
 #pragma unroll
   for (int q = 0; q < NI; ++q) {
-    const int nb = wave * NI + q;
+    const int nb = q * 4 + wave;  // interleaved: the 4 waves of a block get similar occupancy
     const int tx = nb / blocks_per_plane, ty = (nb % blocks_per_plane) * rpb + dyl;
     lbase[q] = ((tx + 1) * (TY + 2) + (ty + 1)) * RS + C3_ZOFF + zl;
     gvox[q] = ((X0 + tx) * R + (Y0 + ty)) * R + zl;
@@ -84,6 +101,44 @@ __global__ __launch_bounds__(256) void conv3d_kernel(int Cin, int Cout, const fl
     for (int q = 0; q < NI; ++q)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][q][i] = 0.f;
+
+  // wave-uniform occupancy bits: bit t9 of occ[q] = "column block q shifted by (dx,dy) = t9 touches a non-empty row"
+  unsigned occ[NI];
+  if constexpr (SPARSE) {
+    const unsigned char *ro = rowocc + (size_t)bi * R2;
+    unsigned any = 0;
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+      const int nb = q * 4 + wave;  // interleaved: the 4 waves of a block get similar occupancy
+      const int tx = nb / blocks_per_plane, ty0 = (nb % blocks_per_plane) * rpb;
+      unsigned m = 0;
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int gx = X0 + tx + t9 / 3 - 1;
+        unsigned hit = 0;
+#pragma unroll
+        for (int rr = 0; rr < rpb; ++rr) {
+          const int gy = Y0 + ty0 + rr + t9 % 3 - 1;
+          if (gx >= 0 && gx < R && gy >= 0 && gy < R) hit |= ro[gx * R + gy];
+        }
+        m |= (hit ? 1u : 0u) << t9;
+      }
+      occ[q] = __builtin_amdgcn_readfirstlane(m);
+      any |= occ[q];
+    }
+    if (!__syncthreads_or(any != 0)) {  // nothing but zeros under this tile's halo: the output is the bias
+#pragma unroll
+      for (int p = 0; p < MI; ++p)
+#pragma unroll
+        for (int q = 0; q < NI; ++q)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int m = m0 + p * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            if (m < Cout) yb[(size_t)m * R3 + gvox[q]] = bias ? bias[m] : 0.f;
+          }
+      return;
+    }
+  }
 
   // zero the halo tile once: z pads and out-of-grid rows are never written again
   for (int e = tid; e < C3_BKC * HALO; e += 256) Xs[e] = 0.f;
@@ -134,37 +189,68 @@ __global__ __launch_bounds__(256) void conv3d_kernel(int Cin, int Cout, const fl
     store_chunk();
     __syncthreads();
     if (c0 + C3_BKC < Cin) load_chunk(c0 + C3_BKC);  // in flight during the MFMA block below
-    // ---- 27 taps x 4 k-steps, operands of step s+1 fetched from LDS ahead of the MFMAs of step s
-    float a_cur[MI], b_cur[NI];
-    {
-      const int toff = (-(TY + 2) - 1) * RS - 1;
+    if constexpr (SPARSE) {
 #pragma unroll
-      for (int p = 0; p < MI; ++p) a_cur[p] = Ws[lh * BM + li + p * 32];
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int toff9 = ((t9 / 3 - 1) * (TY + 2) + (t9 % 3 - 1)) * RS;
 #pragma unroll
-      for (int q = 0; q < NI; ++q) b_cur[q] = Xs[lh * HALO + toff + lbase[q]];
-    }
+        for (int q = 0; q < NI; ++q) {
+          if ((occ[q] >> t9) & 1u) {
+            // 12 k-steps (3 dz x 4 channel pairs) in two batches: all LDS operands of a batch are requested
+            // before its MFMAs so the read latency is paid once per batch, not once per MFMA
 #pragma unroll
-    for (int s = 0; s < 27 * (C3_BKC / 2); ++s) {
-      float a_nxt[MI], b_nxt[NI];
-      if (s + 1 < 27 * (C3_BKC / 2)) {
-        const int tap = (s + 1) / (C3_BKC / 2), kk = (s + 1) % (C3_BKC / 2);
-        const int dx = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dz = tap % 3 - 1;
-        const int toff = (dx * (TY + 2) + dy) * RS + dz;
+            for (int h = 0; h < 2; ++h) {
+              float bv[6], av[6][MI];
 #pragma unroll
-        for (int p = 0; p < MI; ++p) a_nxt[p] = Ws[(tap * C3_BKC + 2 * kk + lh) * BM + li + p * 32];
+              for (int j = 0; j < 6; ++j) {
+                const int st = h * 6 + j, dz = st / (C3_BKC / 2) - 1, kk = st % (C3_BKC / 2);
+                const int tap = t9 * 3 + dz + 1;
+                bv[j] = Xs[(2 * kk + lh) * HALO + toff9 + dz + lbase[q]];
 #pragma unroll
-        for (int q = 0; q < NI; ++q) b_nxt[q] = Xs[(2 * kk + lh) * HALO + toff + lbase[q]];
+                for (int p = 0; p < MI; ++p) av[j][p] = Ws[(tap * C3_BKC + 2 * kk + lh) * BM + li + p * 32];
+              }
+#pragma unroll
+              for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int p = 0; p < MI; ++p)
+                  acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][p], bv[j], acc[p][q], 0, 0, 0);
+            }
+          }
+        }
       }
-#pragma unroll
-      for (int p = 0; p < MI; ++p)
-#pragma unroll
-        for (int q = 0; q < NI; ++q)
-          acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[p], b_cur[q], acc[p][q], 0, 0, 0);
-      if (s + 1 < 27 * (C3_BKC / 2)) {
-#pragma unroll
-        for (int p = 0; p < MI; ++p) a_cur[p] = a_nxt[p];
-#pragma unroll
-        for (int q = 0; q < NI; ++q) b_cur[q] = b_nxt[q];
+    } else {
+      // ---- 27 taps x 4 k-steps, operands of step s+1 fetched from LDS ahead of the MFMAs of step s
+      float a_cur[MI], b_cur[NI];
+      {
+        const int toff = (-(TY + 2) - 1) * RS - 1;
+  #pragma unroll
+        for (int p = 0; p < MI; ++p) a_cur[p] = Ws[lh * BM + li + p * 32];
+  #pragma unroll
+        for (int q = 0; q < NI; ++q) b_cur[q] = Xs[lh * HALO + toff + lbase[q]];
+      }
+  #pragma unroll
+      for (int s = 0; s < 27 * (C3_BKC / 2); ++s) {
+        float a_nxt[MI], b_nxt[NI];
+        if (s + 1 < 27 * (C3_BKC / 2)) {
+          const int tap = (s + 1) / (C3_BKC / 2), kk = (s + 1) % (C3_BKC / 2);
+          const int dx = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dz = tap % 3 - 1;
+          const int toff = (dx * (TY + 2) + dy) * RS + dz;
+  #pragma unroll
+          for (int p = 0; p < MI; ++p) a_nxt[p] = Ws[(tap * C3_BKC + 2 * kk + lh) * BM + li + p * 32];
+  #pragma unroll
+          for (int q = 0; q < NI; ++q) b_nxt[q] = Xs[(2 * kk + lh) * HALO + toff + lbase[q]];
+        }
+  #pragma unroll
+        for (int p = 0; p < MI; ++p)
+  #pragma unroll
+          for (int q = 0; q < NI; ++q)
+            acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[p], b_cur[q], acc[p][q], 0, 0, 0);
+        if (s + 1 < 27 * (C3_BKC / 2)) {
+  #pragma unroll
+          for (int p = 0; p < MI; ++p) a_cur[p] = a_nxt[p];
+  #pragma unroll
+          for (int q = 0; q < NI; ++q) b_cur[q] = b_nxt[q];
+        }
       }
     }
   }
@@ -193,8 +279,31 @@ static size_t conv3d_smem(const C3Cfg &c, int r) {
   return sizeof(float) * ((size_t)C3_BKC * (c.tx + 2) * (c.ty + 2) * (r + 8) + (size_t)27 * C3_BKC * 32 * c.mi);
 }
 
+__global__ void row_occupancy_kernel(int r, const int *__restrict__ cnt, unsigned char *__restrict__ rowocc) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.y;
+  if (row >= r * r) return;
+  const int *c = cnt + ((size_t)bi * r * r + row) * r;
+  int any = 0;
+  for (int z = 0; z < r; ++z) any |= c[z];
+  rowocc[(size_t)bi * r * r + row] = any ? 1 : 0;
+}
+extern "C" int bdm_voxel_row_occupancy(int b, int r, const int *cnt, unsigned char *rowocc, void *stream) {
+  BDM_REQUIRE(b >= 0 && r >= 1, "voxel_row_occupancy: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(row_occupancy_kernel, dim3(cdiv(r * r, 256), b), dim3(256), 0, (hipStream_t)stream, r, cnt, rowocc);
+  return launch_status("voxel_row_occupancy");
+}
+
+extern "C" int bdm_conv3d_3x3x3_sparse(int b, int cin, int cout, int r, const float *x, const float *packed_w,
+                                       const float *bias, const unsigned char *rowocc, float *y, void *stream);
+
 extern "C" int bdm_conv3d_3x3x3(int b, int cin, int cout, int r, const float *x, const float *packed_w,
                                 const float *bias, float *y, void *stream) {
+  return bdm_conv3d_3x3x3_sparse(b, cin, cout, r, x, packed_w, bias, nullptr, y, stream);
+}
+
+extern "C" int bdm_conv3d_3x3x3_sparse(int b, int cin, int cout, int r, const float *x, const float *packed_w,
+                                       const float *bias, const unsigned char *rowocc, float *y, void *stream) {
   BDM_REQUIRE(b >= 0 && cin >= 1 && cout >= 1, "conv3d: bad sizes");
   BDM_REQUIRE(cout % 4 == 0, "conv3d: cout must be a multiple of 4 (GroupNorm(8) widths are)");
   if (r != 8 && r != 16 && r != 32) {
@@ -206,11 +315,17 @@ extern "C" int bdm_conv3d_3x3x3(int b, int cin, int cout, int r, const float *x,
   const size_t smem = conv3d_smem(c, r);
   dim3 grid((r / c.tx) * (r / c.ty), cdiv(cout, 32 * c.mi), b);
   hipStream_t s = (hipStream_t)stream;
-#define C3_LAUNCH(MI, NI, R, TX, TY)                                                                          \
-  do {                                                                                                        \
-    BDM_ALLOW_LDS((conv3d_kernel<MI, NI, R, TX, TY>), smem);                                                  \
-    hipLaunchKernelGGL((conv3d_kernel<MI, NI, R, TX, TY>), grid, dim3(256), smem, s, cin, cout, x, packed_w,  \
-                       bias, y);                                                                              \
+#define C3_LAUNCH(MI, NI, R, TX, TY)                                                                              \
+  do {                                                                                                            \
+    if (rowocc) {                                                                                                 \
+      BDM_ALLOW_LDS((conv3d_kernel<MI, NI, R, TX, TY, true>), smem);                                              \
+      hipLaunchKernelGGL((conv3d_kernel<MI, NI, R, TX, TY, true>), grid, dim3(256), smem, s, cin, cout, x,        \
+                         packed_w, bias, rowocc, y);                                                              \
+    } else {                                                                                                      \
+      BDM_ALLOW_LDS((conv3d_kernel<MI, NI, R, TX, TY, false>), smem);                                             \
+      hipLaunchKernelGGL((conv3d_kernel<MI, NI, R, TX, TY, false>), grid, dim3(256), smem, s, cin, cout, x,       \
+                         packed_w, bias, rowocc, y);                                                              \
+    }                                                                                                             \
   } while (0)
   if (r == 32) { if (c.mi == 2) C3_LAUNCH(2, 4, 32, 2, 8); else C3_LAUNCH(1, 4, 32, 2, 8); }
   else if (r == 16) { if (c.mi == 2) C3_LAUNCH(2, 4, 16, 2, 16); else C3_LAUNCH(1, 4, 16, 2, 16); }

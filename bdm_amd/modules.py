@@ -85,9 +85,9 @@ class Voxelization(nn.Module):
         if not normalize:
             raise NotImplementedError("normalize=False is not used by the denoisers")
 
-    def forward(self, features, coords):
+    def forward(self, features, coords, with_row_occupancy=False):
         norm_coords, vox_coords = ops.voxel_coords(coords, self.r, self.eps)
-        return ops.avg_voxelize(features, vox_coords, self.r), norm_coords
+        return ops.avg_voxelize(features, vox_coords, self.r, with_row_occupancy), norm_coords
 
 
 class Attention(nn.Module):
@@ -172,8 +172,14 @@ class PVConv(nn.Module):
         se = next((m for m in rest if isinstance(m, SE3d)), None)
 
         features = ops.materialize(features)
-        vox, norm_coords = self.voxelization(features, coords)
-        v = ops.conv3d(vox, self._packed_weight(conv1), conv1.bias, r)
+        # the first conv's input is the freshly voxelised cloud: on the 32^3 grids (<= 12.5 % occupied cells) the
+        # occupancy-skipping variant wins (measured 1.3-1.4x); on 16^3 / 8^3 the dense kernel is as fast or faster
+        sparse = r >= 32
+        vox, norm_coords = self.voxelization(features, coords, with_row_occupancy=sparse)
+        rowocc = None
+        if sparse:
+            vox, rowocc = vox
+        v = ops.conv3d(vox, self._packed_weight(conv1), conv1.bias, r, rowocc=rowocc)
         ops.group_norm_(v, gn1.weight, gn1.bias, 8, gn1.eps, swish=True)
         v = ops.conv3d(v, self._packed_weight(conv2), conv2.bias, r)
         ops.group_norm_(v, gn2.weight, gn2.bias, 8, gn2.eps, swish=(att is None))
@@ -194,10 +200,12 @@ class BallQuery(nn.Module):
         self.num_neighbors = num_neighbors
         self.include_coordinates = include_coordinates
 
-    def forward(self, points_coords, centers_coords, temb, points_features=None):
+    def forward(self, points_coords, centers_coords, temb, points_features=None, neighbor_indices=None):
         points_coords = points_coords.contiguous()
         centers_coords = centers_coords.contiguous()
-        idx = F.ball_query(centers_coords, points_coords, self.radius, self.num_neighbors)
+        idx = neighbor_indices
+        if idx is None:
+            idx = F.ball_query(centers_coords, points_coords, self.radius, self.num_neighbors)
         if points_features is None:
             assert self.include_coordinates, "No Features For Grouping"
             points_features = points_coords[:, :0]
@@ -238,12 +246,27 @@ class PointNetSAModule(nn.Module):
         self.groupers = nn.ModuleList(groupers)
         self.mlps = nn.ModuleList(mlps)
 
+    def plan(self, coords):
+        """Geometry-only part of the module (furthest point sampling + ball query): depends on the coordinates
+        alone, so the denoiser's encoder runs it for all levels on a side stream while the first PVConvs compute."""
+        coords = coords.contiguous()
+        centers_coords = F.furthest_point_sample(coords, self.num_centers)
+        g = self.groupers[0]
+        idx = F.ball_query(centers_coords, coords, g.radius, g.num_neighbors)
+        return centers_coords, idx
+
     def forward(self, inputs):
         features, coords, temb = inputs
         coords = coords.contiguous()
-        centers_coords = F.furthest_point_sample(coords, self.num_centers)
         assert len(self.groupers) == 1, "multi-radius grouping is not used by the denoisers"
-        grouped, g_t = self.groupers[0](coords, centers_coords, temb, features)
+        planned = getattr(self, "_planned", None)
+        self._planned = None
+        if planned is not None:
+            centers_coords, idx, event = planned
+            event.wait()  # the current stream waits for the side stream's sampler
+        else:
+            centers_coords, idx = self.plan(coords)
+        grouped, g_t = self.groupers[0](coords, centers_coords, temb, features, neighbor_indices=idx)
         h = self.mlps[0].run(grouped)
         out = ops.max_over_neighbors(h)
         if g_t.stride(2) == 0 and g_t.stride(3) == 0:

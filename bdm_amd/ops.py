@@ -184,7 +184,7 @@ def voxel_coords(coords, r, eps=0.0):
     return nc, vc
 
 
-def avg_voxelize(features, vox_coords, r):
+def avg_voxelize(features, vox_coords, r, with_row_occupancy=False):
     f = features.contiguous()
     B, C, n = f.shape
     dev = f.device
@@ -194,6 +194,10 @@ def avg_voxelize(features, vox_coords, r):
     ws = workspace(L.lib().bdm_voxelize_workspace_bytes(B, n, r), dev, "vox")
     L.check(L.lib().bdm_avg_voxelize_forward(B, C, n, r, L.ptr(f), L.ptr(vox_coords), L.ptr(out), L.ptr(ind), L.ptr(cnt),
                                              L.ptr(ws), L.stream()), "avg_voxelize")
+    if with_row_occupancy:
+        rowocc = torch.empty(B, r * r, dtype=torch.uint8, device=dev)
+        L.check(L.lib().bdm_voxel_row_occupancy(B, r, L.ptr(cnt), L.ptr(rowocc), L.stream()), "voxel_row_occupancy")
+        return out, rowocc
     return out
 
 
@@ -244,12 +248,12 @@ def conv3d_pack(weight):
     return packed
 
 
-def conv3d(x, packed_w, bias, r):
-    """x (B, Cin, r^3) contiguous -> (B, Cout, r^3)."""
+def conv3d(x, packed_w, bias, r, rowocc=None):
+    """x (B, Cin, r^3) contiguous -> (B, Cout, r^3).  rowocc: row-occupancy flags of a freshly voxelised input."""
     x = x.contiguous()
     B, cin = x.shape[:2]
     cout = packed_w.shape[2]
     y = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=x.device)
-    L.check(L.lib().bdm_conv3d_3x3x3(B, cin, cout, int(r), L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(y), L.stream()),
-            "conv3d")
+    L.check(L.lib().bdm_conv3d_3x3x3_sparse(B, cin, cout, int(r), L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(rowocc),
+                                            L.ptr(y), L.stream()), "conv3d")
     return y

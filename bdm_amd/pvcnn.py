@@ -113,9 +113,34 @@ def embed_time(embedf, t, embed_dim, n):
     return te[:, :, None].expand(-1, -1, n)
 
 
+_side_streams = {}
+
+
+def plan_sampling_chain(sa_layers, coords):
+    """Furthest point sampling + ball query of ALL set-abstraction levels depend on the input coordinates only
+    (1 356 strictly sequential sampler rounds on 16 CUs).  They are enqueued on a side stream so that they overlap
+    the level-0 PVConvs; each SA module waits on its own event."""
+    cur = torch.cuda.current_stream()
+    side = _side_streams.get(coords.device)
+    if side is None:
+        side = _side_streams[coords.device] = torch.cuda.Stream(device=coords.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        c = coords
+        for blocks in sa_layers:
+            sa = blocks[-1] if isinstance(blocks, nn.Sequential) else blocks
+            centers, idx = sa.plan(c)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            sa._planned = (centers, idx, ev)
+            c = centers
+
+
 def encode(sa_layers, global_att, inputs, t_emb):
     """Down path (pvcnn.py:90-110)."""
     coords = inputs[:, :3, :].contiguous()
+    if coords.is_cuda and not torch.cuda.is_current_stream_capturing():
+        plan_sampling_chain(sa_layers, coords)
     features = inputs
     coords_list, in_features_list = [], []
     for i, sa_blocks in enumerate(sa_layers):

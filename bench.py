@@ -70,14 +70,14 @@ def install_conv_timer(timer):
     from bdm_amd import ops
     raw = ops.conv3d
 
-    def timed(x, packed_w, bias, r):
+    def timed(x, packed_w, bias, r, rowocc=None):
         cout = packed_w.shape[2]
         if timer is not None and timer.wants(cout, r):
             tok = timer.begin(x.shape[0], x.shape[1], cout, r)
-            y = raw(x, packed_w, bias, r)
+            y = raw(x, packed_w, bias, r, rowocc)
             timer.end(tok)
             return y
-        return raw(x, packed_w, bias, r)
+        return raw(x, packed_w, bias, r, rowocc)
 
     ops.conv3d = timed
     return raw

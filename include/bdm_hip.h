@@ -173,6 +173,12 @@ int bdm_attention_core(int b, int c, int l, const float *q, const float *k, cons
 int bdm_conv3d_pack_weights(int cout, int cin, const float *w, float *packed, void *stream);
 int bdm_conv3d_3x3x3(int b, int cin, int cout, int r, const float *x, const float *packed_w,
                      const float *bias, float *y, void *stream);
+/* Same convolution for an input that is a freshly voxelised point cloud (first Conv3d of a PVConv): rowocc
+ * (b, r*r) uint8 flags the (x, y) grid rows holding at least one point (bdm_voxel_row_occupancy from the
+ * voxeliser's cnt); work on all-zero operand rows is skipped.  Results are bit-identical to the dense call. */
+int bdm_voxel_row_occupancy(int b, int r, const int *cnt, unsigned char *rowocc, void *stream);
+int bdm_conv3d_3x3x3_sparse(int b, int cin, int cout, int r, const float *x, const float *packed_w,
+                            const float *bias, const unsigned char *rowocc, float *y, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * 3. Per-step glue of the coupled DDPM loop

@@ -161,3 +161,27 @@ def test_pvconv_tail_and_sa_group(ops, oracle_ops):
     ref = torch.cat([oracle_ops.grouping_forward(pts, nb) - ctr.unsqueeze(-1), oracle_ops.grouping_forward(f, nb)], 1)
     got = ops.sa_group(pts.cuda(), ctr.cuda(), f.cuda(), nb.cuda()).cpu()
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("cin,cout,r,npts", [(35, 32, 32, 4096), (64, 64, 32, 4096), (128, 64, 16, 1024), (256, 256, 8, 64),
+                                             (192, 128, 8, 256), (16, 8, 32, 50)])
+def test_conv3d_sparse_input_bit_identical(ops, cin, cout, r, npts):
+    """first conv of a PVConv: row-occupancy skipping must not change a single bit."""
+    B = 2
+    g = torch.Generator().manual_seed(cin + r)
+    vc = (torch.randn(B, 3, npts, generator=g) * r / 8 + r / 2).round().clamp(0, r - 1).to(torch.int32)
+    vc[1] = vc[1] // 2  # second shape squeezed into one octant: large empty regions
+    f = torch.randn(B, cin, npts, generator=g)
+    vox, rowocc = ops.avg_voxelize(f.cuda(), vc.cuda(), r, with_row_occupancy=True)
+    occ_ref = torch.zeros(B, r * r, dtype=torch.uint8)
+    for b in range(B):
+        occ_ref[b, (vc[b, 0] * r + vc[b, 1]).long()] = 1
+    assert torch.equal(rowocc.cpu(), occ_ref)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    pw = ops.conv3d_pack(w.cuda())
+    dense = ops.conv3d(vox, pw, bias.cuda(), r)
+    sparse = ops.conv3d(vox, pw, bias.cuda(), r, rowocc=rowocc)
+    assert torch.equal(dense, sparse)
+    ref = TF.conv3d(vox.cpu().double().view(B, cin, r, r, r), w.double(), bias.double(), padding=1).float().reshape(B, cout, -1)
+    assert rel(sparse.cpu(), ref) < 2e-6
