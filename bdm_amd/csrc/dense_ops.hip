@@ -202,6 +202,124 @@ __global__ void gn_apply_kernel(int cg, int L, const float *__restrict__ x, long
   }
 }
 
+// ---- fast paths for densely packed chunks (row stride == L, L % 4 == 0, 16-B aligned): one (shape, group) chunk is a
+// contiguous run of cg*L floats.
+//   * gn_onepass_kernel: chunk <= 64 Ki floats -> ONE workgroup keeps it in registers: single HBM read, mean then
+//     centred variance (two reductions on registers), normalise, Swish, store.  One launch instead of two.
+//   * gn_stats_vec / gn_apply_vec: float4 versions of the two-pass kernels for the big voxel / grouped tensors.
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double a = 0.0;
+  for (int w = 0; w < nw; ++w) a += sh[w];
+  return a;
+}
+
+#define GN1_MAXV 16  // float4 per thread
+__global__ __launch_bounds__(1024) void gn_onepass_kernel(int cg, int L, const float *__restrict__ x, long long bs,
+                                                          const float *__restrict__ res, long long bs_r, int G,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          float eps, int act, float *__restrict__ y, long long bs_y) {
+  __shared__ double sh[16];
+  const int bg = blockIdx.x, bi = bg / G, g = bg % G;
+  const int n4 = cg * L / 4;
+  const float4 *xb = reinterpret_cast<const float4 *>(x + (size_t)bi * bs + (size_t)g * cg * L);
+  const float4 *rb = res ? reinterpret_cast<const float4 *>(res + (size_t)bi * bs_r + (size_t)g * cg * L) : nullptr;
+  float4 *yb = reinterpret_cast<float4 *>(y + (size_t)bi * bs_y + (size_t)g * cg * L);
+  float4 v[GN1_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < GN1_MAXV; ++i) {
+    const int e = threadIdx.x + i * 1024;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < n4) {
+      v[i] = xb[e];
+      if (rb) { const float4 r = rb[e]; v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w; }
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const double cnt = (double)cg * L;
+  const float mean = (float)(block_sum((double)s, sh) / cnt);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < GN1_MAXV; ++i) {
+    const int e = threadIdx.x + i * 1024;
+    if (e < n4) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rstd = (float)(1.0 / sqrt(block_sum((double)q, sh) / cnt + (double)eps));
+  const int L4 = L / 4;
+#pragma unroll
+  for (int i = 0; i < GN1_MAXV; ++i) {
+    const int e = threadIdx.x + i * 1024;
+    if (e < n4) {
+      const int ch = g * cg + e / L4;
+      const float ga = gamma[ch] * rstd, be = beta[ch] - mean * ga;
+      float4 o;
+      o.x = v[i].x * ga + be; o.y = v[i].y * ga + be; o.z = v[i].z * ga + be; o.w = v[i].w * ga + be;
+      if (act == 1) { o.x = swishf(o.x); o.y = swishf(o.y); o.z = swishf(o.z); o.w = swishf(o.w); }
+      yb[e] = o;
+    }
+  }
+}
+
+__global__ void gn_stats_vec_kernel(int cg, int L, const float *__restrict__ x, long long bs,
+                                    const float *__restrict__ res, long long bs_r, int G, double *__restrict__ partial) {
+  __shared__ double sh[16];
+  const int S = gridDim.x, s = blockIdx.x, bg = blockIdx.y, bi = bg / G, g = bg % G;
+  const int n4 = cg * L / 4;
+  const float4 *xb = reinterpret_cast<const float4 *>(x + (size_t)bi * bs + (size_t)g * cg * L);
+  const float4 *rb = res ? reinterpret_cast<const float4 *>(res + (size_t)bi * bs_r + (size_t)g * cg * L) : nullptr;
+  const int per = (n4 + S - 1) / S, lo = s * per, hi = min(lo + per, n4);
+  float sum = 0.f, sq = 0.f;  // <= 2048 addends per thread; combined in fp64 below
+  for (int e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+    float4 v = xb[e];
+    if (rb) { const float4 r = rb[e]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    sum += (v.x + v.y) + (v.z + v.w);
+    sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  const double a = block_sum((double)sum, sh), q = block_sum((double)sq, sh);
+  if (threadIdx.x == 0) {
+    partial[((size_t)bg * S + s) * 2 + 0] = a;
+    partial[((size_t)bg * S + s) * 2 + 1] = q;
+  }
+}
+
+__global__ void gn_apply_vec_kernel(int cg, int L, const float *__restrict__ x, long long bs,
+                                    const float *__restrict__ res, long long bs_r, int G, int S,
+                                    const double *__restrict__ partial, const float *__restrict__ gamma,
+                                    const float *__restrict__ beta, float eps, int act, float *__restrict__ y,
+                                    long long bs_y) {
+  const int bg = blockIdx.y, bi = bg / G, g = bg % G;
+  double a = 0.0, q = 0.0;
+  for (int s = 0; s < S; ++s) { a += partial[((size_t)bg * S + s) * 2]; q += partial[((size_t)bg * S + s) * 2 + 1]; }
+  const double cnt = (double)cg * L;
+  const double mean_d = a / cnt;
+  double var = q / cnt - mean_d * mean_d;
+  if (var < 0) var = 0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const int n4 = cg * L / 4, L4 = L / 4;
+  const float4 *xb = reinterpret_cast<const float4 *>(x + (size_t)bi * bs + (size_t)g * cg * L);
+  const float4 *rb = res ? reinterpret_cast<const float4 *>(res + (size_t)bi * bs_r + (size_t)g * cg * L) : nullptr;
+  float4 *yb = reinterpret_cast<float4 *>(y + (size_t)bi * bs_y + (size_t)g * cg * L);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += gridDim.x * blockDim.x) {
+    float4 v = xb[e];
+    if (rb) { const float4 r = rb[e]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    const int ch = g * cg + e / L4;
+    const float ga = gamma[ch], be = beta[ch];
+    float4 o;
+    o.x = (v.x - mean) * rstd * ga + be; o.y = (v.y - mean) * rstd * ga + be;
+    o.z = (v.z - mean) * rstd * ga + be; o.w = (v.w - mean) * rstd * ga + be;
+    if (act == 1) { o.x = swishf(o.x); o.y = swishf(o.y); o.z = swishf(o.z); o.w = swishf(o.w); }
+    yb[e] = o;
+  }
+}
+
 extern "C" size_t bdm_group_norm_workspace_bytes(int b, int groups) {
   return sizeof(double) * 2 * (size_t)b * groups * GN_MAX_SLICES;
 }
@@ -217,10 +335,28 @@ extern "C" int bdm_group_norm(int b, int c, int l, int groups, const float *x, l
   hipStream_t s = (hipStream_t)stream;
   const int cg = c / groups;
   const long long total = (long long)cg * l;
-  int S = (int)((total + 8191) / 8192);
+  double *partial = (double *)workspace;
+  auto al16 = [](const void *p) { return (((uintptr_t)p) & 15) == 0; };
+  const bool packed = ld_x == l && ld_y == l && (!residual || ld_r == l) && (l % 4 == 0) && al16(x) && al16(y) &&
+                      (!residual || al16(residual)) && (bs_x % 4 == 0) && (bs_y % 4 == 0) && (!residual || bs_r % 4 == 0) &&
+                      total < (1ll << 30);
+  if (packed && total <= 4ll * 1024 * GN1_MAXV) {
+    hipLaunchKernelGGL(gn_onepass_kernel, dim3(b * groups), dim3(1024), 0, s, cg, l, x, bs_x, residual, bs_r, groups, gamma,
+                       beta, eps, act, y, bs_y);
+    return launch_status("gn_onepass");
+  }
+  int S = (int)((total + 16383) / 16384);
   if (S < 1) S = 1;
   if (S > GN_MAX_SLICES) S = GN_MAX_SLICES;
-  double *partial = (double *)workspace;
+  if (packed) {
+    hipLaunchKernelGGL(gn_stats_vec_kernel, dim3(S, b * groups), dim3(256), 0, s, cg, l, x, bs_x, residual, bs_r, groups,
+                       partial);
+    int gx = (int)((total / 4 + 1023) / 1024);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(gn_apply_vec_kernel, dim3(gx, b * groups), dim3(256), 0, s, cg, l, x, bs_x, residual, bs_r, groups, S,
+                       partial, gamma, beta, eps, act, y, bs_y);
+    return launch_status("gn_vec");
+  }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(S, b * groups), dim3(256), 0, s, cg, l, x, bs_x, ld_x, residual, bs_r,
                      ld_r, groups, partial);
   int rc = launch_status("gn_stats");
