@@ -50,18 +50,18 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-  for (int k0 = 0; k0 < K; k0 += PW_BK) {
-    // ---- stage W tile (BM x 16), transposed to k-major
+  // register-prefetched staging: the global loads of K-chunk c+1 are in flight during the MFMAs of chunk c
+  constexpr int AI = (BM * PW_BK) / 256, BI = (PW_BK * BN / 4) / 256;
+  float ar[AI];
+  float4 br[BI];
+  auto load_chunk = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < (BM * PW_BK) / 256; ++i) {
+    for (int i = 0; i < AI; ++i) {
       const int e = tid + i * 256, m = e >> 4, k = e & 15;
-      float v = 0.f;
-      if (m0 + m < M && k0 + k < K) v = W[(size_t)(m0 + m) * ldw + k0 + k];
-      As[k * LDA + m] = v;
+      ar[i] = (m0 + m < M && k0 + k < K) ? W[(size_t)(m0 + m) * ldw + k0 + k] : 0.f;
     }
-    // ---- stage X tile (16 x BN)
 #pragma unroll
-    for (int i = 0; i < (PW_BK * BN / 4) / 256; ++i) {
+    for (int i = 0; i < BI; ++i) {
       const int e = tid + i * 256, k = e / (BN / 4), c4 = (e % (BN / 4)) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (k0 + k < K) {
@@ -75,9 +75,24 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
           if (n0 + c4 + 3 < N) v.w = src[3];
         }
       }
-      *reinterpret_cast<float4 *>(&Bs[k * BN + c4]) = v;
+      br[i] = v;
+    }
+  };
+  load_chunk(0);
+  for (int k0 = 0; k0 < K; k0 += PW_BK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int e = tid + i * 256, m = e >> 4, k = e & 15;
+      As[k * LDA + m] = ar[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int e = tid + i * 256, k = e / (BN / 4), c4 = (e % (BN / 4)) * 4;
+      *reinterpret_cast<float4 *>(&Bs[k * BN + c4]) = br[i];
     }
     __syncthreads();
+    if (k0 + PW_BK < K) load_chunk(k0 + PW_BK);
 #pragma unroll
     for (int kk = 0; kk < PW_BK / 2; ++kk) {
       float a[MI], b[NI];
@@ -91,7 +106,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
         for (int y = 0; y < NI; ++y)
           acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
     }
-    __syncthreads();
   }
   // ---- epilogue: C/D map  row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
 #pragma unroll
