@@ -26,10 +26,11 @@ class RefDDPM:
         self.betas = torch.linspace(beta_start, beta_end, T, dtype=torch.float32)
         self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
 
-    def step(self, eps, t, x, z):
+    def step(self, eps, t, x, z, prev_t=None):
         ac = self.alphas_cumprod
+        prev_t = t - 1 if prev_t is None else prev_t
         abar_t = ac[t]
-        abar_prev = ac[t - 1] if t - 1 >= 0 else torch.tensor(1.0)
+        abar_prev = ac[prev_t] if prev_t >= 0 else torch.tensor(1.0)
         beta_prod_t, beta_prod_prev = 1 - abar_t, 1 - abar_prev
         cur_alpha = abar_t / abar_prev
         cur_beta = 1 - cur_alpha
@@ -98,17 +99,54 @@ def rasterize_bruteforce(points, cam, H, W, radius):
     return idx
 
 
+def rasterize_windowed(points, cam, H, W, radius, win=2):
+    """Same index image as rasterize_bruteforce, visiting for every point only the pixels within +-win of its nearest
+    pixel (valid while radius < win pixel pitches; equality with the brute-force version is a CPU test).  Used for
+    long trajectories where the brute-force form would dominate the oracle's run time."""
+    u, v, d = project_points(points, cam)
+    r2 = np.float32(radius) * np.float32(radius)
+    n = points.shape[0]
+    xc = torch.round(((1.0 - u) * W - 1.0) * 0.5).long()
+    yc = torch.round(((1.0 - v) * H - 1.0) * 0.5).long()
+    offs = torch.arange(-win, win + 1)
+    yi = (yc[:, None, None] + offs[None, :, None]).expand(n, 2 * win + 1, 2 * win + 1)
+    xi = (xc[:, None, None] + offs[None, None, :]).expand(n, 2 * win + 1, 2 * win + 1)
+    yf = 1.0 - (2.0 * yi.float() + 1.0) / H
+    xf = 1.0 - (2.0 * xi.float() + 1.0) / W
+    dx, dy = xf - u[:, None, None], yf - v[:, None, None]
+    hit = (dx * dx + dy * dy < r2) & (d >= 0)[:, None, None] & (yi >= 0) & (yi < H) & (xi >= 0) & (xi < W)
+    pix = (yi * W + xi)[hit]
+    pid = torch.arange(n)[:, None, None].expand_as(hit)[hit]
+    z = d[:, None, None].expand_as(hit)[hit]
+    idx = torch.full((H * W,), -1, dtype=torch.int64)
+    if pix.numel():
+        # winner per pixel: smallest z, then smallest point index -> sort by (pixel, z, index), keep the first of each pixel
+        order = np.lexsort((pid.numpy(), z.numpy(), pix.numpy()))
+        pix_s, pid_s = pix.numpy()[order], pid.numpy()[order]
+        first = np.ones(len(order), dtype=bool)
+        first[1:] = pix_s[1:] != pix_s[:-1]
+        idx[torch.from_numpy(pix_s[first])] = torch.from_numpy(pid_s[first])
+    return idx.view(H, W)
+
+
+FAST_RASTER = True
+
+
 def surface_projection(points, cam, local_features, radius):
     """projection_model.py:127-157 for one sample: (N, C) features; sequential-assignment semantics for
     points owning several pixels (the LAST owned pixel in row-major order wins)."""
     C, H, W = local_features.shape
-    idx = rasterize_bruteforce(points, cam, H, W, radius)
+    idx = (rasterize_windowed if FAST_RASTER else rasterize_bruteforce)(points, cam, H, W, radius)
     out = torch.zeros(points.shape[0], C)
     visible = idx > -1
     pts = idx[visible]                       # row-major pixel order
     feats = local_features.permute(1, 2, 0)[visible]
-    for k in range(pts.shape[0]):            # later pixels overwrite earlier ones
-        out[pts[k]] = feats[k]
+    # later pixels overwrite earlier ones: keep, for every point, its LAST occurrence in row-major pixel order
+    if pts.numel():
+        last = torch.full((points.shape[0],), -1, dtype=torch.int64)
+        last.scatter_reduce_(0, pts, torch.arange(pts.shape[0]), reduce="amax", include_self=True)
+        sel = last >= 0
+        out[sel] = feats[last[sel]]
     return out
 
 

@@ -1,0 +1,68 @@
+"""Config C1 of BASELINE.json as a parity case: vanilla PC^2 sampling of ONE shape, N = 1024 points, 100 DDPM
+steps (leading spacing: t = 990, 980, ..., 0), projection conditioning at every step, identical injected noise on
+both sides.  HIP path vs CPU oracle.
+
+Criterion: the sampler contains discrete decisions (which pixel a point owns, ball-query membership,
+FPS arg-max, voxel rounding) that flip on 1-ulp input changes, and with random-init weights the denoiser amplifies a flip.
+The oracle's OWN sensitivity is therefore measured in the same test (same trajectory started from x0 perturbed by one
+float32 ulp) and the HIP path must satisfy  final rel-L2 <= max(1e-3, 4 x oracle self-sensitivity);  before the first
+flip (first 10 steps) it must stay below 1e-5."""
+import pytest
+import torch
+
+from helpers import rel_l2, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c1_vanilla_pc2_100_steps(hip, oracle_ops):
+    from bdm_amd.cameras import join_cameras
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.model import get_model
+    from bdm_amd.utils.procedural import fill_module_
+    from oracle import ref_net, ref_sampler as R
+    B, N, STEPS = 1, 1024, 100
+    cfg = ProjectConfig()
+    model = fill_module_(get_model(cfg).eval(), seed=11)
+    batch = next(iter(SyntheticShapes(range(B), B, seed=5, image_size=224, num_points=N)))
+    ts = list(range(1000 - 1000 // STEPS, -1, -(1000 // STEPS)))
+    noise = {t: seeded((B, N, 3), 3000 + t) for t in ts}
+    x0 = seeded((B, N, 3), 99)
+    # oracle
+    local = model.get_local_conditioning(batch.image_rgb)
+    cams = join_cameras(batch.camera).packed()
+    sd = model.state_dict()
+    ddpm = R.RefDDPM()
+
+    def oracle_run(start):
+        x, curve = start.clone(), []
+        for t in ts:
+            x_in = R.get_input_with_conditioning(x, cams, local)
+            eps = ref_net.point_cloud_model_forward(sd, x_in, torch.full((B,), t), prefix="point_cloud_model.model.")
+            x = ddpm.step(eps, t, x, noise[t] if t > 0 else None, prev_t=t - 1000 // STEPS)
+            curve.append(x.clone())
+        return curve
+
+    curve_ref = oracle_run(x0)
+    curve_pert = oracle_run(torch.nextafter(x0, torch.full_like(x0, float("inf"))))  # +1 ulp on every coordinate
+    self_sens = [rel_l2(a, b) for a, b in zip(curve_pert, curve_ref)]
+    # HIP path
+    model = model.cuda()
+    sched = model.schedulers_map["ddpm"]
+    sched.set_timesteps(STEPS)
+    assert [int(v) for v in sched.timesteps] == ts
+    it = iter([noise[t] for t in ts if t > 0])
+    sched.noise_source = lambda shape, dev: next(it).to(dev)
+    b = batch.to("cuda")
+    y, worst, curve = x0.cuda(), 0.0, []
+    for i, t in enumerate(ts):
+        y = model._denoise_loop(y, b.camera, b.image_rgb, None, sched, [t])
+        curve.append(rel_l2(y.cpu(), curve_ref[i]))
+        worst = max(worst, curve[-1])
+    print("divergence curve (every 10th step):", " ".join(f"{c:.1e}" for c in curve[::10]))
+    final = rel_l2(y.cpu(), curve_ref[-1])
+    print("oracle self-sensitivity (1 ulp)     :", " ".join(f"{c:.1e}" for c in self_sens[::10]))
+    print(f"C1 trajectory: final rel-L2 {final:.3e} (oracle self-sensitivity {self_sens[-1]:.3e}), worst {worst:.3e}")
+    assert max(curve[:10]) < 1e-5
+    assert final <= max(1e-3, 4 * self_sens[-1])

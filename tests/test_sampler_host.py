@@ -129,3 +129,21 @@ print("OK", rank)
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.count("OK") == 2
+
+
+def test_windowed_rasterizer_equals_bruteforce():
+    from bdm_amd.cameras import r2n2_camera
+    from oracle import ref_sampler as R
+    g = torch.Generator().manual_seed(4)
+    for H, radius, n in [(32, 0.05, 300), (64, 0.02, 800)]:
+        cam = r2n2_camera(75.0, 28.0, 1.5).packed()[0]
+        pts = torch.randn(n, 3, generator=g) * 0.3
+        pts[:5] = pts[5:10]
+        a = R.rasterize_bruteforce(pts, cam, H, H, radius)
+        b = R.rasterize_windowed(pts, cam, H, H, radius)
+        assert torch.equal(a, b)
+        feat = torch.randn(6, H, H, generator=g)
+        R.FAST_RASTER = False
+        slow = R.surface_projection(pts, cam, feat, radius)
+        R.FAST_RASTER = True
+        assert torch.equal(slow, R.surface_projection(pts, cam, feat, radius))
