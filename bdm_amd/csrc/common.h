@@ -65,4 +65,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// workspace layout of the deterministic voxeliser (pvcnn_ops.hip: vox_plan_kernel)
+struct VoxWs {
+  int *start;   // [b][r3]  exclusive prefix of the per-voxel counts
+  int *tmp;     // [b][n]
+  int *sorted;  // [b][n]   per-voxel point lists, ascending point index inside a voxel
+};
+static inline VoxWs vox_ws(void *ws, int b, int n, int r3) {
+  VoxWs w;
+  w.start = (int *)ws;
+  w.tmp = w.start + (size_t)b * r3;
+  w.sorted = w.tmp + (size_t)b * n;
+  return w;
+}
+
 }  // namespace bdm

@@ -334,6 +334,28 @@ __global__ void gn_apply_vec_kernel(int cg, int L, const float *__restrict__ x, 
   }
 }
 
+// (sum, sumsq) slice partials of a contiguous (b, c, l) tensor; *slices_out = number of slices per (shape, group)
+extern "C" int bdm_group_norm_stats(int b, int c, int l, int groups, const float *x, long long bs_x, void *workspace,
+                                    int *slices_out, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && l >= 1 && groups >= 1 && c % groups == 0 && workspace != nullptr, "group_norm_stats: bad arguments");
+  const int cg = c / groups;
+  const long long total = (long long)cg * l;
+  int S = (int)((total + 16383) / 16384);
+  if (S < 1) S = 1;
+  if (S > GN_MAX_SLICES) S = GN_MAX_SLICES;
+  *slices_out = S;
+  if (b == 0) return BDM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const bool packed = (l % 4 == 0) && ((((uintptr_t)x) & 15) == 0) && (bs_x % 4 == 0) && total < (1ll << 30);
+  if (packed)
+    hipLaunchKernelGGL(gn_stats_vec_kernel, dim3(S, b * groups), dim3(256), 0, s, cg, l, x, bs_x, (const float *)nullptr,
+                       0ll, groups, (double *)workspace);
+  else
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(S, b * groups), dim3(256), 0, s, cg, l, x, bs_x, l, (const float *)nullptr,
+                       0ll, 0, groups, (double *)workspace);
+  return launch_status("group_norm_stats");
+}
+
 extern "C" size_t bdm_group_norm_workspace_bytes(int b, int groups) {
   return sizeof(double) * 2 * (size_t)b * groups * GN_MAX_SLICES;
 }

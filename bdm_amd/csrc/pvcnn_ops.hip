@@ -351,18 +351,6 @@ extern "C" int bdm_three_nn_interpolate_forward(int b, int c, int m, int n, cons
 //   ind[i], cnt[v]  ->  start[v] (exclusive scan)  ->  per-voxel point lists, each list in
 //   ascending point index (unordered atomic fill, then rank-within-list placement).
 // Reduce kernel: out[c][v] = sum over list(v), in list order, of feat[c][p] * (1/cnt[v]).
-struct VoxWs {
-  int *start;   // [b][r3]
-  int *tmp;     // [b][n]
-  int *sorted;  // [b][n]
-};
-static inline VoxWs vox_ws(void *ws, int b, int n, int r3) {
-  VoxWs w;
-  w.start = (int *)ws;
-  w.tmp = w.start + (size_t)b * r3;
-  w.sorted = w.tmp + (size_t)b * n;
-  return w;
-}
 extern "C" size_t bdm_voxelize_workspace_bytes(int b, int n, int r) {
   return sizeof(int) * ((size_t)b * r * r * r + 2 * (size_t)b * n);
 }
@@ -436,19 +424,28 @@ __global__ void vox_reduce_kernel(int c, int n, int r3, const float *__restrict_
   }
 }
 
-extern "C" int bdm_avg_voxelize_forward(int b, int c, int n, int r, const float *features, const int *coords,
-                                        float *out, int *ind, int *cnt, void *workspace, void *stream) {
-  BDM_REQUIRE(b >= 0 && c >= 0 && n >= 1 && r >= 1 && r <= 32, "avg_voxelize: bad sizes (r<=32 supported)");
-  BDM_REQUIRE(workspace != nullptr, "avg_voxelize: workspace is NULL");
+extern "C" int bdm_voxelize_plan(int b, int n, int r, const int *coords, int *ind, int *cnt, void *workspace,
+                                 void *stream) {
+  BDM_REQUIRE(b >= 0 && n >= 1 && r >= 1 && r <= 32, "voxelize_plan: bad sizes (r<=32 supported)");
+  BDM_REQUIRE(workspace != nullptr, "voxelize_plan: workspace is NULL");
   if (b == 0) return BDM_OK;
-  hipStream_t s = (hipStream_t)stream;
   const int r3 = r * r * r;
   VoxWs w = vox_ws(workspace, b, n, r3);
   const size_t smem = (size_t)r3 * sizeof(int);
   BDM_ALLOW_LDS(vox_plan_kernel, smem);
-  hipLaunchKernelGGL(vox_plan_kernel, dim3(b), dim3(1024), smem, s, n, r, coords, ind, cnt, w.start, w.tmp,
-                     w.sorted);
-  int rc = launch_status("vox_plan");
+  hipLaunchKernelGGL(vox_plan_kernel, dim3(b), dim3(1024), smem, (hipStream_t)stream, n, r, coords, ind, cnt, w.start,
+                     w.tmp, w.sorted);
+  return launch_status("vox_plan");
+}
+
+extern "C" int bdm_avg_voxelize_forward(int b, int c, int n, int r, const float *features, const int *coords,
+                                        float *out, int *ind, int *cnt, void *workspace, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 0 && n >= 1 && r >= 1 && r <= 32, "avg_voxelize: bad sizes (r<=32 supported)");
+  if (b == 0) return BDM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int r3 = r * r * r;
+  int rc = bdm_voxelize_plan(b, n, r, coords, ind, cnt, workspace, stream);
+  VoxWs w = vox_ws(workspace, b, n, r3);
   if (rc || c == 0) return rc;
   dim3 grid(cdiv(r3, 256), c < 64 ? c : 64, b);
   hipLaunchKernelGGL(vox_reduce_kernel, grid, dim3(256), 0, s, c, n, r3, features, cnt, w.start, w.sorted, out);

@@ -7,6 +7,8 @@ The torch.nn layers held inside (nn.Conv1d, nn.Conv3d, nn.GroupNorm, nn.Linear) 
 CONTAINERS only: their forward is never called.  Every forward below runs hand-written gfx950
 kernels through the C ABI (bdm_amd/ops.py, bdm_amd/functional).  Inference only.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -152,12 +154,18 @@ class PVConv(nn.Module):
         self.point_features = SharedMLP(in_channels, out_channels)
         self._packed = {}
 
-    def _packed_weight(self, conv):
-        key = id(conv)
+    # Voxel-convolution arithmetic (both are fp32-accurate, tests/test_hip_dense.py):
+    #   "bf16x6": exact 3-way bf16 split of both operands, six partial products on the bf16 matrix cores (default);
+    #   "fp32"  : v_mfma_f32_32x32x2_f32 kernels of conv3d.hip (BDM_CONV=fp32).
+    conv_impl = os.environ.get("BDM_CONV", "bf16x6")
+
+    def _packed_weight(self, conv, impl):
+        key = (id(conv), impl)
         sig = (conv.weight._version, conv.weight.data_ptr())
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
-            hit = (sig, ops.conv3d_pack(conv.weight.detach()))
+            pack = ops.conv3d_s3_pack if impl == "bf16x6" else ops.conv3d_pack
+            hit = (sig, pack(conv.weight.detach()))
             self._packed[key] = hit
         return hit[1]
 
@@ -172,6 +180,18 @@ class PVConv(nn.Module):
         se = next((m for m in rest if isinstance(m, SE3d)), None)
 
         features = ops.materialize(features)
+        if self.conv_impl == "bf16x6":
+            norm_coords, vox_coords = ops.voxel_coords(coords, r, self.voxelization.eps)
+            x3 = ops.avg_voxelize_s3(features, vox_coords, r)
+            v = ops.conv3d_s3(x3, self._packed_weight(conv1, "bf16x6"), conv1.bias, conv1.in_channels, conv1.out_channels, r)
+            v3 = ops.to_s3(v, gn1, swish=True)  # GroupNorm + Swish fused into the operand split of the second conv
+            v = ops.conv3d_s3(v3, self._packed_weight(conv2, "bf16x6"), conv2.bias, conv2.in_channels, conv2.out_channels, r)
+            ops.group_norm_(v, gn2.weight, gn2.bias, 8, gn2.eps, swish=(att is None))
+            if att is not None:
+                v = att(v)
+            gate = se.gate(v) if se is not None else None
+            pf = self.point_features.run(features)
+            return ops.devoxelize_gate_add(norm_coords, v, r, gate=gate, add=pf), coords, temb
         # the first conv's input is the freshly voxelised cloud: on the 32^3 grids (<= 12.5 % occupied cells) the
         # occupancy-skipping variant wins (measured 1.3-1.4x); on 16^3 / 8^3 the dense kernel is as fast or faster
         sparse = r >= 32
@@ -179,9 +199,9 @@ class PVConv(nn.Module):
         rowocc = None
         if sparse:
             vox, rowocc = vox
-        v = ops.conv3d(vox, self._packed_weight(conv1), conv1.bias, r, rowocc=rowocc)
+        v = ops.conv3d(vox, self._packed_weight(conv1, "fp32"), conv1.bias, r, rowocc=rowocc)
         ops.group_norm_(v, gn1.weight, gn1.bias, 8, gn1.eps, swish=True)
-        v = ops.conv3d(v, self._packed_weight(conv2), conv2.bias, r)
+        v = ops.conv3d(v, self._packed_weight(conv2, "fp32"), conv2.bias, r)
         ops.group_norm_(v, gn2.weight, gn2.bias, 8, gn2.eps, swish=(att is None))
         if att is not None:
             v = att(v)

@@ -257,3 +257,52 @@ def conv3d(x, packed_w, bias, r, rowocc=None):
     L.check(L.lib().bdm_conv3d_3x3x3_sparse(B, cin, cout, int(r), L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(rowocc),
                                             L.ptr(y), L.stream()), "conv3d")
     return y
+
+
+# ---- bf16x6 ("S3") convolution path: fp32 accuracy on the bf16 matrix cores (csrc/conv3d_s3.hip) -------------------
+def conv3d_s3_pack(weight):
+    import ctypes
+    cout, cin = weight.shape[:2]
+    w = weight.contiguous()
+    L.lib().bdm_conv3d_s3_weight_elems.restype = ctypes.c_size_t
+    packed = torch.empty(L.lib().bdm_conv3d_s3_weight_elems(cout, cin), dtype=torch.bfloat16, device=w.device)
+    L.check(L.lib().bdm_conv3d_s3_pack_weights(cout, cin, L.ptr(w), L.ptr(packed), L.stream()), "conv3d_s3_pack_weights")
+    return packed
+
+
+def to_s3(x, gn=None, swish=False):
+    """x (B, C, V) fp32 contiguous -> S3 (B, ceil(C/8), 3, V, 8) bf16, optionally through GroupNorm(+Swish)."""
+    x = x.contiguous()
+    B, C = x.shape[:2]
+    V = x.numel() // (B * C)
+    out = torch.empty(B, (C + 7) // 8, 3, V, 8, dtype=torch.bfloat16, device=x.device)
+    if gn is not None:
+        ws = workspace(L.lib().bdm_group_norm_workspace_bytes(B, gn.num_groups), x.device, "gn")
+        L.check(L.lib().bdm_group_norm_to_s3(B, C, V, gn.num_groups, L.ptr(x), L.ptr(gn.weight), L.ptr(gn.bias),
+                                             L.c_float(gn.eps), 1 if swish else 0, L.ptr(out), L.ptr(ws), L.stream()),
+                "group_norm_to_s3")
+    else:
+        L.check(L.lib().bdm_group_norm_to_s3(B, C, V, 0, L.ptr(x), L.ptr(None), L.ptr(None), L.c_float(0.0), 0, L.ptr(out),
+                                             L.ptr(None), L.stream()), "to_s3")
+    return out
+
+
+def avg_voxelize_s3(features, vox_coords, r):
+    f, B, C, n, bs_f, ld_f = _bcl(features)
+    dev = f.device
+    out = torch.empty(B, (C + 7) // 8, 3, r ** 3, 8, dtype=torch.bfloat16, device=dev)
+    ind = torch.empty(B, n, dtype=torch.int32, device=dev)
+    cnt = torch.empty(B, r ** 3, dtype=torch.int32, device=dev)
+    ws = workspace(L.lib().bdm_voxelize_workspace_bytes(B, n, r), dev, "vox")
+    L.check(L.lib().bdm_avg_voxelize_s3(B, C, n, r, L.ptr(f), L.c_ll(bs_f), ld_f, L.ptr(vox_coords), L.ptr(out), L.ptr(ind),
+                                        L.ptr(cnt), L.ptr(ws), L.stream()), "avg_voxelize_s3")
+    return out
+
+
+def conv3d_s3(x_s3, packed_w, bias, cin, cout, r):
+    """x_s3 (B, ceil(cin/8), 3, r^3, 8) bf16 -> (B, cout, r^3) fp32."""
+    B = x_s3.shape[0]
+    y = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=x_s3.device)
+    L.check(L.lib().bdm_conv3d_3x3x3_s3(B, cin, cout, int(r), L.ptr(x_s3), L.ptr(packed_w), L.ptr(bias), L.ptr(y), L.stream()),
+            "conv3d_s3")
+    return y

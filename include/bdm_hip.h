@@ -180,6 +180,25 @@ int bdm_voxel_row_occupancy(int b, int r, const int *cnt, unsigned char *rowocc,
 int bdm_conv3d_3x3x3_sparse(int b, int cin, int cout, int r, const float *x, const float *packed_w,
                             const float *bias, const unsigned char *rowocc, float *y, void *stream);
 
+/* --- the same convolution at fp32 accuracy on the BF16 matrix cores ("bf16x6", conv3d_s3.hip) ---
+ * Every fp32 operand is split exactly into three bf16 terms and the six leading partial products are accumulated in
+ * fp32 (dropped terms <= 2^-23 of the product).  Activations travel in the S3 layout (b, ceil(c/8), 3, r^3, 8) bf16,
+ * produced directly by the voxeliser and by the GroupNorm(+Swish) between the two convolutions of a PVConv. */
+size_t bdm_conv3d_s3_weight_elems(int cout, int cin);   /* number of bf16 elements of the packed weights */
+int bdm_conv3d_s3_pack_weights(int cout, int cin, const float *w, void *packed, void *stream);
+int bdm_conv3d_3x3x3_s3(int b, int cin, int cout, int r, const void *x_s3, const void *packed_w,
+                        const float *bias, float *y, void *stream);
+/* x (b, c, v) fp32 contiguous -> S3 of GroupNorm(groups)(x) [Swish when act == 1]; groups == 0: plain conversion.
+ * workspace: bdm_group_norm_workspace_bytes. */
+int bdm_group_norm_to_s3(int b, int c, int v, int groups, const float *x, const float *gamma,
+                         const float *beta, float eps, int act, void *out_s3, void *workspace, void *stream);
+int bdm_group_norm_stats(int b, int c, int l, int groups, const float *x, long long bs_x, void *workspace,
+                         int *slices_out, void *stream);
+/* avg_voxelize_forward writing S3 (features strided: bs_f, ld_f); same deterministic summation order. */
+int bdm_voxelize_plan(int b, int n, int r, const int *coords, int *ind, int *cnt, void *workspace, void *stream);
+int bdm_avg_voxelize_s3(int b, int c, int n, int r, const float *features, long long bs_f, int ld_f,
+                        const int *coords, void *out_s3, int *ind, int *cnt, void *workspace, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * 3. Per-step glue of the coupled DDPM loop
  * ---------------------------------------------------------------------------------- */

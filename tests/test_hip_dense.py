@@ -185,3 +185,42 @@ def test_conv3d_sparse_input_bit_identical(ops, cin, cout, r, npts):
     assert torch.equal(dense, sparse)
     ref = TF.conv3d(vox.cpu().double().view(B, cin, r, r, r), w.double(), bias.double(), padding=1).float().reshape(B, cout, -1)
     assert rel(sparse.cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("cin,cout,r", [(35, 32, 32), (64, 64, 32), (128, 64, 16), (128, 128, 16), (192, 128, 8),
+                                        (256, 256, 8), (7, 8, 8), (390, 32, 32)])
+def test_conv3d_bf16x6_has_fp32_accuracy(ops, cin, cout, r):
+    """split-bf16 (6 partial products) convolution: error vs fp64 must be at the fp32-MFMA kernel's level."""
+    B = 2
+    g = torch.Generator().manual_seed(cin * cout + r)
+    x = torch.randn(B, cin, r ** 3, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = TF.conv3d(x.double().view(B, cin, r, r, r), w.double(), b.double(), padding=1).float().reshape(B, cout, -1)
+    xs = ops.to_s3(x.cuda())
+    got = ops.conv3d_s3(xs, ops.conv3d_s3_pack(w.cuda()), b.cuda(), cin, cout, r).cpu()
+    fp32 = ops.conv3d(x.cuda(), ops.conv3d_pack(w.cuda()), b.cuda(), r).cpu()
+    e6, e32 = rel(got, ref), rel(fp32, ref)
+    assert e6 < 2e-6 and e6 < 4 * e32 + 1e-7, (e6, e32)
+
+
+def test_s3_producers(ops, oracle_ops):
+    """GroupNorm(+Swish)->S3 and voxelise->S3 reconstruct (hi+mid+lo) the fp32 values of the fp32 kernels."""
+    g = torch.Generator().manual_seed(8)
+    B, C, r, n = 2, 35, 16, 1000
+
+    def unsplit(s3, C):
+        f = s3.float().sum(2)  # (B, C8, V, 8)
+        return f.permute(0, 1, 3, 2).reshape(s3.shape[0], -1, s3.shape[3])[:, :C]
+    x = torch.randn(B, 40, r ** 3, generator=g) * 2 + 0.5
+    gn = torch.nn.GroupNorm(8, 40)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(40, generator=g)); gn.bias.copy_(torch.randn(40, generator=g))
+    ref = ops.group_norm_(x.clone().cuda(), gn.weight.cuda(), gn.bias.cuda(), swish=True).cpu()
+    got = unsplit(ops.to_s3(x.cuda(), gn.cuda(), swish=True).cpu(), 40)
+    assert rel(got, ref) < 3e-7
+    vc = torch.randint(0, r, (B, 3, n), generator=g, dtype=torch.int32)
+    f = torch.randn(B, C, n, generator=g)
+    ref = oracle_ops.avg_voxelize_forward(f, vc, r)[0]
+    got = unsplit(ops.avg_voxelize_s3(f.cuda(), vc.cuda(), r).cpu(), C)
+    assert float((got - ref).abs().max()) <= 2e-7 * float(ref.abs().max())  # exact 24-bit split up to the last rounding

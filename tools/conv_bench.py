@@ -38,3 +38,16 @@ pats = {"slab x<8": xs < 8, "slab y<8": ys < 8, "disc r=11": (xs - 15.5) ** 2 + 
 for name, m in pats.items():
     ro = m.reshape(1, -1).expand(B, -1).contiguous().to(torch.uint8).cuda()
     print(f"{name:12s} frac={float(m.float().mean()):.2f}  {t(lambda: ops.conv3d(vox, w, bias, r, rowocc=ro)):8.1f} us")
+
+print("--- bf16x6 vs fp32 MFMA")
+for cin, cout, r in [(64, 64, 32), (390, 32, 32), (32, 32, 32), (128, 128, 16), (128, 64, 16), (256, 256, 8)]:
+    x = torch.randn(B, cin, r ** 3).cuda()
+    wt = (torch.randn(cout, cin, 3, 3, 3) / (27 * cin) ** 0.5).cuda()
+    bias = torch.zeros(cout).cuda()
+    w32, w16 = ops.conv3d_pack(wt), ops.conv3d_s3_pack(wt)
+    xs = ops.to_s3(x)
+    fl = 2 * 27 * cin * cout * r ** 3 * B
+    t32 = t(lambda: ops.conv3d(x, w32, bias, r))
+    t16 = t(lambda: ops.conv3d_s3(xs, w16, bias, cin, cout, r))
+    tcv = t(lambda: ops.to_s3(x))
+    print(f"{cin:4d}->{cout:4d} r={r:2d}  fp32 {t32:7.1f} us ({fl/t32/1e6:6.1f} TF/s)   bf16x6 {t16:7.1f} us ({fl/t16/1e6:6.1f} TF/s)   to_s3 {tcv:6.1f} us")
