@@ -25,8 +25,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // stored k-major in LDS so A-operand reads are conflict-free too.
 // Tile: (32*MI) x (128*NI) per 256-thread workgroup, K chunk 16, 4 waves side by side along N.
 #define PW_BK 16
-template <int MI, int NI>
+template <int MI, int NI, bool ATRANS = false>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const float *__restrict__ W, int ldw,
+                                                      long long bsw, const int *__restrict__ m_count,
                                                       const float *__restrict__ X, long long bsx, int ldx,
                                                       const float *__restrict__ bias,
                                                       const float *__restrict__ bbias, int ldbb,
@@ -38,6 +39,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
   __shared__ __align__(16) float Bs[PW_BK * BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, bi = blockIdx.z;
+  if (m_count && m0 >= m_count[bi]) return;  // rows beyond this shape's live count (sparse convolution GEMM)
+  W += (size_t)bi * bsw;
   const float *Xb = X + (size_t)bi * bsx;
   float *Yb = Y + (size_t)bi * bsy;
   const bool vec_ok = ((ldx & 3) == 0) && ((((uintptr_t)Xb) & 15) == 0);
@@ -57,8 +60,14 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
   auto load_chunk = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int e = tid + i * 256, m = e >> 4, k = e & 15;
-      ar[i] = (m0 + m < M && k0 + k < K) ? W[(size_t)(m0 + m) * ldw + k0 + k] : 0.f;
+      const int e = tid + i * 256;
+      if constexpr (ATRANS) {  // A given as A^T (K x M, row stride ldw): coalesced along m
+        const int m = e % BM, k = e / BM;
+        ar[i] = (m0 + m < M && k0 + k < K) ? W[(size_t)(k0 + k) * ldw + m0 + m] : 0.f;
+      } else {
+        const int m = e >> 4, k = e & 15;
+        ar[i] = (m0 + m < M && k0 + k < K) ? W[(size_t)(m0 + m) * ldw + k0 + k] : 0.f;
+      }
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -83,7 +92,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int e = tid + i * 256, m = e >> 4, k = e & 15;
+      const int e = tid + i * 256;
+      const int m = ATRANS ? e % BM : e >> 4, k = ATRANS ? e / BM : e & 15;
       As[k * LDA + m] = ar[i];
     }
 #pragma unroll
@@ -138,7 +148,8 @@ extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, in
   hipStream_t s = (hipStream_t)stream;
 #define PW_LAUNCH(MI, NI)                                                                                   \
   hipLaunchKernelGGL((pw_gemm_kernel<MI, NI>), dim3(cdiv(n, 128 * NI), cdiv(m, 32 * MI), b), dim3(256), 0, s, \
-                     m, k, n, w, ldw, x, bs_x, ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r, y, bs_y, ld_y, act, slope)
+                     m, k, n, w, ldw, 0ll, (const int *)nullptr, x, bs_x, ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r,  \
+                     y, bs_y, ld_y, act, slope)
   if (m <= 32) {
     if (n <= 128) PW_LAUNCH(1, 1); else PW_LAUNCH(1, 2);
   } else {
@@ -146,6 +157,19 @@ extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, in
   }
 #undef PW_LAUNCH
   return launch_status("pointwise_conv");
+}
+
+// Sparse first-convolution GEMM (sparse_conv.hip): Y[b] (n_max x n27) = Xc[b]^T (n_max x cin) . Wt (cin x n27), rows
+// >= n_occ[b] skipped.  Xc is channel-first (b, cin, n_max): the A operand arrives transposed.
+extern "C" int bdm_sparse_conv_gemm(int b, int n_max, int cin, int n27, const float *xc, const float *wt,
+                                    const int *n_occ, float *y, void *stream) {
+  BDM_REQUIRE(b >= 0 && n_max >= 1 && cin >= 1 && n27 >= 1, "sparse_conv_gemm: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL((pw_gemm_kernel<2, 2, true>), dim3(cdiv(n27, 256), cdiv(n_max, 64), b), dim3(256), 0,
+                     (hipStream_t)stream, n_max, cin, n27, xc, n_max, (long long)cin * n_max, n_occ, wt, 0ll, n27,
+                     (const float *)nullptr, (const float *)nullptr, 0, (const float *)nullptr, 0ll, 0, y,
+                     (long long)n_max * n27, n27, 0, 0.f);
+  return launch_status("sparse_conv_gemm");
 }
 
 // =====================================================================================

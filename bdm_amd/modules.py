@@ -158,13 +158,14 @@ class PVConv(nn.Module):
     #   "bf16x6": exact 3-way bf16 split of both operands, six partial products on the bf16 matrix cores (default);
     #   "fp32"  : v_mfma_f32_32x32x2_f32 kernels of conv3d.hip (BDM_CONV=fp32).
     conv_impl = os.environ.get("BDM_CONV", "bf16x6")
+    sparse_first_conv = os.environ.get("BDM_SPARSE_CONV1", "1") == "1"
 
     def _packed_weight(self, conv, impl):
         key = (id(conv), impl)
         sig = (conv.weight._version, conv.weight.data_ptr())
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
-            pack = ops.conv3d_s3_pack if impl == "bf16x6" else ops.conv3d_pack
+            pack = {"bf16x6": ops.conv3d_s3_pack, "sparse": ops.sparse_conv_pack, "fp32": ops.conv3d_pack}[impl]
             hit = (sig, pack(conv.weight.detach()))
             self._packed[key] = hit
         return hit[1]
@@ -182,8 +183,14 @@ class PVConv(nn.Module):
         features = ops.materialize(features)
         if self.conv_impl == "bf16x6":
             norm_coords, vox_coords = ops.voxel_coords(coords, r, self.voxelization.eps)
-            x3 = ops.avg_voxelize_s3(features, vox_coords, r)
-            v = ops.conv3d_s3(x3, self._packed_weight(conv1, "bf16x6"), conv1.bias, conv1.in_channels, conv1.out_channels, r)
+            if self.sparse_first_conv:
+                # conv1 sees the freshly voxelised cloud: evaluate it on the occupied cells only (sparse_conv.hip)
+                v = ops.sparse_first_conv(features, vox_coords, r, self._packed_weight(conv1, "sparse"), conv1.bias,
+                                          conv1.out_channels)
+            else:
+                x3 = ops.avg_voxelize_s3(features, vox_coords, r)
+                v = ops.conv3d_s3(x3, self._packed_weight(conv1, "bf16x6"), conv1.bias, conv1.in_channels,
+                                  conv1.out_channels, r)
             v3 = ops.to_s3(v, gn1, swish=True)  # GroupNorm + Swish fused into the operand split of the second conv
             v = ops.conv3d_s3(v3, self._packed_weight(conv2, "bf16x6"), conv2.bias, conv2.in_channels, conv2.out_channels, r)
             ops.group_norm_(v, gn2.weight, gn2.bias, 8, gn2.eps, swish=(att is None))

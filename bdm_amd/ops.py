@@ -306,3 +306,42 @@ def conv3d_s3(x_s3, packed_w, bias, cin, cout, r):
     L.check(L.lib().bdm_conv3d_3x3x3_s3(B, cin, cout, int(r), L.ptr(x_s3), L.ptr(packed_w), L.ptr(bias), L.ptr(y), L.stream()),
             "conv3d_s3")
     return y
+
+
+# ---- sparse first convolution of a PVConv (csrc/sparse_conv.hip) ----------------------------------------------------
+def sparse_conv_pack(weight):
+    cout, cin = weight.shape[:2]
+    wt = torch.empty(cin, 27 * cout, dtype=torch.float32, device=weight.device)
+    L.check(L.lib().bdm_sparse_conv_pack_weights(cout, cin, L.ptr(weight.contiguous()), L.ptr(wt), L.stream()),
+            "sparse_conv_pack_weights")
+    return wt
+
+
+def sparse_first_conv(features, vox_coords, r, wt, bias, cout):
+    """Conv3d(k3, p1)(avg_voxelize(features, vox_coords, r)) evaluated on the occupied voxels: (B, cout, r^3) fp32."""
+    f, B, C, n, bs_f, ld_f = _bcl(features)
+    dev = f.device
+    r3 = r ** 3
+    n_max = min(n, r3)
+    ind = torch.empty(B, n, dtype=torch.int32, device=dev)
+    cnt = torch.empty(B, r3, dtype=torch.int32, device=dev)
+    ws = workspace(L.lib().bdm_voxelize_workspace_bytes(B, n, r), dev, "vox")
+    lib = L.lib()
+    L.check(lib.bdm_voxelize_plan(B, n, r, L.ptr(vox_coords), L.ptr(ind), L.ptr(cnt), L.ptr(ws), L.stream()), "voxelize_plan")
+    occ_index = torch.empty(B, r3, dtype=torch.int32, device=dev)
+    occ_list = torch.empty(B, n_max, dtype=torch.int32, device=dev)
+    n_occ = torch.empty(B, dtype=torch.int32, device=dev)
+    rowocc = torch.empty(B, r * r, dtype=torch.uint8, device=dev)
+    L.check(lib.bdm_voxel_compact(B, r, n_max, L.ptr(cnt), L.ptr(occ_index), L.ptr(occ_list), L.ptr(n_occ), L.stream()),
+            "voxel_compact")
+    L.check(lib.bdm_voxel_row_occupancy(B, r, L.ptr(cnt), L.ptr(rowocc), L.stream()), "voxel_row_occupancy")
+    xc = torch.empty(B, C, n_max, dtype=torch.float32, device=dev)
+    L.check(lib.bdm_sparse_voxel_features(B, C, n, r, n_max, L.ptr(f), L.c_ll(bs_f), ld_f, L.ptr(cnt), L.ptr(ws),
+                                          L.ptr(occ_list), L.ptr(n_occ), L.ptr(xc), L.stream()), "sparse_voxel_features")
+    y = torch.empty(B, n_max, 27 * cout, dtype=torch.float32, device=dev)
+    L.check(lib.bdm_sparse_conv_gemm(B, n_max, C, 27 * cout, L.ptr(xc), L.ptr(wt), L.ptr(n_occ), L.ptr(y), L.stream()),
+            "sparse_conv_gemm")
+    out = torch.empty(B, cout, r3, dtype=torch.float32, device=dev)
+    L.check(lib.bdm_sparse_conv_gather(B, cout, r, n_max, L.ptr(y), L.ptr(occ_index), L.ptr(rowocc), L.ptr(bias), L.ptr(out),
+                                       L.stream()), "sparse_conv_gather")
+    return out

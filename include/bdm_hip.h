@@ -199,6 +199,25 @@ int bdm_voxelize_plan(int b, int n, int r, const int *coords, int *ind, int *cnt
 int bdm_avg_voxelize_s3(int b, int c, int n, int r, const float *features, long long bs_f, int ld_f,
                         const int *coords, void *out_s3, int *ind, int *cnt, void *workspace, void *stream);
 
+/* --- first convolution of a PVConv on the occupied voxels only (sparse_conv.hip) ---
+ * out = Conv3d(avg_voxelize(features)) without materialising the dense grid:
+ *   bdm_voxel_compact          cnt (b, r^3) -> occ_index (b, r^3) [-1 = empty], occ_list (b, n_max), n_occ (b)
+ *   bdm_sparse_voxel_features  per-voxel mean features of the occupied cells, xc (b, c, n_max) (zeros beyond n_occ);
+ *                              plan_workspace = the workspace bdm_voxelize_plan filled
+ *   bdm_sparse_conv_gemm       y (b, n_max, 27*cout) = xc^T . wt,   wt = bdm_sparse_conv_pack_weights(w) (cin, 27*cout)
+ *   bdm_sparse_conv_gather     out (b, cout, r^3) = bias + sum over taps (fixed order) of the occupied neighbours' y rows
+ * Deterministic; equals bdm_conv3d_3x3x3(avg_voxelize) up to fp32 summation order. */
+int bdm_voxel_compact(int b, int r, int n_max, const int *cnt, int *occ_index, int *occ_list, int *n_occ,
+                      void *stream);
+int bdm_sparse_voxel_features(int b, int c, int n, int r, int n_max, const float *features, long long bs_f,
+                              int ld_f, const int *cnt, const void *plan_workspace, const int *occ_list,
+                              const int *n_occ, float *xc, void *stream);
+int bdm_sparse_conv_pack_weights(int cout, int cin, const float *w, float *wt, void *stream);
+int bdm_sparse_conv_gemm(int b, int n_max, int cin, int n27, const float *xc, const float *wt,
+                         const int *n_occ, float *y, void *stream);
+int bdm_sparse_conv_gather(int b, int cout, int r, int n_max, const float *y, const int *occ_index,
+                           const unsigned char *rowocc, const float *bias, float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * 3. Per-step glue of the coupled DDPM loop
  * ---------------------------------------------------------------------------------- */

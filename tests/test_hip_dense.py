@@ -224,3 +224,25 @@ def test_s3_producers(ops, oracle_ops):
     ref = oracle_ops.avg_voxelize_forward(f, vc, r)[0]
     got = unsplit(ops.avg_voxelize_s3(f.cuda(), vc.cuda(), r).cpu(), C)
     assert float((got - ref).abs().max()) <= 2e-7 * float(ref.abs().max())  # exact 24-bit split up to the last rounding
+
+
+@pytest.mark.parametrize("cin,cout,r,npts", [(35, 32, 32, 4096), (390, 32, 32, 4096), (64, 64, 32, 1100), (128, 64, 16, 1024),
+                                             (256, 256, 8, 64), (192, 128, 8, 256), (16, 8, 8, 2000)])
+def test_sparse_first_conv_equals_dense(ops, oracle_ops, cin, cout, r, npts):
+    """Conv3d(avg_voxelize(f)) on the occupied voxels only == the dense evaluation (fp32 summation order aside)."""
+    B = 2
+    g = torch.Generator().manual_seed(cin + r + npts)
+    vc = (torch.randn(B, 3, npts, generator=g) * r / 8 + r / 2).round().clamp(0, r - 1).to(torch.int32)
+    vc[1, :, : npts // 2] = 0  # many points in one corner voxel, incl. the grid boundary
+    f = torch.randn(B, cin, npts, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    vox = oracle_ops.avg_voxelize_forward(f, vc, r)[0]
+    ref = TF.conv3d(vox.double().view(B, cin, r, r, r), w.double(), bias.double(), padding=1).float().reshape(B, cout, -1)
+    got = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack(w.cuda()), bias.cuda(), cout).cpu()
+    assert rel(got, ref) < 2e-6
+    # runs of a concat buffer (strided features) give the same result
+    big = torch.randn(B, cin + 6, npts, generator=g).cuda()
+    big[:, 3:3 + cin] = f.cuda()
+    got2 = ops.sparse_first_conv(big[:, 3:3 + cin], vc.cuda(), r, ops.sparse_conv_pack(w.cuda()), bias.cuda(), cout).cpu()
+    assert torch.equal(got, got2)
