@@ -46,13 +46,22 @@ using namespace bdm;
 // Ordering key: (distance bits, ~rank) with rank(k) = (k mod 512) * Q + k / 512,
 // Q = ceil(n / 512): the lexicographic (k mod 512, k) preference of the reference's
 // 512-thread scan + tree (sampling.cu:120-160) as a single u64 max.
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long w = __shfl_xor(v, o, 64);
-    v = w > v ? w : v;
-  }
-  return v;
+// 64-lane max of a u32 in ~10 instructions: rotate-and-max inside each row of 16 lanes with DPP (no LDS crossbar
+// round trips), then one readlane per row.  The result is wave-uniform (SGPR).
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  unsigned t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
+  v = v > t ? v : t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);  // row_ror:4
+  v = v > t ? v : t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);  // row_ror:2
+  v = v > t ? v : t;
+  t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);  // row_ror:1
+  v = v > t ? v : t;
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
 }
 
 template <int PPT>
@@ -64,8 +73,8 @@ __global__ void fps_kernel(int n, int m, const float *__restrict__ coords, int *
   int *out = indices + (size_t)blockIdx.x * m;
   float *cen = centers_out ? centers_out + (size_t)blockIdx.x * 3 * m : nullptr;
 
-  unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_raw);  // [2][16]
-  float *sx = reinterpret_cast<float *>(smem_raw + 2 * 16 * sizeof(unsigned long long));
+  uint2 *slots = reinterpret_cast<uint2 *>(smem_raw);  // [2][16] (distance bits, ~rank)
+  float *sx = reinterpret_cast<float *>(smem_raw + 2 * 16 * sizeof(uint2));
   float *sy = sx + n, *sz = sy + n;
 
   const unsigned Q = (unsigned)((n + 511) / 512);
@@ -80,7 +89,7 @@ __global__ void fps_kernel(int n, int m, const float *__restrict__ coords, int *
       inv_rank[i] = 0xFFFFFFFFu - ((unsigned)(k & 511) * Q + (unsigned)(k >> 9));
     } else {
       px[i] = py[i] = pz[i] = 0.f;
-      inv_rank[i] = 0u;  // key 0 never wins
+      inv_rank[i] = 0u;  // never wins
     }
     dist[i] = 1e38f;  // sampling.cpp:53-54
   }
@@ -95,25 +104,29 @@ __global__ void fps_kernel(int n, int m, const float *__restrict__ coords, int *
     float x1, y1, z1;
     if (use_lds) { x1 = sx[cur]; y1 = sy[cur]; z1 = sz[cur]; }
     else { x1 = cx[cur]; y1 = cy[cur]; z1 = cz[cur]; }
-    unsigned long long best = 0ull;
+    // per-thread best under the order (distance, ~rank); distances are >= 0 so their bits order like unsigned ints
+    unsigned bd = 0u, br = 0u;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       const float d = sqdist3(px[i], py[i], pz[i], x1, y1, z1);
       const float d2 = fminf(d, dist[i]);
       dist[i] = d2;
-      const unsigned long long key =
-          inv_rank[i] ? (((unsigned long long)__float_as_uint(d2) << 32) | inv_rank[i]) : 0ull;
-      best = key > best ? key : best;
+      const unsigned db = inv_rank[i] ? __float_as_uint(d2) : 0u;
+      const bool better = db > bd || (db == bd && inv_rank[i] > br);
+      bd = better ? db : bd;
+      br = better ? inv_rank[i] : br;
     }
-    best = wave_max_u64(best);
-    unsigned long long *slot = slots + (j & 1) * 16;
+    unsigned wd = wave_max_u32(bd);
+    unsigned wr = wave_max_u32(bd == wd ? br : 0u);
     if (nwaves > 1) {
-      if (lane == 0) slot[wave] = best;
+      uint2 *slot = slots + (j & 1) * 16;
+      if (lane == 0) slot[wave] = make_uint2(wd, wr);
       __syncthreads();
-      best = lane < nwaves ? slot[lane] : 0ull;
-      best = wave_max_u64(best);
+      const uint2 sv = lane < nwaves ? slot[lane] : make_uint2(0u, 0u);
+      wd = wave_max_u32(sv.x);
+      wr = wave_max_u32(sv.x == wd ? sv.y : 0u);
     }
-    const unsigned rank = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
+    const unsigned rank = 0xFFFFFFFFu - wr;
     cur = (int)((rank % Q) * 512u + rank / Q);
     if (tid == 0) {
       out[j] = cur;
@@ -138,7 +151,7 @@ extern "C" int bdm_furthest_point_sampling(int b, int n, int m, const float *coo
   while ((n + ppt - 1) / ppt > 1024) ppt *= 2;
   int T = ((n + ppt - 1) / ppt + 63) / 64 * 64;
   const int use_lds = n <= 12288;
-  const size_t smem = 2 * 16 * sizeof(unsigned long long) + (use_lds ? (size_t)3 * n * sizeof(float) : 0);
+  const size_t smem = 2 * 16 * sizeof(uint2) + (use_lds ? (size_t)3 * n * sizeof(float) : 0);
 #define FPS_LAUNCH(P)                                                                                   \
   do {                                                                                                  \
     BDM_ALLOW_LDS(fps_kernel<P>, smem);                                                                 \

@@ -182,12 +182,15 @@ class PVConv(nn.Module):
 
         features = ops.materialize(features)
         if self.conv_impl == "bf16x6":
-            norm_coords, vox_coords = ops.voxel_coords(coords, r, self.voxelization.eps)
             if self.sparse_first_conv:
-                # conv1 sees the freshly voxelised cloud: evaluate it on the occupied cells only (sparse_conv.hip)
-                v = ops.sparse_first_conv(features, vox_coords, r, self._packed_weight(conv1, "sparse"), conv1.bias,
-                                          conv1.out_channels)
+                # conv1 sees the freshly voxelised cloud: evaluate it on the occupied cells only (sparse_conv.hip);
+                # the (coords, r) plan is shared by the PVConvs of one level
+                plan = ops.voxel_plan(coords, r, self.voxelization.eps)
+                norm_coords = plan.norm_coords
+                v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, "sparse"), conv1.bias,
+                                                  conv1.out_channels)
             else:
+                norm_coords, vox_coords = ops.voxel_coords(coords, r, self.voxelization.eps)
                 x3 = ops.avg_voxelize_s3(features, vox_coords, r)
                 v = ops.conv3d_s3(x3, self._packed_weight(conv1, "bf16x6"), conv1.bias, conv1.in_channels,
                                   conv1.out_channels, r)

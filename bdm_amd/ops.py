@@ -317,6 +317,62 @@ def sparse_conv_pack(weight):
     return wt
 
 
+class VoxelPlan:
+    """Everything that depends on (coords, r) only: normalised / integer voxel coordinates, per-voxel point lists,
+    occupied-cell compaction and row occupancy.  PVConvs of one level share it (exactly the same values)."""
+    __slots__ = ("r", "n", "n_max", "norm_coords", "vox_coords", "ind", "cnt", "ws", "occ_index", "occ_list", "n_occ", "rowocc")
+
+
+_plan_cache = {}
+
+
+def clear_plan_cache():
+    _plan_cache.clear()
+
+
+def voxel_plan(coords, r, eps=0.0):
+    key = (coords.data_ptr(), coords._version, tuple(coords.shape), int(r))
+    p = _plan_cache.get(key)
+    if p is not None:
+        return p
+    lib = L.lib()
+    B, _, n = coords.shape
+    dev = coords.device
+    r3 = r ** 3
+    p = VoxelPlan()
+    p.r, p.n, p.n_max = int(r), n, min(n, r3)
+    p.norm_coords, p.vox_coords = voxel_coords(coords, r, eps)
+    p.ind = torch.empty(B, n, dtype=torch.int32, device=dev)
+    p.cnt = torch.empty(B, r3, dtype=torch.int32, device=dev)
+    p.ws = torch.empty(lib.bdm_voxelize_workspace_bytes(B, n, r), dtype=torch.uint8, device=dev)
+    L.check(lib.bdm_voxelize_plan(B, n, r, L.ptr(p.vox_coords), L.ptr(p.ind), L.ptr(p.cnt), L.ptr(p.ws), L.stream()), "voxelize_plan")
+    p.occ_index = torch.empty(B, r3, dtype=torch.int32, device=dev)
+    p.occ_list = torch.empty(B, p.n_max, dtype=torch.int32, device=dev)
+    p.n_occ = torch.empty(B, dtype=torch.int32, device=dev)
+    p.rowocc = torch.empty(B, r * r, dtype=torch.uint8, device=dev)
+    L.check(lib.bdm_voxel_compact(B, r, p.n_max, L.ptr(p.cnt), L.ptr(p.occ_index), L.ptr(p.occ_list), L.ptr(p.n_occ), L.stream()),
+            "voxel_compact")
+    L.check(lib.bdm_voxel_row_occupancy(B, r, L.ptr(p.cnt), L.ptr(p.rowocc), L.stream()), "voxel_row_occupancy")
+    _plan_cache[key] = p
+    return p
+
+
+def sparse_first_conv_planned(features, plan, wt, bias, cout):
+    """Conv3d(k3, p1)(avg_voxelize(features)) on the occupied voxels of `plan`: (B, cout, r^3) fp32."""
+    f, B, C, n, bs_f, ld_f = _bcl(features)
+    dev, lib, r = f.device, L.lib(), plan.r
+    xc = torch.empty(B, C, plan.n_max, dtype=torch.float32, device=dev)
+    L.check(lib.bdm_sparse_voxel_features(B, C, n, r, plan.n_max, L.ptr(f), L.c_ll(bs_f), ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),
+                                          L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xc), L.stream()), "sparse_voxel_features")
+    y = torch.empty(B, plan.n_max, 27 * cout, dtype=torch.float32, device=dev)
+    L.check(lib.bdm_sparse_conv_gemm(B, plan.n_max, C, 27 * cout, L.ptr(xc), L.ptr(wt), L.ptr(plan.n_occ), L.ptr(y), L.stream()),
+            "sparse_conv_gemm")
+    out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
+    L.check(lib.bdm_sparse_conv_gather(B, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index), L.ptr(plan.rowocc), L.ptr(bias),
+                                       L.ptr(out), L.stream()), "sparse_conv_gather")
+    return out
+
+
 def sparse_first_conv(features, vox_coords, r, wt, bias, cout):
     """Conv3d(k3, p1)(avg_voxelize(features, vox_coords, r)) evaluated on the occupied voxels: (B, cout, r^3) fp32."""
     f, B, C, n, bs_f, ld_f = _bcl(features)
