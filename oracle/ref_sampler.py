@@ -212,3 +212,34 @@ def bdm_blending(sd_pc2, sd_pvd, x_init, cams, local_features, milestones, roll_
             k += 1
             x = torch.where(m, pri, rec)
     return x
+
+
+def nstep_fuse(sd_fuse, prior, recon, cams, local_features, t, z, prefix="fusion_model.model."):
+    """model.py:510-570: centre both clouds, condition the recon cloud, PVCNN_fuse forward, one DDPM step on recon."""
+    prior = prior - prior.mean(dim=1, keepdim=True)
+    recon = recon - recon.mean(dim=1, keepdim=True)
+    B = recon.shape[0]
+    x_in = get_input_with_conditioning(recon, cams, local_features)
+    eps = ref_net.pvcnn_fuse_forward(sd_fuse, x_in.transpose(1, 2), prior.transpose(1, 2), torch.full((B,), t), prefix=prefix,
+                                     mode="fusion_nstep").transpose(1, 2)
+    return RefDDPM().step(eps, t, recon, z if t > 0 else None)
+
+
+def bdm_merging(sd_pc2, sd_pvd, sd_fuse, x_init, cams, local_features, fuse_local_features, milestones, roll_step, recon_noise,
+                branch_noise, prior_noise, fuse_noise):
+    """main_merging.py:415-520: branches run roll_step-1 steps, the last step of each window is the fused step."""
+    x = x_init - x_init.mean(dim=1, keepdim=True)
+    times = len(milestones) - 1
+    for i in range(times):
+        if i == 0:
+            x = interaction_sample(sd_pc2, x, cams, local_features, milestones[i], milestones[i + 1] - roll_step, recon_noise)
+        elif i == times - 1:
+            x = interaction_sample(sd_pc2, x, cams, local_features, milestones[i] - roll_step, milestones[i + 1], recon_noise)
+        else:
+            x = interaction_sample(sd_pc2, x, cams, local_features, milestones[i] - roll_step, milestones[i + 1], recon_noise)
+            rec = interaction_sample(sd_pc2, x.clone(), cams, local_features, milestones[i + 1],
+                                     milestones[i + 1] - roll_step + 1, branch_noise)
+            pri = pvd_prior(sd_pvd, x.clone(), milestones[i + 1], milestones[i + 1] - roll_step + 1, prior_noise)
+            t = milestones[i + 1] - roll_step
+            x = nstep_fuse(sd_fuse, pri, rec, cams, fuse_local_features, t, fuse_noise.get(t))
+    return x

@@ -116,3 +116,40 @@ def test_mini_blending_trajectory_vs_oracle(hip, oracle_ops):
     pvd.diffusion.noise_source = lambda shape, dev: prior_noise[993].to(dev)
     out = bdm_blending(None, batch.to("cuda"), cfg, model, pvd, init_noise=init, blend_masks=masks).points_padded().cpu()
     assert rel_l2(out, ref) < 1e-3
+
+
+def test_mini_merging_trajectory_vs_oracle(hip, oracle_ops):
+    """A complete (short) BDM-Merging schedule: PC^2 steps, 1-step recon / prior branches, ONE fused step through
+    PVCNN_fuse (defined semantic for the reference's out-of-bounds t_emb), final PC^2 step."""
+    from bdm_amd.cameras import join_cameras
+    from bdm_amd.model import get_fusion_model
+    from bdm_amd.sampling import bdm_merging
+    from bdm_amd.utils.procedural import fill_module_
+    from oracle import ref_sampler as R
+    B, N = 1, 1024
+    cfg, model, pvd, batch = _tiny_setup(B, N, seed=21)
+    fusion = get_fusion_model(cfg, pvd, model)
+    fill_module_(fusion.fusion_model.model.projs, seed=5, prefix="projs.")  # non-zero "zero convs": exercise the fusion
+    fill_module_(fusion.feature_model, seed=21, prefix="feature_model.")   # same image encoder as the recon model
+    cfg.aux_run.milestones, cfg.aux_run.roll_step = [1000, 996, 993, 990], 2
+    # i=0: 999..994 (end = 996-2) ; i=1: start 996-2=994 -> 993: t=993 ; branch recon 993->992: t=992 ; prior t=992 ;
+    # fuse at t=991 ; i=2: start 993-2=991 -> 990: t=990
+    main_ts = [999, 998, 997, 996, 995, 994, 993, 990]
+    recon_noise = {t: seeded((B, N, 3), 100 + t) for t in main_ts}
+    branch_noise = {992: seeded((B, N, 3), 7000)}
+    prior_noise = {992: seeded((B, 3, N), 8000)}
+    fuse_noise = {991: seeded((B, N, 3), 9000)}
+    init = seeded((B, N, 3), 55)
+    local = model.get_local_conditioning(batch.image_rgb)
+    local_f = fusion.get_local_conditioning(batch.image_rgb)
+    cams = join_cameras(batch.camera).packed()
+    ref = R.bdm_merging(model.state_dict(), pvd.state_dict(), fusion.state_dict(), init, cams, local, local_f,
+                        cfg.aux_run.milestones, 2, recon_noise, branch_noise, prior_noise, fuse_noise)
+    model, pvd, fusion = model.cuda(), pvd.cuda(), fusion.cuda()
+    order = [recon_noise[t] for t in (999, 998, 997, 996, 995, 994, 993)] + [branch_noise[992]] + [recon_noise[990]]
+    it = iter(order)
+    model.scheduler.noise_source = lambda shape, dev: next(it).to(dev)
+    fusion.scheduler.noise_source = lambda shape, dev: fuse_noise[991].to(dev)
+    pvd.diffusion.noise_source = lambda shape, dev: prior_noise[992].to(dev)
+    out = bdm_merging(None, batch.to("cuda"), cfg, pvd, model, fusion, init_noise=init).points_padded().cpu()
+    assert rel_l2(out, ref) < 1e-3
