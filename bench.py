@@ -224,8 +224,14 @@ def main():
             line["invalid"] = "smoke configuration: not the metric's workload"
         if conv:
             peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+            traffic = None  # HBM bytes per launch from the PMC pass committed under profiles/ (separate run, same kernel/shape)
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")))
+                traffic = pm["traffic_mb_per_launch"] * 2 ** 20
+            except (OSError, KeyError, ValueError):
+                pass
             line["roofline"] = {"bound": "mfma", "achieved": conv["tflops"], "peak": peak, "unit": "TFLOP/s",
-                                "frac": conv["tflops"] / peak, "traffic": None,
+                                "frac": conv["tflops"] / peak, "traffic": traffic,
                                 "kernel": "conv3d_s3_kernel<2,4,32,2,8> (3x3x3 voxel conv, bf16x6 split, Cout>32, 32^3 grid)",
                                 "note": "achieved = ALGORITHMIC fp32 FLOPs (2*27*Cin*Cout*r^3*B) / launch time; every fp32 product is "
                                         "6 bf16 MFMA products, so peak = 2500 TFLOP/s dense bf16 / 6; the fp32-input MFMA peak would "
