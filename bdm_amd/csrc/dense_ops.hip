@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
           if (bias) v += bias[m];
           if (bbias) v += bbias[(size_t)bi * ldbb + m];
           if (act == 2) v = v > 0.f ? v : v * slope;
+          else if (act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact GELU (timm Mlp)
           if (R) v += R[(size_t)bi * bsr + (size_t)m * ldr + n];
           Yb[(size_t)m * ldy + n] = v;
         }
@@ -143,7 +144,7 @@ extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, in
                                   int ld_bb, const float *residual, long long bs_r, int ld_r, float *y,
                                   long long bs_y, int ld_y, int act, float slope, void *stream) {
   BDM_REQUIRE(b >= 0 && m >= 1 && k >= 1 && n >= 0, "pointwise_conv: bad sizes m=%d k=%d n=%d", m, k, n);
-  BDM_REQUIRE(act == 0 || act == 2, "pointwise_conv: act must be 0 (none) or 2 (leaky relu)");
+  BDM_REQUIRE(act == 0 || act == 2 || act == 3, "pointwise_conv: act must be 0 (none), 2 (leaky relu) or 3 (gelu)");
   if (b == 0 || n == 0) return BDM_OK;
   hipStream_t s = (hipStream_t)stream;
 #define PW_LAUNCH(MI, NI)                                                                                   \

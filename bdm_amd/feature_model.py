@@ -1,18 +1,20 @@
 """Image encoder of the projection conditioning: ViT-S/16 (MSN) with timm-compatible state-dict keys
-(experiments/model/feature_model.py:41-132; timm 0.9.7 VisionTransformer, third-party, not installed).
+(experiments/model/feature_model.py:41-132; timm 0.9.7 VisionTransformer, third-party, not installed), on the HIP
+path (csrc/vit_ops.hip + the pointwise MFMA GEMM and flash attention of csrc/dense_ops.hip).
 
-SCOPE NOTE: the encoder output depends only on the image, so it is HOISTED out of the
-per-step loop -- the reference recomputes it at every one of the 1000 steps (projection_model.py:199)
-with bit-identical results.  It runs once per batch, outside the per-step hot path, and is written with
-stock torch tensor ops for now (SURVEY.md 8f row 1 "next": a HIP ViT).  Parity status: UNPINNED (timm
-absent; no reference test pins it); the pretrained MSN weights are not reachable offline, so weights are
-procedural unless a checkpoint provides `feature_model.model.*`.
+The encoder output depends only on the image, so it is HOISTED out of the per-step loop -- the reference recomputes
+it at every one of the 1000 steps (projection_model.py:199) with identical results.  The nn.Linear / nn.LayerNorm /
+nn.Conv2d members are parameter containers; their forward is never called.  Parity status: UNPINNED (timm absent; no
+reference test pins it); checked against the torch restatement in oracle/ref_vit.py.  The pretrained MSN weights are
+not reachable offline: weights are procedural unless a checkpoint provides `feature_model.model.*`.
 """
-import math
+import ctypes
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
 
 IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
@@ -30,22 +32,12 @@ class _Attn(nn.Module):
         self.qkv = nn.Linear(dim, dim * 3, bias=True)
         self.proj = nn.Linear(dim, dim)
 
-    def forward(self, x):
-        B, T, D = x.shape
-        qkv = self.qkv(x).reshape(B, T, 3, self.num_heads, D // self.num_heads).permute(2, 0, 3, 1, 4)
-        q, k, v = qkv[0], qkv[1], qkv[2]
-        a = torch.softmax((q * (D // self.num_heads) ** -0.5) @ k.transpose(-2, -1), dim=-1)
-        return self.proj((a @ v).transpose(1, 2).reshape(B, T, D))
-
 
 class _Mlp(nn.Module):
     def __init__(self, dim, hidden):
         super().__init__()
         self.fc1 = nn.Linear(dim, hidden)
         self.fc2 = nn.Linear(hidden, dim)
-
-    def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
 
 
 class _Block(nn.Module):
@@ -55,10 +47,6 @@ class _Block(nn.Module):
         self.attn = _Attn(dim, heads)
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = _Mlp(dim, dim * 4)
-
-    def forward(self, x):
-        x = x + self.attn(self.norm1(x))
-        return x + self.mlp(self.norm2(x))
 
 
 class _PatchEmbed(nn.Module):
@@ -72,18 +60,70 @@ class VisionTransformer(nn.Module):
 
     def __init__(self, img_size=224, patch_size=16, embed_dim=384, depth=12, num_heads=6):
         super().__init__()
-        self.embed_dim = embed_dim
+        self.embed_dim, self.patch_size, self.num_heads = embed_dim, patch_size, num_heads
         self.patch_embed = _PatchEmbed(patch_size, embed_dim)
         n = (img_size // patch_size) ** 2
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, embed_dim))
         self.blocks = nn.Sequential(*[_Block(embed_dim, num_heads) for _ in range(depth)])
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self._scaled_qkv = {}
 
-    def forward(self, x):
-        x = self.patch_embed.proj(x).flatten(2).transpose(1, 2)
-        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
-        return self.norm(self.blocks(x))
+    def _qkv(self, blk):
+        """qkv weights with the 1/sqrt(head_dim) attention scale folded into the q rows (an exact power of two for
+        head_dim = 64: the flash kernel itself is scale-free as in the PVCNN attention)."""
+        w, b = blk.attn.qkv.weight, blk.attn.qkv.bias
+        sig = (w._version, w.data_ptr(), b._version)
+        hit = self._scaled_qkv.get(id(blk))
+        if hit is None or hit[0] != sig:
+            D = self.embed_dim
+            scale = (D // self.num_heads) ** -0.5
+            ws, bs = w.detach().clone(), b.detach().clone()
+            ws[:D] *= scale
+            bs[:D] *= scale
+            hit = (sig, ws.contiguous(), bs.contiguous())
+            self._scaled_qkv[id(blk)] = hit
+        return hit[1], hit[2]
+
+    @torch.no_grad()
+    def tokens(self, img):
+        """(B,3,H,W) in [0,1] on the GPU -> final-norm tokens, channel-first (B, D, T+1)."""
+        lib = L.lib()
+        B, _, H, W = img.shape
+        img = img.contiguous()
+        p, D, heads = self.patch_size, self.embed_dim, self.num_heads
+        T = (H // p) * (W // p)
+        dev = img.device
+        mean = (ctypes.c_float * 3)(*IMAGENET_DEFAULT_MEAN)
+        std = (ctypes.c_float * 3)(*IMAGENET_DEFAULT_STD)
+        patches = torch.empty(B, 3 * p * p, T, dtype=torch.float32, device=dev)
+        L.check(lib.bdm_vit_patchify(B, H, W, p, mean, std, L.ptr(img), L.ptr(patches), L.stream()), "vit_patchify")
+        emb = ops.pointwise_conv(patches, self.patch_embed.proj.weight, self.patch_embed.proj.bias)
+        x = torch.empty(B, D, T + 1, dtype=torch.float32, device=dev)
+        cls, pos = self.cls_token.reshape(D).contiguous(), self.pos_embed.reshape(T + 1, D).contiguous()
+        L.check(lib.bdm_vit_assemble_tokens(B, D, T, L.ptr(emb), L.ptr(cls), L.ptr(pos), L.ptr(x), L.stream()), "vit_assemble_tokens")
+        T1, hd = T + 1, D // heads
+
+        def layer_norm(inp, ln):
+            out = torch.empty_like(inp)
+            L.check(lib.bdm_layer_norm_channels(B, D, T1, L.ptr(inp), L.ptr(ln.weight), L.ptr(ln.bias), L.c_float(ln.eps),
+                                                L.ptr(out), L.stream()), "layer_norm_channels")
+            return out
+
+        for blk in self.blocks:
+            h = layer_norm(x, blk.norm1)
+            wq, bq = self._qkv(blk)
+            qkv = ops.pointwise_conv(h, wq, bq)  # (B, 3D, T1): rows [0,D) q, [D,2D) k, [2D,3D) v, heads contiguous
+            att = torch.empty(B, D, T1, dtype=torch.float32, device=dev)
+            for hh in range(heads):
+                q, k, v = qkv[:, hh * hd:], qkv[:, D + hh * hd:], qkv[:, 2 * D + hh * hd:]
+                L.check(lib.bdm_attention_core(B, hd, T1, L.ptr(q), L.ptr(k), L.ptr(v), L.c_ll(3 * D * T1), T1,
+                                               L.ptr(att[:, hh * hd:]), L.c_ll(D * T1), T1, L.stream()), "attention_core")
+            x = ops.pointwise_conv(att, blk.attn.proj.weight, blk.attn.proj.bias, residual=x)
+            h = layer_norm(x, blk.norm2)
+            h = ops.pointwise_conv(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=3)
+            x = ops.pointwise_conv(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x)
+        return layer_norm(x, self.norm)
 
 
 class FeatureModel(nn.Module):
@@ -91,30 +131,31 @@ class FeatureModel(nn.Module):
         super().__init__()
         self.model_name = model_name
         if model_name == "identity":
-            return
+            raise NotImplementedError("image_feature_model='identity' is not used by the BDM configs")
         self.model = VisionTransformer(img_size=image_size, **MODEL_KWARGS[model_name])
         self.feature_dim = self.model.embed_dim
         self.mean, self.std = IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD
         self.fc = nn.Identity()
 
-    def normalize(self, img):
-        mean = torch.tensor(self.mean, device=img.device).view(1, 3, 1, 1)
-        std = torch.tensor(self.std, device=img.device).view(1, 3, 1, 1)
-        return (img - mean) / std
+    @torch.no_grad()
+    def conditioning_image(self, image_rgb, colors_mean=0.5, colors_std=0.5):
+        """Pixel-major (B, H*W, 3 + D) = cat[(rgb - mean)/std, bilinear-upsampled patch tokens]
+        (projection_model.py:110-125 with local colours + local features), straight from the HIP encoder."""
+        B, _, H, W = image_rgb.shape
+        image_rgb = image_rgb.contiguous()
+        tok = self.model.tokens(image_rgb)
+        D = self.feature_dim
+        grid = int(round((tok.shape[2] - 1) ** 0.5))
+        out = torch.empty(B, H * W, 3 + D, dtype=torch.float32, device=image_rgb.device)
+        L.check(L.lib().bdm_vit_conditioning_image(B, D, grid, H, W, L.c_float(colors_mean), L.c_float(colors_std), L.ptr(tok),
+                                                   L.ptr(image_rgb), L.ptr(out), L.stream()), "vit_conditioning_image")
+        return out
 
     @torch.no_grad()
     def forward(self, x, return_type="features", return_upscaled_features=True):
-        """feature_model.py:85-132: (B,3,H,W) in [0,1] -> (B, D, H, W) bilinearly upsampled patch tokens."""
-        assert return_type in {"cls_token", "features", "all"}
-        if self.model_name == "identity":
-            return x
-        B, C, H, W = x.shape
-        feats = self.model(self.normalize(x))
-        if return_type == "cls_token":
-            return feats[:, 0]
-        B, T, D = feats.shape
-        hw = int(math.sqrt(T - 1))
-        out = feats[:, 1:, :].reshape(B, hw, hw, D).permute(0, 3, 1, 2)
-        if return_upscaled_features:
-            out = F.interpolate(out, size=(H, W), mode="bilinear", align_corners=False)
-        return out if return_type == "features" else (feats[:, 0], out)
+        """feature_model.py:85-132 (return_type='features'): (B, D, H, W) upsampled patch tokens."""
+        if return_type != "features" or not return_upscaled_features:
+            raise NotImplementedError("only the upsampled local features are used by the BDM configs")
+        B, _, H, W = x.shape
+        img = self.conditioning_image(x)  # (B, HW, 3 + D)
+        return img[:, :, 3:].reshape(B, H, W, self.feature_dim).permute(0, 3, 1, 2)

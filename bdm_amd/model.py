@@ -113,9 +113,9 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
         """Pixel-major (B, H*W, D_cond) conditioning image, computed once per image batch (hoisted)."""
         key = (image_rgb.data_ptr(), image_rgb._version, tuple(image_rgb.shape))
         if self._cond_cache is None or self._cond_cache[0] != key:
-            lf = self.get_local_conditioning(image_rgb, mask)
-            B, C, H, W = lf.shape
-            self._cond_cache = (key, lf.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous(), (H, W))
+            assert self.use_local_colors and self.use_local_features
+            H, W = image_rgb.shape[-2:]
+            self._cond_cache = (key, self.feature_model.conditioning_image(image_rgb, self.colors_mean, self.colors_std), (H, W))
         return self._cond_cache[1], self._cond_cache[2]
 
     def surface_projection_indices(self, points, camera, hw):

@@ -105,7 +105,7 @@ int bdm_trilinear_devoxelize_forward(int b, int c, int n, int r, const float *co
  *   y[b] (m x n) = act(w (m x k, row stride ldw) * x[b] (k x n) + bias[m] + batch_bias[b][m]) + residual[b]
  * Replaces nn.Conv1d/nn.Conv2d(k=1) in modules/shared_mlp.py:25-30, the q/k/v/out projections of
  * modules/pvconv.py:21-31, pvcnn_fuse.py:111-123 and the classifier (pvcnn.py:62-69).
- * act: 0 none, 2 LeakyReLU(slope); bias, batch_bias and residual may be NULL (residual: the
+ * act: 0 none, 2 LeakyReLU(slope), 3 exact GELU; bias, batch_bias and residual may be NULL (residual: the
  * `proj(x) + skip` additions of pvcnn_fuse.py:203-212).  f32-input MFMA, fp32 accumulate. */
 int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, int ldw, const float *x,
                        long long bs_x, int ld_x, const float *bias, const float *batch_bias,
@@ -260,6 +260,26 @@ int bdm_rasterize_points(int b, int n, int h, int w, float radius, const float *
  * feature_image is stored pixel-major (b, h*w, c). */
 int bdm_condition_gather(int b, int n, int c, int hw, const float *x_t, const float *feature_image,
                          const int *pix_of_point, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * 4. Image encoder of the projection conditioning (ViT-S/16), once per image batch
+ *    (experiments/model/feature_model.py:85-132; timm VisionTransformer; hoisted out of the per-step loop)
+ *    Tokens are channel-first (b, d, t): Linear layers = bdm_pointwise_conv (bias / GELU / residual fused),
+ *    attention = bdm_attention_core per head.
+ * ---------------------------------------------------------------------------------- */
+/* (b,3,h,w) in [0,1] -> ImageNet-normalised patches (b, 3*p*p, t), row k = c*p*p + py*p + px; mean3/std3 are HOST arrays */
+int bdm_vit_patchify(int b, int h, int w, int patch, const float *host_mean3, const float *host_std3, const float *img,
+                     float *out, void *stream);
+/* out (b, d, t+1): column 0 = cls + pos[0], column 1+i = patches[:, :, i] + pos[1+i]; pos token-major (t+1, d) */
+int bdm_vit_assemble_tokens(int b, int d, int t, const float *patches, const float *cls, const float *pos,
+                            float *out, void *stream);
+/* nn.LayerNorm(d) over the channel axis of (b, d, t) */
+int bdm_layer_norm_channels(int b, int d, int t, const float *x, const float *gamma, const float *beta, float eps,
+                            float *y, void *stream);
+/* conditioning image (b, h*w, 3+d) pixel-major = cat[(img - colors_mean)/colors_std, bilinear(tokens[:, :, 1:] as grid x grid)]
+ * with align_corners=False (projection_model.py:110-125 + feature_model.py:107-119) */
+int bdm_vit_conditioning_image(int b, int d, int grid, int h, int w, float colors_mean, float colors_std,
+                               const float *tokens, const float *img, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ def test_rasterize_and_condition_gather(hip, H, radius, N):
     """bit-exact owning pixels and gathered features vs the brute-force rasteriser restatement."""
     from bdm_amd import _lib as L, ops
     from bdm_amd.cameras import r2n2_camera
-    from oracle import ref_sampler as R
+    from oracle import ref_sampler as R, ref_vit
     B, C = 2, 7
     cams = torch.cat([r2n2_camera(40.0 + 100 * b, 26.0 + b, 1.4 + 0.2 * b).packed() for b in range(B)])
     pts = seeded((B, N, 3), 11, 0.25)
@@ -92,7 +92,7 @@ def test_mini_blending_trajectory_vs_oracle(hip, oracle_ops):
     step, 1 blend, on identical injected noise.  Tolerance: 1e-3 relative L2 on the final cloud (north star)."""
     from bdm_amd.cameras import join_cameras
     from bdm_amd.sampling import bdm_blending
-    from oracle import ref_sampler as R
+    from oracle import ref_sampler as R, ref_vit
     B, N = 1, 1024
     cfg, model, pvd, batch = _tiny_setup(B, N, seed=3)
     cfg.aux_run.milestones, cfg.aux_run.roll_step = [1000, 997, 994, 992], 1
@@ -103,7 +103,7 @@ def test_mini_blending_trajectory_vs_oracle(hip, oracle_ops):
     masks = [torch.randint(0, 2, (B, N), generator=torch.Generator().manual_seed(9))]
     init = seeded((B, N, 3), 77)
     # --- oracle (CPU); the hoisted conditioning image comes from the same FeatureModel weights on the CPU
-    local = model.get_local_conditioning(batch.image_rgb)
+    local = ref_vit.local_conditioning(model.state_dict(), batch.image_rgb)
     cams = join_cameras(batch.camera).packed()
     ref = R.bdm_blending(model.state_dict(), pvd.state_dict(), init, cams, local, cfg.aux_run.milestones, 1,
                          recon_noise, branch_noise, prior_noise, masks)
@@ -125,7 +125,7 @@ def test_mini_merging_trajectory_vs_oracle(hip, oracle_ops):
     from bdm_amd.model import get_fusion_model
     from bdm_amd.sampling import bdm_merging
     from bdm_amd.utils.procedural import fill_module_
-    from oracle import ref_sampler as R
+    from oracle import ref_sampler as R, ref_vit
     B, N = 1, 1024
     cfg, model, pvd, batch = _tiny_setup(B, N, seed=21)
     fusion = get_fusion_model(cfg, pvd, model)
@@ -140,8 +140,8 @@ def test_mini_merging_trajectory_vs_oracle(hip, oracle_ops):
     prior_noise = {992: seeded((B, 3, N), 8000)}
     fuse_noise = {991: seeded((B, N, 3), 9000)}
     init = seeded((B, N, 3), 55)
-    local = model.get_local_conditioning(batch.image_rgb)
-    local_f = fusion.get_local_conditioning(batch.image_rgb)
+    local = ref_vit.local_conditioning(model.state_dict(), batch.image_rgb)
+    local_f = ref_vit.local_conditioning(fusion.state_dict(), batch.image_rgb)
     cams = join_cameras(batch.camera).packed()
     ref = R.bdm_merging(model.state_dict(), pvd.state_dict(), fusion.state_dict(), init, cams, local, local_f,
                         cfg.aux_run.milestones, 2, recon_noise, branch_noise, prior_noise, fuse_noise)
@@ -153,3 +153,21 @@ def test_mini_merging_trajectory_vs_oracle(hip, oracle_ops):
     pvd.diffusion.noise_source = lambda shape, dev: prior_noise[992].to(dev)
     out = bdm_merging(None, batch.to("cuda"), cfg, pvd, model, fusion, init_noise=init).points_padded().cpu()
     assert rel_l2(out, ref) < 1e-3
+
+
+def test_hip_vit_conditioning_image_vs_oracle(hip):
+    """ViT-S/16 encoder + bilinear upsampling + colour normalisation on the HIP path vs the torch restatement
+    (oracle/ref_vit.py).  Tolerance 1e-4 relative L2 (12 transformer blocks in fp32, different summation orders)."""
+    from bdm_amd.feature_model import FeatureModel
+    from bdm_amd.utils.procedural import fill_module_
+    from oracle import ref_vit
+    fm = fill_module_(FeatureModel(224, "vit_small_patch16_224_msn").eval(), seed=4, prefix="feature_model.")
+    img = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    sd = {"feature_model." + k: v for k, v in fm.state_dict().items()}
+    ref = ref_vit.local_conditioning(sd, img)                                   # (B, 387, H, W)
+    got = fm.cuda().conditioning_image(img.cuda()).cpu()                        # (B, H*W, 387)
+    ref_pm = ref.permute(0, 2, 3, 1).reshape(2, 224 * 224, 387)
+    assert rel_l2(got[:, :, :3], ref_pm[:, :, :3]) < 1e-6
+    assert rel_l2(got[:, :, 3:], ref_pm[:, :, 3:]) < 1e-4
+    feats = fm(img.cuda()).cpu()                                                # reference API: (B, D, H, W)
+    assert rel_l2(feats, ref[:, 3:]) < 1e-4

@@ -21,7 +21,7 @@ def test_c1_vanilla_pc2_100_steps(hip, oracle_ops):
     from bdm_amd.data import SyntheticShapes
     from bdm_amd.model import get_model
     from bdm_amd.utils.procedural import fill_module_
-    from oracle import ref_net, ref_sampler as R
+    from oracle import ref_net, ref_sampler as R, ref_vit
     B, N, STEPS = 1, 1024, 100
     cfg = ProjectConfig()
     model = fill_module_(get_model(cfg).eval(), seed=11)
@@ -30,7 +30,7 @@ def test_c1_vanilla_pc2_100_steps(hip, oracle_ops):
     noise = {t: seeded((B, N, 3), 3000 + t) for t in ts}
     x0 = seeded((B, N, 3), 99)
     # oracle
-    local = model.get_local_conditioning(batch.image_rgb)
+    local = ref_vit.local_conditioning(model.state_dict(), batch.image_rgb)
     cams = join_cameras(batch.camera).packed()
     sd = model.state_dict()
     ddpm = R.RefDDPM()
