@@ -239,3 +239,33 @@ extern "C" int bdm_condition_gather(int b, int n, int c, int hw, const float *x_
                      feature_image, pix_of_point, out);
   return launch_status("condition_gather");
 }
+
+// -------------------------------------------------------------------------------------
+// Quality metrics (evaluation/evaluation_cd.py:111-131, evaluation/evaluation_f1.py:90-110): per-point squared
+// distance to the nearest point of the other cloud.  src (b, n, 3), tgt (b, m, 3) point-major -> out (b, n).
+// -------------------------------------------------------------------------------------
+__global__ void nn_sqdist_kernel(int n, int m, const float *__restrict__ src, const float *__restrict__ tgt,
+                                 float *__restrict__ out) {
+  __shared__ float st[3 * 1024];
+  const int bi = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float *s = src + ((size_t)bi * n + (i < n ? i : 0)) * 3;
+  const float x = s[0], y = s[1], z = s[2];
+  float best = INFINITY;
+  for (int base = 0; base < m; base += 1024) {
+    const int len = min(1024, m - base);
+    __syncthreads();
+    for (int t = threadIdx.x; t < 3 * len; t += blockDim.x) st[t] = tgt[((size_t)bi * m + base) * 3 + t];
+    __syncthreads();
+    for (int k = 0; k < len; ++k) {
+      const float dx = x - st[3 * k], dy = y - st[3 * k + 1], dz = z - st[3 * k + 2];
+      best = fminf(best, dx * dx + dy * dy + dz * dz);
+    }
+  }
+  if (i < n) out[(size_t)bi * n + i] = best;
+}
+extern "C" int bdm_nn_sqdist(int b, int n, int m, const float *src, const float *tgt, float *out, void *stream) {
+  BDM_REQUIRE(b >= 0 && n >= 1 && m >= 1, "nn_sqdist: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(nn_sqdist_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, src, tgt, out);
+  return launch_status("nn_sqdist");
+}

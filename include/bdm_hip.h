@@ -261,6 +261,10 @@ int bdm_rasterize_points(int b, int n, int h, int w, float radius, const float *
 int bdm_condition_gather(int b, int n, int c, int hw, const float *x_t, const float *feature_image,
                          const int *pix_of_point, float *out, void *stream);
 
+/* Quality metrics of the evaluation scripts (evaluation/evaluation_cd.py:111-131, evaluation_f1.py:90-110):
+ * out (b, n) = min over the m target points of the squared distance; src (b,n,3), tgt (b,m,3) point-major. */
+int bdm_nn_sqdist(int b, int n, int m, const float *src, const float *tgt, float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * 4. Image encoder of the projection conditioning (ViT-S/16), once per image batch
  *    (experiments/model/feature_model.py:85-132; timm VisionTransformer; hoisted out of the per-step loop)

@@ -171,3 +171,25 @@ def test_hip_vit_conditioning_image_vs_oracle(hip):
     assert rel_l2(got[:, :, 3:], ref_pm[:, :, 3:]) < 1e-4
     feats = fm(img.cuda()).cpu()                                                # reference API: (B, D, H, W)
     assert rel_l2(feats, ref[:, 3:]) < 1e-4
+
+
+def test_quality_metrics(hip, tmp_path):
+    """Chamfer x 1e3 / F1@0.01 (evaluation_cd.py, evaluation_f1.py) vs a numpy brute force; .ply round trip."""
+    from bdm_amd.evaluation import chamfer_distance_x1000, evaluate_dirs, f1_score
+    from bdm_amd.io import save_pointcloud_ply
+    g = torch.Generator().manual_seed(3)
+    gt = torch.randn(2, 700, 3, generator=g) * 0.2
+    pred = gt[:, torch.randperm(700, generator=g)[:600]] + 0.02 * torch.randn(2, 600, 3, generator=g)
+    pc, gc = (pred - pred.mean(1, keepdim=True)).double(), (gt - gt.mean(1, keepdim=True)).double()
+    d = ((pc[:, :, None] - gc[:, None]) ** 2).sum(-1)
+    cd_ref = (d.min(2).values.mean(1) + d.min(1).values.mean(1)) * 1000
+    assert np.allclose(chamfer_distance_x1000(pred.cuda(), gt.cuda()), cd_ref.numpy(), rtol=1e-4)
+    dd = ((pred[:, :, None].double() - gt[:, None].double()) ** 2).sum(-1)
+    prec, rec = (dd.min(1).values < 0.01).double().mean(1), (dd.min(2).values < 0.01).double().mean(1)
+    f_ref = 2 * rec * prec / (rec + prec + 1e-12)
+    assert np.allclose(f1_score(pred.cuda(), gt.cuda()), f_ref.numpy(), atol=2e-3)
+    for i in range(2):
+        save_pointcloud_ply(pred[i].numpy(), tmp_path / "pred" / "chair" / f"s{i}.ply")
+        save_pointcloud_ply(gt[i].numpy(), tmp_path / "gt" / "chair" / f"s{i}.ply")
+    res = evaluate_dirs(str(tmp_path / "pred"), str(tmp_path / "gt"))
+    assert res["num"] == 2 and abs(res["cd_x1000"] - float(cd_ref.mean())) < 1e-3 * float(cd_ref.mean())
