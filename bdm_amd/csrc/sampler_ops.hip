@@ -269,3 +269,27 @@ extern "C" int bdm_nn_sqdist(int b, int n, int m, const float *src, const float 
   hipLaunchKernelGGL(nn_sqdist_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, src, tgt, out);
   return launch_status("nn_sqdist");
 }
+
+// DDIM step (diffusers 0.21.0 DDIMScheduler.step, epsilon prediction, clip_sample=False):
+//   x0 = (x - sqrt(1-abar_t) eps) / sqrt(abar_t);  out = sqrt(abar_prev) x0 + sqrt(1 - abar_prev - std^2) eps [+ std z]
+__global__ void ddim_step_kernel(long long n, const float *__restrict__ x, const float *__restrict__ eps,
+                                 const float *__restrict__ z, float sqrt_beta_prod, float sqrt_alpha_prod, float c_x0,
+                                 float c_eps, float sigma, float *__restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float e = eps[i];
+    const float x0 = (x[i] - sqrt_beta_prod * e) / sqrt_alpha_prod;
+    float v = c_x0 * x0 + c_eps * e;
+    if (z) v = v + sigma * z[i];
+    out[i] = v;
+  }
+}
+extern "C" int bdm_ddim_step(long long n, const float *x, const float *eps, const float *noise, float sqrt_beta_prod,
+                             float sqrt_alpha_prod, float coef_x0, float coef_eps, float sigma, float *out, void *stream) {
+  BDM_REQUIRE(n >= 0, "ddim_step: bad size");
+  if (n == 0) return BDM_OK;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, x, eps, noise, sqrt_beta_prod,
+                     sqrt_alpha_prod, coef_x0, coef_eps, sigma, out);
+  return launch_status("ddim_step");
+}

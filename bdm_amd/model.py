@@ -181,13 +181,15 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
         self.point_cloud_model = PointCloudModel(model_type=point_cloud_model, embed_dim=point_cloud_model_embed_dim,
                                                  in_channels=self.in_channels, out_channels=self.out_channels)
 
+    _step_kwargs = {}  # e.g. {"eta": 0.0} for DDIM (the reference forwards eta only to schedulers that accept it)
+
     def _denoise_loop(self, x_t, camera, image_rgb, mask, scheduler, timesteps, generator=None):
         B = x_t.shape[0]
         for t in timesteps:
             tt = torch.full((B,), t, dtype=torch.int64, device=x_t.device)
             x_in = self.get_input_with_conditioning(x_t, camera=camera, image_rgb=image_rgb, mask=mask, t=tt)
             noise_pred = self.point_cloud_model(x_in, tt)
-            x_t = scheduler.step(noise_pred, t, x_t, generator=generator).prev_sample
+            x_t = scheduler.step(noise_pred, t, x_t, generator=generator, **self._step_kwargs).prev_sample
         return x_t
 
     @torch.no_grad()

@@ -46,11 +46,18 @@ def blend_select(recon, prior, indices):
 
 
 def _schedule(cfg):
+    """(roll_step, milestones, prior_roll_step, prior_milestones, times) -- main_blending.py:207-221: with DDIM the recon
+    model runs on a 64-step grid while the PVD prior keeps its 1000-step DDPM chain (x16 roll, milestones * 1000 / 64)."""
     roll_step = cfg.aux_run.roll_step
     milestones = list(cfg.aux_run.milestones or DEFAULT_MILESTONES)
-    if cfg.run.diffusion_scheduler != "ddpm":
-        raise NotImplementedError("BDM sampling on the MI355X path is DDPM-only (DDIM milestone mapping: later scope)")
-    return roll_step, milestones, len(milestones) - 1
+    if cfg.run.diffusion_scheduler == "ddim":
+        prior_roll_step = int(roll_step * 16)
+        prior_milestones = [int(i / 64 * 1000) for i in milestones]
+    elif cfg.run.diffusion_scheduler == "ddpm":
+        prior_roll_step, prior_milestones = roll_step, milestones
+    else:
+        raise NotImplementedError(f"scheduler {cfg.run.diffusion_scheduler!r}")
+    return roll_step, milestones, prior_roll_step, prior_milestones, len(milestones) - 1
 
 
 def _initial_cloud(B, num_points, device, init_noise=None):
@@ -62,7 +69,7 @@ def _initial_cloud(B, num_points, device, init_noise=None):
 def bdm_blending(accelerator, batch, cfg, model, pvd_model, generator=None, init_noise=None, blend_masks=None):
     """main_blending.py:186-347.  Returns Pointclouds of (B, N, 3)."""
     img, mask, camera = batch.image_rgb, batch.fg_probability, batch.camera
-    roll_step, milestones, times = _schedule(cfg)
+    roll_step, milestones, prior_roll_step, prior_milestones, times = _schedule(cfg)
     B, num_points = img.shape[0], cfg.dataset.max_points
     device = model.point_cloud_model.device
     common = dict(scheduler=cfg.run.diffusion_scheduler, num_inference_steps=cfg.run.num_inference_steps, disable_tqdm=True)
@@ -82,8 +89,8 @@ def bdm_blending(accelerator, batch, cfg, model, pvd_model, generator=None, init
             out_recon = model.interaction_sample(pred_pc.clone(), camera, img, mask, start_time=milestones[i + 1],
                                                  end_time=milestones[i + 1] - roll_step, **common)
             # Branch 2: prior model, roll_step steps from the same cloud
-            out_prior = pvd_prior(pvd_model, pred_pc.clone(), start_time=milestones[i + 1],
-                                  end_time=milestones[i + 1] - roll_step)
+            out_prior = pvd_prior(pvd_model, pred_pc.clone(), start_time=prior_milestones[i + 1],
+                                  end_time=prior_milestones[i + 1] - prior_roll_step)
             if blend_masks is not None:
                 indices = blend_masks[blends]
             else:
@@ -97,7 +104,7 @@ def bdm_blending(accelerator, batch, cfg, model, pvd_model, generator=None, init
 def bdm_merging(accelerator, batch, cfg, prior_model, recon_model, fusion_model, init_noise=None):
     """main_merging.py:369-523.  Returns Pointclouds of (B, N, 3)."""
     img, mask, camera = batch.image_rgb, batch.fg_probability, batch.camera
-    roll_step, milestones, times = _schedule(cfg)
+    roll_step, milestones, prior_roll_step, prior_milestones, times = _schedule(cfg)
     B, num_points = img.shape[0], cfg.dataset.max_points
     device = recon_model.point_cloud_model.device
     common = dict(scheduler=cfg.run.diffusion_scheduler, num_inference_steps=cfg.run.num_inference_steps, disable_tqdm=True)
@@ -114,8 +121,8 @@ def bdm_merging(accelerator, batch, cfg, prior_model, recon_model, fusion_model,
                                                      end_time=milestones[i + 1], **common)
             out_recon = recon_model.interaction_sample(pred_pc.clone(), camera, img, mask, start_time=milestones[i + 1],
                                                        end_time=milestones[i + 1] - roll_step + 1, **common)
-            out_prior = pvd_prior(prior_model, pred_pc.clone(), start_time=milestones[i + 1],
-                                  end_time=milestones[i + 1] - roll_step + 1)
+            out_prior = pvd_prior(prior_model, pred_pc.clone(), start_time=prior_milestones[i + 1],
+                                  end_time=prior_milestones[i + 1] - prior_roll_step + 1)
             pred_pc = fusion_model.nstep_fuse(out_prior.contiguous(), out_recon.contiguous(), camera, img, mask,
                                               scheduler=cfg.run.diffusion_scheduler,
                                               num_inference_steps=cfg.run.num_inference_steps,

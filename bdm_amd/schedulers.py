@@ -115,17 +115,46 @@ class DDPMScheduler:
         return self.num_train_timesteps
 
 
+class DDIMScheduler(DDPMScheduler):
+    """diffusers 0.21.0 DDIMScheduler (epsilon prediction, clip_sample=False, set_alpha_to_one=True, leading spacing):
+        prev_t = t - T // n;  abar_prev = alphas_cumprod[prev_t] if prev_t >= 0 else 1
+        x0 = (x - sqrt(1 - abar_t) eps) / sqrt(abar_t)
+        std = eta * sqrt((1 - abar_prev) / (1 - abar_t) * (1 - abar_t / abar_prev))
+        x_prev = sqrt(abar_prev) x0 + sqrt(1 - abar_prev - std^2) eps  [+ std * randn  if eta > 0]
+    Parity status: unpinned (diffusers absent), closed-form tested."""
+
+    def step_coefficients(self, t, eta=0.0):
+        t = int(t)
+        prev_t = self.previous_timestep(t)
+        abar_t = self.alphas_cumprod[t]
+        abar_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        beta_prod_t = 1 - abar_t
+        variance = (1 - abar_prev) / (1 - abar_t) * (1 - abar_t / abar_prev)
+        std = eta * variance ** 0.5
+        return dict(sqrt_beta_prod=float(beta_prod_t ** 0.5), sqrt_alpha_prod=float(abar_t ** 0.5),
+                    coef_x0=float(abar_prev ** 0.5), coef_eps=float((1 - abar_prev - std ** 2) ** 0.5), sigma=float(std))
+
+    def step(self, model_output, timestep, sample, eta=0.0, generator=None, return_dict=True):
+        c = self.step_coefficients(timestep, eta)
+        x, eps = sample.contiguous(), model_output.contiguous()
+        noise = self._noise(x.shape, x.device, generator) if eta > 0 else None
+        out = torch.empty_like(x)
+        L.check(L.lib().bdm_ddim_step(L.c_ll(x.numel()), L.ptr(x), L.ptr(eps), L.ptr(noise), L.c_float(c["sqrt_beta_prod"]),
+                                      L.c_float(c["sqrt_alpha_prod"]), L.c_float(c["coef_x0"]), L.c_float(c["coef_eps"]),
+                                      L.c_float(c["sigma"]), L.ptr(out), L.stream()), "ddim_step")
+        return SimpleNamespace(prev_sample=out) if return_dict else (out,)
+
+
 class _UnsupportedScheduler:
-    """DDIM / PNDM exist in the reference's schedulers_map (model.py:60-61) but the BDM recipes sample
-    with DDPM (example_sample_blending.sh:24); they are a later scope row."""
+    """PNDM exists in the reference's schedulers_map (model.py:61) but no BDM recipe selects it; not built."""
 
     def __init__(self, name):
         self.name = name
 
     def __getattr__(self, item):
-        raise NotImplementedError(f"{self.name} scheduler is not implemented on the MI355X path yet (DDPM only)")
+        raise NotImplementedError(f"{self.name} scheduler is not implemented on the MI355X path (DDPM and DDIM are)")
 
 
 def make_schedulers_map(**scheduler_kwargs):
     return {"ddpm": DDPMScheduler(**scheduler_kwargs, clip_sample=False),
-            "ddim": _UnsupportedScheduler("ddim"), "pndm": _UnsupportedScheduler("pndm")}
+            "ddim": DDIMScheduler(**scheduler_kwargs, clip_sample=False), "pndm": _UnsupportedScheduler("pndm")}

@@ -231,6 +231,11 @@ int bdm_ddpm_step(long long n, const float *x, const float *eps, const float *no
                   float sqrt_beta_prod, float sqrt_alpha_prod, float coef_x0, float coef_x,
                   float sigma, float *out, void *stream);
 
+/* DDIM step (diffusers 0.21.0 DDIMScheduler.step; the reference's schedulers_map['ddim'], model/model.py:60):
+ *   x0 = (x - sqrt_beta_prod * eps) / sqrt_alpha_prod;  out = coef_x0 * x0 + coef_eps * eps [+ sigma * noise when eta > 0] */
+int bdm_ddim_step(long long n, const float *x, const float *eps, const float *noise, float sqrt_beta_prod,
+                  float sqrt_alpha_prod, float coef_x0, float coef_eps, float sigma, float *out, void *stream);
+
 /* PVD scheduler step: GaussianDiffusion.p_sample (experiments/pvd/__init__.py:136-224):
  *   x0 = sqrt_recip_abar * x - sqrt_recipm1_abar * eps;  mean = coef1 * x0 + coef2 * x;
  *   out = mean + sigma * noise      (sigma = 0 at t == 0; noise is always drawn, as the reference does) */

@@ -193,3 +193,22 @@ def test_quality_metrics(hip, tmp_path):
         save_pointcloud_ply(gt[i].numpy(), tmp_path / "gt" / "chair" / f"s{i}.ply")
     res = evaluate_dirs(str(tmp_path / "pred"), str(tmp_path / "gt"))
     assert res["num"] == 2 and abs(res["cd_x1000"] - float(cd_ref.mean())) < 1e-3 * float(cd_ref.mean())
+
+
+def test_ddim_step_kernel_and_ddim_blending_schedule(hip):
+    from bdm_amd.sampling import bdm_blending
+    from bdm_amd.schedulers import DDIMScheduler
+    s = DDIMScheduler(beta_start=1e-5, beta_end=8e-3, clip_sample=False)
+    s.set_timesteps(64)
+    x, eps = seeded((2, 512, 3), 1), seeded((2, 512, 3), 2)
+    for t in (945, 465, 0):
+        c = s.step_coefficients(t)
+        x0 = (x - c["sqrt_beta_prod"] * eps) / c["sqrt_alpha_prod"]
+        ref = c["coef_x0"] * x0 + c["coef_eps"] * eps
+        assert torch.allclose(s.step(eps.cuda(), t, x.cuda()).prev_sample.cpu(), ref, rtol=0, atol=1e-6)
+    # the reference's DDIM coupling: 64 recon steps, prior on its 1000-step chain (x16 roll, milestones * 1000/64)
+    cfg, model, pvd, batch = _tiny_setup(1, 1024, seed=2)
+    cfg.run.diffusion_scheduler, cfg.run.num_inference_steps = "ddim", 64
+    cfg.aux_run.milestones, cfg.aux_run.roll_step = [64, 63, 62, 61], 1
+    out = bdm_blending(None, batch.to("cuda"), cfg, model.cuda(), pvd.cuda()).points_padded()
+    assert out.shape == (1, 1024, 3) and bool(torch.isfinite(out).all())

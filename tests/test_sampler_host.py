@@ -147,3 +147,22 @@ def test_windowed_rasterizer_equals_bruteforce():
         slow = R.surface_projection(pts, cam, feat, radius)
         R.FAST_RASTER = True
         assert torch.equal(slow, R.surface_projection(pts, cam, feat, radius))
+
+
+def test_ddim_scheduler_closed_form_and_schedule_mapping():
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.sampling import _schedule
+    from bdm_amd.schedulers import DDIMScheduler
+    s = DDIMScheduler(beta_start=1e-5, beta_end=8e-3, clip_sample=False)
+    s.set_timesteps(64)  # the reference's DDIM recipe: 64 recon steps, stride 15
+    assert s.timesteps.tolist()[:3] == [945, 930, 915] and s.timesteps.tolist()[-1] == 0
+    abar = np.cumprod(1 - np.linspace(1e-5, 8e-3, 1000, dtype=np.float32).astype(np.float64))
+    c = s.step_coefficients(945)
+    assert math.isclose(c["coef_x0"], math.sqrt(abar[930]), rel_tol=1e-5)
+    assert math.isclose(c["coef_eps"], math.sqrt(1 - abar[930]), rel_tol=1e-4) and c["sigma"] == 0.0
+    c0 = s.step_coefficients(0)
+    assert math.isclose(c0["coef_x0"], 1.0) and abs(c0["coef_eps"]) < 1e-6  # last step lands on x0
+    cfg = ProjectConfig()
+    cfg.run.diffusion_scheduler, cfg.aux_run.roll_step, cfg.aux_run.milestones = "ddim", 1, [64, 62, 60, 56, 8, 4, 2, 0]
+    roll, ms, proll, pms, times = _schedule(cfg)
+    assert (proll, pms, times) == (16, [1000, 968, 937, 875, 125, 62, 31, 0], 7)  # main_blending.py:214-218
