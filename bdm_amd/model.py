@@ -122,9 +122,16 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
         """Per-point owning pixel (or -1): rasterisation part of projection_model.py:127-157."""
         B, N, _ = points.shape
         H, W = hw
-        cam = join_cameras(camera).clone()
-        cam.T = cam.T * self.scale_factor
-        cams = cam.packed().to(points.device)
+        # packed camera parameters live on the device for the lifetime of the batch: a per-step pageable host->device
+        # copy would block the host until the stream drains and serialise CPU launch work with the GPU
+        key = (id(camera), str(points.device), float(self.scale_factor))
+        hit = getattr(self, "_cam_cache", None)
+        if hit is None or hit[0] != key:
+            cam = join_cameras(camera).clone()
+            cam.T = cam.T * self.scale_factor
+            hit = (key, cam.packed().to(points.device), camera)  # keeps `camera` alive so its id stays unique
+            self._cam_cache = hit
+        cams = hit[1]
         assert cams.shape[0] == B
         points = points.contiguous()  # bound to a local: raw pointers must not outlive their tensor
         pix = torch.empty(B, N, dtype=torch.int32, device=points.device)

@@ -159,6 +159,7 @@ class PVConv(nn.Module):
     #   "fp32"  : v_mfma_f32_32x32x2_f32 kernels of conv3d.hip (BDM_CONV=fp32).
     conv_impl = os.environ.get("BDM_CONV", "bf16x6")
     sparse_first_conv = os.environ.get("BDM_SPARSE_CONV1", "1") == "1"
+    sparse_resolutions = {int(v) for v in os.environ.get("BDM_SPARSE_R", "8,16,32").split(",") if v}
 
     def _packed_weight(self, conv, impl):
         key = (id(conv), impl)
@@ -182,7 +183,7 @@ class PVConv(nn.Module):
 
         features = ops.materialize(features)
         if self.conv_impl == "bf16x6":
-            if self.sparse_first_conv:
+            if self.sparse_first_conv and r in self.sparse_resolutions:
                 # conv1 sees the freshly voxelised cloud: evaluate it on the occupied cells only (sparse_conv.hip);
                 # the (coords, r) plan is shared by the PVConvs of one level
                 plan = ops.voxel_plan(coords, r, self.voxelization.eps)

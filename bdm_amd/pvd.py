@@ -82,11 +82,13 @@ class GaussianDiffusion:
         return mean + mask * torch.exp(0.5 * self.posterior_log_variance_clipped[t] * torch.ones_like(x)) * z
 
     def p_sample(self, denoise_fn, data, t, noise_fn=torch.randn, clip_denoised=False, return_pred_xstart=False,
-                 use_var=True):
+                 use_var=True, t_int=None):
         """:196-224.  `t` is a (B,) int64 tensor with one value (the sampler's loops fill it with a scalar)."""
         if clip_denoised or return_pred_xstart:
             raise NotImplementedError("BDM samples the prior with clip_denoised=False (pvd/__init__.py:397)")
-        tt = int(t[0]) if torch.is_tensor(t) else int(t)
+        # the loop passes the timestep as a Python int too: reading it back from the device tensor would be a
+        # device->host synchronisation at every step
+        tt = int(t_int) if t_int is not None else (int(t[0]) if torch.is_tensor(t) else int(t))
         eps = denoise_fn(data, t)
         c = self.step_coefficients(tt)
         if self.noise_source is not None:
@@ -113,7 +115,7 @@ class GaussianDiffusion:
             img_t = constrain_fn(img_t, t)
             t_ = torch.full((shape[0],), t, dtype=torch.int64, device=device)
             img_t = self.p_sample(denoise_fn=denoise_fn, data=img_t, t=t_, noise_fn=noise_fn,
-                                  clip_denoised=clip_denoised, return_pred_xstart=False)
+                                  clip_denoised=clip_denoised, return_pred_xstart=False, t_int=t)
         assert img_t.shape == tuple(shape) or img_t.shape == shape
         return img_t
 

@@ -42,3 +42,12 @@ xp = x.transpose(1, 2).contiguous()
 print(f"PVD forward       {timeit(lambda: pvd.model(xp, t), iters):9.2f} ms")
 step = lambda: model.interaction_sample(x, batch.camera, batch.image_rgb, None, start_time=500, end_time=499)
 print(f"full PC2 step     {timeit(step, iters):9.2f} ms")
+
+# CPU-side enqueue cost of one PC2 forward (no synchronisation inside the loop)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(iters):
+    model.point_cloud_model(xin, t)
+cpu_ms = (time.perf_counter() - t0) / iters * 1e3
+torch.cuda.synchronize()
+print(f"CPU enqueue / forward {cpu_ms:7.2f} ms")
