@@ -45,7 +45,14 @@ def lib():
     return _lib
 
 
+_DEBUG_SYNC = os.environ.get("BDM_DEBUG_SYNC")  # path of a breadcrumb file: serialise every call, remember the last one
+
+
 def check(rc: int, what: str = ""):
+    if _DEBUG_SYNC:
+        with open(_DEBUG_SYNC, "w") as f:
+            f.write(what)
+        torch.cuda.synchronize()
     if rc != 0:
         msg = lib().bdm_last_error()
         raise BdmHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -137,6 +137,12 @@ __device__ __forceinline__ Cam load_cam(const float *cams, int bi) {
   c.f[0] = p[12]; c.f[1] = p[13]; c.p[0] = p[14]; c.p[1] = p[15];
   return c;
 }
+// nearest pixel index of an NDC coordinate, clamped in FLOAT to [-4, size+4] before the conversion: points that project
+// far outside the image (or at infinity, z -> 0+) would otherwise overflow the int conversion and the window loops
+__device__ __forceinline__ int nearest_pixel(float ndc, int size) {
+  const float p = rintf(((1.f - ndc) * size - 1.f) * 0.5f);
+  return (int)fminf(fmaxf(p, -4.f), (float)size + 4.f);  // NaN -> -4 (fmaxf returns the non-NaN operand)
+}
 #define RAST_WIN 2  // candidate window: pixels within +-2 of the nearest one (radius < 2 pixel pitches)
 
 __global__ void raster_clear_kernel(long long n, unsigned long long *zbuf) {
@@ -154,7 +160,7 @@ __global__ void raster_splat_kernel(int n, int H, int W, float radius2, const fl
   project(c, p[0], p[1], p[2], u, v, d);
   if (!(d >= 0.f)) return;  // behind the camera (or NaN)
   // nearest pixel column/row:  u = 1 - (2 xi + 1)/W  ->  xi = ((1 - u) W - 1) / 2
-  const int xc = (int)rintf(((1.f - u) * W - 1.f) * 0.5f), yc = (int)rintf(((1.f - v) * H - 1.f) * 0.5f);
+  const int xc = nearest_pixel(u, W), yc = nearest_pixel(v, H);
   unsigned long long *zb = zbuf + (size_t)bi * H * W;
   const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
   for (int yi = yc - RAST_WIN; yi <= yc + RAST_WIN; ++yi) {
@@ -181,7 +187,7 @@ __global__ void raster_owner_kernel(int n, int H, int W, float radius2, const fl
   project(c, p[0], p[1], p[2], u, v, d);
   int owner = -1;
   if (d >= 0.f) {
-    const int xc = (int)rintf(((1.f - u) * W - 1.f) * 0.5f), yc = (int)rintf(((1.f - v) * H - 1.f) * 0.5f);
+    const int xc = nearest_pixel(u, W), yc = nearest_pixel(v, H);
     const unsigned long long *zb = zbuf + (size_t)bi * H * W;
     for (int yi = yc - RAST_WIN; yi <= yc + RAST_WIN; ++yi) {
       if (yi < 0 || yi >= H) continue;

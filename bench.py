@@ -141,6 +141,9 @@ def cpu_baseline(model, pvd_model, n_points, budget_s=25.0):
 
 
 def main():
+    if os.environ.get("BDM_WATCHDOG"):  # debugging aid: dump every thread's Python stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BDM_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1, help="timed trajectories (each = 1000 DDPM steps of a 16-shape batch)")

@@ -106,8 +106,8 @@ def rasterize_windowed(points, cam, H, W, radius, win=2):
     u, v, d = project_points(points, cam)
     r2 = np.float32(radius) * np.float32(radius)
     n = points.shape[0]
-    xc = torch.round(((1.0 - u) * W - 1.0) * 0.5).long()
-    yc = torch.round(((1.0 - v) * H - 1.0) * 0.5).long()
+    xc = torch.nan_to_num(torch.round(((1.0 - u) * W - 1.0) * 0.5), nan=-4.0).clamp(-4, W + 4).long()
+    yc = torch.nan_to_num(torch.round(((1.0 - v) * H - 1.0) * 0.5), nan=-4.0).clamp(-4, H + 4).long()
     offs = torch.arange(-win, win + 1)
     yi = (yc[:, None, None] + offs[None, :, None]).expand(n, 2 * win + 1, 2 * win + 1)
     xi = (xc[:, None, None] + offs[None, None, :]).expand(n, 2 * win + 1, 2 * win + 1)

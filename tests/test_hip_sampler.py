@@ -212,3 +212,28 @@ def test_ddim_step_kernel_and_ddim_blending_schedule(hip):
     cfg.aux_run.milestones, cfg.aux_run.roll_step = [64, 63, 62, 61], 1
     out = bdm_blending(None, batch.to("cuda"), cfg, model.cuda(), pvd.cuda()).points_padded()
     assert out.shape == (1, 1024, 3) and bool(torch.isfinite(out).all())
+
+
+def test_rasterizer_survives_degenerate_projections(hip):
+    """points at the camera plane (z -> 0), behind it, at infinity and NaN must neither fault nor own a pixel."""
+    from bdm_amd import _lib as L, ops
+    from bdm_amd.cameras import r2n2_camera
+    cam = r2n2_camera(10.0, 26.0, 1.5)
+    cams = cam.packed().cuda()
+    R, T = cam.R[0], cam.T[0]
+    centre = -T @ R.T  # camera position in world coordinates (X_view = X R + T = 0)
+    pts = torch.randn(1, 256, 3) * 0.2
+    pts[0, 0] = centre                       # z = 0 exactly
+    pts[0, 1] = centre + 1e-30 * torch.ones(3)
+    pts[0, 2] = centre - 0.5 * R[:, 2]       # behind the camera
+    pts[0, 3] = torch.tensor([1e30, -1e30, 1e30])
+    pts[0, 4] = torch.tensor([float("nan"), 0.0, 0.0])
+    pts[0, 5] = torch.tensor([float("inf"), 0.0, 0.0])
+    d = pts.cuda()
+    pix = torch.empty(1, 256, dtype=torch.int32, device="cuda")
+    ws = ops.workspace(L.lib().bdm_rasterize_workspace_bytes(1, 224, 224), "cuda", "raster")
+    L.check(L.lib().bdm_rasterize_points(1, 256, 224, 224, L.c_float(0.0075), L.ptr(d), L.ptr(cams), L.ptr(pix), L.ptr(ws), L.stream()))
+    torch.cuda.synchronize()
+    p = pix.cpu()[0]
+    assert int(p.max()) < 224 * 224 and int(p.min()) >= -1
+    assert all(int(p[i]) == -1 for i in (2, 3, 4, 5))
