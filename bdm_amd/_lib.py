@@ -39,9 +39,7 @@ def lib():
         _lib = ctypes.CDLL(SO_PATH)
         _lib.bdm_last_error.restype = ctypes.c_char_p
         _lib.bdm_voxelize_workspace_bytes.restype = ctypes.c_size_t
-        for name in ("bdm_workspace_bytes_conv3d",):
-            if hasattr(_lib, name):
-                getattr(_lib, name).restype = ctypes.c_size_t
+        _lib.bdm_sa_group_workspace_bytes.restype = ctypes.c_size_t
     return _lib
 
 

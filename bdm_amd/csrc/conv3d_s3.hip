@@ -22,21 +22,9 @@
 #include "common.h"
 
 using namespace bdm;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#include "s3_split.h"
 
 #define S3_PAIRS 14
-
-__device__ __forceinline__ void split3(float x, unsigned short &h, unsigned short &m, unsigned short &l) {
-  const unsigned u = __float_as_uint(x);
-  h = (unsigned short)(u >> 16);
-  const float r1 = x - __uint_as_float(u & 0xFFFF0000u);  // exact
-  const unsigned u1 = __float_as_uint(r1);
-  m = (unsigned short)(u1 >> 16);
-  const float r2 = r1 - __uint_as_float(u1 & 0xFFFF0000u);  // exact
-  const unsigned u2 = __float_as_uint(r2);
-  l = (unsigned short)((u2 + 0x7FFFu + ((u2 >> 16) & 1u)) >> 16);  // round to nearest even (r2 is finite)
-}
 
 // ---------------------------------------------------------------------------------------------------
 // weight packing: (Cout, Cin, 3,3,3) fp32 -> [C8][14][3][2][Cout][8] bf16
@@ -235,21 +223,6 @@ extern "C" int bdm_conv3d_3x3x3_s3(int b, int cin, int cout, int r, const void *
 // ---------------------------------------------------------------------------------------------------
 // producers of the S3 layout
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_s3(unsigned short *base, size_t rec, size_t split_stride, const float v[8]) {
-  // base points at split 0 of this (shape, channel group); records are 8 bf16 = 16 bytes
-  unsigned short h[8], m[8], l[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) split3(v[j], h[j], m[j], l[j]);
-  uint4 ph, pm, pl;
-  ph.x = h[0] | (h[1] << 16); ph.y = h[2] | (h[3] << 16); ph.z = h[4] | (h[5] << 16); ph.w = h[6] | (h[7] << 16);
-  pm.x = m[0] | (m[1] << 16); pm.y = m[2] | (m[3] << 16); pm.z = m[4] | (m[5] << 16); pm.w = m[6] | (m[7] << 16);
-  pl.x = l[0] | (l[1] << 16); pl.y = l[2] | (l[3] << 16); pl.z = l[4] | (l[5] << 16); pl.w = l[6] | (l[7] << 16);
-  uint4 *o = reinterpret_cast<uint4 *>(base);
-  o[rec] = ph;
-  o[split_stride + rec] = pm;
-  o[2 * split_stride + rec] = pl;
-}
-
 // fp32 channel-first (B, C, V)  ->  S3, optionally through GroupNorm (+ Swish): the fused normalise step between
 // the two convolutions of a PVConv (pvconv.py:78-82).  stats = per-(shape, group) fp64 (sum, sumsq) slice partials.
 __global__ void to_s3_kernel(int C, int V, int G, int S, const float *__restrict__ x, const double *__restrict__ partial,

@@ -484,11 +484,84 @@ __global__ void sa_group_kernel(int c, int n, int m, int u, const float *__restr
   for (int ci = blockIdx.y; ci < c; ci += gridDim.y) ob[(size_t)(3 + ci) * mu + e] = fb[(size_t)ci * ld_f + src];
 }
 
+// --- point-major path ---------------------------------------------------------------------------
+// The direct kernel above issues one scattered 4-byte load per (element, channel): a wave's 64 lanes hit 64
+// different lines, so the texture-address unit, not HBM, sets its rate (~4 B / clk / CU).  With a workspace the
+// op first repacks [coords ; features] point-major, (B, N, P) with P = 4*ceil((3+C)/4), so that a neighbour's
+// channels are one contiguous row: the gather is then 16-byte loads (4x fewer address lookups per byte), each
+// lane keeps its element's channels in registers and the stores out[ch][e] are coalesced across lanes as before.
+__global__ __launch_bounds__(256) void sa_pack_points_kernel(int c, int n, int p, const float *__restrict__ coords,
+                                                             const float *__restrict__ feat, long long bs_f, int ld_f,
+                                                             float *__restrict__ ws) {
+  // thread = (point, 3 four-channel columns): twelve coalesced row reads in flight, three 16-byte stores into the row
+  const int pt = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.z;
+  if (pt >= n) return;
+  float v[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int ch = blockIdx.y * 12 + i;
+    v[i] = ch < 3 ? coords[((size_t)bi * 3 + ch) * n + pt]
+                  : (ch < 3 + c ? feat[(size_t)bi * bs_f + (size_t)(ch - 3) * ld_f + pt] : 0.f);
+  }
+  float4 *dst = reinterpret_cast<float4 *>(ws + ((size_t)bi * n + pt) * p) + blockIdx.y * 3;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if ((blockIdx.y * 3 + i) * 4 < p) dst[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+
+constexpr int SAQ = 12;  // float4 columns of a point-major row per thread (48 channels in registers)
+__global__ __launch_bounds__(256) void sa_group_pm_kernel(int c, int n, int m, int u, int p,
+                                                          const float *__restrict__ ws, const float *__restrict__ centers,
+                                                          const int *__restrict__ idx, float *__restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z, mu = m * u;
+  if (e >= mu) return;
+  const int src = idx[(size_t)bi * mu + e];
+  const int q0 = blockIdx.y * SAQ, q1 = min(q0 + SAQ, p >> 2);  // this block's float4 columns of the row
+  const float4 *row = reinterpret_cast<const float4 *>(ws + ((size_t)bi * n + src) * p);
+  float4 v[SAQ];
+#pragma unroll
+  for (int q = 0; q < SAQ; ++q)
+    if (q0 + q < q1) v[q] = row[q0 + q];
+  if (blockIdx.y == 0) {
+    const int j = e / u;
+    const float *cc = centers + (size_t)bi * 3 * m;
+    v[0].x -= cc[j]; v[0].y -= cc[m + j]; v[0].z -= cc[2 * m + j];
+  }
+  float *ob = out + (size_t)bi * (c + 3) * mu + e;
+  const int rows = c + 3;
+#pragma unroll
+  for (int q = 0; q < SAQ; ++q) {
+    const int ch = (q0 + q) * 4;
+    if (q0 + q < q1) {
+      if (ch + 0 < rows) ob[(size_t)(ch + 0) * mu] = v[q].x;
+      if (ch + 1 < rows) ob[(size_t)(ch + 1) * mu] = v[q].y;
+      if (ch + 2 < rows) ob[(size_t)(ch + 2) * mu] = v[q].z;
+      if (ch + 3 < rows) ob[(size_t)(ch + 3) * mu] = v[q].w;
+    }
+  }
+}
+
+static inline int sa_row_floats(int c) { return ((c + 3 + 3) / 4) * 4; }
+
+extern "C" size_t bdm_sa_group_workspace_bytes(int b, int c, int n) {
+  return (size_t)b * n * sa_row_floats(c) * sizeof(float);
+}
+
 extern "C" int bdm_sa_group(int b, int c, int n, int m, int u, const float *coords, const float *centers,
                             const float *features, long long bs_f, int ld_f, const int *indices, float *out,
-                            void *stream) {
+                            void *workspace, void *stream) {
   BDM_REQUIRE(b >= 0 && c >= 0 && n >= 1 && m >= 1 && u >= 1, "sa_group: bad sizes");
   if (b == 0) return BDM_OK;
+  if (workspace != nullptr) {
+    const int p = sa_row_floats(c);
+    BDM_REQUIRE((reinterpret_cast<size_t>(workspace) & 15) == 0, "sa_group: workspace must be 16-byte aligned");
+    hipLaunchKernelGGL(sa_pack_points_kernel, dim3(cdiv(n, 256), cdiv(p / 4, 3), b), dim3(256), 0, (hipStream_t)stream, c, n, p,
+                       coords, features, bs_f, ld_f, (float *)workspace);
+    hipLaunchKernelGGL(sa_group_pm_kernel, dim3(cdiv(m * u, 256), cdiv(p / 4, SAQ), b), dim3(256), 0, (hipStream_t)stream, c,
+                       n, m, u, p, (const float *)workspace, centers, indices, out);
+    return launch_status("sa_group");
+  }
   int gy = c < 32 ? (c < 1 ? 1 : c) : 32;
   hipLaunchKernelGGL(sa_group_kernel, dim3(cdiv(m * u, 256), gy, b), dim3(256), 0, (hipStream_t)stream, c, n, m, u,
                      coords, centers, features, bs_f, ld_f, indices, out);

@@ -194,35 +194,144 @@ extern "C" int bdm_gather_features_forward(int b, int c, int n, int m, const flo
 // =====================================================================================
 // Ball query: one wave per centre, 64 candidates per step, ballot-ordered append
 // =====================================================================================
-__global__ void ball_query_kernel(int n, int m, float r2, int u, const float *__restrict__ centers,
-                                  const float *__restrict__ points, int *__restrict__ neighbors) {
+// Two phases per tile of up to 4096 candidates, both branch-free in the part that scales with N:
+//  scan   - the tile is staged in LDS so that lane l owns the S = len/64 CONSECUTIVE candidates [l*S, l*S+S) and
+//           step s reads them at consecutive LDS addresses (row pitch 65: conflict-free both ways).  One step costs
+//           three LDS reads shared by the CW centres of the wave, packed-fp32 distance arithmetic for two centres
+//           per instruction (v_pk_add/mul_f32: the same IEEE single operations as the scalar form, so indices stay
+//           bit-identical to the oracle) and "bits = 2*bits + hit" per centre -- no ballots, no appends.
+//  emit   - per centre, a wave prefix sum of the per-lane hit counts gives every hit its rank in candidate order
+//           (lane-major = index order); the first u ranks are stored.  Runs once per tile, not once per step.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int BQ_TILE = 4096, BQ_PITCH = 65;
+
+// inclusive prefix sum over the 64 lanes on the DPP network (no LDS round trips): shifts within rows of 16, then
+// row broadcasts of lane 15 / 31 to the following rows (the scan sequence of LLVM's AMDGPU atomic optimizer)
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+// bits = 2 * bits + (d < r2): the compare's carry goes straight into an add-with-carry
+__device__ __forceinline__ void push_hit(unsigned &bits, float d, float r2) {
+  asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(d), "s"(r2) : "vcc");
+}
+
+template <int CW, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ball_query_kernel(int n, int m, float r2, int u, const float *__restrict__ centers,
+                                                         const float *__restrict__ points, int *__restrict__ neighbors) {
+  static_assert(CW % 2 == 0, "CW even");
+  constexpr int CP = CW / 2;
+  __shared__ float sx[64 * BQ_PITCH], sy[64 * BQ_PITCH], sz[64 * BQ_PITCH];
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int j0 = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * CW;
   const int bi = blockIdx.y;
-  if (j >= m) return;  // whole wave exits together
   const float *px = points + (size_t)bi * 3 * n, *py = px + n, *pz = py + n;
   const float *cb = centers + (size_t)bi * 3 * m;
-  const float cx = cb[j], cy = cb[m + j], cz = cb[2 * m + j];
-  int *nb = neighbors + ((size_t)bi * m + j) * u;
+  f32x2 cx[CP], cy[CP], cz[CP];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    const int j = min(j0 + c, m - 1);  // slots past the last centre repeat it; nothing is stored for them
+    cx[c >> 1][c & 1] = cb[j]; cy[c >> 1][c & 1] = cb[m + j]; cz[c >> 1][c & 1] = cb[2 * m + j];
+  }
+  int cnt[CW], first[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) { cnt[c] = (j0 + c < m) ? 0 : u; first[c] = 0; }  // a full list takes no more hits
+  bool open = j0 < m;
 
-  int cnt = 0, first = 0;
-  for (int k0 = 0; k0 < n && cnt < u; k0 += 64) {
-    const int k = k0 + lane;
-    bool hit = false;
-    if (k < n) hit = sqdist3(cx, cy, cz, px[k], py[k], pz[k]) < r2;
-    const unsigned long long mask = __ballot(hit);
-    if (mask) {
-      const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-      if (hit && pos < u) nb[pos] = k;
-      if (cnt == 0) first = k0 + (__ffsll((long long)mask) - 1);
-      cnt += __popcll(mask);
+  for (int t0 = 0; t0 < n; t0 += BQ_TILE) {
+    const int len = min(BQ_TILE, n - t0);
+    int lg = 0;  // S = 2^lg candidates per lane, S * 64 >= len
+    while ((64 << lg) < len) ++lg;
+    const int S = 1 << lg;
+    if (t0) __syncthreads();
+    for (int k = threadIdx.x; k < (64 << lg); k += WAVES * 64) {
+      const bool in = k < len;
+      const int a = (k & (S - 1)) * BQ_PITCH + (k >> lg);
+      // beyond the end: +inf coordinates -> distance inf or NaN -> never a hit
+      sx[a] = in ? px[t0 + k] : INFINITY; sy[a] = in ? py[t0 + k] : INFINITY; sz[a] = in ? pz[t0 + k] : INFINITY;
     }
+    __syncthreads();
+    if (!open) continue;
+    unsigned wa[CW], wb[CW];  // hit bits of steps [0,32) and [32,64), newest in bit 0
+#pragma unroll
+    for (int c = 0; c < CW; ++c) { wa[c] = 0u; wb[c] = 0u; }
+    const int na = min(S, 32), nbits = S - na;
+    // four steps per batch: their 12 LDS reads are issued together, ahead of the arithmetic
+    auto scan = [&](unsigned (&W)[CW], int s0, int s1) {
+      const float *qx = sx + lane, *qy = sy + lane, *qz = sz + lane;
+      int st = s0;
+      for (; st + 4 <= s1; st += 4) {
+        float xs[4], ys[4], zs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          xs[i] = qx[(st + i) * BQ_PITCH]; ys[i] = qy[(st + i) * BQ_PITCH]; zs[i] = qz[(st + i) * BQ_PITCH];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int cp = 0; cp < CP; ++cp) {
+            const f32x2 dx = cx[cp] - xs[i], dy = cy[cp] - ys[i], dz = cz[cp] - zs[i];
+            const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+            push_hit(W[2 * cp], d[0], r2);
+            push_hit(W[2 * cp + 1], d[1], r2);
+          }
+        }
+      }
+      for (; st < s1; ++st) {
+        const float xk = qx[st * BQ_PITCH], yk = qy[st * BQ_PITCH], zk = qz[st * BQ_PITCH];
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+          const f32x2 dx = cx[cp] - xk, dy = cy[cp] - yk, dz = cz[cp] - zk;
+          const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+          push_hit(W[2 * cp], d[0], r2);
+          push_hit(W[2 * cp + 1], d[1], r2);
+        }
+      }
+    };
+    scan(wa, 0, na);
+    scan(wb, 32, S);
+    bool any_open = false;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      unsigned long long w = ((unsigned long long)wa[c] << nbits) | wb[c];  // step s at bit S-1-s
+      if (cnt[c] < u && __ballot(w != 0ull)) {
+        const int mine = __popcll(w);
+        const int incl = wave_inclusive_sum(mine);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int kbase = t0 + (lane << lg) + S - 1;  // candidate of bit b: kbase - b
+        if (cnt[c] == 0) {
+          const int fl = __ffsll((long long)__ballot(mine > 0)) - 1;
+          first[c] = __shfl(kbase - (63 - __clzll((long long)w)), fl, 64);
+        }
+        int pos = cnt[c] + incl - mine;
+        int *nb = neighbors + ((size_t)bi * m + j0 + c) * u;
+        while (w && pos < u) {
+          const int bit = 63 - __clzll((long long)w);
+          nb[pos++] = kbase - bit;
+          w ^= 1ull << bit;
+        }
+        cnt[c] += total;
+      }
+      any_open |= cnt[c] < u;
+    }
+    open = any_open;
   }
   // slots never reached: first hit (ball_query.cu:40-44), or 0 when there was none
   // (the reference's output tensor is torch::zeros, ball_query.cpp:20-22)
-  const int fill = cnt > 0 ? first : 0;
-  for (int s = lane; s < u; s += 64)
-    if (s >= cnt) nb[s] = fill;
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    if (j0 + c >= m) break;
+    int *nb = neighbors + ((size_t)bi * m + j0 + c) * u;
+    const int fill = cnt[c] > 0 ? first[c] : 0;
+    for (int s = lane; s < u; s += 64)
+      if (s >= cnt[c]) nb[s] = fill;
+  }
 }
 
 extern "C" int bdm_ball_query(int b, int n, int m, float radius, int u, const float *centers,
@@ -230,9 +339,17 @@ extern "C" int bdm_ball_query(int b, int n, int m, float radius, int u, const fl
   BDM_REQUIRE(b >= 0 && n >= 1 && m >= 0 && u >= 1, "ball_query: bad sizes");
   if (b == 0 || m == 0) return BDM_OK;
   const float r2 = radius * radius;  // ball_query.cpp:24
-  dim3 grid(cdiv(m, 4), b);
-  hipLaunchKernelGGL(ball_query_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, r2, u, centers,
-                     points, neighbors);
+  // centres per wave / waves per workgroup: a workgroup stages one 4096-candidate tile (50 KB of LDS) for all its
+  // centres, so big launches use 8 waves x 4 centres (2 workgroups = 16 waves per CU), small ones spread out
+  const long long centres = (long long)b * m;
+  hipStream_t st = (hipStream_t)stream;
+  if (centres >= 16384) {
+    hipLaunchKernelGGL((ball_query_kernel<4, 8>), dim3(cdiv(m, 32), b), dim3(512), 0, st, n, m, r2, u, centers, points, neighbors);
+  } else if (centres >= 4096) {
+    hipLaunchKernelGGL((ball_query_kernel<4, 4>), dim3(cdiv(m, 16), b), dim3(256), 0, st, n, m, r2, u, centers, points, neighbors);
+  } else {
+    hipLaunchKernelGGL((ball_query_kernel<2, 4>), dim3(cdiv(m, 8), b), dim3(256), 0, st, n, m, r2, u, centers, points, neighbors);
+  }
   return launch_status("ball_query");
 }
 

@@ -15,6 +15,7 @@
 // Deterministic (no atomics); differs from the dense kernel only in fp32 summation order.
 #include "../../include/bdm_hip.h"
 #include "common.h"
+#include "s3_split.h"
 
 using namespace bdm;
 
@@ -115,6 +116,185 @@ extern "C" int bdm_sparse_conv_pack_weights(int cout, int cin, const float *w, f
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 2'. bf16x6 form of steps 1b + 2 (the default): both GEMM operands are stored pre-split ("S3", s3_split.h) so the
+//     GEMM is pure v_mfma_f32_32x32x16_bf16 work -- six exact 8x8-bit partial products per fp32 product, fp32
+//     accumulation, smallest terms first; ~2.6x the rate of the fp32-input MFMA at fp32-grade accuracy (~2^-22).
+//       Xs (B, G, 3, n_max) records : G = ceil(Cin/8) channel groups of the occupied cells' mean features
+//       Ws (G, 3, 27*Cout) records  : Ws[g][s][tap*Cout+co] = split_s(w[co][8g..8g+7][tap])
+// ---------------------------------------------------------------------------------------------------
+// XCD-aware launch: the 8 feature rows of a (shape, channel group) unit (8 x 4N bytes) are gathered 4 bytes at a time by
+// all k-blocks of the unit; consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
+// 1-D grid is decoded such that every k-block of a unit has the same id mod 8: the rows are fetched into ONE L2 once
+// instead of missing in all eight (measured 329 -> see DESIGN.md for the 390-channel level).
+__global__ void sparse_vox_features_s3_kernel(int c, int n, int r3, int n_max, int G, int units, int kblocks,
+                                              const float *__restrict__ feat,
+                                              long long bs_f, int ld_f, const int *__restrict__ cnt,
+                                              const int *__restrict__ start, const int *__restrict__ sorted,
+                                              const int *__restrict__ occ_list, const int *__restrict__ n_occ,
+                                              unsigned short *__restrict__ xs) {
+#pragma clang fp contract(off)  // same arithmetic as vox_reduce_kernel: the values equal the dense grid's bit for bit
+  const int wg = blockIdx.x, span = 8 * kblocks;
+  const int unit = (wg / span) * 8 + (wg % span) % 8, kb = (wg % span) / 8;
+  if (unit >= units) return;
+  const int bi = unit / G, g = unit % G;
+  const int k = kb * blockDim.x + threadIdx.x;
+  if (k >= n_max) return;
+  const bool live = k < n_occ[bi];
+  int cv = 0, s = 0;
+  if (live) {
+    const int v = occ_list[(size_t)bi * n_max + k];
+    cv = cnt[(size_t)bi * r3 + v];
+    s = start[(size_t)bi * r3 + v];
+  }
+  const int *so = sorted + (size_t)bi * n + s;
+  const float inv = cv > 0 ? (float)(1.0 / (double)(float)cv) : 0.f;
+  const float *fb = feat + (size_t)bi * bs_f + (size_t)g * 8 * ld_f;
+  const int nch = min(8, c - g * 8);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int q = 0; q < cv; ++q) {
+    const int p = so[q];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < nch) acc[j] = acc[j] + fb[(size_t)j * ld_f + p] * inv;
+  }
+  store_s3(xs + ((size_t)bi * G + g) * 3 * (size_t)n_max * 8, (size_t)k, (size_t)n_max, acc);
+}
+
+extern "C" int bdm_sparse_voxel_features_s3(int b, int c, int n, int r, int n_max, const float *features, long long bs_f,
+                                            int ld_f, const int *cnt, const void *plan_workspace, const int *occ_list,
+                                            const int *n_occ, void *xs, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && n >= 1 && r >= 1 && n_max >= 1, "sparse_voxel_features_s3: bad sizes");
+  if (b == 0) return BDM_OK;
+  const int r3 = r * r * r;
+  VoxWs w = vox_ws(const_cast<void *>(plan_workspace), b, n, r3);
+  const int G = (c + 7) / 8, units = b * G, kblocks = cdiv(n_max, 128);
+  hipLaunchKernelGGL(sparse_vox_features_s3_kernel, dim3(cdiv(units, 8) * 8 * kblocks), dim3(128), 0, (hipStream_t)stream, c,
+                     n, r3, n_max, G, units, kblocks, features, bs_f, ld_f, cnt, w.start, w.sorted, occ_list, n_occ,
+                     (unsigned short *)xs);
+  return launch_status("sparse_voxel_features_s3");
+}
+
+__global__ void sparse_pack_s3_kernel(int cout, int cin, const float *__restrict__ w, unsigned short *__restrict__ ws) {
+  const int n27 = 27 * cout, G = (cin + 7) / 8;
+  const long long total = (long long)G * n27;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(e / n27), col = (int)(e % n27), tap = col / cout, co = col % cout;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ci = g * 8 + j;
+      v[j] = ci < cin ? w[((size_t)co * cin + ci) * 27 + tap] : 0.f;
+    }
+    store_s3(ws + (size_t)g * 3 * n27 * 8, (size_t)col, (size_t)n27, v);
+  }
+}
+extern "C" size_t bdm_sparse_conv_s3_weight_elems(int cout, int cin) { return (size_t)((cin + 7) / 8) * 3 * 27 * cout * 8; }
+extern "C" int bdm_sparse_conv_pack_weights_s3(int cout, int cin, const float *w, void *ws, void *stream) {
+  BDM_REQUIRE(cout >= 1 && cin >= 1, "sparse_conv_pack_weights_s3: bad sizes");
+  hipLaunchKernelGGL(sparse_pack_s3_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, cout, cin, w, (unsigned short *)ws);
+  return launch_status("sparse_conv_pack_weights_s3");
+}
+
+// Y[b] (M x N) = Xs[b]^T . Ws : 128 x 128 tile per workgroup (2 x 2 waves of 64 x 64), K = 32 (four record groups)
+// per stage, register-prefetched: the 12 global loads of stage c+1 are in flight during the 48 MFMAs of stage c.
+__global__ __launch_bounds__(256) void sparse_gemm_s3_kernel(int M, int G, int N, const uint4 *__restrict__ A,
+                                                             const uint4 *__restrict__ Bw, const int *__restrict__ m_count,
+                                                             float *__restrict__ Y) {
+  constexpr int BM = 128, BN = 128, AI = 12 * BM / 256, BI = 12 * BN / 256;
+  __shared__ uint4 As[12 * BM], Bs[12 * BN];  // [group-in-stage][split][row]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, bi = blockIdx.z;
+  if (m_count && m0 >= m_count[bi]) return;  // rows beyond this shape's occupied cells
+  const uint4 *Ab = A + (size_t)bi * G * 3 * M;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  uint4 ar[AI], br[BI];
+  auto load_stage = [&](int g0) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int e = tid + i * 256, row = e % BM, gs = e / BM, g = g0 + gs / 3, sp = gs % 3;
+      const bool ok = g < G && m0 + row < M;  // branch-free: load a valid record, then select (keeps ar[] in registers)
+      const uint4 v = Ab[ok ? ((size_t)g * 3 + sp) * M + m0 + row : 0];
+      ar[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int e = tid + i * 256, col = e % BN, gs = e / BN, g = g0 + gs / 3, sp = gs % 3;
+      const bool ok = g < G && n0 + col < N;
+      const uint4 v = Bw[ok ? ((size_t)g * 3 + sp) * N + n0 + col : 0];
+      br[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+  };
+  load_stage(0);
+  for (int g0 = 0; g0 < G; g0 += 4) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < AI; ++i) As[tid + i * 256] = ar[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) Bs[tid + i * 256] = br[i];
+    __syncthreads();
+    if (g0 + 4 < G) load_stage(g0 + 4);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+          a[x][sp] = *reinterpret_cast<const bf16x8 *>(&As[((2 * kk + lh) * 3 + sp) * BM + (wr * 2 + x) * 32 + li]);
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+          b[y][sp] = *reinterpret_cast<const bf16x8 *>(&Bs[((2 * kk + lh) * 3 + sp) * BN + (wc * 2 + y) * 32 + li]);
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+          f32x16 c = acc[x][y];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][2], b[y][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][0], c, 0, 0, 0);
+          acc[x][y] = c;
+        }
+    }
+  }
+  // C/D map: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 -> 128-byte runs along n
+  float *Yb = Y + (size_t)bi * M * N;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int nn = n0 + (wc * 2 + y) * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wr * 2 + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && nn < N) Yb[(size_t)m * N + nn] = acc[x][y][r];
+      }
+    }
+}
+
+extern "C" int bdm_sparse_conv_gemm_s3(int b, int n_max, int cin, int n27, const void *xs, const void *ws, const int *n_occ,
+                                       float *y, void *stream) {
+  BDM_REQUIRE(b >= 0 && n_max >= 1 && cin >= 1 && n27 >= 1, "sparse_conv_gemm_s3: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(sparse_gemm_s3_kernel, dim3(cdiv(n27, 128), cdiv(n_max, 128), b), dim3(256), 0, (hipStream_t)stream,
+                     n_max, (cin + 7) / 8, n27, (const uint4 *)xs, (const uint4 *)ws, n_occ, y);
+  return launch_status("sparse_conv_gemm_s3");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 3. output-stationary gather.  One workgroup = one grid row (x, y): r cells x Cout channels.
 //    A wave sums one cell at a time over 64 channels (coalesced 256-B reads of a Y row segment); the tile is
 //    transposed through LDS so that the channel-first output is written as contiguous z-runs.
@@ -185,11 +365,91 @@ __global__ __launch_bounds__(256) void sparse_gather_kernel(int cout, int r, int
   }
 }
 
+// Same sums in the same order, with more memory parallelism (Cout % 4 == 0): a lane owns (cell z, 4 channels) and
+// reads its cell's occupied taps as 16-byte pieces of the Y rows, four loads in flight; a wave therefore works on
+// 64 / (Cout/4) cells at once instead of one, and issues a quarter of the load instructions.
+__global__ __launch_bounds__(256) void sparse_gather_v4_kernel(int cout, int r, int n_max, const float *__restrict__ y,
+                                                               const int *__restrict__ occ_index,
+                                                               const unsigned char *__restrict__ rowocc,
+                                                               const float *__restrict__ bias, float *__restrict__ out) {
+  extern __shared__ float tile[];  // [r][cout + 1] floats, 9 * (r + 2) neighbour indices, r tap masks
+  const int row = blockIdx.x, bi = blockIdx.y, x = row / r, yy = row % r;
+  const int r2 = r * r, r3 = r2 * r, tid = threadIdx.x;
+  const int ldt = cout + 1, rs = r + 2;
+  int *nbr = reinterpret_cast<int *>(tile + r * ldt);  // nbr[t9][1 + z], -1 = empty / outside the grid
+  unsigned *zmask = reinterpret_cast<unsigned *>(nbr + 9 * rs);
+  float *ob = out + (size_t)bi * cout * r3;
+  const unsigned char *ro = rowocc + (size_t)bi * r2;
+  bool any = false;
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9) {
+    const int gx = x + t9 / 3 - 1, gy = yy + t9 % 3 - 1;
+    if (gx >= 0 && gx < r && gy >= 0 && gy < r) any |= ro[gx * r + gy] != 0;
+  }
+  if (!any) {  // no occupied cell anywhere under this row's 3x3x3 stencils: pure bias
+    for (int e = tid; e < cout * r; e += 256) {
+      const int co = e / r, z = e % r;
+      ob[(size_t)co * r3 + row * r + z] = bias ? bias[co] : 0.f;
+    }
+    return;
+  }
+  const int *oi = occ_index + (size_t)bi * r3;
+  for (int e = tid; e < 9 * rs; e += 256) {
+    const int t9 = e / rs, zz = e % rs - 1;
+    const int gx = x + t9 / 3 - 1, gy = yy + t9 % 3 - 1;
+    int k = -1;
+    if (gx >= 0 && gx < r && gy >= 0 && gy < r && zz >= 0 && zz < r && ro[gx * r + gy]) k = oi[(gx * r + gy) * r + zz];
+    nbr[e] = k;
+  }
+  __syncthreads();
+  if (tid < r) {
+    unsigned mk = 0u;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) mk |= (nbr[(t / 3) * rs + 1 + tid + t % 3 - 1] >= 0 ? 1u : 0u) << t;
+    zmask[tid] = mk;
+  }
+  __syncthreads();
+  const float *yb = y + (size_t)bi * n_max * 27 * cout;
+  const int c4n = cout >> 2;
+  for (int item = tid; item < r * c4n; item += 256) {
+    const int z = item / c4n, co = (item % c4n) * 4;
+    unsigned mask = zmask[z];
+    float4 acc = bias ? make_float4(bias[co], bias[co + 1], bias[co + 2], bias[co + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    while (mask) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mask) {
+          const int t = __ffs((int)mask) - 1;
+          mask &= mask - 1;
+          const int k = nbr[(t / 3) * rs + 1 + z + t % 3 - 1];
+          v[u] = *reinterpret_cast<const float4 *>(yb + ((size_t)k * 27 + t) * cout + co);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    float *tp = tile + z * ldt + co;
+    tp[0] = acc.x; tp[1] = acc.y; tp[2] = acc.z; tp[3] = acc.w;
+  }
+  __syncthreads();
+  for (int e = tid; e < cout * r; e += 256) {
+    const int co = e / r, z = e % r;
+    ob[(size_t)co * r3 + row * r + z] = tile[z * ldt + co];
+  }
+}
+
 extern "C" int bdm_sparse_conv_gather(int b, int cout, int r, int n_max, const float *y, const int *occ_index,
                                       const unsigned char *rowocc, const float *bias, float *out, void *stream) {
   BDM_REQUIRE(b >= 0 && cout >= 1 && r >= 1 && n_max >= 1, "sparse_conv_gather: bad sizes");
   if (b == 0) return BDM_OK;
   const size_t smem = sizeof(float) * (size_t)r * (cout + 1) + sizeof(int) * 9 * (size_t)(r + 2);
+  if ((cout & 3) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0) {
+    hipLaunchKernelGGL(sparse_gather_v4_kernel, dim3(r * r, b), dim3(256), smem + sizeof(unsigned) * r, (hipStream_t)stream,
+                       cout, r, n_max, y, occ_index, rowocc, bias, out);
+    return launch_status("sparse_conv_gather");
+  }
   hipLaunchKernelGGL(sparse_gather_kernel, dim3(r * r, b), dim3(256), smem, (hipStream_t)stream, cout, r, n_max, y,
                      occ_index, rowocc, bias, out);
   return launch_status("sparse_conv_gather");

@@ -160,13 +160,15 @@ class PVConv(nn.Module):
     conv_impl = os.environ.get("BDM_CONV", "bf16x6")
     sparse_first_conv = os.environ.get("BDM_SPARSE_CONV1", "1") == "1"
     sparse_resolutions = {int(v) for v in os.environ.get("BDM_SPARSE_R", "8,16,32").split(",") if v}
+    sparse_gemm = "sparse" if os.environ.get("BDM_SPARSE_GEMM", "bf16x6") == "fp32" else "sparse_s3"
 
     def _packed_weight(self, conv, impl):
         key = (id(conv), impl)
         sig = (conv.weight._version, conv.weight.data_ptr())
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
-            pack = {"bf16x6": ops.conv3d_s3_pack, "sparse": ops.sparse_conv_pack, "fp32": ops.conv3d_pack}[impl]
+            pack = {"bf16x6": ops.conv3d_s3_pack, "sparse": ops.sparse_conv_pack, "sparse_s3": ops.sparse_conv_pack_s3,
+                    "fp32": ops.conv3d_pack}[impl]
             hit = (sig, pack(conv.weight.detach()))
             self._packed[key] = hit
         return hit[1]
@@ -188,7 +190,7 @@ class PVConv(nn.Module):
                 # the (coords, r) plan is shared by the PVConvs of one level
                 plan = ops.voxel_plan(coords, r, self.voxelization.eps)
                 norm_coords = plan.norm_coords
-                v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, "sparse"), conv1.bias,
+                v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, self.sparse_gemm), conv1.bias,
                                                   conv1.out_channels)
             else:
                 norm_coords, vox_coords = ops.voxel_coords(coords, r, self.voxelization.eps)

@@ -4,6 +4,8 @@ Tensors are (B, C, L) or (B, C, M, U) fp32 on a HIP device; any view whose inner
 are contiguous (e.g. a channel slice of a concat buffer) is passed by (batch stride,
 row stride) without a copy.  Torch supplies memory and the current stream only.
 """
+import ctypes
+
 import torch
 
 from . import _lib as L
@@ -98,14 +100,17 @@ def max_over_neighbors(x, out=None):
     return out
 
 
-def sa_group(coords, centers, features, indices):
+def sa_group(coords, centers, features, indices, point_major=None):
     """cat[grouping(coords) - centers, grouping(features)] -> (B, 3+C, M, U)."""
     B, _, n = coords.shape
     m, u = indices.shape[1], indices.shape[2]
     f, _, C, _, bs_f, ld_f = _bcl(features)
     out = torch.empty(B, 3 + C, m, u, dtype=torch.float32, device=coords.device)
+    if point_major is None:  # the repack pays off only for the big first level (measured: tools/query_bench.py)
+        point_major = B * m * u >= (1 << 18) and C <= 64
+    ws = workspace(L.lib().bdm_sa_group_workspace_bytes(B, C, n), coords.device, "sa_group") if point_major else None
     L.check(L.lib().bdm_sa_group(B, C, n, m, u, L.ptr(coords), L.ptr(centers), L.ptr(f), L.c_ll(bs_f), ld_f,
-                                 L.ptr(indices), L.ptr(out), L.stream()), "sa_group")
+                                 L.ptr(indices), L.ptr(out), L.ptr(ws), L.stream()), "sa_group")
     return out
 
 
@@ -317,6 +322,17 @@ def sparse_conv_pack(weight):
     return wt
 
 
+def sparse_conv_pack_s3(weight):
+    """(Cout, Cin, 3,3,3) fp32 -> pre-split bf16 GEMM operand (ceil(Cin/8), 3, 27*Cout, 8)."""
+    cout, cin = weight.shape[:2]
+    lib = L.lib()
+    lib.bdm_sparse_conv_s3_weight_elems.restype = ctypes.c_size_t
+    ws = torch.empty(lib.bdm_sparse_conv_s3_weight_elems(cout, cin), dtype=torch.bfloat16, device=weight.device)
+    L.check(lib.bdm_sparse_conv_pack_weights_s3(cout, cin, L.ptr(weight.contiguous()), L.ptr(ws), L.stream()),
+            "sparse_conv_pack_weights_s3")
+    return ws
+
+
 class VoxelPlan:
     """Everything that depends on (coords, r) only: normalised / integer voxel coordinates, per-voxel point lists,
     occupied-cell compaction and row occupancy.  PVConvs of one level share it (exactly the same values)."""
@@ -361,12 +377,21 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout):
     """Conv3d(k3, p1)(avg_voxelize(features)) on the occupied voxels of `plan`: (B, cout, r^3) fp32."""
     f, B, C, n, bs_f, ld_f = _bcl(features)
     dev, lib, r = f.device, L.lib(), plan.r
-    xc = torch.empty(B, C, plan.n_max, dtype=torch.float32, device=dev)
-    L.check(lib.bdm_sparse_voxel_features(B, C, n, r, plan.n_max, L.ptr(f), L.c_ll(bs_f), ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),
-                                          L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xc), L.stream()), "sparse_voxel_features")
     y = torch.empty(B, plan.n_max, 27 * cout, dtype=torch.float32, device=dev)
-    L.check(lib.bdm_sparse_conv_gemm(B, plan.n_max, C, 27 * cout, L.ptr(xc), L.ptr(wt), L.ptr(plan.n_occ), L.ptr(y), L.stream()),
-            "sparse_conv_gemm")
+    if wt.dtype == torch.bfloat16:  # bf16x6: pre-split operands (sparse_conv_pack_s3)
+        xs = torch.empty(B, (C + 7) // 8, 3, plan.n_max, 8, dtype=torch.bfloat16, device=dev)
+        L.check(lib.bdm_sparse_voxel_features_s3(B, C, n, r, plan.n_max, L.ptr(f), L.c_ll(bs_f), ld_f, L.ptr(plan.cnt),
+                                                 L.ptr(plan.ws), L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xs), L.stream()),
+                "sparse_voxel_features_s3")
+        L.check(lib.bdm_sparse_conv_gemm_s3(B, plan.n_max, C, 27 * cout, L.ptr(xs), L.ptr(wt), L.ptr(plan.n_occ), L.ptr(y),
+                                            L.stream()), "sparse_conv_gemm_s3")
+    else:
+        xc = torch.empty(B, C, plan.n_max, dtype=torch.float32, device=dev)
+        L.check(lib.bdm_sparse_voxel_features(B, C, n, r, plan.n_max, L.ptr(f), L.c_ll(bs_f), ld_f, L.ptr(plan.cnt),
+                                              L.ptr(plan.ws), L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xc), L.stream()),
+                "sparse_voxel_features")
+        L.check(lib.bdm_sparse_conv_gemm(B, plan.n_max, C, 27 * cout, L.ptr(xc), L.ptr(wt), L.ptr(plan.n_occ), L.ptr(y),
+                                         L.stream()), "sparse_conv_gemm")
     out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
     L.check(lib.bdm_sparse_conv_gather(B, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index), L.ptr(plan.rowocc), L.ptr(bias),
                                        L.ptr(out), L.stream()), "sparse_conv_gather")
@@ -374,30 +399,22 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout):
 
 
 def sparse_first_conv(features, vox_coords, r, wt, bias, cout):
-    """Conv3d(k3, p1)(avg_voxelize(features, vox_coords, r)) evaluated on the occupied voxels: (B, cout, r^3) fp32."""
-    f, B, C, n, bs_f, ld_f = _bcl(features)
-    dev = f.device
-    r3 = r ** 3
-    n_max = min(n, r3)
-    ind = torch.empty(B, n, dtype=torch.int32, device=dev)
-    cnt = torch.empty(B, r3, dtype=torch.int32, device=dev)
-    ws = workspace(L.lib().bdm_voxelize_workspace_bytes(B, n, r), dev, "vox")
-    lib = L.lib()
-    L.check(lib.bdm_voxelize_plan(B, n, r, L.ptr(vox_coords), L.ptr(ind), L.ptr(cnt), L.ptr(ws), L.stream()), "voxelize_plan")
-    occ_index = torch.empty(B, r3, dtype=torch.int32, device=dev)
-    occ_list = torch.empty(B, n_max, dtype=torch.int32, device=dev)
-    n_occ = torch.empty(B, dtype=torch.int32, device=dev)
-    rowocc = torch.empty(B, r * r, dtype=torch.uint8, device=dev)
-    L.check(lib.bdm_voxel_compact(B, r, n_max, L.ptr(cnt), L.ptr(occ_index), L.ptr(occ_list), L.ptr(n_occ), L.stream()),
+    """Conv3d(k3, p1)(avg_voxelize(features, vox_coords, r)) evaluated on the occupied voxels: (B, cout, r^3) fp32.
+    Builds a one-off plan from integer voxel coordinates (the modules share cached plans: voxel_plan)."""
+    B, _, n = vox_coords.shape
+    dev, lib, r3 = vox_coords.device, L.lib(), r ** 3
+    p = VoxelPlan()
+    p.r, p.n, p.n_max = int(r), n, min(n, r3)
+    p.norm_coords, p.vox_coords = None, vox_coords
+    p.ind = torch.empty(B, n, dtype=torch.int32, device=dev)
+    p.cnt = torch.empty(B, r3, dtype=torch.int32, device=dev)
+    p.ws = torch.empty(lib.bdm_voxelize_workspace_bytes(B, n, r), dtype=torch.uint8, device=dev)
+    L.check(lib.bdm_voxelize_plan(B, n, r, L.ptr(vox_coords), L.ptr(p.ind), L.ptr(p.cnt), L.ptr(p.ws), L.stream()), "voxelize_plan")
+    p.occ_index = torch.empty(B, r3, dtype=torch.int32, device=dev)
+    p.occ_list = torch.empty(B, p.n_max, dtype=torch.int32, device=dev)
+    p.n_occ = torch.empty(B, dtype=torch.int32, device=dev)
+    p.rowocc = torch.empty(B, r * r, dtype=torch.uint8, device=dev)
+    L.check(lib.bdm_voxel_compact(B, r, p.n_max, L.ptr(p.cnt), L.ptr(p.occ_index), L.ptr(p.occ_list), L.ptr(p.n_occ), L.stream()),
             "voxel_compact")
-    L.check(lib.bdm_voxel_row_occupancy(B, r, L.ptr(cnt), L.ptr(rowocc), L.stream()), "voxel_row_occupancy")
-    xc = torch.empty(B, C, n_max, dtype=torch.float32, device=dev)
-    L.check(lib.bdm_sparse_voxel_features(B, C, n, r, n_max, L.ptr(f), L.c_ll(bs_f), ld_f, L.ptr(cnt), L.ptr(ws),
-                                          L.ptr(occ_list), L.ptr(n_occ), L.ptr(xc), L.stream()), "sparse_voxel_features")
-    y = torch.empty(B, n_max, 27 * cout, dtype=torch.float32, device=dev)
-    L.check(lib.bdm_sparse_conv_gemm(B, n_max, C, 27 * cout, L.ptr(xc), L.ptr(wt), L.ptr(n_occ), L.ptr(y), L.stream()),
-            "sparse_conv_gemm")
-    out = torch.empty(B, cout, r3, dtype=torch.float32, device=dev)
-    L.check(lib.bdm_sparse_conv_gather(B, cout, r, n_max, L.ptr(y), L.ptr(occ_index), L.ptr(rowocc), L.ptr(bias), L.ptr(out),
-                                       L.stream()), "sparse_conv_gather")
-    return out
+    L.check(lib.bdm_voxel_row_occupancy(B, r, L.ptr(p.cnt), L.ptr(p.rowocc), L.stream()), "voxel_row_occupancy")
+    return sparse_first_conv_planned(features, p, wt, bias, cout)

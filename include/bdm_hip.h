@@ -126,10 +126,13 @@ int bdm_max_over_neighbors(int b, int c, int m, int u, const float *x, float *y,
                            int ld_y, void *stream);
 
 /* BallQuery.forward's grouped tensor (modules/ball_query.py:16-30) in one launch:
- * out (b, 3+c, m, u) = cat[ grouping(coords, idx) - centers[..., None], grouping(features, idx) ]. */
+ * out (b, 3+c, m, u) = cat[ grouping(coords, idx) - centers[..., None], grouping(features, idx) ].
+ * workspace: NULL -> direct channel-first gather; else >= bdm_sa_group_workspace_bytes(b, c, n) bytes (16-byte aligned):
+ * [coords ; features] are first repacked point-major so the gather reads 16-byte runs (same values). */
+size_t bdm_sa_group_workspace_bytes(int b, int c, int n);
 int bdm_sa_group(int b, int c, int n, int m, int u, const float *coords, const float *centers,
                  const float *features, long long bs_f, int ld_f, const int *indices, float *out,
-                 void *stream);
+                 void *workspace, void *stream);
 
 /* y[b][ci][:] = v[b][ci]   -- t_emb[:, :, None].expand(-1, -1, N) (pvcnn.py:88) written into a concat slice. */
 int bdm_broadcast_rows(int b, int c, int l, const float *v, int ld_v, float *y, long long bs_y,
@@ -198,6 +201,17 @@ int bdm_group_norm_stats(int b, int c, int l, int groups, const float *x, long l
 int bdm_voxelize_plan(int b, int n, int r, const int *coords, int *ind, int *cnt, void *workspace, void *stream);
 int bdm_avg_voxelize_s3(int b, int c, int n, int r, const float *features, long long bs_f, int ld_f,
                         const int *coords, void *out_s3, int *ind, int *cnt, void *workspace, void *stream);
+
+/* bf16x6 form of the two steps above (default): operands pre-split into exact bf16 triples ("S3" records of 8
+ * channels x 16 bytes), GEMM on v_mfma_f32_32x32x16_bf16 with six partial products per fp32 product.
+ *   xs (b, ceil(c/8), 3, n_max) records; ws (ceil(cin/8), 3, 27*cout) records = bdm_sparse_conv_s3_weight_elems bf16. */
+int bdm_sparse_voxel_features_s3(int b, int c, int n, int r, int n_max, const float *features, long long bs_f,
+                                 int ld_f, const int *cnt, const void *plan_workspace, const int *occ_list,
+                                 const int *n_occ, void *xs, void *stream);
+size_t bdm_sparse_conv_s3_weight_elems(int cout, int cin);
+int bdm_sparse_conv_pack_weights_s3(int cout, int cin, const float *w, void *ws, void *stream);
+int bdm_sparse_conv_gemm_s3(int b, int n_max, int cin, int n27, const void *xs, const void *ws, const int *n_occ,
+                            float *y, void *stream);
 
 /* --- first convolution of a PVConv on the occupied voxels only (sparse_conv.hip) ---
  * out = Conv3d(avg_voxelize(features)) without materialising the dense grid:

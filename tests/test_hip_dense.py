@@ -159,8 +159,14 @@ def test_pvconv_tail_and_sa_group(ops, oracle_ops):
     nb = oracle_ops.ball_query(ctr, pts, 0.2, 32)
     f = torch.randn(B, 11, n, generator=g)
     ref = torch.cat([oracle_ops.grouping_forward(pts, nb) - ctr.unsqueeze(-1), oracle_ops.grouping_forward(f, nb)], 1)
-    got = ops.sa_group(pts.cuda(), ctr.cuda(), f.cuda(), nb.cuda()).cpu()
-    assert torch.equal(got, ref)
+    for point_major in (False, True):
+        got = ops.sa_group(pts.cuda(), ctr.cuda(), f.cuda(), nb.cuda(), point_major=point_major).cpu()
+        assert torch.equal(got, ref)
+    big = torch.zeros(B, 300, n)  # channel slice of a wider buffer (strided rows), 259 channels: 9 column blocks
+    big[:, 20:279] = torch.randn(B, 259, n, generator=g)
+    fv = big[:, 20:279]
+    ref = torch.cat([oracle_ops.grouping_forward(pts, nb) - ctr.unsqueeze(-1), oracle_ops.grouping_forward(fv.contiguous(), nb)], 1)
+    assert torch.equal(ops.sa_group(pts.cuda(), ctr.cuda(), big.cuda()[:, 20:279], nb.cuda()).cpu(), ref)
 
 
 @pytest.mark.parametrize("cin,cout,r,npts", [(35, 32, 32, 4096), (64, 64, 32, 4096), (128, 64, 16, 1024), (256, 256, 8, 64),
@@ -241,6 +247,9 @@ def test_sparse_first_conv_equals_dense(ops, oracle_ops, cin, cout, r, npts):
     ref = TF.conv3d(vox.double().view(B, cin, r, r, r), w.double(), bias.double(), padding=1).float().reshape(B, cout, -1)
     got = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack(w.cuda()), bias.cuda(), cout).cpu()
     assert rel(got, ref) < 2e-6
+    # bf16x6 GEMM on pre-split operands: same bound (fp32-grade products, fp32 accumulation)
+    got6 = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack_s3(w.cuda()), bias.cuda(), cout).cpu()
+    assert rel(got6, ref) < 2e-6
     # runs of a concat buffer (strided features) give the same result
     big = torch.randn(B, cin + 6, npts, generator=g).cuda()
     big[:, 3:3 + cin] = f.cuda()

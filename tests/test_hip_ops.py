@@ -50,6 +50,17 @@ def test_ball_query_bit_exact(hip, oracle_ops, n, m, radius):
     assert torch.equal(ref, got)
 
 
+@pytest.mark.parametrize("B,n,m,radius,scale", [(9, 4096, 1023, 0.1, 0.25), (16, 2000, 513, 0.1, 0.05), (5, 700, 600, 0.3, 1.0)])
+def test_ball_query_multi_centre_waves_bit_exact(hip, oracle_ops, B, n, m, radius, scale):
+    """large batches take the 4- and 2-centres-per-wave kernels; ragged m exercises the unused centre slots."""
+    g = torch.Generator().manual_seed(n + m)
+    pts = torch.randn(B, 3, n, generator=g) * scale
+    ctr = pts[:, :, torch.randperm(n, generator=g)[:m]].contiguous()
+    ref = oracle_ops.ball_query(ctr, pts, radius, 32)
+    got = hip.ball_query(ctr.cuda(), pts.cuda(), radius, 32).cpu()
+    assert torch.equal(ref, got)
+
+
 def test_gather_grouping_exact(hip, oracle_ops):
     B, C, N, M, U = 2, 35, 1000, 130, 32
     g = torch.Generator().manual_seed(1)

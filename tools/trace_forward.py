@@ -1,0 +1,28 @@
+"""One PC2 forward (B=16, N=4096) between two marker kernels, for `rocprofv3 --kernel-trace`: tools/trace_summary.py then
+lists every launch of that forward in order with its duration and grid."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bdm_amd.config import ProjectConfig
+from bdm_amd.data import SyntheticShapes
+from bdm_amd.model import get_model
+from bdm_amd.pvd import prepare_pvd_model
+from bdm_amd.utils.procedural import fill_module_
+
+B, N = 16, 4096
+which = sys.argv[1] if len(sys.argv) > 1 else "pc2"
+cfg = ProjectConfig(); cfg.dataset.max_points = N
+model = fill_module_(get_model(cfg).eval(), seed=1).cuda()
+pvd = prepare_pvd_model({"model": None, "nc": 3, "embed_dim": 64, "attention": True, "dropout": 0.1}, "cuda")
+batch = next(iter(SyntheticShapes(range(B), B, num_points=N))).to("cuda")
+x = torch.randn(B, N, 3, device="cuda") * float(os.environ.get("SCALE", "0.5"))
+t = torch.full((B,), 500, dtype=torch.int64, device="cuda")
+xin = model.get_input_with_conditioning(x, batch.camera, batch.image_rgb, None, t)
+xp = x.transpose(1, 2).contiguous()
+fn = (lambda: model.point_cloud_model(xin, t)) if which == "pc2" else (lambda: pvd.model(xp, t))
+for _ in range(2): fn()
+torch.cuda.synchronize()
+marker = torch.zeros(7, device="cuda")
+torch.cumsum(marker, 0); torch.cuda.synchronize()   # marker kernel 1
+fn(); torch.cuda.synchronize()
+torch.cumsum(marker, 0); torch.cuda.synchronize()   # marker kernel 2
