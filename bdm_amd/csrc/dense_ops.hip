@@ -151,10 +151,17 @@ extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, in
   hipLaunchKernelGGL((pw_gemm_kernel<MI, NI>), dim3(cdiv(n, 128 * NI), cdiv(m, 32 * MI), b), dim3(256), 0, s, \
                      m, k, n, w, ldw, 0ll, (const int *)nullptr, x, bs_x, ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r,  \
                      y, bs_y, ld_y, act, slope)
+  // biggest tile that still gives the 256 CUs two workgroups each; small problems (the 16..256-point levels) are
+  // latency-bound and prefer many small tiles over operand reuse
+  auto blocks = [&](int mi, int ni) { return (long long)cdiv(n, 128 * ni) * cdiv(m, 32 * mi) * b; };
   if (m <= 32) {
-    if (n <= 128) PW_LAUNCH(1, 1); else PW_LAUNCH(1, 2);
+    if (n <= 128 || blocks(1, 2) < 512) PW_LAUNCH(1, 1); else PW_LAUNCH(1, 2);
+  } else if (n > 128 && blocks(2, 2) >= 512) {
+    PW_LAUNCH(2, 2);
+  } else if (blocks(2, 1) >= 512) {
+    PW_LAUNCH(2, 1);
   } else {
-    if (n <= 128) PW_LAUNCH(2, 1); else PW_LAUNCH(2, 2);
+    PW_LAUNCH(1, 1);
   }
 #undef PW_LAUNCH
   return launch_status("pointwise_conv");
