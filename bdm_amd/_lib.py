@@ -40,6 +40,7 @@ def lib():
         _lib.bdm_last_error.restype = ctypes.c_char_p
         _lib.bdm_voxelize_workspace_bytes.restype = ctypes.c_size_t
         _lib.bdm_sa_group_workspace_bytes.restype = ctypes.c_size_t
+        _lib.bdm_attention_workspace_bytes.restype = ctypes.c_size_t
     return _lib
 
 

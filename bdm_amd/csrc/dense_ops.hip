@@ -934,21 +934,47 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(int C, int L, const flo
   }
 }
 
-// (b) small-sequence kernel (global attention: 16 tokens x 512 channels): one workgroup per shape
-__global__ void attn_small_kernel(int C, int L, const float *__restrict__ q, const float *__restrict__ k,
-                                  const float *__restrict__ v, long long bs, int ld, float *__restrict__ out,
-                                  long long bs_o, int ld_o) {
-  extern __shared__ float S[];  // [L][L]
+// (b) small-sequence kernel (global attention: 16 tokens x 512 channels): one workgroup per shape.  q, k, v are staged
+//     in LDS with coalesced reads first; the C-long dot products are split over T / L^2 channel slices whose partials
+//     are reduced in a fixed order.
+__global__ __launch_bounds__(1024) void attn_small_kernel(int C, int L, int nsl, const float *__restrict__ q,
+                                                          const float *__restrict__ k, const float *__restrict__ v,
+                                                          long long bs, int ld, float *__restrict__ out, long long bs_o,
+                                                          int ld_o) {
+  extern __shared__ float sm[];
+  const int LL = L * L, T = blockDim.x, tid = threadIdx.x;
+  float *S = sm, *Sp = S + LL, *Qs = Sp + nsl * LL, *Ks = Qs + C * L, *Vs = Ks + C * L;
   const int bi = blockIdx.x;
   const float *qb = q + (size_t)bi * bs, *kb = k + (size_t)bi * bs, *vb = v + (size_t)bi * bs;
-  for (int e = threadIdx.x; e < L * L; e += blockDim.x) {
-    const int i = e / L, j = e % L;
-    float a = 0.f;
-    for (int c = 0; c < C; ++c) a += qb[(size_t)c * ld + i] * kb[(size_t)c * ld + j];
-    S[e] = a;
+  for (int e = tid; e < C * L; e += T) {
+    const int c = e / L, i = e % L;
+    Qs[e] = qb[(size_t)c * ld + i]; Ks[e] = kb[(size_t)c * ld + i]; Vs[e] = vb[(size_t)c * ld + i];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+  if (nsl > 1) {  // L^2 <= T / 2: thread = (slice, pair)
+    const int sl = tid / LL, pr = tid % LL;
+    if (sl < nsl) {
+      const int i = pr / L, j = pr % L;
+      float a = 0.f;
+      for (int c = sl; c < C; c += nsl) a += Qs[c * L + i] * Ks[c * L + j];
+      Sp[sl * LL + pr] = a;
+    }
+    __syncthreads();
+    if (tid < LL) {
+      float a = 0.f;
+      for (int s2 = 0; s2 < nsl; ++s2) a += Sp[s2 * LL + tid];
+      S[tid] = a;
+    }
+  } else {
+    for (int e = tid; e < LL; e += T) {
+      const int i = e / L, j = e % L;
+      float a = 0.f;
+      for (int c = 0; c < C; ++c) a += Qs[c * L + i] * Ks[c * L + j];
+      S[e] = a;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < L; i += T) {
     float mx = -INFINITY;
     for (int j = 0; j < L; ++j) mx = fmaxf(mx, S[i * L + j]);
     float sum = 0.f;
@@ -958,23 +984,31 @@ __global__ void attn_small_kernel(int C, int L, const float *__restrict__ q, con
   }
   __syncthreads();
   float *ob = out + (size_t)bi * bs_o;
-  for (int e = threadIdx.x; e < C * L; e += blockDim.x) {
+  for (int e = tid; e < C * L; e += T) {
     const int c = e / L, i = e % L;
     float a = 0.f;
-    for (int j = 0; j < L; ++j) a += vb[(size_t)c * ld + j] * S[i * L + j];
+    for (int j = 0; j < L; ++j) a += Vs[c * L + j] * S[i * L + j];
     ob[(size_t)c * ld_o + i] = a;
   }
 }
 
+int attention_flash_s3(int b, int c, int l, const float *q, const float *k, const float *v, long long bs_qkv, int ld_qkv,
+                       float *out, long long bs_o, int ld_o, void *workspace, hipStream_t s);  // attention_s3.hip
+
 extern "C" int bdm_attention_core(int b, int c, int l, const float *q, const float *k, const float *v,
                                   long long bs_qkv, int ld_qkv, float *out, long long bs_o, int ld_o,
-                                  void *stream) {
+                                  void *workspace, void *stream) {
   BDM_REQUIRE(b >= 0 && c >= 1 && l >= 1, "attention_core: bad sizes");
   if (b == 0) return BDM_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (workspace != nullptr && l > 64 && c <= 64)
+    return attention_flash_s3(b, c, l, q, k, v, bs_qkv, ld_qkv, out, bs_o, ld_o, workspace, s);
   if (l <= 64) {
-    hipLaunchKernelGGL(attn_small_kernel, dim3(b), dim3(256), (size_t)l * l * sizeof(float), s, c, l, q, k, v, bs_qkv,
-                       ld_qkv, out, bs_o, ld_o);
+    const int nsl = 1024 / (l * l) >= 2 ? 1024 / (l * l) : 1;
+    const size_t smem = sizeof(float) * ((size_t)(1 + nsl) * l * l + 3 * (size_t)c * l);
+    BDM_REQUIRE(smem <= 160 * 1024, "attention_core: %d channels x %d tokens do not fit the small-sequence kernel", c, l);
+    BDM_ALLOW_LDS(attn_small_kernel, smem);
+    hipLaunchKernelGGL(attn_small_kernel, dim3(b), dim3(1024), smem, s, c, l, nsl, q, k, v, bs_qkv, ld_qkv, out, bs_o, ld_o);
     return launch_status("attention_small");
   }
   BDM_REQUIRE(c <= 64, "attention_core: the flash kernel supports at most 64 channels at %d tokens (got %d)", l, c);

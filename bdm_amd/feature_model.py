@@ -110,6 +110,8 @@ class VisionTransformer(nn.Module):
                                                 L.ptr(out), L.stream()), "layer_norm_channels")
             return out
 
+        nbytes = lib.bdm_attention_workspace_bytes(B, hd, T1) if ops.ATTENTION_IMPL == "bf16x6" else 0
+        att_ws = ops.workspace(nbytes, dev, "attention") if nbytes else None
         for blk in self.blocks:
             h = layer_norm(x, blk.norm1)
             wq, bq = self._qkv(blk)
@@ -118,7 +120,8 @@ class VisionTransformer(nn.Module):
             for hh in range(heads):
                 q, k, v = qkv[:, hh * hd:], qkv[:, D + hh * hd:], qkv[:, 2 * D + hh * hd:]
                 L.check(lib.bdm_attention_core(B, hd, T1, L.ptr(q), L.ptr(k), L.ptr(v), L.c_ll(3 * D * T1), T1,
-                                               L.ptr(att[:, hh * hd:]), L.c_ll(D * T1), T1, L.stream()), "attention_core")
+                                               L.ptr(att[:, hh * hd:]), L.c_ll(D * T1), T1, L.ptr(att_ws), L.stream()),
+                        "attention_core")
             x = ops.pointwise_conv(att, blk.attn.proj.weight, blk.attn.proj.bias, residual=x)
             h = layer_norm(x, blk.norm2)
             h = ops.pointwise_conv(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=3)

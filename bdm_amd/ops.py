@@ -5,6 +5,7 @@ are contiguous (e.g. a channel slice of a concat buffer) is passed by (batch str
 row stride) without a copy.  Torch supplies memory and the current stream only.
 """
 import ctypes
+import os
 
 import torch
 
@@ -235,13 +236,19 @@ def devoxelize_gate_add(norm_coords, grid, r, gate=None, add=None, out=None):
     return out
 
 
-def attention_core(qkv, C):
+ATTENTION_IMPL = os.environ.get("BDM_ATTENTION", "bf16x6")  # "fp32": the fp32-input MFMA flash kernel
+
+
+def attention_core(qkv, C, impl=None):
     """qkv (B, 3C, L): rows [0,C) = q, [C,2C) = k, [2C,3C) = v  ->  (B, C, L)."""
     B, _, l = qkv.shape
     out = torch.empty(B, C, l, dtype=torch.float32, device=qkv.device)
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-    L.check(L.lib().bdm_attention_core(B, C, l, L.ptr(q), L.ptr(k), L.ptr(v), L.c_ll(qkv.stride(0)), qkv.stride(1),
-                                       L.ptr(out), L.c_ll(C * l), l, L.stream()), "attention_core")
+    lib = L.lib()
+    nbytes = lib.bdm_attention_workspace_bytes(B, C, l) if (impl or ATTENTION_IMPL) == "bf16x6" else 0
+    ws = workspace(nbytes, qkv.device, "attention") if nbytes else None
+    L.check(lib.bdm_attention_core(B, C, l, L.ptr(q), L.ptr(k), L.ptr(v), L.c_ll(qkv.stride(0)), qkv.stride(1),
+                                   L.ptr(out), L.c_ll(C * l), l, L.ptr(ws), L.stream()), "attention_core")
     return out
 
 

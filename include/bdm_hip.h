@@ -166,10 +166,13 @@ int bdm_devoxelize_gate_add(int b, int c, int n, int r, const float *coords, con
 
 /* Attention core (pvconv.py:46-55): out[c][i] = sum_j v[c][j] softmax_j(sum_c' q[c'][i] k[c'][j]),
  * no 1/sqrt(c) scale.  q, k, v share strides.  l <= 64: one workgroup per shape (global attention);
- * otherwise a flash-style MFMA kernel (c <= 64; the 16^3-token voxel attention). */
+ * otherwise a flash-style MFMA kernel (c <= 64; the 16^3-token voxel attention).
+ * workspace: NULL -> fp32-input MFMA kernel; else >= bdm_attention_workspace_bytes(b, c, l) bytes -> the bf16x6
+ * kernel (q, k, v pre-split into exact bf16 triples, six partial products per fp32 product; fp32-grade accuracy). */
+size_t bdm_attention_workspace_bytes(int b, int c, int l);
 int bdm_attention_core(int b, int c, int l, const float *q, const float *k, const float *v,
                        long long bs_qkv, int ld_qkv, float *out, long long bs_o, int ld_o,
-                       void *stream);
+                       void *workspace, void *stream);
 
 /* nn.Conv3d(cin, cout, 3, padding=1) on (b, cin, r, r, r), r in {8, 16, 32} (pvconv.py:75-85).
  * packed_w = bdm_conv3d_pack_weights(w) : [27][cin][cout] from the module's (cout, cin, 3, 3, 3). */

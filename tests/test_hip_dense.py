@@ -91,15 +91,17 @@ def test_conv3d_boundary_exact(ops):
     assert float(y[31, 0, 4, 4]) == 18 * cin and float(y[7, 0, 0, 4]) == 12 * cin
 
 
-@pytest.mark.parametrize("B,C,L", [(2, 64, 4096), (1, 16, 4096), (2, 512, 16), (1, 128, 16), (1, 64, 512), (1, 24, 200)])
+@pytest.mark.parametrize("B,C,L", [(2, 64, 4096), (1, 16, 4096), (2, 512, 16), (1, 128, 16), (1, 64, 512), (1, 24, 200),
+                                   (3, 64, 197), (2, 40, 1000)])
 def test_attention_core(ops, B, C, L):
     g = torch.Generator().manual_seed(C * L)
     qkv = torch.randn(B, 3 * C, L, generator=g) * (0.5 if L > 64 else 0.2)
     q, k, v = qkv[:, :C].double(), qkv[:, C:2 * C].double(), qkv[:, 2 * C:].double()
     w = torch.softmax(torch.matmul(q.permute(0, 2, 1), k), -1)
     ref = torch.matmul(v, w.permute(0, 2, 1)).float()
-    got = ops.attention_core(qkv.cuda(), C).cpu()
-    assert rel(got, ref) < 5e-6
+    for impl in ("bf16x6", "fp32"):
+        got = ops.attention_core(qkv.cuda(), C, impl=impl).cpu()
+        assert rel(got, ref) < 5e-6, impl
 
 
 def test_small_ops(ops):
