@@ -13,9 +13,9 @@ collective on the data path; one barrier + MAX-over-ranks for timing).
         bench.py --gpus N --steps K --warmup W
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel (3x3x3 voxel convolution, f32 MFMA): algorithmic FLOPs of the launches
-                  timed with HIP events inside the timed region / their summed duration, vs the dense fp32
-                  matrix peak of MI355X_MICROARCH.md (157.3 TFLOP/s).
+  roofline     -- the dominant kernel (3x3x3 voxel convolution 64->64 on the 32^3 grid, bf16x6 arithmetic): algorithmic
+                  fp32 FLOPs of the launches timed with HIP events inside the timed region / their summed duration,
+                  vs the dense bf16 matrix peak of MI355X_MICROARCH.md (2.5 PFLOP/s) / 6 partial products.
   cpu_baseline -- the CPU oracle ("port": oracle/ref_net.py + oracle/pvcnn_ops_ref.c, the reference has no CPU
                   path) timed on this box's host cores on a bounded sample and extrapolated to a trajectory.
 """
