@@ -37,6 +37,29 @@ extern "C" int bdm_ddpm_step(long long n, const float *x, const float *eps, cons
   return launch_status("ddpm_step");
 }
 
+// Same arithmetic with the five per-timestep scalars read from DEVICE memory: the form a captured hipGraph replays for
+// every timestep (the host refreshes coef[0..4] between replays; sigma == 0 marks t == 0: no noise is added).
+__global__ void ddpm_step_dev_kernel(long long n, const float *__restrict__ x, const float *__restrict__ eps,
+                                     const float *__restrict__ z, const float *__restrict__ coef, float *__restrict__ out) {
+  const float sqrt_beta_prod = coef[0], sqrt_alpha_prod = coef[1], c_x0 = coef[2], c_x = coef[3], sigma = coef[4];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float xi = x[i];
+    const float x0 = (xi - sqrt_beta_prod * eps[i]) / sqrt_alpha_prod;
+    float v = c_x0 * x0 + c_x * xi;
+    if (sigma != 0.f) v = v + sigma * z[i];
+    out[i] = v;
+  }
+}
+extern "C" int bdm_ddpm_step_dev(long long n, const float *x, const float *eps, const float *noise, const float *coef,
+                                 float *out, void *stream) {
+  BDM_REQUIRE(n >= 0 && noise != nullptr && coef != nullptr, "ddpm_step_dev: bad arguments");
+  if (n == 0) return BDM_OK;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(ddpm_step_dev_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, x, eps, noise, coef, out);
+  return launch_status("ddpm_step_dev");
+}
+
 // x0 = a*x - b*eps ; mean = c1*x0 + c2*x ; out = mean + sigma*z   (sigma = 0 at t == 0)
 __global__ void pvd_step_kernel(long long n, const float *__restrict__ x, const float *__restrict__ eps,
                                 const float *__restrict__ z, float a, float b, float c1, float c2, float sigma,

@@ -7,7 +7,10 @@ so main_blending.py / main_merging.py drive it unchanged.  Sampling only.
 """
 from typing import Optional
 
+import os
+
 import numpy as np
+
 import torch
 import torch.nn as nn
 from torch import Tensor
@@ -17,7 +20,7 @@ from . import ops
 from .cameras import PerspectiveCameras, Pointclouds, join_cameras
 from .feature_model import FeatureModel
 from .pvcnn import PVCNN2_PC2, PVCNN_fuse
-from .schedulers import make_schedulers_map
+from .schedulers import DDPMScheduler, make_schedulers_map
 
 
 class _DeviceMixin:
@@ -173,6 +176,13 @@ def _timestep_list(scheduler, num_inference_steps, start_time, end_time):
     return [int(v) for v in ts]
 
 
+# BDM_GRAPH=1 captures the PC^2 reverse step into a hipGraph and replays it per timestep.  Opt-in: on ROCm 7.2 the replay
+# of the ~300-node step costs the host as much as enqueueing the kernels one by one (measured 4.5 vs 4.8 ms per step at
+# B=1, identical GPU time at B=16: tools/time_loop.py), so the eager loop stays the default.
+GRAPH_STEPS = os.environ.get("BDM_GRAPH", "0") == "1"
+GRAPH_MIN_STEPS = 8  # shorter segments do not amortise the capture
+
+
 class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
     """model.py:23-318."""
 
@@ -191,6 +201,9 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
     _step_kwargs = {}  # e.g. {"eta": 0.0} for DDIM (the reference forwards eta only to schedulers that accept it)
 
     def _denoise_loop(self, x_t, camera, image_rgb, mask, scheduler, timesteps, generator=None):
+        if (GRAPH_STEPS and x_t.is_cuda and len(timesteps) >= GRAPH_MIN_STEPS and type(scheduler) is DDPMScheduler
+                and not self._step_kwargs):
+            return self._denoise_loop_graph(x_t, camera, image_rgb, mask, scheduler, timesteps, generator)
         B = x_t.shape[0]
         for t in timesteps:
             tt = torch.full((B,), t, dtype=torch.int64, device=x_t.device)
@@ -198,6 +211,61 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
             noise_pred = self.point_cloud_model(x_in, tt)
             x_t = scheduler.step(noise_pred, t, x_t, generator=generator, **self._step_kwargs).prev_sample
         return x_t
+
+    # ---- hipGraph form of the reverse loop -------------------------------------------------------------------
+    # One reverse step (rasterise + feature gather, the ~300 launches of the denoiser incl. its side-stream sampler
+    # chain, the scheduler arithmetic) is captured ONCE on static buffers and replayed per timestep: the timestep
+    # tensor, the five scheduler scalars and the step's Gaussian noise are refreshed in device memory between replays
+    # (three tiny eager ops), so the host enqueues one graph instead of ~300 kernels per step.  Values are identical
+    # to the eager loop (same kernels, same arguments, same RNG stream: the noise is drawn eagerly, in order).
+    def _step_graph(self, x_t, camera, image_rgb, mask, scheduler):
+        feat, _ = self.conditioning_image(image_rgb, mask)
+        key = (tuple(x_t.shape), str(x_t.device), id(camera), id(scheduler), scheduler.num_inference_steps)
+        g = getattr(self, "_graph_cache", None)
+        if g is not None and g["key"] == key and g["feat"] is feat and g["image"] is image_rgb:
+            return g
+        dev, B = x_t.device, x_t.shape[0]
+        g = {"key": key, "feat": feat, "image": image_rgb, "camera": camera,
+             "x": torch.empty_like(x_t, memory_format=torch.contiguous_format), "noise": torch.zeros_like(x_t),
+             "t": torch.zeros(B, dtype=torch.int64, device=dev), "coef": torch.ones(5, dtype=torch.float32, device=dev)}
+        g["x"].copy_(x_t)
+
+        def step():
+            x_in = self.get_input_with_conditioning(g["x"], camera=camera, image_rgb=image_rgb, mask=mask, t=g["t"])
+            eps = self.point_cloud_model(x_in, g["t"])
+            scheduler.step_dev(eps, g["coef"], g["x"], g["noise"], out=g["x"])
+
+        cur = torch.cuda.current_stream()
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(cur)
+        with torch.cuda.stream(warm):  # allocator, workspaces, weight packs, kernel attributes: everything lazy happens here
+            step()
+        cur.wait_stream(warm)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            step()
+        g["graph"] = graph
+        self._graph_cache = g
+        return g
+
+    def _denoise_loop_graph(self, x_t, camera, image_rgb, mask, scheduler, timesteps, generator=None):
+        g = self._step_graph(x_t, camera, image_rgb, mask, scheduler)
+        table = scheduler.coefficient_table(x_t.device)
+        g["x"].copy_(x_t)
+        probe = int(getattr(self, "eager_probe_every", 0))  # bench.py: every k-th step runs eagerly so that single
+        for i, t in enumerate(timesteps):                     # kernels can be timed with HIP events inside the loop
+            if probe and i % probe == probe - 1:
+                tt = torch.full((x_t.shape[0],), t, dtype=torch.int64, device=x_t.device)
+                x_in = self.get_input_with_conditioning(g["x"], camera=camera, image_rgb=image_rgb, mask=mask, t=tt)
+                g["x"].copy_(scheduler.step(self.point_cloud_model(x_in, tt), t, g["x"], generator=generator).prev_sample)
+                continue
+            g["t"].fill_(t)
+            g["coef"].copy_(table[t])
+            if t > 0:
+                g["noise"].copy_(scheduler._noise(g["x"].shape, x_t.device, generator))
+            g["graph"].replay()
+        return g["x"].clone()
 
     @torch.no_grad()
     def forward_sample(self, num_points: int, camera, image_rgb: Optional[Tensor], mask: Optional[Tensor],

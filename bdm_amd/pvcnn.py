@@ -140,7 +140,7 @@ def encode(sa_layers, global_att, inputs, t_emb):
     """Down path (pvcnn.py:90-110)."""
     coords = inputs[:, :3, :].contiguous()
     ops.clear_plan_cache()  # voxel plans are valid within one encoder/decoder pass
-    if coords.is_cuda and not torch.cuda.is_current_stream_capturing():
+    if coords.is_cuda:  # also inside a hipGraph capture: the side stream forks from and joins the capturing stream
         plan_sampling_chain(sa_layers, coords)
     features = inputs
     coords_list, in_features_list = [], []

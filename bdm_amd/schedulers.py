@@ -102,6 +102,28 @@ class DDPMScheduler:
                                       L.c_float(c["sigma"]), L.ptr(out), L.stream()), "ddpm_step")
         return SimpleNamespace(prev_sample=out) if return_dict else (out,)
 
+    def coefficient_table(self, device):
+        """(num_train_timesteps, 5) float32 on `device`: row t = the step's five scalars for the CURRENT set_timesteps
+        grid, sigma = 0 at t = 0 (no noise).  Lets a captured hipGraph of one reverse step serve every timestep."""
+        key = (self.num_inference_steps, str(device))
+        hit = getattr(self, "_coef_table", None)
+        if hit is None or hit[0] != key:
+            rows = []
+            for t in range(self.num_train_timesteps):
+                c = self.step_coefficients(t)
+                rows.append([c["sqrt_beta_prod"], c["sqrt_alpha_prod"], c["coef_x0"], c["coef_x"], c["sigma"] if t > 0 else 0.0])
+            hit = (key, torch.tensor(rows, dtype=torch.float32).to(device))
+            self._coef_table = hit
+        return hit[1]
+
+    def step_dev(self, model_output, coef_dev, sample, noise, out):
+        """step() with the coefficients in device memory (coef_dev: 5 floats); graph-capturable, `out` may be `sample`."""
+        eps = model_output.contiguous()
+        assert sample.is_contiguous() and eps.shape == sample.shape == noise.shape
+        L.check(L.lib().bdm_ddpm_step_dev(L.c_ll(sample.numel()), L.ptr(sample), L.ptr(eps), L.ptr(noise), L.ptr(coef_dev),
+                                          L.ptr(out), L.stream()), "ddpm_step_dev")
+        return out
+
     def add_noise(self, original_samples, noise, timesteps):
         """Training-side helper (model.py:99); plain tensor arithmetic, not on the sampling path."""
         ac = self.alphas_cumprod.to(original_samples.device)

@@ -247,6 +247,11 @@ int bdm_sparse_conv_gather(int b, int cout, int r, int n_max, const float *y, co
 int bdm_ddpm_step(long long n, const float *x, const float *eps, const float *noise,
                   float sqrt_beta_prod, float sqrt_alpha_prod, float coef_x0, float coef_x,
                   float sigma, float *out, void *stream);
+/* The same step with {sqrt_beta_prod, sqrt_alpha_prod, coef_x0, coef_x, sigma} read from device memory (coef[5]), so
+ * that ONE captured hipGraph of a reverse step can be replayed for every timestep; sigma == 0 (t == 0) adds no noise.
+ * out may alias x. */
+int bdm_ddpm_step_dev(long long n, const float *x, const float *eps, const float *noise, const float *coef,
+                      float *out, void *stream);
 
 /* DDIM step (diffusers 0.21.0 DDIMScheduler.step; the reference's schedulers_map['ddim'], model/model.py:60):
  *   x0 = (x - sqrt_beta_prod * eps) / sqrt_alpha_prod;  out = coef_x0 * x0 + coef_eps * eps [+ sigma * noise when eta > 0] */

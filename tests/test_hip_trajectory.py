@@ -66,3 +66,34 @@ def test_c1_vanilla_pc2_100_steps(hip, oracle_ops):
     print(f"C1 trajectory: final rel-L2 {final:.3e} (oracle self-sensitivity {self_sens[-1]:.3e}), worst {worst:.3e}")
     assert max(curve[:10]) < 1e-5
     assert final <= max(1e-3, 4 * self_sens[-1])
+
+
+def test_graph_replay_equals_eager_loop(hip, monkeypatch):
+    """The hipGraph form of the reverse loop (one captured step replayed per timestep) gives the bits of the eager loop."""
+    import bdm_amd.model as M
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.utils.procedural import fill_module_
+    B, N, steps = 2, 1024, 12
+    cfg = ProjectConfig()
+    cfg.dataset.max_points = N
+    model = fill_module_(M.get_model(cfg).eval(), seed=3).cuda()
+    batch = next(iter(SyntheticShapes(range(B), B, num_points=N))).to("cuda")
+    x0 = torch.randn(B, N, 3, generator=torch.Generator().manual_seed(5)).cuda()
+    noise = [torch.randn(B, N, 3, generator=torch.Generator().manual_seed(100 + i)).cuda() for i in range(steps)]
+
+    def run(graph):
+        monkeypatch.setattr(M, "GRAPH_STEPS", graph)
+        it = iter(noise)
+        model.scheduler.noise_source = lambda shape, device: next(it)
+        try:
+            return model.interaction_sample(x0.clone(), batch.camera, batch.image_rgb, None, start_time=500,
+                                            end_time=500 - steps).cpu()
+        finally:
+            model.scheduler.noise_source = None
+
+    eager, graphed = run(False), run(True)
+    assert getattr(model, "_graph_cache", None) is not None  # the graph path was taken
+    assert torch.equal(eager, graphed)
+    again = run(True)  # second use replays the cached graph
+    assert torch.equal(eager, again)
