@@ -67,7 +67,9 @@ def ptr(t):
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's current stream on the current device (the raw C accessors: `torch.cuda.current_stream()`
+    costs ~8 us of Python per call, which at ~300 launches per denoiser forward was a quarter of the enqueue time)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def f32(t):
