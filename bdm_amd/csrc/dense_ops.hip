@@ -792,13 +792,18 @@ extern "C" int bdm_se_gate(int b, int c, int hidden, int l, const float *x, cons
 // =====================================================================================
 // PVConv tail: out = trilinear_devoxelize(grid * gate) + point_branch   (pvconv.py:95-96)
 // =====================================================================================
-__global__ void devox_fused_kernel(int c, int n, int r, const float *__restrict__ coords,
+__global__ void devox_fused_kernel(int b, int cslots, int pblocks, int c, int n, int r, const float *__restrict__ coords,
                                    const float *__restrict__ grid, const float *__restrict__ gate,
                                    const float *__restrict__ add, long long bs_a, int ld_a, float *__restrict__ out,
                                    long long bs_o, int ld_o) {
 #pragma clang fp contract(off)  // same unfused order as the stand-alone operator and the oracle
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int bi = blockIdx.z;
+  // XCD-aware 1-D launch: unit = (shape, channel slot); all point blocks of a unit get the same workgroup id mod 8, so the
+  // unit's voxel rows (r^3 floats per channel) are pulled into ONE XCD's L2 instead of all eight
+  const int span = 8 * pblocks, wg = blockIdx.x;
+  const int unit = (wg / span) * 8 + (wg % span) % 8, pb = (wg % span) / 8;
+  if (unit >= b * cslots) return;
+  const int bi = unit / cslots, c_first = unit % cslots;
+  const int i = pb * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int r2 = r * r, r3 = r2 * r;
   const float *pc = coords + (size_t)bi * 3 * n;
@@ -812,7 +817,7 @@ __global__ void devox_fused_kernel(int c, int n, int r, const float *__restrict_
   const int i000 = (int)xl * r2 + (int)yl * r + (int)zl;
   const int i001 = i000 + sz, i010 = i000 + sy, i011 = i010 + sz;
   const int i100 = i000 + sx, i101 = i100 + sz, i110 = i100 + sy, i111 = i110 + sz;
-  for (int ci = blockIdx.y; ci < c; ci += gridDim.y) {
+  for (int ci = c_first; ci < c; ci += cslots) {
     const float *g = grid + ((size_t)bi * c + ci) * r3;
     const float s = gate ? gate[(size_t)bi * c + ci] : 1.0f;
     float acc = w000 * (g[i000] * s);
@@ -832,8 +837,9 @@ extern "C" int bdm_devoxelize_gate_add(int b, int c, int n, int r, const float *
                                        float *out, long long bs_o, int ld_o, void *stream) {
   BDM_REQUIRE(b >= 0 && c >= 1 && n >= 1 && r >= 1, "devoxelize_gate_add: bad sizes");
   if (b == 0) return BDM_OK;
-  hipLaunchKernelGGL(devox_fused_kernel, dim3(cdiv(n, 256), c < 64 ? c : 64, b), dim3(256), 0, (hipStream_t)stream, c,
-                     n, r, coords, grid, gate, add, bs_a, ld_a, out, bs_o, ld_o);
+  const int cslots = c < 64 ? c : 64, pblocks = cdiv(n, 256);
+  hipLaunchKernelGGL(devox_fused_kernel, dim3(cdiv(b * cslots, 8) * 8 * pblocks), dim3(256), 0, (hipStream_t)stream, b, cslots,
+                     pblocks, c, n, r, coords, grid, gate, add, bs_a, ld_a, out, bs_o, ld_o);
   return launch_status("devoxelize_gate_add");
 }
 

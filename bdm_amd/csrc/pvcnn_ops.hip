@@ -379,12 +379,29 @@ extern "C" int bdm_grouping_forward(int b, int c, int n, int m, int u, const flo
 // =====================================================================================
 // Three nearest neighbours + inverse-squared-distance interpolation
 // =====================================================================================
-__global__ void three_nn_search_kernel(int m, int n, const float *__restrict__ points,
-                                       const float *__restrict__ centers, int *__restrict__ indices,
-                                       float *__restrict__ weights) {
-  extern __shared__ float sc[];  // centres, staged in chunks
-  const int bi = blockIdx.y;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+// One workgroup = 64 points; its four waves each scan a quarter of the staged centres (4x shorter serial chain, 4 waves
+// per SIMD) in batches of four with one test of the batch minimum against the current third-best, then the per-wave
+// top-3 lists are merged by (distance, index): the same triple as the reference's sequential strict-< scan.
+__device__ __forceinline__ void top3_insert(float d, int idx, float &b0, float &b1, float &b2, int &i0, int &i1, int &i2) {
+  if (d < b2) {
+    b2 = d; i2 = idx;
+    if (d < b1) {
+      b2 = b1; i2 = i1; b1 = d; i1 = idx;
+      if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = idx; }
+    }
+  }
+}
+__device__ __forceinline__ bool lex_less(float d, int i, float e, int j) { return d < e || (d == e && i < j); }
+
+__global__ __launch_bounds__(256) void three_nn_search_kernel(int m, int n, const float *__restrict__ points,
+                                                              const float *__restrict__ centers, int *__restrict__ indices,
+                                                              float *__restrict__ weights) {
+  constexpr int CH = 1024;
+  __shared__ __align__(16) float sc[3 * CH];  // centres, staged in chunks; padded with +inf (never selected)
+  __shared__ float md[3][3][64];
+  __shared__ int mi[3][3][64];
+  const int bi = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
   const float *cb = centers + (size_t)bi * 3 * m;
   const float *pb = points + (size_t)bi * 3 * n;
   float ux = 0.f, uy = 0.f, uz = 0.f;
@@ -392,26 +409,49 @@ __global__ void three_nn_search_kernel(int m, int n, const float *__restrict__ p
   // running bests hold float values (the reference keeps them in doubles, :37)
   float b0 = INFINITY, b1 = INFINITY, b2 = INFINITY;
   int i0 = 0, i1 = 0, i2 = 0;
-  const int CH = 1024;
   for (int base = 0; base < m; base += CH) {
-    const int len = min(CH, m - base);
+    const int len = min(CH, m - base), lenp = (len + 15) & ~15;
     __syncthreads();
-    for (int t = threadIdx.x; t < len; t += blockDim.x) {
-      sc[t] = cb[base + t]; sc[CH + t] = cb[m + base + t]; sc[2 * CH + t] = cb[2 * m + base + t];
+    for (int t = threadIdx.x; t < lenp; t += 256) {
+      const bool in = t < len;
+      sc[t] = in ? cb[base + t] : INFINITY; sc[CH + t] = in ? cb[m + base + t] : INFINITY;
+      sc[2 * CH + t] = in ? cb[2 * m + base + t] : INFINITY;
     }
     __syncthreads();
-    for (int k = 0; k < len; ++k) {
-      const float d = sqdist3(ux, uy, uz, sc[k], sc[CH + k], sc[2 * CH + k]);
-      if (d < b2) {
-        b2 = d; i2 = base + k;
-        if (d < b1) {
-          b2 = b1; i2 = i1; b1 = d; i1 = base + k;
-          if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = base + k; }
-        }
+    const int q = lenp >> 2, k0 = wave * q;
+    for (int k = k0; k < k0 + q; k += 4) {
+      const float4 cx = *reinterpret_cast<const float4 *>(sc + k), cy = *reinterpret_cast<const float4 *>(sc + CH + k),
+                   cz = *reinterpret_cast<const float4 *>(sc + 2 * CH + k);
+      const float d0 = sqdist3(ux, uy, uz, cx.x, cy.x, cz.x), d1 = sqdist3(ux, uy, uz, cx.y, cy.y, cz.y),
+                  d2 = sqdist3(ux, uy, uz, cx.z, cy.z, cz.z), d3 = sqdist3(ux, uy, uz, cx.w, cy.w, cz.w);
+      if (fminf(fminf(d0, d1), fminf(d2, d3)) < b2) {
+        top3_insert(d0, base + k, b0, b1, b2, i0, i1, i2);
+        top3_insert(d1, base + k + 1, b0, b1, b2, i0, i1, i2);
+        top3_insert(d2, base + k + 2, b0, b1, b2, i0, i1, i2);
+        top3_insert(d3, base + k + 3, b0, b1, b2, i0, i1, i2);
       }
     }
   }
-  if (j >= n) return;
+  if (wave > 0) {
+    md[wave - 1][0][lane] = b0; md[wave - 1][1][lane] = b1; md[wave - 1][2][lane] = b2;
+    mi[wave - 1][0][lane] = i0; mi[wave - 1][1][lane] = i1; mi[wave - 1][2][lane] = i2;
+  }
+  __syncthreads();
+  if (wave > 0 || j >= n) return;
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const float d = md[w][s][lane];
+      const int idx = mi[w][s][lane];
+      if (d == INFINITY) continue;  // unfilled slot
+      if (lex_less(d, idx, b2, i2)) {
+        b2 = d; i2 = idx;
+        if (lex_less(d, idx, b1, i1)) {
+          b2 = b1; i2 = i1; b1 = d; i1 = idx;
+          if (lex_less(d, idx, b0, i0)) { b1 = b0; i1 = i0; b0 = d; i0 = idx; }
+        }
+      }
+    }
   b0 = fmaxf(fminf(1e10f, b0), 1e-10f);
   b1 = fmaxf(fminf(1e10f, b1), 1e-10f);
   b2 = fmaxf(fminf(1e10f, b2), 1e-10f);
@@ -448,9 +488,8 @@ extern "C" int bdm_three_nn_search(int b, int m, int n, const float *points, con
                                    int *indices, float *weights, void *stream) {
   BDM_REQUIRE(b >= 0 && m >= 1 && n >= 0, "three_nn_search: bad sizes");
   if (b == 0 || n == 0) return BDM_OK;
-  dim3 grid(cdiv(n, 256), b);
-  hipLaunchKernelGGL(three_nn_search_kernel, grid, dim3(256), 3 * 1024 * sizeof(float), (hipStream_t)stream,
-                     m, n, points, centers, indices, weights);
+  dim3 grid(cdiv(n, 64), b);
+  hipLaunchKernelGGL(three_nn_search_kernel, grid, dim3(256), 0, (hipStream_t)stream, m, n, points, centers, indices, weights);
   return launch_status("three_nn_search");
 }
 
