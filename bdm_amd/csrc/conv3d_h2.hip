@@ -1,0 +1,334 @@
+// conv3d_h2.hip -- the 3x3x3 voxel convolution at fp32 accuracy on the FP16 matrix cores ("fp16x3").
+//
+// Half the matrix work of the bf16x6 form (conv3d_s3.hip) at the same accuracy class.  An fp32 operand is stored as
+// TWO fp16 terms  x * 2^s = hi + lo  (hi = RN_11(x 2^s), lo = RN_11(x 2^s - hi); 11 + 11 signed bits capture x to
+// <= 2^-24 |x|), and a product is the three partial products  lo.hi + hi.lo + hi.hi , each exact in fp32 (11 x 11
+// bits) and accumulated in fp32 by v_mfma_f32_32x32x16_f16; the dropped lo.lo term is <= 2^-24 |a b|.
+// fp16 has a 5-bit exponent, so both operands are pre-scaled by exact powers of two that keep hi AND lo in the normal
+// range, and the scales are divided out of the fp32 accumulator in the epilogue:
+//   weights      per output channel: max |w[co]| -> [2^9, 2^10)  (pack time; inv_scale[co] for the epilogue)
+//   activations  one power of two per call, chosen by the caller from what it knows about the tensor: on this path
+//                they are GroupNorm + Swish outputs, |y| <= |gamma| |z| + |beta|, and the host picks the scale from
+//                the layer's gamma / beta so that a 64-sigma value still fits (larger ones saturate at 65504
+//                instead of overflowing to inf)
+// Below the normal range an operand keeps an ABSOLUTE error <= 2^-25 in scaled units: 2^-25 / act_scale for
+// activations, 2^-35 max|w[co]| for weights -- under the fp32 resolution of any sum those operands take part in.
+// Measured <= 3e-7 relative L2 vs fp64 (tests/test_hip_dense.py), the same as the fp32-input MFMA kernel.
+//
+// Layouts ("H2"): activations (B, ceil(C/8), 2, r^3, 8) fp16; weights [ceil(Cin/8)][14 tap pairs][2][2][Cout][8] fp16.
+// Geometry, staging and tap addressing are those of conv3d_s3.hip.
+#include "../../include/bdm_hip.h"
+#include "common.h"
+
+using namespace bdm;
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+#define H2_PAIRS 14
+
+__device__ __forceinline__ void split2(float v, unsigned short &h, unsigned short &l) {
+  v = fminf(fmaxf(v, -65504.f), 65504.f);  // saturate instead of overflowing to inf
+  const _Float16 hi = (_Float16)v;          // round to nearest even
+  const _Float16 lo = (_Float16)(v - (float)hi);  // the remainder is exact in fp32
+  h = __builtin_bit_cast(unsigned short, hi);
+  l = __builtin_bit_cast(unsigned short, lo);
+}
+
+__device__ __forceinline__ void store_h2(unsigned short *base, size_t rec, size_t split_stride, const float v[8]) {
+  unsigned short h[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split2(v[j], h[j], l[j]);
+  uint4 ph, pl;
+  ph.x = h[0] | (h[1] << 16); ph.y = h[2] | (h[3] << 16); ph.z = h[4] | (h[5] << 16); ph.w = h[6] | (h[7] << 16);
+  pl.x = l[0] | (l[1] << 16); pl.y = l[2] | (l[3] << 16); pl.z = l[4] | (l[5] << 16); pl.w = l[6] | (l[7] << 16);
+  uint4 *o = reinterpret_cast<uint4 *>(base);
+  o[rec] = ph;
+  o[split_stride + rec] = pl;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight packing: per-output-channel power-of-two scale, then (Cout, Cin, 3,3,3) fp32 -> [C8][14][2][2][Cout][8] fp16
+// ---------------------------------------------------------------------------------------------------
+__global__ void h2_weight_scale_kernel(int cout, int cin, const float *__restrict__ w, float *__restrict__ scale,
+                                       float *__restrict__ inv_scale) {
+  __shared__ float sh[256];
+  const int co = blockIdx.x;
+  float m = 0.f;
+  for (int e = threadIdx.x; e < cin * 27; e += blockDim.x) m = fmaxf(m, fabsf(w[(size_t)co * cin * 27 + e]));
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int ex = 0;
+    const float mx = sh[0];
+    if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)
+    const int e = (mx > 0.f && mx < INFINITY) ? 10 - ex : 0;  // mx * 2^e in [2^9, 2^10)
+    scale[co] = ldexpf(1.0f, e);
+    inv_scale[co] = ldexpf(1.0f, -e);
+  }
+}
+__global__ void pack_h2_kernel(int cout, int cin, const float *__restrict__ w, const float *__restrict__ scale,
+                               unsigned short *__restrict__ wq) {
+  const int c8n = (cin + 7) / 8;
+  const long long total = (long long)c8n * H2_PAIRS * 2 * cout * 8;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(e % 8);
+    const int co = (int)((e / 8) % cout);
+    const int h = (int)((e / (8ll * cout)) % 2);
+    const int p = (int)((e / (16ll * cout)) % H2_PAIRS);
+    const int c8 = (int)(e / (16ll * cout * H2_PAIRS));
+    const int ci = c8 * 8 + j, tap = 2 * p + h;
+    const float v = (ci < cin && tap < 27) ? w[((size_t)co * cin + ci) * 27 + tap] * scale[co] : 0.f;  // exact scaling
+    unsigned short s[2];
+    split2(v, s[0], s[1]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) wq[((((size_t)(c8 * H2_PAIRS + p) * 2 + q) * 2 + h) * cout + co) * 8 + j] = s[q];
+  }
+}
+extern "C" size_t bdm_conv3d_h2_weight_elems(int cout, int cin) {
+  return (size_t)((cin + 7) / 8) * H2_PAIRS * 2 * 2 * cout * 8;
+}
+extern "C" int bdm_conv3d_h2_pack_weights(int cout, int cin, const float *w, void *packed, float *scale_ws,
+                                          float *inv_scale, void *stream) {
+  BDM_REQUIRE(cout >= 1 && cin >= 1 && scale_ws != nullptr && inv_scale != nullptr, "conv3d_h2_pack_weights: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(h2_weight_scale_kernel, dim3(cout), dim3(256), 0, s, cout, cin, w, scale_ws, inv_scale);
+  hipLaunchKernelGGL(pack_h2_kernel, dim3(512), dim3(256), 0, s, cout, cin, w, scale_ws, (unsigned short *)packed);
+  return launch_status("conv3d_h2_pack_weights");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the convolution
+// ---------------------------------------------------------------------------------------------------
+template <int MI, int NI, int R, int TX, int TY>
+__global__ __launch_bounds__(256) void conv3d_h2_kernel(int C8, int Cout, const float4 *__restrict__ x,
+                                                        const float4 *__restrict__ wq, const float *__restrict__ inv_scale,
+                                                        float x_inv_scale, const float *__restrict__ bias,
+                                                        float *__restrict__ y) {
+  extern __shared__ __align__(16) float4 smem4[];
+  constexpr int BM = 32 * MI;
+  constexpr int RSV = R + 2;                 // voxel records per halo row (one zero pad at each end)
+  constexpr int ROWS = (TX + 2) * (TY + 2);
+  constexpr int HALO = ROWS * RSV;           // records per split
+  constexpr int R2 = R * R, R3 = R2 * R;
+  constexpr int XV = 2 * ROWS * R, XI = (XV + 255) / 256;          // 16-byte pieces of the input tile
+  constexpr int WV = H2_PAIRS * 2 * 2 * BM, WI = (WV + 255) / 256;  // 16-byte pieces of the weight tile
+  float4 *Xs = smem4;              // [2][HALO]
+  float4 *Ws = smem4 + 2 * HALO;   // [14][2][2][BM]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  constexpr int tiles_y = R / TY;
+  const int X0 = (blockIdx.x / tiles_y) * TX, Y0 = (blockIdx.x % tiles_y) * TY;
+  const int m0 = blockIdx.y * BM, bi = blockIdx.z;
+  const float4 *xb = x + (size_t)bi * C8 * 2 * R3;
+  float *yb = y + (size_t)bi * Cout * R3;
+
+  constexpr int rpb = 32 / R;
+  const int dyl = li / R, zl = li % R;
+  constexpr int blocks_per_plane = TY / rpb;
+  int lbase[NI], gvox[NI];
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int nb = q * 4 + wave;
+    const int tx = nb / blocks_per_plane, ty = (nb % blocks_per_plane) * rpb + dyl;
+    lbase[q] = ((tx + 1) * (TY + 2) + (ty + 1)) * RSV + 1 + zl;
+    gvox[q] = ((X0 + tx) * R + (Y0 + ty)) * R + zl;
+  }
+  // this lane half's tap of pair p is 2p + lh; record offset of that tap (pad tap 27 reuses tap 26's address)
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int a = 0; a < MI; ++a)
+#pragma unroll
+    for (int q = 0; q < NI; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][q][i] = 0.f;
+
+  for (int e = tid; e < 2 * HALO; e += 256) Xs[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  float4 xr[XI], wr[WI];
+  auto load_chunk = [&](int c8) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int e = tid + i * 256;
+      const int z = e % R, row = (e / R) % ROWS, s = e / (R * ROWS);
+      const int gx = X0 + row / (TY + 2) - 1, gy = Y0 + row % (TY + 2) - 1;
+      xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < XV && gx >= 0 && gx < R && gy >= 0 && gy < R)
+        xr[i] = xb[((size_t)c8 * 2 + s) * R3 + (gx * R + gy) * R + z];
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int e = tid + i * 256;
+      const int m = e % BM, psh = e / BM;  // psh = (p*2 + s)*2 + h
+      wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < WV && m0 + m < Cout) wr[i] = wq[((size_t)c8 * (H2_PAIRS * 4) + psh) * Cout + m0 + m];
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int e = tid + i * 256;
+      const int z = e % R, row = (e / R) % ROWS, s = e / (R * ROWS);
+      const int gx = X0 + row / (TY + 2) - 1, gy = Y0 + row % (TY + 2) - 1;
+      if (e < XV && gx >= 0 && gx < R && gy >= 0 && gy < R) Xs[s * HALO + row * RSV + 1 + z] = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int e = tid + i * 256;
+      if (e < WV) Ws[e] = wr[i];
+    }
+  };
+
+  load_chunk(0);
+  for (int c8 = 0; c8 < C8; ++c8) {
+    __syncthreads();
+    store_chunk();
+    __syncthreads();
+    if (c8 + 1 < C8) load_chunk(c8 + 1);
+#pragma unroll
+    for (int p = 0; p < H2_PAIRS; ++p) {
+      // tap of this lane half: 2p + lh  (compile-time pair, run-time half -> select between two constants)
+      const int t0 = 2 * p, t1 = (2 * p + 1 < 27) ? 2 * p + 1 : 26;
+      const int off0 = ((t0 / 9 - 1) * (TY + 2) + ((t0 / 3) % 3 - 1)) * RSV + (t0 % 3 - 1);
+      const int off1 = ((t1 / 9 - 1) * (TY + 2) + ((t1 / 3) % 3 - 1)) * RSV + (t1 % 3 - 1);
+      const int toff = lh ? off1 : off0;
+      f16x8 a[MI][2], b[NI][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const float4 t = Ws[((p * 2 + s) * 2 + lh) * BM + mi * 32 + li];
+          a[mi][s] = *reinterpret_cast<const f16x8 *>(&t);
+        }
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+          const float4 t = Xs[s * HALO + lbase[q] + toff];
+          b[q][s] = *reinterpret_cast<const f16x8 *>(&t);
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+          f32x16 c = acc[mi][q];
+          // smallest terms first: lo.hi, hi.lo, hi.hi (lo.lo <= 2^-24 |a b| is dropped)
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][1], b[q][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[q][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[q][0], c, 0, 0, 0);
+          acc[mi][q] = c;
+        }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < MI; ++p)
+#pragma unroll
+    for (int q = 0; q < NI; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = m0 + p * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        if (m < Cout) yb[(size_t)m * R3 + gvox[q]] = acc[p][q][i] * (inv_scale[m] * x_inv_scale) + (bias ? bias[m] : 0.f);
+      }
+}
+
+extern "C" int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale,
+                                   const void *packed_w, const float *inv_scale, const float *bias, float *y,
+                                   void *stream) {
+  BDM_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && inv_scale != nullptr, "conv3d_h2: bad arguments");
+  if (r != 8 && r != 16 && r != 32) {
+    set_error("conv3d_h2: resolution %d unsupported (8, 16, 32)", r);
+    return BDM_ERR_UNSUPPORTED;
+  }
+  if (b == 0) return BDM_OK;
+  const int c8 = (cin + 7) / 8;
+  int tx, ty, ni, mi;
+  if (r == 32) { tx = 2; ty = 8; ni = 4; }
+  else if (r == 16) { tx = 2; ty = 16; ni = 4; }
+  else { tx = 4; ty = 8; ni = 2; }
+  mi = (cout > 32 && ni == 4) ? 2 : 1;
+  const size_t smem = 16 * ((size_t)2 * (tx + 2) * (ty + 2) * (r + 2) + (size_t)H2_PAIRS * 4 * 32 * mi);
+  dim3 grid((r / tx) * (r / ty), cdiv(cout, 32 * mi), b);
+  hipStream_t s = (hipStream_t)stream;
+#define H2_LAUNCH(MI, NI, R, TX, TY)                                                                            \
+  do {                                                                                                          \
+    BDM_ALLOW_LDS((conv3d_h2_kernel<MI, NI, R, TX, TY>), smem);                                                 \
+    hipLaunchKernelGGL((conv3d_h2_kernel<MI, NI, R, TX, TY>), grid, dim3(256), smem, s, c8, cout,               \
+                       (const float4 *)x_h2, (const float4 *)packed_w, inv_scale, x_inv_scale, bias, y);                     \
+  } while (0)
+  if (r == 32) { if (mi == 2) H2_LAUNCH(2, 4, 32, 2, 8); else H2_LAUNCH(1, 4, 32, 2, 8); }
+  else if (r == 16) { if (mi == 2) H2_LAUNCH(2, 4, 16, 2, 16); else H2_LAUNCH(1, 4, 16, 2, 16); }
+  else H2_LAUNCH(1, 2, 8, 4, 8);
+#undef H2_LAUNCH
+  return launch_status("conv3d_h2");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// producer of the H2 layout: fp32 channel-first (B, C, V) through GroupNorm (+ Swish), times 16, split in two.
+// The fused normalise step between the two convolutions of a PVConv (pvconv.py:78-82).
+// ---------------------------------------------------------------------------------------------------
+__global__ void to_h2_kernel(int C, int V, int G, int S, const float *__restrict__ x, const double *__restrict__ partial,
+                             const float *__restrict__ gamma, const float *__restrict__ beta, float eps, int act,
+                             float act_scale, unsigned short *__restrict__ out) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int bi = blockIdx.z, c8 = blockIdx.y, C8 = gridDim.y;
+  const int cg = C / G;
+  if (partial) {
+    if (threadIdx.x < G) {
+      double a = 0.0, q = 0.0;
+      const size_t bg = (size_t)bi * G + threadIdx.x;
+      for (int s = 0; s < S; ++s) { a += partial[(bg * S + s) * 2]; q += partial[(bg * S + s) * 2 + 1]; }
+      const double cnt = (double)cg * V, mean = a / cnt;
+      double var = q / cnt - mean * mean;
+      if (var < 0) var = 0;
+      s_mean[threadIdx.x] = (float)mean;
+      s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+  }
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  float val[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = c8 * 8 + j;
+    float t = 0.f;
+    if (ch < C) {
+      t = x[((size_t)bi * C + ch) * V + v];
+      if (partial) {
+        const int g = ch / cg;
+        t = (t - s_mean[g]) * s_rstd[g] * gamma[ch] + beta[ch];
+        if (act == 1) t = t / (1.0f + expf(-t));
+      }
+    }
+    val[j] = t * act_scale;  // a power of two: exact
+  }
+  store_h2(out + ((size_t)bi * C8 + c8) * 2 * (size_t)V * 8, (size_t)v, (size_t)V, val);
+}
+
+extern "C" int bdm_group_norm_stats(int b, int c, int l, int groups, const float *x, long long bs_x, void *workspace,
+                                    int *slices_out, void *stream);
+
+extern "C" int bdm_group_norm_to_h2(int b, int c, int v, int groups, const float *x, const float *gamma,
+                                    const float *beta, float eps, int act, float act_scale, void *out_h2, void *workspace,
+                                    void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && v >= 1, "group_norm_to_h2: bad sizes");
+  {
+    int ex = 0;
+    BDM_REQUIRE(act_scale > 0.f && act_scale < INFINITY && frexpf(act_scale, &ex) == 0.5f,
+                "group_norm_to_h2: act_scale must be a power of two (got %g)", (double)act_scale);
+  }
+  BDM_REQUIRE(groups == 0 || (c % groups == 0 && groups <= 64 && workspace != nullptr), "group_norm_to_h2: bad groups %d", groups);
+  if (b == 0) return BDM_OK;
+  int S = 0;
+  if (groups > 0) {
+    int rc = bdm_group_norm_stats(b, c, v, groups, x, (long long)c * v, workspace, &S, stream);
+    if (rc) return rc;
+  }
+  dim3 grid(cdiv(v, 256), (c + 7) / 8, b);
+  hipLaunchKernelGGL(to_h2_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, v, groups > 0 ? groups : 1, S, x,
+                     groups > 0 ? (const double *)workspace : nullptr, gamma, beta, eps, act, act_scale, (unsigned short *)out_h2);
+  return launch_status("group_norm_to_h2");
+}

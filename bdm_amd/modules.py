@@ -155,9 +155,11 @@ class PVConv(nn.Module):
         self._packed = {}
 
     # Voxel-convolution arithmetic (both are fp32-accurate, tests/test_hip_dense.py):
-    #   "bf16x6": exact 3-way bf16 split of both operands, six partial products on the bf16 matrix cores (default);
+    #   "fp16x3": (default) second convolution on two-term fp16 operands, three partial products (conv3d_h2.hip); the
+    #             first convolution (raw point features, unbounded range) stays on the bf16x6 kernels;
+    #   "bf16x6": exact 3-way bf16 split of both operands, six partial products on the bf16 matrix cores;
     #   "fp32"  : v_mfma_f32_32x32x2_f32 kernels of conv3d.hip (BDM_CONV=fp32).
-    conv_impl = os.environ.get("BDM_CONV", "bf16x6")
+    conv_impl = os.environ.get("BDM_CONV", "fp16x3")
     sparse_first_conv = os.environ.get("BDM_SPARSE_CONV1", "1") == "1"
     sparse_resolutions = {int(v) for v in os.environ.get("BDM_SPARSE_R", "8,16,32").split(",") if v}
     sparse_gemm = "sparse" if os.environ.get("BDM_SPARSE_GEMM", "bf16x6") == "fp32" else "sparse_s3"
@@ -167,7 +169,8 @@ class PVConv(nn.Module):
         sig = (conv.weight._version, conv.weight.data_ptr())
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
-            pack = {"bf16x6": ops.conv3d_s3_pack, "sparse": ops.sparse_conv_pack, "sparse_s3": ops.sparse_conv_pack_s3,
+            pack = {"bf16x6": ops.conv3d_s3_pack, "fp16x3": ops.conv3d_h2_pack, "sparse": ops.sparse_conv_pack,
+                    "sparse_s3": ops.sparse_conv_pack_s3,
                     "fp32": ops.conv3d_pack}[impl]
             hit = (sig, pack(conv.weight.detach()))
             self._packed[key] = hit
@@ -184,7 +187,7 @@ class PVConv(nn.Module):
         se = next((m for m in rest if isinstance(m, SE3d)), None)
 
         features = ops.materialize(features)
-        if self.conv_impl == "bf16x6":
+        if self.conv_impl in ("bf16x6", "fp16x3"):
             if self.sparse_first_conv and r in self.sparse_resolutions:
                 # conv1 sees the freshly voxelised cloud: evaluate it on the occupied cells only (sparse_conv.hip);
                 # the (coords, r) plan is shared by the PVConvs of one level
@@ -197,8 +200,13 @@ class PVConv(nn.Module):
                 x3 = ops.avg_voxelize_s3(features, vox_coords, r)
                 v = ops.conv3d_s3(x3, self._packed_weight(conv1, "bf16x6"), conv1.bias, conv1.in_channels,
                                   conv1.out_channels, r)
-            v3 = ops.to_s3(v, gn1, swish=True)  # GroupNorm + Swish fused into the operand split of the second conv
-            v = ops.conv3d_s3(v3, self._packed_weight(conv2, "bf16x6"), conv2.bias, conv2.in_channels, conv2.out_channels, r)
+            # GroupNorm + Swish fused into the operand split of the second conv
+            if self.conv_impl == "fp16x3":
+                v = ops.conv3d_h2(ops.to_h2(v, gn1, swish=True), self._packed_weight(conv2, "fp16x3"), conv2.bias,
+                                  conv2.in_channels, conv2.out_channels, r)
+            else:
+                v = ops.conv3d_s3(ops.to_s3(v, gn1, swish=True), self._packed_weight(conv2, "bf16x6"), conv2.bias,
+                                  conv2.in_channels, conv2.out_channels, r)
             ops.group_norm_(v, gn2.weight, gn2.bias, 8, gn2.eps, swish=(att is None))
             if att is not None:
                 v = att(v)

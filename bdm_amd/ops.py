@@ -320,6 +320,73 @@ def conv3d_s3(x_s3, packed_w, bias, cin, cout, r):
     return y
 
 
+# ---- fp16x3 ("H2") convolution path: two fp16 terms per operand, three MFMA products (csrc/conv3d_h2.hip) ------------
+def conv3d_h2_pack(weight):
+    """-> (packed fp16 weights, inv_scale (Cout,) fp32)."""
+    cout, cin = weight.shape[:2]
+    w = weight.contiguous()
+    lib = L.lib()
+    lib.bdm_conv3d_h2_weight_elems.restype = ctypes.c_size_t
+    packed = torch.empty(lib.bdm_conv3d_h2_weight_elems(cout, cin), dtype=torch.float16, device=w.device)
+    scale = torch.empty(cout, dtype=torch.float32, device=w.device)
+    inv_scale = torch.empty(cout, dtype=torch.float32, device=w.device)
+    L.check(lib.bdm_conv3d_h2_pack_weights(cout, cin, L.ptr(w), L.ptr(packed), L.ptr(scale), L.ptr(inv_scale), L.stream()),
+            "conv3d_h2_pack_weights")
+    return packed, inv_scale
+
+
+_h2_scale_cache = {}
+
+
+def _pow2_below(v):
+    import math
+    return 2.0 ** math.floor(math.log2(v))
+
+
+def h2_activation_scale(gn, sigmas=64.0):
+    """Power-of-two scale for GroupNorm(+Swish) outputs: |y| <= |gamma| |z| + |beta|, so that a `sigmas`-sigma value of
+    the widest channel still fits fp16 (beyond that the split saturates).  Depends on the parameters only: cached per
+    (module, parameter version), one small device->host read when the weights change."""
+    key = id(gn)
+    sig = (gn.weight._version, gn.bias._version, gn.weight.data_ptr())
+    hit = _h2_scale_cache.get(key)
+    if hit is None or hit[0] != sig:
+        bound = float((gn.weight.detach().abs() * sigmas + gn.bias.detach().abs()).max())
+        hit = (sig, _pow2_below(32768.0 / max(bound, 1e-30)))
+        _h2_scale_cache[key] = hit
+    return hit[1]
+
+
+def to_h2(x, gn=None, swish=False, scale=None):
+    """x (B, C, V) fp32 contiguous -> (H2 tensor (B, ceil(C/8), 2, V, 8) fp16 of scale * [swish(group_norm(x))], 1 / scale).
+    scale: power of two; default from the GroupNorm parameters, or (no GroupNorm: test path, host sync) from max |x|."""
+    x = x.contiguous()
+    B, C = x.shape[:2]
+    V = x.numel() // (B * C)
+    out = torch.empty(B, (C + 7) // 8, 2, V, 8, dtype=torch.float16, device=x.device)
+    if gn is not None:
+        scale = h2_activation_scale(gn) if scale is None else scale
+        ws = workspace(L.lib().bdm_group_norm_workspace_bytes(B, gn.num_groups), x.device, "gn")
+        L.check(L.lib().bdm_group_norm_to_h2(B, C, V, gn.num_groups, L.ptr(x), L.ptr(gn.weight), L.ptr(gn.bias),
+                                             L.c_float(gn.eps), 1 if swish else 0, L.c_float(scale), L.ptr(out), L.ptr(ws),
+                                             L.stream()), "group_norm_to_h2")
+    else:
+        scale = _pow2_below(32768.0 / max(float(x.abs().max()), 1e-30)) if scale is None else scale
+        L.check(L.lib().bdm_group_norm_to_h2(B, C, V, 0, L.ptr(x), L.ptr(None), L.ptr(None), L.c_float(0.0), 0,
+                                             L.c_float(scale), L.ptr(out), L.ptr(None), L.stream()), "to_h2")
+    return out, 1.0 / scale
+
+
+def conv3d_h2(x_h2, packed, bias, cin, cout, r):
+    """x_h2 = to_h2(...) -> ((B, ceil(cin/8), 2, r^3, 8) fp16, 1/scale); packed = conv3d_h2_pack(w) -> (B, cout, r^3) fp32."""
+    (xh, x_inv_scale), (packed_w, inv_scale) = x_h2, packed
+    B = xh.shape[0]
+    y = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=xh.device)
+    L.check(L.lib().bdm_conv3d_3x3x3_h2(B, cin, cout, int(r), L.ptr(xh), L.c_float(x_inv_scale), L.ptr(packed_w),
+                                        L.ptr(inv_scale), L.ptr(bias), L.ptr(y), L.stream()), "conv3d_h2")
+    return y
+
+
 # ---- sparse first convolution of a PVConv (csrc/sparse_conv.hip) ----------------------------------------------------
 def sparse_conv_pack(weight):
     cout, cin = weight.shape[:2]

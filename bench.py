@@ -32,7 +32,8 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
-SPLIT_PRODUCTS = 6  # bf16 MFMA products issued per fp32 multiply-add by the bf16x6 convolution
+CONV_IMPL = os.environ.get("BDM_CONV", "fp16x3")
+SPLIT_PRODUCTS = 3 if CONV_IMPL == "fp16x3" else 6  # 16-bit MFMA products issued per fp32 multiply-add by the convolution
 MILESTONES = [1000, 968, 936, 872, 128, 64, 32, 0]
 
 
@@ -71,17 +72,18 @@ class ConvTimer:
 
 def install_conv_timer(timer):
     from bdm_amd import ops
-    raw = ops.conv3d_s3
+    name = "conv3d_h2" if CONV_IMPL == "fp16x3" else "conv3d_s3"
+    raw = getattr(ops, name)
 
-    def timed(x_s3, packed_w, bias, cin, cout, r):
+    def timed(x_split, packed_w, bias, cin, cout, r):
         if timer is not None and timer.wants(cout, r) and not torch.cuda.is_current_stream_capturing():
-            tok = timer.begin(x_s3.shape[0], cin, cout, r)
-            y = raw(x_s3, packed_w, bias, cin, cout, r)
+            tok = timer.begin((x_split[0] if isinstance(x_split, tuple) else x_split).shape[0], cin, cout, r)
+            y = raw(x_split, packed_w, bias, cin, cout, r)
             timer.end(tok)
             return y
-        return raw(x_s3, packed_w, bias, cin, cout, r)
+        return raw(x_split, packed_w, bias, cin, cout, r)
 
-    ops.conv3d_s3 = timed
+    setattr(ops, name, timed)
     return raw
 
 
@@ -218,7 +220,10 @@ def main():
             "metric": "sampled shapes/sec (4096 pts, 1000 DDPM steps)", "value": value, "unit": "shapes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "conv_arithmetic": os.environ.get("BDM_CONV", "bf16x6") + " (fp32-accurate: exact 3-way bf16 operand split, fp32 accumulate)",
+            "conv_arithmetic": CONV_IMPL + (" (fp32-grade: operands as two fp16 terms after power-of-two scaling, three partial "
+                                                    "products, fp32 accumulate; first conv of each PVConv: sparse, bf16x6)"
+                                                    if CONV_IMPL == "fp16x3" else " (fp32-grade: exact 3-way bf16 operand split, "
+                                                    "six partial products, fp32 accumulate)"),
             "config": {"workload": "C2: BDM-Blending, N=4096 pts, 1000 DDPM steps, batch=16 per GPU, synthetic R2N2-style "
                                    "inputs, procedural random-init PC2 + PVD weights",
                        "shapes_per_gpu": args.batch, "points": args.points, "pc2_forwards": pc2_f, "pvd_forwards": pvd_f,
@@ -236,11 +241,13 @@ def main():
                 pass
             line["roofline"] = {"bound": "mfma", "achieved": conv["tflops"], "peak": peak, "unit": "TFLOP/s",
                                 "frac": conv["tflops"] / peak, "traffic": traffic,
-                                "kernel": "conv3d_s3_kernel<2,4,32,2,8> (3x3x3 voxel conv, bf16x6 split, Cout>32, 32^3 grid)",
+                                "kernel": ("conv3d_h2_kernel<2,4,32,2,8> (3x3x3 voxel conv, fp16x3, Cout>32, 32^3 grid)"
+                                           if CONV_IMPL == "fp16x3" else
+                                           "conv3d_s3_kernel<2,4,32,2,8> (3x3x3 voxel conv, bf16x6 split, Cout>32, 32^3 grid)"),
                                 "note": "achieved = ALGORITHMIC fp32 FLOPs (2*27*Cin*Cout*r^3*B) / launch time; every fp32 product is "
-                                        "6 bf16 MFMA products, so peak = 2500 TFLOP/s dense bf16 / 6; the fp32-input MFMA peak would "
-                                        "be 157.3 TFLOP/s",
-                                "executed_bf16_tflops": conv["tflops"] * SPLIT_PRODUCTS,
+                                        f"{SPLIT_PRODUCTS} 16-bit MFMA products, so peak = 2500 TFLOP/s dense fp16/bf16 / {SPLIT_PRODUCTS}; "
+                                        "the fp32-input MFMA peak would be 157.3 TFLOP/s",
+                                "executed_16bit_tflops": conv["tflops"] * SPLIT_PRODUCTS,
                                 "frac_of_fp32_mfma_peak": conv["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                                 "avg_launch_us": conv["avg_us"], "launches_timed": conv["launches_timed"],
                                 "launches_total": conv["launches_total"]}

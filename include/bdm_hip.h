@@ -205,6 +205,23 @@ int bdm_voxelize_plan(int b, int n, int r, const int *coords, int *ind, int *cnt
 int bdm_avg_voxelize_s3(int b, int c, int n, int r, const float *features, long long bs_f, int ld_f,
                         const int *coords, void *out_s3, int *ind, int *cnt, void *workspace, void *stream);
 
+/* fp16x3 form of the dense convolution (default for the second convolution of every PVConv): operands stored as two
+ * fp16 terms (hi, lo) after exact power-of-two scaling, three partial products per fp32 product on
+ * v_mfma_f32_32x32x16_f16 -- half the matrix work of bf16x6 at the same accuracy (csrc/conv3d_h2.hip).
+ *   packed_w : bdm_conv3d_h2_weight_elems(cout, cin) fp16; inv_scale (cout floats) = 2^-e[co] for the epilogue;
+ *              scale_ws (cout floats) is scratch of the pack.
+ *   x_h2     : (b, ceil(c/8), 2, v, 8) fp16 = act_scale * swish(group_norm(x)) split in two, from
+ *              bdm_group_norm_to_h2 (groups = 0: plain split of act_scale * x).  act_scale is a power of two chosen by
+ *              the caller so that the scaled values sit high in fp16's range (|act_scale * x| saturates at 65504);
+ *              the convolution receives x_inv_scale = 1 / act_scale. */
+size_t bdm_conv3d_h2_weight_elems(int cout, int cin);
+int bdm_conv3d_h2_pack_weights(int cout, int cin, const float *w, void *packed, float *scale_ws, float *inv_scale,
+                               void *stream);
+int bdm_group_norm_to_h2(int b, int c, int v, int groups, const float *x, const float *gamma, const float *beta,
+                         float eps, int act, float act_scale, void *out_h2, void *workspace, void *stream);
+int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale, const void *packed_w,
+                        const float *inv_scale, const float *bias, float *y, void *stream);
+
 /* bf16x6 form of the two steps above (default): operands pre-split into exact bf16 triples ("S3" records of 8
  * channels x 16 bytes), GEMM on v_mfma_f32_32x32x16_bf16 with six partial products per fp32 product.
  *   xs (b, ceil(c/8), 3, n_max) records; ws (ceil(cin/8), 3, 27*cout) records = bdm_sparse_conv_s3_weight_elems bf16. */

@@ -212,6 +212,49 @@ def test_conv3d_bf16x6_has_fp32_accuracy(ops, cin, cout, r):
     assert e6 < 2e-6 and e6 < 4 * e32 + 1e-7, (e6, e32)
 
 
+@pytest.mark.parametrize("cin,cout,r,kind", [(35, 32, 32, "normal"), (64, 64, 32, "normal"), (128, 64, 16, "wide"), (128, 128, 16, "normal"),
+                                             (192, 128, 8, "tiny"), (256, 256, 8, "normal"), (7, 8, 8, "wide"), (64, 64, 16, "saturate")])
+def test_conv3d_fp16x3_has_fp32_accuracy(ops, cin, cout, r, kind):
+    """two-term fp16 operands, three partial products, power-of-two scaling: error vs fp64 at the fp32-MFMA kernel's level,
+    also for weights spanning 8 decades per layer, activations of very different magnitudes and tiny values."""
+    B = 2
+    g = torch.Generator().manual_seed(cin * cout + r)
+    x = torch.randn(B, cin, r ** 3, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    if kind == "wide":    # per-channel weight scales from 1e-4 to 1e4, activations with a 1e-3 .. 30 spread
+        w = w * (10.0 ** torch.linspace(-4, 4, cout)).view(-1, 1, 1, 1, 1)
+        x = x * (10.0 ** torch.linspace(-3, 1.5, cin)).view(1, -1, 1)
+    elif kind == "tiny":  # everything far below fp16's normal range before scaling
+        x, w = x * 1e-6, w * 1e-5
+    b = torch.randn(cout, generator=g) * float(w.abs().mean() * x.abs().mean()) * 10
+    ref = TF.conv3d(x.double().view(B, cin, r, r, r), w.double(), b.double(), padding=1).float().reshape(B, cout, -1)
+    if kind == "saturate":  # |scale * x| > 65504 saturates (documented), it must not produce inf / nan
+        x[0, 0, 0] = 1e6
+        got = ops.conv3d_h2(ops.to_h2(x.cuda(), scale=16.0), ops.conv3d_h2_pack(w.cuda()), b.cuda(), cin, cout, r).cpu()
+        assert bool(torch.isfinite(got).all())
+        return
+    got = ops.conv3d_h2(ops.to_h2(x.cuda()), ops.conv3d_h2_pack(w.cuda()), b.cuda(), cin, cout, r).cpu()
+    fp32 = ops.conv3d(x.cuda(), ops.conv3d_pack(w.cuda()), b.cuda(), r).cpu()
+    # per output channel (the weight scales differ by decades): every channel must be fp32-grade
+    e3 = ((got - ref).norm(dim=(0, 2)) / ref.norm(dim=(0, 2))).max().item()
+    e32 = ((fp32 - ref).norm(dim=(0, 2)) / ref.norm(dim=(0, 2))).max().item()
+    assert e3 < 2e-6 and e3 < 4 * e32 + 1e-7, (e3, e32)
+
+
+def test_h2_producer(ops):
+    """GroupNorm + Swish -> H2 reconstructs ((hi + lo) / 16) the fp32 values of the fp32 GroupNorm kernel."""
+    g = torch.Generator().manual_seed(18)
+    B, r = 2, 16
+    x = torch.randn(B, 40, r ** 3, generator=g) * 2 + 0.5
+    gn = torch.nn.GroupNorm(8, 40)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(40, generator=g)); gn.bias.copy_(torch.randn(40, generator=g))
+    ref = ops.group_norm_(x.clone().cuda(), gn.weight.cuda(), gn.bias.cuda(), swish=True).cpu()
+    h2, inv = ops.to_h2(x.cuda(), gn.cuda(), swish=True)
+    got = (h2.cpu().double().sum(2) * inv).permute(0, 1, 3, 2).reshape(B, -1, r ** 3)[:, :40].float()
+    assert rel(got, ref) < 3e-7
+
+
 def test_s3_producers(ops, oracle_ops):
     """GroupNorm(+Swish)->S3 and voxelise->S3 reconstruct (hi+mid+lo) the fp32 values of the fp32 kernels."""
     g = torch.Generator().manual_seed(8)
