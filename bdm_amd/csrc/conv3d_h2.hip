@@ -210,17 +210,15 @@ __global__ __launch_bounds__(256) void conv3d_h2_kernel(int C8, int Cout, const 
           b[q][s] = *reinterpret_cast<const f16x8 *>(&t);
         }
       }
+      // smallest terms first: lo.hi, hi.lo, hi.hi (lo.lo <= 2^-24 |a b| is dropped).  Term-major order: the MI*NI
+      // accumulators are independent, so no MFMA waits on the one issued just before it.
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+      for (int term = 0; term < 3; ++term)
 #pragma unroll
-        for (int q = 0; q < NI; ++q) {
-          f32x16 c = acc[mi][q];
-          // smallest terms first: lo.hi, hi.lo, hi.hi (lo.lo <= 2^-24 |a b| is dropped)
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][1], b[q][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[q][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[q][0], c, 0, 0, 0);
-          acc[mi][q] = c;
-        }
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int q = 0; q < NI; ++q)
+            acc[mi][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][term == 0 ? 1 : 0], b[q][term == 1 ? 1 : 0], acc[mi][q], 0, 0, 0);
     }
   }
 #pragma unroll
