@@ -17,6 +17,8 @@
 //
 // Layouts ("H2"): activations (B, ceil(C/8), 2, r^3, 8) fp16; weights [ceil(Cin/8)][14 tap pairs][2][2][Cout][8] fp16.
 // Geometry, staging and tap addressing are those of conv3d_s3.hip.
+#include <stdlib.h>
+
 #include "../../include/bdm_hip.h"
 #include "common.h"
 
@@ -104,8 +106,8 @@ extern "C" int bdm_conv3d_h2_pack_weights(int cout, int cin, const float *w, voi
 // ---------------------------------------------------------------------------------------------------
 // the convolution
 // ---------------------------------------------------------------------------------------------------
-template <int MI, int NI, int R, int TX, int TY>
-__global__ __launch_bounds__(256) void conv3d_h2_kernel(int C8, int Cout, const float4 *__restrict__ x,
+template <int MI, int NI, int R, int TX, int TY, int NW>  // NW waves per workgroup; NI * NW column blocks of 32 voxels
+__global__ __launch_bounds__(NW * 64) void conv3d_h2_kernel(int C8, int Cout, const float4 *__restrict__ x,
                                                         const float4 *__restrict__ wq, const float *__restrict__ inv_scale,
                                                         float x_inv_scale, const float *__restrict__ bias,
                                                         float *__restrict__ y) {
@@ -115,8 +117,9 @@ __global__ __launch_bounds__(256) void conv3d_h2_kernel(int C8, int Cout, const 
   constexpr int ROWS = (TX + 2) * (TY + 2);
   constexpr int HALO = ROWS * RSV;           // records per split
   constexpr int R2 = R * R, R3 = R2 * R;
-  constexpr int XV = 2 * ROWS * R, XI = (XV + 255) / 256;          // 16-byte pieces of the input tile
-  constexpr int WV = H2_PAIRS * 2 * 2 * BM, WI = (WV + 255) / 256;  // 16-byte pieces of the weight tile
+  constexpr int NT = NW * 64;
+  constexpr int XV = 2 * ROWS * R, XI = (XV + NT - 1) / NT;          // 16-byte pieces of the input tile
+  constexpr int WV = H2_PAIRS * 2 * 2 * BM, WI = (WV + NT - 1) / NT;  // 16-byte pieces of the weight tile
   float4 *Xs = smem4;              // [2][HALO]
   float4 *Ws = smem4 + 2 * HALO;   // [14][2][2][BM]
 
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void conv3d_h2_kernel(int C8, int Cout, const 
   int lbase[NI], gvox[NI];
 #pragma unroll
   for (int q = 0; q < NI; ++q) {
-    const int nb = q * 4 + wave;
+    const int nb = q * NW + wave;
     const int tx = nb / blocks_per_plane, ty = (nb % blocks_per_plane) * rpb + dyl;
     lbase[q] = ((tx + 1) * (TY + 2) + (ty + 1)) * RSV + 1 + zl;
     gvox[q] = ((X0 + tx) * R + (Y0 + ty)) * R + zl;
@@ -147,13 +150,13 @@ __global__ __launch_bounds__(256) void conv3d_h2_kernel(int C8, int Cout, const 
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][q][i] = 0.f;
 
-  for (int e = tid; e < 2 * HALO; e += 256) Xs[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = tid; e < 2 * HALO; e += NT) Xs[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   float4 xr[XI], wr[WI];
   auto load_chunk = [&](int c8) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NT;
       const int z = e % R, row = (e / R) % ROWS, s = e / (R * ROWS);
       const int gx = X0 + row / (TY + 2) - 1, gy = Y0 + row % (TY + 2) - 1;
       xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) void conv3d_h2_kernel(int C8, int Cout, const 
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NT;
       const int m = e % BM, psh = e / BM;  // psh = (p*2 + s)*2 + h
       wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (e < WV && m0 + m < Cout) wr[i] = wq[((size_t)c8 * (H2_PAIRS * 4) + psh) * Cout + m0 + m];
@@ -171,14 +174,14 @@ __global__ __launch_bounds__(256) void conv3d_h2_kernel(int C8, int Cout, const 
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NT;
       const int z = e % R, row = (e / R) % ROWS, s = e / (R * ROWS);
       const int gx = X0 + row / (TY + 2) - 1, gy = Y0 + row % (TY + 2) - 1;
       if (e < XV && gx >= 0 && gx < R && gy >= 0 && gy < R) Xs[s * HALO + row * RSV + 1 + z] = xr[i];
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NT;
       if (e < WV) Ws[e] = wr[i];
     }
   };
@@ -232,6 +235,12 @@ __global__ __launch_bounds__(256) void conv3d_h2_kernel(int C8, int Cout, const 
       }
 }
 
+static int h2_waves() {  // experiment switch: BDM_H2_WAVES=4 selects the 4-wave tiling
+  static int w = 0;
+  if (!w) { const char *e = getenv("BDM_H2_WAVES"); w = (e && e[0] == '4') ? 4 : 8; }
+  return w;
+}
+
 extern "C" int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale,
                                    const void *packed_w, const float *inv_scale, const float *bias, float *y,
                                    void *stream) {
@@ -242,23 +251,32 @@ extern "C" int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *
   }
   if (b == 0) return BDM_OK;
   const int c8 = (cin + 7) / 8;
-  int tx, ty, ni, mi;
-  if (r == 32) { tx = 2; ty = 8; ni = 4; }
-  else if (r == 16) { tx = 2; ty = 16; ni = 4; }
-  else { tx = 4; ty = 8; ni = 2; }
-  mi = (cout > 32 && ni == 4) ? 2 : 1;
+  // tile = TX x TY grid rows x R cells = NI * NW column blocks of 32 voxels; 8 waves (two per SIMD) with NI = 2 keep the
+  // matrix pipe fed while the other wave of the SIMD waits on LDS (measured vs 4 waves with NI = 4)
+  int tx, ty, mi;
+  if (r == 32) { tx = 2; ty = 8; }
+  else if (r == 16) { tx = 2; ty = 16; }
+  else { tx = 4; ty = 8; }
+  mi = (cout > 32 && r != 8) ? 2 : 1;
   const size_t smem = 16 * ((size_t)2 * (tx + 2) * (ty + 2) * (r + 2) + (size_t)H2_PAIRS * 4 * 32 * mi);
   dim3 grid((r / tx) * (r / ty), cdiv(cout, 32 * mi), b);
   hipStream_t s = (hipStream_t)stream;
-#define H2_LAUNCH(MI, NI, R, TX, TY)                                                                            \
+#define H2_LAUNCH(MI, NI, R, TX, TY, NW)                                                                        \
   do {                                                                                                          \
-    BDM_ALLOW_LDS((conv3d_h2_kernel<MI, NI, R, TX, TY>), smem);                                                 \
-    hipLaunchKernelGGL((conv3d_h2_kernel<MI, NI, R, TX, TY>), grid, dim3(256), smem, s, c8, cout,               \
-                       (const float4 *)x_h2, (const float4 *)packed_w, inv_scale, x_inv_scale, bias, y);                     \
+    BDM_ALLOW_LDS((conv3d_h2_kernel<MI, NI, R, TX, TY, NW>), smem);                                             \
+    hipLaunchKernelGGL((conv3d_h2_kernel<MI, NI, R, TX, TY, NW>), grid, dim3(NW * 64), smem, s, c8, cout,       \
+                       (const float4 *)x_h2, (const float4 *)packed_w, inv_scale, x_inv_scale, bias, y);        \
   } while (0)
-  if (r == 32) { if (mi == 2) H2_LAUNCH(2, 4, 32, 2, 8); else H2_LAUNCH(1, 4, 32, 2, 8); }
-  else if (r == 16) { if (mi == 2) H2_LAUNCH(2, 4, 16, 2, 16); else H2_LAUNCH(1, 4, 16, 2, 16); }
-  else H2_LAUNCH(1, 2, 8, 4, 8);
+  const bool w8 = h2_waves() == 8;
+  if (r == 32) {
+    if (mi == 2) { if (w8) H2_LAUNCH(2, 2, 32, 2, 8, 8); else H2_LAUNCH(2, 4, 32, 2, 8, 4); }
+    else { if (w8) H2_LAUNCH(1, 2, 32, 2, 8, 8); else H2_LAUNCH(1, 4, 32, 2, 8, 4); }
+  } else if (r == 16) {
+    if (mi == 2) { if (w8) H2_LAUNCH(2, 2, 16, 2, 16, 8); else H2_LAUNCH(2, 4, 16, 2, 16, 4); }
+    else { if (w8) H2_LAUNCH(1, 2, 16, 2, 16, 8); else H2_LAUNCH(1, 4, 16, 2, 16, 4); }
+  } else {
+    if (w8) H2_LAUNCH(1, 1, 8, 4, 8, 8); else H2_LAUNCH(1, 2, 8, 4, 8, 4);
+  }
 #undef H2_LAUNCH
   return launch_status("conv3d_h2");
 }
