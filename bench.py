@@ -241,7 +241,7 @@ def main():
                 pass
             line["roofline"] = {"bound": "mfma", "achieved": conv["tflops"], "peak": peak, "unit": "TFLOP/s",
                                 "frac": conv["tflops"] / peak, "traffic": traffic,
-                                "kernel": ("conv3d_h2_kernel<2,4,32,2,8> (3x3x3 voxel conv, fp16x3, Cout>32, 32^3 grid)"
+                                "kernel": ("conv3d_h2_kernel<2,2,32,2,8,8> (3x3x3 voxel conv, fp16x3, Cout>32, 32^3 grid)"
                                            if CONV_IMPL == "fp16x3" else
                                            "conv3d_s3_kernel<2,4,32,2,8> (3x3x3 voxel conv, bf16x6 split, Cout>32, 32^3 grid)"),
                                 "note": "achieved = ALGORITHMIC fp32 FLOPs (2*27*Cin*Cout*r^3*B) / launch time; every fp32 product is "
