@@ -74,7 +74,7 @@ def test_fuse_full_golden(hip):
     assert rel_l2(y, torch.from_numpy(g["out"])) < TOL
 
 
-@pytest.mark.parametrize("N,B", [(4096, 2), (2048, 1)])
+@pytest.mark.parametrize("N,B", [(4096, 2), (2048, 1), (8192, 1), (1100, 3)])
 def test_pvd_vs_oracle_fresh_inputs(hip, oracle_ops, N, B):
     """level-0 sizes of the benchmark (N = 4096) against the oracle."""
     from bdm_amd.pvcnn import PVCNN2_PVD
@@ -83,6 +83,20 @@ def test_pvd_vs_oracle_fresh_inputs(hip, oracle_ops, N, B):
     net = fill_module_(PVCNN2_PVD(3, 64, extra_feature_channels=0).eval(), seed=7)
     x = point_cloud_inputs(B, 3, N, seed=100 + N)
     t = torch.tensor([250] * B)
+    ref = ref_net.pvcnn_forward(net.state_dict(), x, t)
+    got = net.cuda()(x.cuda(), t.cuda()).cpu()
+    assert rel_l2(got, ref) < TOL
+
+
+@pytest.mark.parametrize("N,B", [(4096, 1), (1500, 2)])
+def test_pc2_vs_oracle_fresh_inputs(hip, oracle_ops, N, B):
+    """the 390-channel PC^2 denoiser at benchmark size and at a ragged point count, against the oracle."""
+    from bdm_amd.pvcnn import PVCNN2_PC2
+    from bdm_amd.utils.procedural import fill_module_
+    from oracle import ref_net
+    net = fill_module_(PVCNN2_PC2(3, 64, extra_feature_channels=387).eval(), seed=11)
+    x = point_cloud_inputs(B, 390, N, seed=200 + N)
+    t = torch.tensor([[730], [5, 999]][B - 1])
     ref = ref_net.pvcnn_forward(net.state_dict(), x, t)
     got = net.cuda()(x.cuda(), t.cuda()).cpu()
     assert rel_l2(got, ref) < TOL
