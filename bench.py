@@ -142,6 +142,52 @@ def cpu_baseline(model, pvd_model, n_points, budget_s=25.0):
             "s_per_pc2_step": s_pc2, "s_per_pvd_step": s_pvd}
 
 
+def c1_full(device, n_points=1024, steps=100):
+    """Config C1 (BASELINE.json configs[0], the reference's own CPU-runnable case) IN FULL on both sides: vanilla PC^2
+    sampling of one shape, 100 DDPM steps with projection conditioning at every step (image encoder hoisted on both
+    sides).  Returns seconds per trajectory: HIP path on the GPU, CPU oracle on the host cores."""
+    from bdm_amd.cameras import join_cameras
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.model import get_model
+    from bdm_amd.utils.procedural import fill_module_
+    from oracle import ref_net, ref_sampler as R, ref_vit
+    cfg = ProjectConfig()
+    cfg.dataset.max_points = n_points
+    model = fill_module_(get_model(cfg).eval(), seed=11)
+    batch = next(iter(SyntheticShapes(range(1), 1, seed=5, image_size=224, num_points=n_points)))
+    ts = list(range(1000 - 1000 // steps, -1, -(1000 // steps)))
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(1, n_points, 3, generator=g)
+    noise = {t: torch.randn(1, n_points, 3, generator=g) for t in ts}
+    sd = model.state_dict()
+    t0 = time.perf_counter()
+    local = ref_vit.local_conditioning(sd, batch.image_rgb)
+    cams = join_cameras(batch.camera).packed()
+    ddpm, x = R.RefDDPM(), x0.clone()
+    for t in ts:
+        x_in = R.get_input_with_conditioning(x, cams, local)
+        eps = ref_net.point_cloud_model_forward(sd, x_in, torch.full((1,), t), prefix="point_cloud_model.model.")
+        x = ddpm.step(eps, t, x, noise[t] if t > 0 else None, prev_t=t - 1000 // steps)
+    cpu_s = time.perf_counter() - t0
+    model = model.to(device)
+    b = batch.to(device)
+
+    def gpu_run():
+        model._cond_cache = None
+        return model.forward_sample(num_points=n_points, camera=b.camera, image_rgb=b.image_rgb, mask=None,
+                                    scheduler="ddpm", num_inference_steps=steps)
+    gpu_run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = gpu_run()
+    torch.cuda.synchronize()
+    gpu_s = time.perf_counter() - t0
+    assert torch.isfinite(out.points_padded()).all() and torch.isfinite(x).all()
+    return {"workload": f"C1: vanilla PC2, 1 shape, N={n_points}, {steps} DDPM steps, conditioning every step", "gpu_s": gpu_s,
+            "cpu_s": cpu_s, "speedup": cpu_s / gpu_s}
+
+
 def main():
     if os.environ.get("BDM_WATCHDOG"):  # debugging aid: dump every thread's Python stack and exit after N seconds
         import faulthandler
@@ -259,6 +305,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(model, pvd_model, args.points)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+            line["cpu_baseline"]["c1_full"] = c1_full(device)  # the reference's CPU-runnable config, run in full on both sides
         print(json.dumps(line), flush=True)
     barrier()
 

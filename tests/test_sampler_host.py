@@ -166,3 +166,21 @@ def test_ddim_scheduler_closed_form_and_schedule_mapping():
     cfg.run.diffusion_scheduler, cfg.aux_run.roll_step, cfg.aux_run.milestones = "ddim", 1, [64, 62, 60, 56, 8, 4, 2, 0]
     roll, ms, proll, pms, times = _schedule(cfg)
     assert (proll, pms, times) == (16, [1000, 968, 937, 875, 125, 62, 31, 0], 7)  # main_blending.py:214-218
+
+
+def test_screen_space_and_pix3d_cameras():
+    """in_ndc=False intrinsics convert to NDC with pytorch3d's rule; the Pix3D adapter composes crop + resize with K."""
+    from bdm_amd.cameras import PerspectiveCameras, pix3d_camera
+    c = PerspectiveCameras(focal_length=[[300.0, 300.0]], principal_point=[[100.0, 140.0]], in_ndc=False, image_size=(224, 224))
+    assert torch.allclose(c.focal_length, torch.tensor([[300 * 2 / 224.0] * 2]))
+    assert torch.allclose(c.principal_point, torch.tensor([[-(100 - 112) * 2 / 224.0, -(140 - 112) * 2 / 224.0]]))
+    # a 640x480 photo, object box (200,100)-(440,420): crop half-side 160 around (320, 260), resized to 224
+    cam = pix3d_camera(torch.eye(3).numpy(), [0.0, 0.0, 2.0], [0.0, 0.0, 0.0], 1.0, (640, 480), (200, 100, 440, 420), 35.0)
+    f, s = 35.0 * 640 / 32, 224 / 320.0
+    assert torch.allclose(cam.focal_length, torch.tensor([[s * f * 2 / 224] * 2]))
+    tx, ty = s * (320 - 160), s * (240 - 100)
+    assert torch.allclose(cam.principal_point, torch.tensor([[-(tx - 112) * 2 / 224, -(ty - 112) * 2 / 224]]), atol=1e-6)
+    # unit-std normalisation scales the rotation, the mean shifts the translation; OpenCV -> pytorch3d axis swap
+    cam2 = pix3d_camera(torch.eye(3).numpy(), [0.0, 0.0, 2.0], [0.1, 0.0, 0.0], 2.0, (640, 480), (200, 100, 440, 420), 35.0)
+    assert torch.allclose(cam2.T, torch.tensor([[0.1, 0.0, 2.0]]))
+    assert torch.allclose(cam2.R[0], 2.0 * torch.tensor([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [-1.0, 0.0, 0.0]]).T)
