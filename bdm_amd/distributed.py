@@ -15,8 +15,8 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # BDM_DIST_BACKEND=gloo: used to exercise the multi-rank path on a single-GPU box
+            backend = os.environ.get("BDM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -55,6 +55,6 @@ def gather_clouds(local, num_shapes, rank, world):
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -213,6 +213,8 @@ def main():
 
     rank, local_rank, world = init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("BDM_SHARE_GPU") == "1":  # test aid: every rank on cuda:0 (with BDM_DIST_BACKEND=gloo) on a 1-GPU box
+        local_rank = 0
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     _lib.lib()  # fail loudly if the HIP extension is missing
@@ -308,6 +310,8 @@ def main():
             line["cpu_baseline"]["c1_full"] = c1_full(device)  # the reference's CPU-runnable config, run in full on both sides
         print(json.dumps(line), flush=True)
     barrier()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
