@@ -6,7 +6,7 @@ import bdm_amd.model as M
 from bdm_amd.config import ProjectConfig
 from bdm_amd.data import SyntheticShapes
 from bdm_amd.utils.procedural import fill_module_
-B, N, steps = 16, 4096, 30
+B, N, steps = int(os.environ.get("PB", 16)), int(os.environ.get("PN", 4096)), 30
 cfg = ProjectConfig(); cfg.dataset.max_points = N
 model = fill_module_(M.get_model(cfg).eval(), seed=1).cuda()
 batch = next(iter(SyntheticShapes(range(B), B, num_points=N))).to("cuda")
