@@ -41,7 +41,10 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, tag="ws"):
-    key = (tag, str(device))
+    """Cached scratch buffer per (tag, device, current stream): kernels of different streams never share one."""
+    dev = torch.device(device)
+    raw = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch._C._cuda_getDevice()) if dev.type == "cuda" else 0
+    key = (tag, str(device), raw)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
