@@ -100,3 +100,21 @@ def test_pc2_vs_oracle_fresh_inputs(hip, oracle_ops, N, B):
     ref = ref_net.pvcnn_forward(net.state_dict(), x, t)
     got = net.cuda()(x.cuda(), t.cuda()).cpu()
     assert rel_l2(got, ref) < TOL
+
+
+@pytest.mark.parametrize("conv,sparse_gemm,attention,point_stream", [("fp16x3", "sparse_s3", "bf16x6", True), ("bf16x6", "sparse_s3", "bf16x6", False),
+                                                                   ("fp32", "sparse", "fp32", True), ("bf16x6", "sparse", "fp32", False)])
+def test_arithmetic_and_stream_modes_all_match_the_golden(hip, monkeypatch, conv, sparse_gemm, attention, point_stream):
+    """every selectable kernel family (BDM_CONV / BDM_SPARSE_GEMM / BDM_ATTENTION / BDM_POINT_STREAM) reproduces the reference."""
+    from bdm_amd import ops
+    from bdm_amd.modules import PVConv
+    from bdm_amd.pvcnn import PVCNN2_PVD
+    monkeypatch.setattr(PVConv, "conv_impl", conv)
+    monkeypatch.setattr(PVConv, "sparse_gemm", sparse_gemm)
+    monkeypatch.setattr(PVConv, "point_stream", point_stream)
+    monkeypatch.setattr(ops, "ATTENTION_IMPL", attention)
+    g = load("pvd_full_n1024.npz")
+    net = build(PVCNN2_PVD, g, extra_feature_channels=0)
+    x = point_cloud_inputs(2, 3, 1024, int(g["input_seed"]))
+    y = net(x.cuda(), torch.from_numpy(g["t"]).cuda()).cpu()
+    assert rel_l2(y, torch.from_numpy(g["out"])) < TOL
