@@ -118,3 +118,16 @@ def test_arithmetic_and_stream_modes_all_match_the_golden(hip, monkeypatch, conv
     x = point_cloud_inputs(2, 3, 1024, int(g["input_seed"]))
     y = net(x.cuda(), torch.from_numpy(g["t"]).cuda()).cpu()
     assert rel_l2(y, torch.from_numpy(g["out"])) < TOL
+
+
+def test_forward_is_run_to_run_deterministic(hip):
+    """No float atomics anywhere on the path (the reference's voxeliser has them): two forwards give identical bits, also
+    with the sampler chain and the point branches running on their own streams."""
+    from bdm_amd.pvcnn import PVCNN2_PC2
+    from bdm_amd.utils.procedural import fill_module_
+    net = fill_module_(PVCNN2_PC2(3, 64, extra_feature_channels=387).eval(), seed=2).cuda()
+    x = point_cloud_inputs(3, 390, 2048, seed=77).cuda()
+    t = torch.tensor([10, 500, 990]).cuda()
+    a = net(x, t).clone()
+    for _ in range(3):
+        assert torch.equal(net(x, t), a)
