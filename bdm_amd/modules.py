@@ -183,7 +183,7 @@ class PVConv(nn.Module):
     _streams = {}
 
     def _point_branch(self, features):
-        if not (self.point_stream and features.is_cuda):
+        if not (self.point_stream and features.is_cuda and features.shape[0] * features.shape[2] >= 8192):
             return self.point_features.run(features), None
         dev = features.device
         side = PVConv._streams.get(dev)

@@ -8,6 +8,8 @@ Topology quirks reproduced on purpose: set-abstraction levels 1-
 although their tables say 3 (pvcnn_utils.py:98-101); voxel attention exists only in sa_layers.1.0;
 feature-propagation PVConvs never get attention (pvcnn_utils.py:139,150).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -114,6 +116,8 @@ def embed_time(embedf, t, embed_dim, n):
 
 
 _side_streams = {}
+SIDE_STREAM = os.environ.get("BDM_SIDE_STREAM", "1") == "1"  # sampler chain on its own stream (0: inline, for experiments)
+SIDE_STREAM_MIN_POINTS = 8192  # B * N below which the streams are not used (measured: tools/time_loop.py at B=1, N=1024)
 
 
 def plan_sampling_chain(sa_layers, coords):
@@ -140,7 +144,9 @@ def encode(sa_layers, global_att, inputs, t_emb):
     """Down path (pvcnn.py:90-110)."""
     coords = inputs[:, :3, :].contiguous()
     ops.clear_plan_cache()  # voxel plans are valid within one encoder/decoder pass
-    if coords.is_cuda:  # also inside a hipGraph capture: the side stream forks from and joins the capturing stream
+    # also inside a hipGraph capture: the side stream forks from and joins the capturing stream.  Small problems (one
+    # small shape) are bound by kernel-to-kernel dispatch latency, where the extra events cost more than the overlap gains
+    if coords.is_cuda and SIDE_STREAM and coords.shape[0] * coords.shape[2] >= SIDE_STREAM_MIN_POINTS:
         plan_sampling_chain(sa_layers, coords)
     features = inputs
     coords_list, in_features_list = [], []
