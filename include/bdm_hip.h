@@ -154,9 +154,10 @@ int bdm_voxel_coords(int b, int n, int r, float eps, const float *coords, float 
                      int *vox_coords, void *stream);
 
 /* SE3d gate (modules/se.py:8-19, ReLU variant): gate (b,c) = sigmoid(w2 relu(w1 mean_l x)).
- * x (b,c,l) contiguous; mean_ws (b,c) scratch. */
+ * x (b,c,l) contiguous; mean_ws (b,c) scratch.  counters: NULL -> two launches (row means, then the FC layers); else b
+ * ints that are ZERO on entry (and are left zero) -> one launch, the last workgroup of each shape runs the FC layers. */
 int bdm_se_gate(int b, int c, int hidden, int l, const float *x, const float *w1, const float *w2,
-                float *mean_ws, float *gate, void *stream);
+                float *mean_ws, float *gate, int *counters, void *stream);
 
 /* PVConv tail (pvconv.py:95-96): out = trilinear_devoxelize(grid * gate[:, :, None]) + add.
  * gate and add may be NULL. */

@@ -113,7 +113,16 @@ def test_small_ops(ops):
     v = torch.randn(2, C, r ** 3, generator=g)
     w1, w2 = torch.randn(C // 8, C, generator=g) / 8, torch.randn(C, C // 8, generator=g) / 3
     ref = torch.sigmoid(TF.linear(torch.relu(TF.linear(v.mean(-1), w1)), w2))
-    assert rel(ops.se_gate(v.cuda(), w1.cuda(), w2.cuda()).cpu(), ref) < 2e-6
+    two = ops.se_gate(v.cuda(), w1.cuda(), w2.cuda(), fused=False).cpu()
+    assert rel(two, ref) < 2e-6
+    # one-launch form (last workgroup of a shape runs the FC layers): identical bits, repeatedly, on big batches too
+    for _ in range(20):
+        assert torch.equal(ops.se_gate(v.cuda(), w1.cuda(), w2.cuda(), fused=True).cpu(), two)
+    vb = torch.randn(16, 256, 512, generator=g).cuda()
+    w1b, w2b = (torch.randn(32, 256, generator=g) / 16).cuda(), (torch.randn(256, 32, generator=g) / 6).cuda()
+    twob = ops.se_gate(vb, w1b, w2b, fused=False)
+    for _ in range(10):
+        assert torch.equal(ops.se_gate(vb, w1b, w2b, fused=True), twob)
     # time embedding
     from oracle import ref_net
     sd = {"0.weight": torch.randn(64, 64, generator=g) / 8, "0.bias": torch.randn(64, generator=g),
