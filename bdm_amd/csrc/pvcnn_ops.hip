@@ -526,7 +526,8 @@ extern "C" size_t bdm_voxelize_workspace_bytes(int b, int n, int r) {
 
 __global__ void vox_plan_kernel(int n, int r, const int *__restrict__ coords, int *__restrict__ ind,
                                 int *__restrict__ cnt, int *__restrict__ start, int *__restrict__ tmp,
-                                int *__restrict__ sorted) {
+                                int *__restrict__ sorted, int n_max, int *__restrict__ occ_index,
+                                int *__restrict__ occ_list, int *__restrict__ n_occ, unsigned char *__restrict__ rowocc) {
   extern __shared__ int lcnt[];  // [r3] counters, then cursors
   __shared__ int wave_tot[16];
   const int r2 = r * r, r3 = r2 * r;
@@ -573,6 +574,36 @@ __global__ void vox_plan_kernel(int n, int r, const int *__restrict__ coords, in
     for (int q = 0; q < cv; ++q) rank += tp[s + q] < i;
     so[s + rank] = i;
   }
+  if (occ_index == nullptr) return;
+  // ---- optional tail (bdm_voxelize_plan_full): occupied-cell compaction and row occupancy of the same shape, in the
+  // launch that already owns it (what bdm_voxel_compact + bdm_voxel_row_occupancy do in two more launches)
+  __syncthreads();
+  int *oi = occ_index + (size_t)bi * r3;
+  int *ol = occ_list + (size_t)bi * n_max;
+  int occ_local = 0;
+  for (int v = lo; v < hi; ++v) occ_local += gc[v] > 0;
+  int oincl = occ_local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(oincl, o, 64);
+    if (lane >= o) oincl += t;
+  }
+  __syncthreads();
+  if (lane == 63) wave_tot[wave] = oincl;
+  __syncthreads();
+  int off = 0, total = 0;
+  for (int w = 0; w < (T >> 6); ++w) { if (w < wave) off += wave_tot[w]; total += wave_tot[w]; }
+  int orun = off + oincl - occ_local;
+  for (int v = lo; v < hi; ++v) {
+    if (gc[v] > 0) { oi[v] = orun; ol[orun] = v; ++orun; }
+    else oi[v] = -1;
+  }
+  if (tid == 0) n_occ[bi] = total;
+  for (int row = tid; row < r2; row += T) {
+    int any = 0;
+    for (int z = 0; z < r; ++z) any |= gc[row * r + z];
+    rowocc[(size_t)bi * r2 + row] = any ? 1 : 0;
+  }
 }
 
 __global__ void vox_reduce_kernel(int c, int n, int r3, const float *__restrict__ feat,
@@ -603,8 +634,22 @@ extern "C" int bdm_voxelize_plan(int b, int n, int r, const int *coords, int *in
   const size_t smem = (size_t)r3 * sizeof(int);
   BDM_ALLOW_LDS(vox_plan_kernel, smem);
   hipLaunchKernelGGL(vox_plan_kernel, dim3(b), dim3(1024), smem, (hipStream_t)stream, n, r, coords, ind, cnt, w.start,
-                     w.tmp, w.sorted);
+                     w.tmp, w.sorted, 0, (int *)nullptr, (int *)nullptr, (int *)nullptr, (unsigned char *)nullptr);
   return launch_status("vox_plan");
+}
+
+extern "C" int bdm_voxelize_plan_full(int b, int n, int r, int n_max, const int *coords, int *ind, int *cnt, void *workspace,
+                                      int *occ_index, int *occ_list, int *n_occ, unsigned char *rowocc, void *stream) {
+  BDM_REQUIRE(b >= 0 && n >= 1 && r >= 1 && r <= 32 && n_max >= 1, "voxelize_plan_full: bad sizes (r<=32 supported)");
+  BDM_REQUIRE(workspace && occ_index && occ_list && n_occ && rowocc, "voxelize_plan_full: NULL buffer");
+  if (b == 0) return BDM_OK;
+  const int r3 = r * r * r;
+  VoxWs w = vox_ws(workspace, b, n, r3);
+  const size_t smem = (size_t)r3 * sizeof(int);
+  BDM_ALLOW_LDS(vox_plan_kernel, smem);
+  hipLaunchKernelGGL(vox_plan_kernel, dim3(b), dim3(1024), smem, (hipStream_t)stream, n, r, coords, ind, cnt, w.start,
+                     w.tmp, w.sorted, n_max, occ_index, occ_list, n_occ, rowocc);
+  return launch_status("vox_plan_full");
 }
 
 extern "C" int bdm_avg_voxelize_forward(int b, int c, int n, int r, const float *features, const int *coords,

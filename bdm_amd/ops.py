@@ -456,14 +456,13 @@ def voxel_plan(coords, r, eps=0.0):
     p.ind = torch.empty(B, n, dtype=torch.int32, device=dev)
     p.cnt = torch.empty(B, r3, dtype=torch.int32, device=dev)
     p.ws = torch.empty(lib.bdm_voxelize_workspace_bytes(B, n, r), dtype=torch.uint8, device=dev)
-    L.check(lib.bdm_voxelize_plan(B, n, r, L.ptr(p.vox_coords), L.ptr(p.ind), L.ptr(p.cnt), L.ptr(p.ws), L.stream()), "voxelize_plan")
     p.occ_index = torch.empty(B, r3, dtype=torch.int32, device=dev)
     p.occ_list = torch.empty(B, p.n_max, dtype=torch.int32, device=dev)
     p.n_occ = torch.empty(B, dtype=torch.int32, device=dev)
     p.rowocc = torch.empty(B, r * r, dtype=torch.uint8, device=dev)
-    L.check(lib.bdm_voxel_compact(B, r, p.n_max, L.ptr(p.cnt), L.ptr(p.occ_index), L.ptr(p.occ_list), L.ptr(p.n_occ), L.stream()),
-            "voxel_compact")
-    L.check(lib.bdm_voxel_row_occupancy(B, r, L.ptr(p.cnt), L.ptr(p.rowocc), L.stream()), "voxel_row_occupancy")
+    L.check(lib.bdm_voxelize_plan_full(B, n, r, p.n_max, L.ptr(p.vox_coords), L.ptr(p.ind), L.ptr(p.cnt), L.ptr(p.ws),
+                                       L.ptr(p.occ_index), L.ptr(p.occ_list), L.ptr(p.n_occ), L.ptr(p.rowocc), L.stream()),
+            "voxelize_plan_full")
     _plan_cache[key] = p
     return p
 

@@ -203,6 +203,9 @@ int bdm_group_norm_stats(int b, int c, int l, int groups, const float *x, long l
                          int *slices_out, void *stream);
 /* avg_voxelize_forward writing S3 (features strided: bs_f, ld_f); same deterministic summation order. */
 int bdm_voxelize_plan(int b, int n, int r, const int *coords, int *ind, int *cnt, void *workspace, void *stream);
+/* the plan plus bdm_voxel_compact and bdm_voxel_row_occupancy of the same shape in ONE launch (same values) */
+int bdm_voxelize_plan_full(int b, int n, int r, int n_max, const int *coords, int *ind, int *cnt, void *workspace,
+                           int *occ_index, int *occ_list, int *n_occ, unsigned char *rowocc, void *stream);
 int bdm_avg_voxelize_s3(int b, int c, int n, int r, const float *features, long long bs_f, int ld_f,
                         const int *coords, void *out_s3, int *ind, int *cnt, void *workspace, void *stream);
 

@@ -309,3 +309,27 @@ def test_sparse_first_conv_equals_dense(ops, oracle_ops, cin, cout, r, npts):
     big[:, 3:3 + cin] = f.cuda()
     got2 = ops.sparse_first_conv(big[:, 3:3 + cin], vc.cuda(), r, ops.sparse_conv_pack(w.cuda()), bias.cuda(), cout).cpu()
     assert torch.equal(got, got2)
+
+
+@pytest.mark.parametrize("r,n", [(32, 4096), (16, 1000), (8, 64), (8, 700)])
+def test_plan_full_equals_separate_kernels(ops, r, n):
+    """one-launch plan (+ compaction + row occupancy) gives the arrays of the three separate launches."""
+    from bdm_amd import _lib as L
+    B = 3
+    g = torch.Generator().manual_seed(r * n)
+    pts = (torch.randn(B, 3, n, generator=g) * 0.3).cuda()
+    ops.clear_plan_cache()
+    p = ops.voxel_plan(pts, r)
+    lib, r3, n_max = L.lib(), r ** 3, min(n, r ** 3)
+    ind = torch.empty(B, n, dtype=torch.int32, device="cuda"); cnt = torch.empty(B, r3, dtype=torch.int32, device="cuda")
+    ws = torch.empty(lib.bdm_voxelize_workspace_bytes(B, n, r), dtype=torch.uint8, device="cuda")
+    L.check(lib.bdm_voxelize_plan(B, n, r, L.ptr(p.vox_coords), L.ptr(ind), L.ptr(cnt), L.ptr(ws), L.stream()))
+    oi = torch.empty(B, r3, dtype=torch.int32, device="cuda"); ol = torch.full((B, n_max), -7, dtype=torch.int32, device="cuda")
+    no = torch.empty(B, dtype=torch.int32, device="cuda"); ro = torch.empty(B, r * r, dtype=torch.uint8, device="cuda")
+    L.check(lib.bdm_voxel_compact(B, r, n_max, L.ptr(cnt), L.ptr(oi), L.ptr(ol), L.ptr(no), L.stream()))
+    L.check(lib.bdm_voxel_row_occupancy(B, r, L.ptr(cnt), L.ptr(ro), L.stream()))
+    assert torch.equal(p.ind, ind) and torch.equal(p.cnt, cnt)  # (the workspace also holds an unordered scratch list)
+    assert torch.equal(p.occ_index, oi) and torch.equal(p.n_occ, no) and torch.equal(p.rowocc, ro)
+    for b in range(B):
+        k = int(no[b])
+        assert torch.equal(p.occ_list[b, :k], ol[b, :k])
