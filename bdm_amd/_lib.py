@@ -36,12 +36,41 @@ def lib():
             raise BdmHipError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C bdm_amd/csrc`). There is no CPU fallback for the HIP path.")
-        _lib = ctypes.CDLL(SO_PATH)
-        _lib.bdm_last_error.restype = ctypes.c_char_p
-        _lib.bdm_voxelize_workspace_bytes.restype = ctypes.c_size_t
-        _lib.bdm_sa_group_workspace_bytes.restype = ctypes.c_size_t
-        _lib.bdm_attention_workspace_bytes.restype = ctypes.c_size_t
+        handle = ctypes.CDLL(SO_PATH)
+        for name, (restype, argtypes) in abi_signatures().items():
+            fn = getattr(handle, name)  # AttributeError here = header and library disagree: fail loudly
+            fn.restype, fn.argtypes = restype, argtypes
+        _lib = handle
     return _lib
+
+
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "bdm_hip.h")
+_CTYPES = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
+           "unsigned long long": ctypes.c_ulonglong, "double": ctypes.c_double, "int64_t": ctypes.c_int64}
+
+
+def abi_signatures(header: str = HEADER):
+    """{function: (restype, [argtypes])} parsed from include/bdm_hip.h, the single source of truth for the C ABI:
+    every exported function gets its ctypes prototype from its declaration (a size_t result or a long long stride
+    is never squeezed through ctypes' default 32-bit int)."""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", open(header).read(), flags=re.S)
+    text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)
+    sigs = {}
+    for ret, name, args in re.findall(r"([A-Za-z_][\w \*]*?)\b(bdm_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret = " ".join(ret.replace("const", " ").split())
+        restype = ctypes.c_char_p if ret == "char *" else (ctypes.c_void_p if ret.endswith("*") else _CTYPES[ret])
+        argtypes = []
+        for a in [a.strip() for a in args.split(",")]:
+            if a in ("void", ""):
+                continue
+            if "*" in a:
+                argtypes.append(ctypes.c_void_p)
+                continue
+            ty = " ".join(a.replace("const", " ").split()[:-1])  # drop the parameter name
+            argtypes.append(_CTYPES[ty])
+        sigs[name] = (restype, argtypes)
+    return sigs
 
 
 _DEBUG_SYNC = os.environ.get("BDM_DEBUG_SYNC")  # path of a breadcrumb file: serialise every call, remember the last one

@@ -14,10 +14,14 @@ namespace bdm {
 // (the reference's CUDA_CHECK_ERRORS calls exit(-1), cuda_utils.cuh:28-37).
 void set_error(const char *fmt, ...);
 
+// hipGetLastError() is per host thread and sticky: it also returns (and clears) an error left behind by an EARLIER
+// runtime call of this thread that nobody checked (e.g. one of the host framework's).  The message says so, so that
+// such an error is not mistaken for a fault of the kernel named here.
 inline int launch_status(const char *what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
-    set_error("%s: %s", what, hipGetErrorString(e));
+    set_error("%s: %s (HIP's per-thread last-error state: raised by this launch or left by an earlier unchecked call)",
+              what, hipGetErrorString(e));
     return BDM_ERR_LAUNCH;
   }
   return BDM_OK;
@@ -32,11 +36,17 @@ inline int launch_status(const char *what) {
   } while (0)
 
 // Raise a kernel's dynamic-LDS ceiling (up to the CU's 160 KiB); not a stream operation.
-#define BDM_ALLOW_LDS(kernel, bytes)                                                              \
-  do {                                                                                            \
-    if ((bytes) > 48 * 1024)                                                                      \
-      (void)hipFuncSetAttribute((const void *)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)(bytes));                                                    \
+#define BDM_ALLOW_LDS(kernel, bytes)                                                                      \
+  do {                                                                                                    \
+    if ((bytes) > 48 * 1024) {                                                                            \
+      hipError_t e_ = hipFuncSetAttribute((const void *)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)(bytes));                                                  \
+      if (e_ != hipSuccess) {                                                                             \
+        bdm::set_error("%s: cannot raise the dynamic LDS limit to %d bytes: %s", #kernel, (int)(bytes),   \
+                       hipGetErrorString(e_));                                                            \
+        return BDM_ERR_LAUNCH;                                                                            \
+      }                                                                                                   \
+    }                                                                                                     \
   } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -114,12 +114,16 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
 
     def conditioning_image(self, image_rgb, mask=None):
         """Pixel-major (B, H*W, D_cond) conditioning image, computed once per image batch (hoisted)."""
-        key = (image_rgb.data_ptr(), image_rgb._version, tuple(image_rgb.shape))
-        if self._cond_cache is None or self._cond_cache[0] != key:
+        # The entry holds the image tensor itself and is matched by identity (+ in-place version): a freed batch's
+        # address can be handed to the next batch by the caching allocator, so a data_ptr key alone would alias.
+        hit = self._cond_cache
+        if hit is None or hit[0] is not image_rgb or hit[1] != image_rgb._version:
             assert self.use_local_colors and self.use_local_features
             H, W = image_rgb.shape[-2:]
-            self._cond_cache = (key, self.feature_model.conditioning_image(image_rgb, self.colors_mean, self.colors_std), (H, W))
-        return self._cond_cache[1], self._cond_cache[2]
+            hit = (image_rgb, image_rgb._version,
+                   self.feature_model.conditioning_image(image_rgb, self.colors_mean, self.colors_std), (H, W))
+            self._cond_cache = hit
+        return hit[2], hit[3]
 
     def surface_projection_indices(self, points, camera, hw):
         """Per-point owning pixel (or -1): rasterisation part of projection_model.py:127-157."""

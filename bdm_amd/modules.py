@@ -325,8 +325,10 @@ class PointNetSAModule(nn.Module):
         assert len(self.groupers) == 1, "multi-radius grouping is not used by the denoisers"
         planned = getattr(self, "_planned", None)
         self._planned = None
-        if planned is not None:
-            centers_coords, idx, event = planned
+        # a plan is valid for the very coordinate tensor it was computed from (a forward that aborted midway, or
+        # sa_layers shared between networks, must never leave a plan behind for other coordinates)
+        if planned is not None and planned[3] is coords:
+            centers_coords, idx, event, _ = planned
             event.wait()  # the current stream waits for the side stream's sampler
         else:
             centers_coords, idx = self.plan(coords)

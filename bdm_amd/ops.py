@@ -297,7 +297,6 @@ def conv3d_s3_pack(weight):
     import ctypes
     cout, cin = weight.shape[:2]
     w = weight.contiguous()
-    L.lib().bdm_conv3d_s3_weight_elems.restype = ctypes.c_size_t
     packed = torch.empty(L.lib().bdm_conv3d_s3_weight_elems(cout, cin), dtype=torch.bfloat16, device=w.device)
     L.check(L.lib().bdm_conv3d_s3_pack_weights(cout, cin, L.ptr(w), L.ptr(packed), L.stream()), "conv3d_s3_pack_weights")
     return packed
@@ -347,16 +346,12 @@ def conv3d_h2_pack(weight):
     cout, cin = weight.shape[:2]
     w = weight.contiguous()
     lib = L.lib()
-    lib.bdm_conv3d_h2_weight_elems.restype = ctypes.c_size_t
     packed = torch.empty(lib.bdm_conv3d_h2_weight_elems(cout, cin), dtype=torch.float16, device=w.device)
     scale = torch.empty(cout, dtype=torch.float32, device=w.device)
     inv_scale = torch.empty(cout, dtype=torch.float32, device=w.device)
     L.check(lib.bdm_conv3d_h2_pack_weights(cout, cin, L.ptr(w), L.ptr(packed), L.ptr(scale), L.ptr(inv_scale), L.stream()),
             "conv3d_h2_pack_weights")
     return packed, inv_scale
-
-
-_h2_scale_cache = {}
 
 
 def _pow2_below(v):
@@ -368,13 +363,12 @@ def h2_activation_scale(gn, sigmas=64.0):
     """Power-of-two scale for GroupNorm(+Swish) outputs: |y| <= |gamma| |z| + |beta|, so that a `sigmas`-sigma value of
     the widest channel still fits fp16 (beyond that the split saturates).  Depends on the parameters only: cached per
     (module, parameter version), one small device->host read when the weights change."""
-    key = id(gn)
-    sig = (gn.weight._version, gn.bias._version, gn.weight.data_ptr())
-    hit = _h2_scale_cache.get(key)
+    sig = (gn.weight._version, gn.bias._version, gn.weight.data_ptr(), sigmas)
+    hit = getattr(gn, "_bdm_h2_scale", None)  # lives on the module: no id() reuse after garbage collection
     if hit is None or hit[0] != sig:
         bound = float((gn.weight.detach().abs() * sigmas + gn.bias.detach().abs()).max())
         hit = (sig, _pow2_below(32768.0 / max(bound, 1e-30)))
-        _h2_scale_cache[key] = hit
+        gn._bdm_h2_scale = hit
     return hit[1]
 
 
@@ -421,7 +415,6 @@ def sparse_conv_pack_s3(weight):
     """(Cout, Cin, 3,3,3) fp32 -> pre-split bf16 GEMM operand (ceil(Cin/8), 3, 27*Cout, 8)."""
     cout, cin = weight.shape[:2]
     lib = L.lib()
-    lib.bdm_sparse_conv_s3_weight_elems.restype = ctypes.c_size_t
     ws = torch.empty(lib.bdm_sparse_conv_s3_weight_elems(cout, cin), dtype=torch.bfloat16, device=weight.device)
     L.check(lib.bdm_sparse_conv_pack_weights_s3(cout, cin, L.ptr(weight.contiguous()), L.ptr(ws), L.stream()),
             "sparse_conv_pack_weights_s3")

@@ -136,7 +136,7 @@ def plan_sampling_chain(sa_layers, coords):
             centers, idx = sa.plan(c)
             ev = torch.cuda.Event()
             ev.record(side)
-            sa._planned = (centers, idx, ev)
+            sa._planned = (centers, idx, ev, c)
             c = centers
 
 
@@ -144,6 +144,8 @@ def encode(sa_layers, global_att, inputs, t_emb):
     """Down path (pvcnn.py:90-110)."""
     coords = inputs[:, :3, :].contiguous()
     ops.clear_plan_cache()  # voxel plans are valid within one encoder/decoder pass
+    for blocks in sa_layers:  # sampler plans too: never inherit one from an aborted or foreign forward
+        (blocks[-1] if isinstance(blocks, nn.Sequential) else blocks)._planned = None
     # also inside a hipGraph capture: the side stream forks from and joins the capturing stream.  Small problems (one
     # small shape) are bound by kernel-to-kernel dispatch latency, where the extra events cost more than the overlap gains
     if coords.is_cuda and SIDE_STREAM and coords.shape[0] * coords.shape[2] >= SIDE_STREAM_MIN_POINTS:

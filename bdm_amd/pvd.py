@@ -181,13 +181,21 @@ def prepare_pvd_model(opt, device):
     ckpt = opt.get("model")
     if ckpt and not str(ckpt).startswith("procedural"):
         resumed = torch.load(ckpt, map_location="cpu")
-        try:
+        # the reference tries 'model_state' and falls back to 'prior_model' (pvd/__init__.py:490-494); here the key is
+        # selected explicitly so that a key MISMATCH inside the chosen state dict is raised, not swallowed
+        if "model_state" in resumed:
             model.load_state_dict(resumed["model_state"])
-        except Exception:
+        elif "prior_model" in resumed:
             model.load_state_dict(resumed["prior_model"])
+        else:
+            raise KeyError(f"{ckpt}: neither 'model_state' nor 'prior_model' in the checkpoint (keys: {list(resumed)[:8]})")
     else:
+        import warnings
         from .utils.procedural import fill_module_
         seed = int(str(ckpt).split(":")[1]) if ckpt and ":" in str(ckpt) else 0
+        if not ckpt:
+            warnings.warn("prepare_pvd_model: no prior checkpoint given (aux_run.prior_ckpt is empty): the PVD prior runs on "
+                          "PROCEDURAL RANDOM-INIT weights (benchmark mode); samples are not meaningful shapes", stacklevel=2)
         fill_module_(model, seed=seed)
     model = model.to(device)
     model.eval()

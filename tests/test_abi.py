@@ -25,6 +25,23 @@ def test_library_exports_every_declared_symbol():
     assert lib.bdm_abi_version() >= 1
 
 
+def test_every_declared_symbol_has_a_ctypes_prototype():
+    """_lib.lib() declares restype + argtypes for every function of the header (no 32-bit default int for size_t
+    results or long long strides)."""
+    from bdm_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    sigs = _lib.abi_signatures()
+    assert sorted(sigs) == declared_symbols()
+    lib = _lib.lib()
+    for name, (restype, argtypes) in sigs.items():
+        fn = getattr(lib, name)
+        assert fn.restype is restype and list(fn.argtypes) == argtypes, name
+    assert lib.bdm_rasterize_workspace_bytes.restype is ctypes.c_size_t
+    assert lib.bdm_group_norm_workspace_bytes.restype is ctypes.c_size_t
+    assert ctypes.c_longlong in lib.bdm_pointwise_conv.argtypes
+
+
 def test_no_cpu_fallback():
     """Host tensors are refused: the product path must not silently run on the CPU."""
     import pytest
