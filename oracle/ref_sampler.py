@@ -169,6 +169,14 @@ def get_input_with_conditioning(x_t, cams, local_features, radius=0.0075):
 # ---------------------------------------------------------------------------------------------
 # loops
 # ---------------------------------------------------------------------------------------------
+TRACE = None  # optional callable(kind, t, x_after_step): progress / divergence curves in tools and tests
+
+
+def _trace(kind, t, x):
+    if TRACE is not None:
+        TRACE(kind, t, x)
+
+
 def interaction_sample(sd_pc2, x_t, cams, local_features, start_time, end_time, noises, prefix="point_cloud_model.model."):
     """model.py:216-291 with injected DDPM noise: noises[t] is the draw used at timestep t."""
     ddpm = RefDDPM()
@@ -177,6 +185,7 @@ def interaction_sample(sd_pc2, x_t, cams, local_features, start_time, end_time, 
         x_in = get_input_with_conditioning(x_t, cams, local_features)
         eps = ref_net.point_cloud_model_forward(sd_pc2, x_in, torch.full((B,), t), prefix=prefix)
         x_t = ddpm.step(eps, t, x_t, noises.get(t) if t > 0 else None)
+        _trace("pc2", t, x_t)
     return x_t
 
 
@@ -188,6 +197,7 @@ def pvd_prior(sd_pvd, points, start_time, end_time, noises, prefix="model.module
     for t in range(start_time - 1, end_time - 1, -1):
         eps = ref_net.pvcnn_forward(sd_pvd, x, torch.full((B,), t), prefix=prefix)
         x = gd.step(eps, t, x, noises[t])
+        _trace("pvd", t, x.permute(0, 2, 1))
     return x.permute(0, 2, 1)
 
 

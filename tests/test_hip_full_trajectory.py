@@ -1,0 +1,45 @@
+"""Full-length coupled trajectories, HIP path vs CPU oracle, held to the LITERAL north-star bound: relative L2 <= 1e-3 on the
+final cloud, no self-sensitivity escape hatch.
+
+Schedule: the recipes' real milestones [1000, 968, 936, 872, 128, 64, 32, 0], roll_step 16 -- 1000 PC^2 + 80 PVD forwards and
+5 blends (Blending), 995 PC^2 + 75 PVD + 5 fused steps (Merging) -- at N = 1024, B = 1, projection conditioning at every
+step, every random draw injected identically on both sides.
+
+Weights: procedural, with the denoisers' LAST layer scaled by HEAD_SCALE.  The reference itself initialises that layer with
+N(0, 1e-6) (experiments/model/point_cloud_model.py:38-39), i.e. its own fresh model is a near-zero noise predictor; with
+HEAD_SCALE = 1 the procedural network is chaotic (the ORACLE moved by one ulp ends 2.6e-2 away from itself after only 100
+steps).  HEAD_SCALE below is the largest of {1, 0.3, 0.1, 0.03, 0.01} at which the oracle's own 1-ulp self-sensitivity over
+the full 1080-forward schedule stays < 1e-4 (tools/chaos_probe.py; the measured table is in DESIGN.md section 5), so that a
+pass/fail at 1e-3 is a statement about the kernels and not about chaos.  Every layer below the head runs at full scale:
+the per-step teacher-forced tests (tests/test_hip_teacher_forced.py) cover the head at scale 1.
+"""
+import pytest
+
+from helpers import rel_l2
+import trajectory_case as case
+
+pytestmark = pytest.mark.gpu
+HEAD_SCALE = 0.01
+NORTH_STAR = 1e-3
+
+
+def test_full_blending_trajectory_literal_bound(hip, oracle_ops):
+    c = case.build(1024, head_scale=HEAD_SCALE, merging=False)
+    assert len(case.program_order(c.milestones, c.roll_step)) == 1080
+    ref = case.run_oracle(c)
+    got = case.run_hip(c)
+    err = rel_l2(got, ref)
+    print(f"full BDM-Blending trajectory (1000 PC^2 + 80 PVD + 5 blends, N=1024): final rel-L2 {err:.3e}")
+    assert err <= NORTH_STAR
+
+
+def test_full_merging_trajectory_literal_bound(hip, oracle_ops):
+    c = case.build(1024, head_scale=HEAD_SCALE, merging=True)
+    order = case.program_order(c.milestones, c.roll_step, merging=True)
+    assert sum(k in ("recon", "branch") for k, _ in order) == 995 and sum(k == "prior" for k, _ in order) == 75
+    assert sum(k == "fuse" for k, _ in order) == 5
+    ref = case.run_oracle(c)
+    got = case.run_hip(c)
+    err = rel_l2(got, ref)
+    print(f"full BDM-Merging trajectory (995 PC^2 + 75 PVD + 5 fused, N=1024): final rel-L2 {err:.3e}")
+    assert err <= NORTH_STAR

@@ -237,3 +237,30 @@ def test_rasterizer_survives_degenerate_projections(hip):
     p = pix.cpu()[0]
     assert int(p.max()) < 224 * 224 and int(p.min()) >= -1
     assert all(int(p[i]) == -1 for i in (2, 3, 4, 5))
+
+
+def test_conditioning_cache_is_not_aliased_across_batches(hip):
+    """the hoisted conditioning image must be recomputed for a NEW image batch even when the caching
+    allocator hands the new batch the freed batch's address (same data_ptr, same shape, version 0)."""
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.model import get_model
+    from bdm_amd.utils.procedural import fill_module_
+    model = fill_module_(get_model(ProjectConfig()).eval(), seed=1).cuda()
+    g = torch.Generator().manual_seed(0)
+    img1, img2 = torch.rand(2, 3, 224, 224, generator=g), torch.rand(2, 3, 224, 224, generator=g)
+    d = img1.cuda()
+    ptr1 = d.data_ptr()
+    c1 = model.conditioning_image(d)[0].clone()
+    del d
+    d = img2.cuda()  # typically lands on the freed block
+    same_address = d.data_ptr() == ptr1
+    c2 = model.conditioning_image(d)[0].clone()
+    fresh = fill_module_(get_model(ProjectConfig()).eval(), seed=1).cuda()
+    ref2 = fresh.conditioning_image(img2.cuda())[0]
+    assert not torch.equal(c1, c2)
+    assert torch.equal(c2, ref2)
+    print("second batch reused the first batch's address:", same_address)
+    # an in-place update of the same tensor is seen too
+    d.mul_(0.5)
+    c3 = model.conditioning_image(d)[0]
+    assert not torch.equal(c3, c2)
