@@ -46,7 +46,7 @@ def lib():
 
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bdm_hip.h")
 _CTYPES = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
-           "unsigned long long": ctypes.c_ulonglong, "double": ctypes.c_double, "int64_t": ctypes.c_int64}
+           "unsigned long long": ctypes.c_ulonglong, "unsigned int": ctypes.c_uint, "double": ctypes.c_double, "int64_t": ctypes.c_int64}
 
 
 def abi_signatures(header: str = HEADER):

@@ -28,6 +28,10 @@ class RunConfig:  # structured.py:14-56
     interact_timestep: Optional[List] = None
     max_fusion_steps: int = 20000
     save_dir: Optional[str] = None
+    # not in the reference: "reference" = its draws (CPU generator for the initial cloud and the blend masks, the device's
+    # global generator for DDPM / PVD noise, seeded seed + rank); "per_shape" = Philox streams keyed by (seed, global
+    # shape index), identical results for any rank count / batch size (bdm_amd/rng.py)
+    rng: str = "reference"
 
 
 @dataclass

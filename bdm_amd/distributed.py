@@ -22,6 +22,8 @@ def init_from_env(backend=None):
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if os.environ.get("BDM_SHARE_GPU") == "1":  # test aid: every rank drives cuda:0 (with BDM_DIST_BACKEND=gloo) on a 1-GPU box
+        local_rank = 0
     return rank, local_rank, world
 
 
@@ -30,6 +32,15 @@ def shard_indices(num_shapes, rank, world):
     base, extra = divmod(num_shapes, world)
     lo = rank * base + min(rank, extra)
     return list(range(lo, lo + base + (1 if rank < extra else 0)))
+
+
+def shared_run_dir(cfg, rank, world):
+    """${run.save_dir}/${run.name}/<timestamp> chosen ONCE (rank 0) and shared, so that all ranks write into one tree."""
+    from .config import run_dir
+    box = [run_dir(cfg) if rank == 0 else None]
+    if world > 1 and dist.is_initialized():
+        dist.broadcast_object_list(box, src=0)
+    return box[0]
 
 
 def barrier():

@@ -65,6 +65,7 @@ class GaussianDiffusion:
         # sigma_t = exp(0.5 * log variance) (p_sample, :218), tabulated once in float32
         self.sigma = torch.exp(0.5 * logvar)
         self.noise_source = None  # replay hook for parity tests: callable(shape, device)
+        self.streams = None       # optional rng.ShapeStreams: per-shape Philox noise generated inside the step kernel
 
     def step_coefficients(self, t):
         t = int(t)
@@ -91,6 +92,8 @@ class GaussianDiffusion:
         tt = int(t_int) if t_int is not None else (int(t[0]) if torch.is_tensor(t) else int(t))
         eps = denoise_fn(data, t)
         c = self.step_coefficients(tt)
+        if self.streams is not None and self.noise_source is None and use_var:
+            return self.streams.pvd_step(data, eps, c)
         if self.noise_source is not None:
             noise = self.noise_source(tuple(data.shape), data.device)
         else:

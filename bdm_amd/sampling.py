@@ -10,9 +10,12 @@ RNG placement follows the reference: the initial cloud is drawn on the CPU and m
 generator (main_blending.py:330-338).  `noise` (optional) supplies every draw instead -- the replay
 mode used by the parity tests.
 """
+import contextlib
+
 import torch
 
 from . import _lib as L
+from . import rng
 from .cameras import Pointclouds
 from .pvd import generate_pvd_xyz
 
@@ -60,20 +63,68 @@ def _schedule(cfg):
     return roll_step, milestones, prior_roll_step, prior_milestones, len(milestones) - 1
 
 
-def _initial_cloud(B, num_points, device, init_noise=None):
-    x = torch.randn(B, num_points, 3) if init_noise is None else init_noise.clone()
+def _initial_cloud(B, num_points, device, init_noise=None, streams=None):
+    if init_noise is not None:
+        x = init_noise.clone()
+    elif streams is not None:
+        x = streams.normal((B, num_points, 3), rng.INIT)
+    else:
+        x = torch.randn(B, num_points, 3)  # on the CPU, then moved (main_blending.py:228)
     return center_points_(x.to(device).contiguous())
 
 
+@contextlib.contextmanager
+def _streams_on(streams, *owners):
+    """Attach per-shape noise streams to scheduler-like objects (`.streams`) for the duration of one trajectory.
+    owners: (object, purpose or None) pairs."""
+    if streams is None:
+        yield
+        return
+    saved = []
+    for obj, purpose in owners:
+        saved.append((obj, obj.streams, getattr(obj, "stream_purpose", None)))
+        obj.streams = streams
+        if purpose is not None:
+            obj.stream_purpose = purpose
+    try:
+        yield
+    finally:
+        for obj, st, purpose in saved:
+            obj.streams = st
+            if purpose is not None:
+                obj.stream_purpose = purpose
+
+
+def batch_streams(cfg, batch, device, sample_idx=0):
+    """rng.ShapeStreams of a batch keyed by (run.seed, global shape index = batch.frame_number), or None when the
+    configuration asks for the reference's global-generator draws (run.rng = "reference")."""
+    if getattr(cfg.run, "rng", "reference") != "per_shape":
+        return None
+    if batch.frame_number is None:
+        raise ValueError("run.rng=per_shape needs batch.frame_number (the global shape indices)")
+    # run.num_samples > 1: sample k of a shape uses the stream family seed + k * 1000003
+    return rng.ShapeStreams(cfg.run.seed + 1000003 * int(sample_idx), batch.frame_number, device)
+
+
 @torch.no_grad()
-def bdm_blending(accelerator, batch, cfg, model, pvd_model, generator=None, init_noise=None, blend_masks=None):
-    """main_blending.py:186-347.  Returns Pointclouds of (B, N, 3)."""
+def bdm_blending(accelerator, batch, cfg, model, pvd_model, generator=None, init_noise=None, blend_masks=None, streams=None):
+    """main_blending.py:186-347.  Returns Pointclouds of (B, N, 3).
+    streams: rng.ShapeStreams -> every draw (initial cloud, DDPM / PVD noise, blend masks) comes from the shapes' own
+    Philox streams (rank-count invariant); default: the reference's generators (or `run.rng=per_shape` in cfg)."""
+    device = model.point_cloud_model.device
+    streams = batch_streams(cfg, batch, device) if streams is None else streams
+    sched = model.schedulers_map[cfg.run.diffusion_scheduler]
+    with _streams_on(streams, (sched, rng.PC2), (pvd_model.diffusion, None)):
+        return _bdm_blending(batch, cfg, model, pvd_model, generator, init_noise, blend_masks, streams)
+
+
+def _bdm_blending(batch, cfg, model, pvd_model, generator, init_noise, blend_masks, streams):
     img, mask, camera = batch.image_rgb, batch.fg_probability, batch.camera
     roll_step, milestones, prior_roll_step, prior_milestones, times = _schedule(cfg)
     B, num_points = img.shape[0], cfg.dataset.max_points
     device = model.point_cloud_model.device
     common = dict(scheduler=cfg.run.diffusion_scheduler, num_inference_steps=cfg.run.num_inference_steps, disable_tqdm=True)
-    pred_pc = _initial_cloud(B, num_points, device, init_noise)
+    pred_pc = _initial_cloud(B, num_points, device, init_noise, streams)
     blends = 0
     for i in range(times):
         if i == 0:
@@ -93,6 +144,8 @@ def bdm_blending(accelerator, batch, cfg, model, pvd_model, generator=None, init
                                   end_time=prior_milestones[i + 1] - prior_roll_step)
             if blend_masks is not None:
                 indices = blend_masks[blends]
+            elif streams is not None:
+                indices = streams.bits((B, num_points), rng.MASK)
             else:
                 indices = torch.randint(0, 2, (B, num_points), generator=generator).long()
             blends += 1
@@ -101,14 +154,23 @@ def bdm_blending(accelerator, batch, cfg, model, pvd_model, generator=None, init
 
 
 @torch.no_grad()
-def bdm_merging(accelerator, batch, cfg, prior_model, recon_model, fusion_model, init_noise=None):
-    """main_merging.py:369-523.  Returns Pointclouds of (B, N, 3)."""
+def bdm_merging(accelerator, batch, cfg, prior_model, recon_model, fusion_model, init_noise=None, streams=None):
+    """main_merging.py:369-523.  Returns Pointclouds of (B, N, 3).  streams: see bdm_blending."""
+    device = recon_model.point_cloud_model.device
+    streams = batch_streams(cfg, batch, device) if streams is None else streams
+    name = cfg.run.diffusion_scheduler
+    with _streams_on(streams, (recon_model.schedulers_map[name], rng.PC2), (fusion_model.schedulers_map[name], rng.FUSE),
+                     (prior_model.diffusion, None)):
+        return _bdm_merging(batch, cfg, prior_model, recon_model, fusion_model, init_noise, streams)
+
+
+def _bdm_merging(batch, cfg, prior_model, recon_model, fusion_model, init_noise, streams):
     img, mask, camera = batch.image_rgb, batch.fg_probability, batch.camera
     roll_step, milestones, prior_roll_step, prior_milestones, times = _schedule(cfg)
     B, num_points = img.shape[0], cfg.dataset.max_points
     device = recon_model.point_cloud_model.device
     common = dict(scheduler=cfg.run.diffusion_scheduler, num_inference_steps=cfg.run.num_inference_steps, disable_tqdm=True)
-    pred_pc = _initial_cloud(B, num_points, device, init_noise)
+    pred_pc = _initial_cloud(B, num_points, device, init_noise, streams)
     for i in range(times):
         if i == 0:
             pred_pc = recon_model.interaction_sample(pred_pc, camera, img, mask, start_time=milestones[i],

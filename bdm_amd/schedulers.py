@@ -55,6 +55,8 @@ class DDPMScheduler:
         self.num_inference_steps = None
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy())
         self.noise_source = None  # optional callable(shape, device) -> tensor: replay mode for parity tests
+        self.streams = None       # optional rng.ShapeStreams: per-shape Philox noise generated inside the step kernel
+        self.stream_purpose = 1   # rng.PC2 (the fusion model's scheduler uses rng.FUSE)
 
     def set_timesteps(self, num_inference_steps, device=None):
         if num_inference_steps > self.num_train_timesteps:
@@ -87,6 +89,8 @@ class DDPMScheduler:
     def _noise(self, shape, device, generator):
         if self.noise_source is not None:
             return self.noise_source(tuple(shape), device)
+        if self.streams is not None:
+            return self.streams.normal(tuple(shape), self.stream_purpose)
         return torch.randn(shape, generator=generator, device=device, dtype=torch.float32)
 
     def step(self, model_output, timestep, sample, generator=None, return_dict=True):
@@ -95,6 +99,9 @@ class DDPMScheduler:
         x = sample.contiguous()
         eps = model_output.contiguous()
         assert x.shape == eps.shape and x.dtype == torch.float32
+        if self.streams is not None and self.noise_source is None:
+            out = self.streams.ddpm_step(x, eps, dict(c, noise=t > 0), purpose=self.stream_purpose)
+            return SimpleNamespace(prev_sample=out) if return_dict else (out,)
         noise = self._noise(x.shape, x.device, generator) if t > 0 else None
         out = torch.empty_like(x)
         L.check(L.lib().bdm_ddpm_step(L.c_ll(x.numel()), L.ptr(x), L.ptr(eps), L.ptr(noise), L.c_float(c["sqrt_beta_prod"]),

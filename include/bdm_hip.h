@@ -286,6 +286,29 @@ int bdm_pvd_step(long long n, const float *x, const float *eps, const float *noi
                  float sqrt_recip_abar, float sqrt_recipm1_abar, float coef1, float coef2,
                  float sigma, float *out, void *stream);
 
+/* Per-shape counter-based random streams (rng_ops.hip).  The reference draws the initial cloud, the DDPM / PVD noise and
+ * the blend masks from ONE per-process generator seeded seed + rank (training_utils.py:373-378; draw sites
+ * main_blending.py:228,330-338, model/model.py:286, pvd/__init__.py:213,232), so a shape's sample depends on its rank and
+ * batch slot.  Here element e of draw `draw` of purpose `purpose` of the shape with key keys[s] is
+ *   Philox4x32-10(key = keys[s], counter = (e / 4, 0, draw, purpose))[e % 4]
+ * (keys[s] is derived on the host from (run seed, GLOBAL shape index)): rank-count- and batch-invariant, one launch per
+ * batch.  Normals: Box-Muller on 24-bit uniforms.  out (b, per_shape) float / int64 (bit 0 of each word: Bernoulli 1/2,
+ * the `torch.randint(0, 2, ...)` of main_blending.py:330-338). */
+int bdm_philox_normal(int b, long long per_shape, const unsigned long long *keys, unsigned int draw,
+                      unsigned int purpose, float *out, void *stream);
+int bdm_philox_bits(int b, long long per_shape, const unsigned long long *keys, unsigned int draw,
+                    unsigned int purpose, long long *out, void *stream);
+/* bdm_ddpm_step / bdm_pvd_step with the noise of bdm_philox_normal(b, per_shape, keys, draw, purpose) generated inside the
+ * kernel (never written to memory); same bits as the two-launch form.  DDPM: sigma == 0 (t == 0) uses no draw. */
+int bdm_ddpm_step_philox(int b, long long per_shape, const float *x, const float *eps,
+                         const unsigned long long *keys, unsigned int draw, unsigned int purpose,
+                         float sqrt_beta_prod, float sqrt_alpha_prod, float coef_x0, float coef_x, float sigma,
+                         float *out, void *stream);
+int bdm_pvd_step_philox(int b, long long per_shape, const float *x, const float *eps,
+                        const unsigned long long *keys, unsigned int draw, unsigned int purpose,
+                        float sqrt_recip_abar, float sqrt_recipm1_abar, float coef1, float coef2, float sigma,
+                        float *out, void *stream);
+
 /* x (b, n, 3) point-major: subtract the per-shape mean over points, in place
  * (main_blending.py:229; model/model.py:530-531). */
 int bdm_center_points(int b, int n, float *x, void *stream);

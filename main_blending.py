@@ -1,5 +1,5 @@
 """BDM-Blending sampling entry point -- drop-in for experiments/main_blending.py (same `group.key=value`
-overrides, same job name, same output tree sample_bdm_blending/{gt,pred}/<category>/<name>.ply under
+overrides, same job name, same output tree sample_bdm_blending/{gt,pred,images}/<category>/<name>.{ply,png} under
 ${run.save_dir}/${run.name}/<timestamp>).  One process per GPU; launch with
 `python -m torch.distributed.run --nproc-per-node N main_blending.py ...` to shard batches over GPUs.
 
@@ -53,18 +53,22 @@ def get_dataloader(cfg, rank, world):
 
 
 def save_outputs(output_dir, batch, clouds, sample_idx, num_samples):
-    from bdm_amd.io import save_pointcloud_ply
+    """main_blending.py:413-455: {gt,pred}/<category>/<name>.ply and images/<category>/<name>.png."""
+    from bdm_amd.io import save_image_png, save_pointcloud_ply
     for i in range(clouds.shape[0]):
         name, cat = batch.sequence_name[i], batch.sequence_category[i]
-        fname = f"{name}-{sample_idx}.ply" if num_samples > 1 else f"{name}.ply"
-        save_pointcloud_ply(batch.sequence_point_cloud[i].cpu().numpy(), output_dir / "gt" / cat / fname)
-        save_pointcloud_ply(clouds[i].cpu().numpy(), output_dir / "pred" / cat / fname)
+        stem = f"{name}-{sample_idx}" if num_samples > 1 else f"{name}"
+        gt = batch.sequence_point_cloud[i]
+        gt = gt.points_padded()[0] if hasattr(gt, "points_padded") else gt
+        save_pointcloud_ply(gt.cpu().numpy(), output_dir / "gt" / cat / f"{stem}.ply")
+        save_pointcloud_ply(clouds[i].cpu().numpy(), output_dir / "pred" / cat / f"{stem}.ply")
+        save_image_png(batch.image_rgb[i].cpu().numpy(), output_dir / "images" / cat / f"{stem}.png")
 
 
 def main(argv=None):
-    from bdm_amd.config import parse_overrides, run_dir
-    from bdm_amd.distributed import init_from_env
-    from bdm_amd.sampling import bdm_blending
+    from bdm_amd.config import parse_overrides
+    from bdm_amd.distributed import barrier, init_from_env, shared_run_dir
+    from bdm_amd.sampling import batch_streams, bdm_blending
     cfg = parse_overrides(sys.argv[1:] if argv is None else argv)
     rank, local_rank, world = init_from_env()
     device = torch.device("cuda", local_rank)
@@ -72,7 +76,7 @@ def main(argv=None):
     torch.manual_seed(cfg.run.seed + rank)  # training_utils.py:373-378
     if cfg.run.job != "sample_bdm_blending":
         raise ValueError(f"Invalid job: {cfg.run.job}")
-    out_root = Path(run_dir(cfg)) / "sample_bdm_blending"
+    out_root = Path(shared_run_dir(cfg, rank, world)) / "sample_bdm_blending"
     model, pvd_model, _ = build_models(cfg, device)
     generator = torch.Generator().manual_seed(cfg.run.manual_seed) if cfg.run.manual_seed else None
     for batch_idx, batch in enumerate(get_dataloader(cfg, rank, world)):
@@ -80,10 +84,13 @@ def main(argv=None):
             break
         batch = batch.to(device)
         for sample_idx in range(cfg.run.num_samples):
-            output = bdm_blending(None, batch, cfg, model, pvd_model, generator=generator)
+            output = bdm_blending(None, batch, cfg, model, pvd_model, generator=generator,
+                                  streams=batch_streams(cfg, batch, device, sample_idx))
             save_outputs(out_root, batch, output.points_padded(), sample_idx, cfg.run.num_samples)
+    barrier()
     if rank == 0:
         print("Saved samples to:", out_root.absolute())
+    return out_root
 
 
 if __name__ == "__main__":

@@ -10,9 +10,9 @@ from main_blending import build_models, get_dataloader, save_outputs
 
 
 def main(argv=None):
-    from bdm_amd.config import parse_overrides, run_dir
-    from bdm_amd.distributed import init_from_env
-    from bdm_amd.sampling import bdm_merging
+    from bdm_amd.config import parse_overrides
+    from bdm_amd.distributed import barrier, init_from_env, shared_run_dir
+    from bdm_amd.sampling import batch_streams, bdm_merging
     cfg = parse_overrides(sys.argv[1:] if argv is None else argv)
     rank, local_rank, world = init_from_env()
     device = torch.device("cuda", local_rank)
@@ -22,17 +22,20 @@ def main(argv=None):
         raise NotImplementedError("fusion-decoder training is out of scope (sampling hot path only)")
     if cfg.run.job != "sample_bdm_merging":
         raise ValueError(f"Invalid job: {cfg.run.job}")
-    out_root = Path(run_dir(cfg)) / "sample_bdm_merging"
+    out_root = Path(shared_run_dir(cfg, rank, world)) / "sample_bdm_merging"
     recon_model, prior_model, fusion_model = build_models(cfg, device, need_fusion=True)
     for batch_idx, batch in enumerate(get_dataloader(cfg, rank, world)):
         if cfg.run.num_sample_batches is not None and batch_idx >= cfg.run.num_sample_batches:
             break
         batch = batch.to(device)
         for sample_idx in range(cfg.run.num_samples):
-            output = bdm_merging(None, batch, cfg, prior_model, recon_model, fusion_model)
+            output = bdm_merging(None, batch, cfg, prior_model, recon_model, fusion_model,
+                                 streams=batch_streams(cfg, batch, device, sample_idx))
             save_outputs(out_root, batch, output.points_padded(), sample_idx, cfg.run.num_samples)
+    barrier()
     if rank == 0:
         print("Saved samples to:", out_root.absolute())
+    return out_root
 
 
 if __name__ == "__main__":

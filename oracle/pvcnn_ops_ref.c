@@ -30,6 +30,14 @@
 
 #define FPS_LANES 512 /* sampling.cu:171 launches 512 threads; the tie rule depends on it */
 
+/* Mutation switch for tests/test_oracle_mutations.py ONLY: -DORACLE_MUTATION=k builds a deliberately WRONG variant of one
+ * documented rule, and the test shows that the known-answer cases of tests/test_oracle_ops.py reject it (i.e. that they
+ * really pin the rule).  The shipped oracle is built with ORACLE_MUTATION = 0: every MUT(k) below is then constant false. */
+#ifndef ORACLE_MUTATION
+#define ORACLE_MUTATION 0
+#endif
+#define MUT(k) (ORACLE_MUTATION == (k))
+
 /* sampling.cu:86-167 + sampling.cpp:43-58.  coords (b,3,n) -> indices (b,m).
  * The winner among equal maxima is the candidate with the smallest (k mod 512),
  * then the smallest k: stage 1 = per-thread strict '>' scan over k = tid, tid+512, ...
@@ -54,13 +62,13 @@ void oracle_furthest_point_sampling(int b, int n, int m, const float *coords, in
         const float d = (ex * ex + ey * ey) + ez * ez;
         const float d2 = d < dist[k] ? d : dist[k]; /* min(d, td) */
         dist[k] = d2;
-        const int t = k % FPS_LANES;
-        if (d2 > lane_best[t]) { lane_best[t] = d2; lane_idx[t] = k; }
+        const int t = MUT(3) ? 0 : k % FPS_LANES; /* MUT 3: plain first-index arg-max, no 512-lane rule */
+        if (MUT(4) ? d2 >= lane_best[t] : d2 > lane_best[t]) { lane_best[t] = d2; lane_idx[t] = k; } /* MUT 4: '>=' */
       }
       /* tree over lanes: left keeps unless right is strictly larger */
       for (int stride = 1; stride < FPS_LANES; stride <<= 1)
         for (int t = 0; t + stride < FPS_LANES; t += 2 * stride)
-          if (lane_best[t] < lane_best[t + stride]) {
+          if (MUT(5) ? lane_best[t] <= lane_best[t + stride] : lane_best[t] < lane_best[t + stride]) { /* MUT 5: '<=' */
             lane_best[t] = lane_best[t + stride];
             lane_idx[t] = lane_idx[t + stride];
           }
@@ -98,8 +106,8 @@ void oracle_ball_query(int b, int n, int m, float radius, int u, const float *ce
       for (int k = 0; k < n && cnt < u; ++k) {
         const float dx = cx[j] - px[k], dy = cy[j] - py[k], dz = cz[j] - pz[k];
         const float d2 = (dx * dx + dy * dy) + dz * dz;
-        if (d2 < r2) {
-          if (cnt == 0)
+        if (MUT(1) ? d2 <= r2 : d2 < r2) { /* MUT 1: non-strict radius test */
+          if (cnt == 0 && !MUT(2)) /* MUT 2: no first-hit fill (slots stay 0) */
             for (int v = 0; v < u; ++v) nb[(size_t)j * u + v] = k;
           nb[(size_t)j * u + cnt] = k;
           ++cnt;
@@ -138,16 +146,17 @@ void oracle_three_nn_interpolate(int b, int c, int m, int n, const float *points
       for (int k = 0; k < m; ++k) {
         const float ex = ux[j] - cx[k], ey = uy[j] - cy[k], ez = uz[j] - cz[k];
         const float d = (ex * ex + ey * ey) + ez * ez;
-        if (d < b2) {
+        /* MUT 6: '<=' cascades (ties would keep the LATER centre) */
+        if (MUT(6) ? d <= b2 : d < b2) {
           b2 = d; i2 = k;
-          if (d < b1) {
+          if (MUT(6) ? d <= b1 : d < b1) {
             b2 = b1; i2 = i1; b1 = d; i1 = k;
-            if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = k; }
+            if (MUT(6) ? d <= b0 : d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = k; }
           }
         }
       }
       /* :61-63 clamp in double against the float constants */
-      const double lo = (double)1e-10f, hi = (double)1e10f;
+      const double lo = MUT(7) ? 0.0 : (double)1e-10f, hi = (double)1e10f; /* MUT 7: no lower clamp */
       b0 = fmax(fmin(hi, b0), lo);
       b1 = fmax(fmin(hi, b1), lo);
       b2 = fmax(fmin(hi, b2), lo);
@@ -185,7 +194,8 @@ void oracle_avg_voxelize(int b, int c, int n, int r, const float *features, cons
     for (int ci = 0; ci < c; ++ci) {
       const float *f = features + ((size_t)bi * c + ci) * n;
       float *o = out + ((size_t)bi * c + ci) * r3;
-      for (int i = 0; i < n; ++i) {
+      for (int q = 0; q < n; ++q) {
+        const int i = MUT(8) ? n - 1 - q : q; /* MUT 8: descending point order */
         const int pos = id[i];
         const float inv = (float)(1.0 / (double)(float)cn[pos]); /* vox.cu:66 */
         o[pos] += f[i] * inv;
@@ -208,7 +218,9 @@ void oracle_trilinear_devoxelize(int b, int c, int n, int r, const float *coords
       const float w000 = x0 * y0 * z0, w001 = x0 * y0 * z1, w010 = x0 * y1 * z0,
                   w011 = x0 * y1 * z1, w100 = x1 * y0 * z0, w101 = x1 * y0 * z1,
                   w110 = x1 * y1 * z0, w111 = x1 * y1 * z1;
-      const int sx = x1 > 0 ? r2 : 0, sy = y1 > 0 ? r : 0, sz = z1 > 0 ? 1 : 0;
+      /* MUT 9: the +1 neighbour is always addressed (kept inside the grid so that the mutant cannot fault) */
+      const int sx = (x1 > 0 || (MUT(9) && (int)xl + 1 < r)) ? r2 : 0, sy = (y1 > 0 || (MUT(9) && (int)yl + 1 < r)) ? r : 0,
+                sz = (z1 > 0 || (MUT(9) && (int)zl + 1 < r)) ? 1 : 0;
       const int i000 = (int)xl * r2 + (int)yl * r + (int)zl;
       const int i001 = i000 + sz, i010 = i000 + sy, i011 = i010 + sz;
       const int i100 = i000 + sx, i101 = i100 + sz, i110 = i100 + sy, i111 = i110 + sz;

@@ -123,3 +123,35 @@ def test_argument_errors_raise_not_exit(hip):
     from bdm_amd import _lib
     with pytest.raises(_lib.BdmHipError):
         hip.furthest_point_sampling(torch.zeros(1, 3, 20000).cuda(), 4)  # beyond the sampler's limit
+
+
+# ---- every hand-derived known-answer case of tests/test_oracle_ops.py, run against the HIP backend ------------------
+import test_oracle_ops as _KA  # noqa: E402
+
+_KA_CASES = [n for n in dir(_KA) if n.startswith("test_")]
+
+
+class _HipAsOps:
+    """The `_pvcnn_backend` surface of the HIP library on CPU tensors (moves operands to the GPU and results back), so that
+    the oracle's known-answer functions can be called with it unchanged."""
+
+    def __init__(self, backend):
+        self._b = backend
+
+    def __getattr__(self, name):
+        fn = getattr(self._b, name)
+
+        def call(*args):
+            dev = [a.cuda().contiguous() if torch.is_tensor(a) else a for a in args]
+            out = fn(*dev)
+            if isinstance(out, (list, tuple)):
+                return [o.cpu() for o in out]
+            return out.cpu()
+        return call
+
+
+@pytest.mark.parametrize("case", _KA_CASES)
+def test_known_answer_cases_on_the_hip_backend(hip, case):
+    """strict '<', first-hit fill, zero rows, FPS (k mod 512, k) ties, 3-NN ties / clamp, voxel summation order, the
+    devoxelisation corner rule: the SAME known answers that pin the oracle, asked of the HIP kernels."""
+    getattr(_KA, case)(_HipAsOps(hip))

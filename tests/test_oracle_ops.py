@@ -87,6 +87,22 @@ def test_three_nn_weights_and_ties(oracle_ops):
     assert abs(float(out[0, 0, 1]) - 40.0) < 1e-4
 
 
+def test_three_nn_point_on_two_coincident_centres_is_clamped(oracle_ops):
+    """two centres AT the query point: both squared distances are 0 and clamp to 1e-10 (neighbor_interpolate.cu:61-63);
+    without the clamp the weights would be 0/0."""
+    ctr = T([[[1.0, 1.0, 4.0], [0] * 3, [0] * 3]])
+    pts = T([[[1.0], [0], [0]]])
+    feat = T([[[10.0, 30.0, 99.0]]])
+    out, idx, w = oracle_ops.three_nearest_neighbors_interpolate_forward(pts, ctr, feat)
+    assert idx[0, :, 0].tolist() == [0, 1, 2]
+    d0 = d1 = np.float64(np.float32(1e-10))
+    d2 = np.float64(9.0)
+    p01, p02, p12 = np.float32(d0 * d1), np.float32(d0 * d2), np.float32(d1 * d2)
+    inv = np.float32(1.0) / np.float32(np.float32(p01 + p02) + p12)
+    assert w[0, :, 0].tolist() == [float(p12 * inv), float(p02 * inv), float(p01 * inv)]
+    assert abs(float(out[0, 0, 0]) - 20.0) < 1e-4
+
+
 def test_avg_voxelize_counts_mean_and_empty(oracle_ops):
     r = 2
     coords = T([[[0, 0, 1, 1], [0, 0, 1, 1], [0, 0, 1, 0]]], torch.int32)  # voxels 0,0,7,6
@@ -100,12 +116,12 @@ def test_avg_voxelize_counts_mean_and_empty(oracle_ops):
 
 def test_avg_voxelize_order_is_ascending_point_index(oracle_ops):
     # three addends whose float sum depends on the order
-    vals = np.array([1e8, 1.0, -1e8], dtype=np.float32)
+    vals = np.array([1.0, 1e8, -1e8], dtype=np.float32)  # ascending: (1/3 + 1e8/3) - 1e8/3 = 0; descending: 1/3
     coords = torch.zeros(1, 3, 3, dtype=torch.int32)
     out, _, _ = oracle_ops.avg_voxelize_forward(T(vals).view(1, 1, 3), coords, 1)
     inv = np.float32(1.0 / 3.0)
     exp = np.float32(np.float32(np.float32(vals[0] * inv) + np.float32(vals[1] * inv)) + np.float32(vals[2] * inv))
-    assert float(out[0, 0, 0]) == float(exp)
+    assert float(out[0, 0, 0]) == float(exp) == 0.0
 
 
 def test_devoxelize_corner_rule_and_constant_grid(oracle_ops):
@@ -123,6 +139,30 @@ def test_devoxelize_corner_rule_and_constant_grid(oracle_ops):
     pts = torch.rand(1, 3, 50) * 2.0
     o = oracle_ops.trilinear_devoxelize_forward(r, False, pts.contiguous(), const)[0]
     assert torch.allclose(o, torch.full_like(o, 3.5), atol=1e-5)
+
+
+def test_devoxelize_integer_coordinate_never_reads_the_upper_neighbour(oracle_ops):
+    """frac == 0 on an axis: the '+1' cell is NOT addressed (trilinear_devox.cu:64-75) -- a NaN stored there must not
+    reach the output (0 * NaN would)."""
+    r = 3
+    grid = torch.arange(27, dtype=torch.float32).view(1, 1, 27).clone()
+    grid[0, 0, 1 * 9 + 1 * 3 + 2] = float("nan")   # cell (1,1,2) = z-neighbour of (1,1,1)
+    grid[0, 0, 2 * 9 + 1 * 3 + 1] = float("nan")   # cell (2,1,1) = x-neighbour
+    grid[0, 0, 1 * 9 + 2 * 3 + 1] = float("nan")   # cell (1,2,1) = y-neighbour
+    coords = T([[[1.0], [1.0], [1.0]]])
+    out = oracle_ops.trilinear_devoxelize_forward(r, False, coords, grid)[0]
+    assert float(out[0, 0, 0]) == 13.0
+
+
+def test_fps_equal_distances_in_one_lane_keep_the_first(oracle_ops):
+    """stage 1 is a strict '>' scan (sampling.cu:128-131): of two equally far points handled by the same thread
+    (k and k + 512) the smaller k wins; stage 2 keeps the LEFT lane on ties (:154)."""
+    n = 1100
+    c = torch.zeros(1, 3, n)
+    c[0, 2, 7] = 3.0
+    c[0, 2, 7 + 512] = -3.0
+    c[0, 2, 8] = 3.0            # a neighbouring lane with the same distance: lane 7 (left) still wins
+    assert oracle_ops.furthest_point_sampling(c, 2)[0].tolist() == [0, 7]
 
 
 def test_properties_random(oracle_ops):
