@@ -21,7 +21,7 @@ def state_dict_from(g, prefix=""):
     return {prefix + k: procedural_tensor(str(k), sh, int(g["weight_seed"])) for k, sh in zip(g["keys"], shapes)}
 
 
-@pytest.mark.parametrize("name", ["pc2_wm025_n1100.npz", "pvd_full_n1024.npz"])
+@pytest.mark.parametrize("name", ["pc2_wm025_n1100.npz", "pvd_full_n1024.npz", "pc2_full_n1024.npz"])
 def test_oracle_matches_reference_golden(name, oracle_ops):
     from oracle import ref_net
     g = load(name)
@@ -29,6 +29,16 @@ def test_oracle_matches_reference_golden(name, oracle_ops):
     x = point_cloud_inputs(B, 3 + S, N, int(g["input_seed"]))
     y = ref_net.pvcnn_forward(state_dict_from(g), x, torch.from_numpy(g["t"]))
     assert rel_l2(y, torch.from_numpy(g["out"])) < 2e-5  # same torch CPU kernels; only thread-order noise
+
+
+def test_oracle_matches_reference_golden_fusion_net(oracle_ops):
+    """PVCNN_fuse (Merging), with the defined semantic for the reference's out-of-bounds t_emb gather."""
+    from oracle import ref_net
+    g = load("fuse_full_n1024.npz")
+    xr = point_cloud_inputs(1, 390, 1024, int(g["recon_seed"]))
+    xp = point_cloud_inputs(1, 3, 1024, int(g["prior_seed"]))
+    y = ref_net.pvcnn_fuse_forward(state_dict_from(g), xr, xp, torch.from_numpy(g["t"]))
+    assert rel_l2(y, torch.from_numpy(g["out"])) < 2e-5
 
 
 def test_pvd_gaussian_diffusion_golden():

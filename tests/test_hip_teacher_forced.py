@@ -7,8 +7,8 @@ Asserted per step:
   * rel-L2(x_{t-1}) <= 1e-5  -- the state the sampler carries forward;
   * rel-L2(eps) <= EPS_TOL    -- the denoiser output itself (x_{t-1} is dominated by the identical x_t term, so this is the
     sharper check).  The conditioning image comes from the HIP ViT, which agrees with the oracle's ViT to <= 1e-4 (12 fp32
-    transformer blocks, different summation order): EPS_TOL = 1e-3 leaves room for that and for an occasional discrete flip
-    inside one forward (a point whose voxel-rounding input differs in the last bit), nothing more.
+    transformer blocks, different summation order).  Measured on MI355X (round 2): worst eps rel-L2 5e-6, worst x rel-L2
+    1e-7 over all 222 checked steps; EPS_TOL = 1e-4 is the per-forward tolerance of tests/test_hip_net.py.
 """
 import pytest
 import torch
@@ -16,7 +16,7 @@ import torch
 from helpers import rel_l2, seeded
 
 pytestmark = pytest.mark.gpu
-X_TOL, EPS_TOL = 1e-5, 1e-3
+X_TOL, EPS_TOL = 1e-5, 1e-4
 
 
 def _setup(B, N, seed):

@@ -23,13 +23,15 @@ def main():
     ap.add_argument("--milestones", type=str, default="1000,968,936,872,128,64,32,0")
     ap.add_argument("--roll", type=int, default=16)
     ap.add_argument("--merging", action="store_true")
+    ap.add_argument("--hip", action="store_true", help="run the twin pair on the HIP path instead of the oracle (fast proxy)")
     a = ap.parse_args()
     import trajectory_case as case
     c = case.build(a.points, a.scale, [int(v) for v in a.milestones.split(",")], a.roll, merging=a.merging, twin=True)
     t0 = time.time()
-    out = case.run_oracle(c, progress=True)
+    out = case.run_hip(c) if a.hip else case.run_oracle(c, progress=True)
     d = float((out[1] - out[0]).norm() / out[0].norm())
-    print(f"scale {a.scale}: final self-sensitivity (1 ulp) = {d:.3e}   [{time.time() - t0:.0f} s]")
+    print(f"{'HIP' if a.hip else 'oracle'} scale {a.scale}{' merging' if a.merging else ''}: final self-sensitivity (1 ulp) = {d:.3e}"
+          f"   [{time.time() - t0:.0f} s]", flush=True)
 
 
 if __name__ == "__main__":
