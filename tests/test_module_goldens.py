@@ -127,8 +127,10 @@ def test_hip_point_voxel_modules(gold, hip):
     d = {k: v.cuda() for k, v in x.items()}
     vox, nc = Voxelization(MF.R)(d["feat16"], d["coords"])
     vox_ref, nc_ref = MF.outs(g, "voxelization")
-    assert torch.equal(nc.cpu(), nc_ref)                                          # normalised coordinates: bit-exact
-    assert torch.equal(vox.cpu().view_as(vox_ref), vox_ref)
+    # normalised coordinates: the per-shape mean / max-norm reductions (voxelization.py:18-20) have no defined summation
+    # order (torch's CPU and CUDA reductions differ from each other too), so agreement is to the last bits, not bitwise
+    assert float((nc.cpu() - nc_ref).abs().max()) < 4e-6                          # values in [0, R-1] = [0, 7]
+    assert rel_l2(vox.cpu().view_as(vox_ref), vox_ref) < 1e-6                     # no rounding flip on this fixture
     for name, att in (("pvconv_plain", False), ("pvconv_attention", True)):
         m = _hip_module(g, name, PVConv(16, 32, 3, resolution=MF.R, attention=att, with_se=True, with_se_relu=True))
         f, c, t = m((d["feat16"], d["coords"], d["temb"]))
