@@ -1,0 +1,354 @@
+// sparse_conv_fused.hip -- the FIRST 3x3x3 convolution of a PVConv in ONE kernel, without the 27x-expanded intermediate.
+//
+// sparse_conv.hip evaluates  out[:, v] = bias + sum_tap W_tap . vox[:, v + tap]  on the occupied cells as a batched GEMM
+// Y (n_occ x 27*Cout) followed by an output-stationary gather; Y is written and read back once (27 * Cout * 4 bytes per
+// occupied cell: 0.66 GB per 64 -> 64 layer at B = 16), which is what that pair of kernels is bound by
+// (profiles/r01_pmc_hbm_traffic.csv).  Here the same products are formed by the matrix cores and accumulated straight into
+// the OUTPUT tile, held in LDS:
+//
+//   workgroup = (shape, slab of SX output x-planes, 32 output channels); LDS holds the slab's SX*R*R x 32 accumulators
+//   (initialised with the bias).  The occupied cells are sorted by voxel index (x major), so the cells that can reach the
+//   slab through kernel column kx are ONE contiguous range of the compact list (planes x0+kx-1 .. x0+SX+kx-2).
+//   for kx in 0..2:  for rounds of 4 chunks (one chunk of 32 occupied cells per wave):
+//       K loop:   acc[ky,kz] (32 cells x 32 channels) += X_chunk (32 x Cin) . W[kx,ky,kz] (Cin x 32)     9 accumulators
+//                 (v_mfma_f32_32x32x16_f16, fp16x3 split operands, see below)
+//       scatter:  for each (ky,kz): row m of acc[ky,kz] is added to the LDS accumulator of cell
+//                 (ux-kx+1, uy-ky+1, uz-kz+1) -- for ONE tap the map cell -> output cell is injective, so within a
+//                 phase no two lanes (of any wave) touch the same address: plain ds_add, no ordering ambiguity.  Phases
+//                 are separated by workgroup barriers, so every output cell receives its contributions in a fixed order
+//                 (kx, round, ky, kz): the result is bit-reproducible run to run (no float atomics racing).
+//   finally the slab is written channel-first (coalesced runs along the voxel index).
+// Every (occupied cell, tap) product is computed exactly once, by the workgroup that owns its output plane.
+//
+// Arithmetic: fp16x3, as conv3d_h2.hip -- an fp32 operand times a power of two is stored as hi + lo (two fp16 terms,
+// 22 signed bits), a product is lo.hi + hi.lo + hi.hi accumulated in fp32.  Weights carry a per-output-channel scale
+// (pack time); the activations (voxel-mean point features, range unknown a priori) are scaled by ONE power of two per
+// call derived on the device from max |x| (bdm_sparse_voxel_features_f32 accumulates it with an integer atomic max --
+// order independent, hence deterministic) and split when the operand is loaded.  fp32-grade: <= 3e-7 relative L2 vs
+// fp64 in tests/test_hip_dense.py.
+#include "../../include/bdm_hip.h"
+#include "common.h"
+
+using namespace bdm;
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+namespace {
+
+__device__ __forceinline__ void split2s(float v, unsigned short &h, unsigned short &l) {
+  v = fminf(fmaxf(v, -65504.f), 65504.f);
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  h = __builtin_bit_cast(unsigned short, hi);
+  l = __builtin_bit_cast(unsigned short, lo);
+}
+
+__device__ __forceinline__ void split_record(const float4 &p, const float4 &q, float s, f16x8 &hi, f16x8 &lo) {
+  const float v[8] = {p.x * s, p.y * s, p.z * s, p.w * s, q.x * s, q.y * s, q.z * s, q.w * s};
+  unsigned short h[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split2s(v[j], h[j], l[j]);
+  uint4 ph, pl;
+  ph.x = h[0] | (h[1] << 16); ph.y = h[2] | (h[3] << 16); ph.z = h[4] | (h[5] << 16); ph.w = h[6] | (h[7] << 16);
+  pl.x = l[0] | (l[1] << 16); pl.y = l[2] | (l[3] << 16); pl.z = l[4] | (l[5] << 16); pl.w = l[6] | (l[7] << 16);
+  hi = *reinterpret_cast<const f16x8 *>(&ph);
+  lo = *reinterpret_cast<const f16x8 *>(&pl);
+}
+
+// power of two s with amax * s in [2^14, 2^15)  (1 when amax is 0 / not finite)
+__device__ __forceinline__ float act_scale_from_max(float amax) {
+  if (!(amax > 0.f) || !(amax < INFINITY)) return 1.f;
+  int ex;
+  (void)frexpf(amax, &ex);  // amax = f * 2^ex, f in [0.5, 1)
+  return ldexpf(1.f, 15 - ex);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// occupied cells' mean features as fp32 records: xr (B, G, n_max) records of 8 channels (32 bytes), rows >= n_occ zero;
+// amax[0] = max |value| over the whole call (must be zero on entry).  Same XCD-aware unit decoding and the same
+// summation order as sparse_vox_features_s3_kernel (sparse_conv.hip): values equal the dense voxel grid's bit for bit.
+// ---------------------------------------------------------------------------------------------------
+__global__ void sparse_vox_features_f32_kernel(int c, int n, int r3, int n_max, int G, int units, int kblocks,
+                                               const float *__restrict__ feat, long long bs_f, int ld_f,
+                                               const int *__restrict__ cnt, const int *__restrict__ start,
+                                               const int *__restrict__ sorted, const int *__restrict__ occ_list,
+                                               const int *__restrict__ n_occ, float4 *__restrict__ xr,
+                                               unsigned *__restrict__ amax) {
+#pragma clang fp contract(off)
+  const int wg = blockIdx.x, span = 8 * kblocks;
+  const int unit = (wg / span) * 8 + (wg % span) % 8, kb = (wg % span) / 8;
+  if (unit >= units) return;
+  const int bi = unit / G, g = unit % G;
+  const int k = kb * blockDim.x + threadIdx.x;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (k < n_max && k < n_occ[bi]) {
+    const int v = occ_list[(size_t)bi * n_max + k];
+    const int cv = cnt[(size_t)bi * r3 + v];
+    const int *so = sorted + (size_t)bi * n + start[(size_t)bi * r3 + v];
+    const float inv = cv > 0 ? (float)(1.0 / (double)(float)cv) : 0.f;
+    const float *fb = feat + (size_t)bi * bs_f + (size_t)g * 8 * ld_f;
+    const int nch = min(8, c - g * 8);
+    for (int q = 0; q < cv; ++q) {
+      const int p = so[q];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < nch) acc[j] = acc[j] + fb[(size_t)j * ld_f + p] * inv;
+    }
+  }
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(acc[j]));
+  if (k < n_max) {
+    float4 *o = xr + (((size_t)bi * G + g) * n_max + k) * 2;
+    o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));  // non-negative floats order as unsigned ints
+}
+
+extern "C" int bdm_sparse_voxel_features_f32(int b, int c, int n, int r, int n_max, const float *features, long long bs_f,
+                                             int ld_f, const int *cnt, const void *plan_workspace, const int *occ_list,
+                                             const int *n_occ, void *xr, float *amax, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && n >= 1 && r >= 1 && n_max >= 1 && amax != nullptr, "sparse_voxel_features_f32: bad arguments");
+  if (b == 0) return BDM_OK;
+  const int r3 = r * r * r;
+  VoxWs w = vox_ws(const_cast<void *>(plan_workspace), b, n, r3);
+  const int G = (c + 7) / 8, units = b * G, kblocks = cdiv(n_max, 128);
+  hipLaunchKernelGGL(sparse_vox_features_f32_kernel, dim3(cdiv(units, 8) * 8 * kblocks), dim3(128), 0, (hipStream_t)stream, c,
+                     n, r3, n_max, G, units, kblocks, features, bs_f, ld_f, cnt, w.start, w.sorted, occ_list, n_occ,
+                     (float4 *)xr, (unsigned *)amax);
+  return launch_status("sparse_voxel_features_f32");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weights (Cout, Cin, 3,3,3) fp32 -> [G][27][2][Cout] records of 8 fp16 (hi / lo of w * 2^e[co]); inv_scale[co] = 2^-e[co]
+// ---------------------------------------------------------------------------------------------------
+__global__ void sparse_fused_weight_scale_kernel(int cout, int cin, const float *__restrict__ w, float *__restrict__ scale,
+                                                 float *__restrict__ inv_scale) {
+  __shared__ float sh[256];
+  const int co = blockIdx.x;
+  float m = 0.f;
+  for (int e = threadIdx.x; e < cin * 27; e += blockDim.x) m = fmaxf(m, fabsf(w[(size_t)co * cin * 27 + e]));
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int ex = 0;
+    const float mx = sh[0];
+    const bool ok = mx > 0.f && mx < INFINITY;
+    if (ok) (void)frexpf(mx, &ex);
+    const int e = ok ? 10 - ex : 0;  // mx * 2^e in [2^9, 2^10)
+    scale[co] = ldexpf(1.0f, e);
+    inv_scale[co] = ldexpf(1.0f, -e);
+  }
+}
+__global__ void sparse_fused_pack_kernel(int cout, int cin, const float *__restrict__ w, const float *__restrict__ scale,
+                                         unsigned short *__restrict__ wq) {
+  const int G = (cin + 7) / 8;
+  const long long total = (long long)G * 27 * cout;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(e % cout), tap = (int)((e / cout) % 27), g = (int)(e / (27ll * cout));
+    unsigned short h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ci = g * 8 + j;
+      const float v = ci < cin ? w[((size_t)co * cin + ci) * 27 + tap] * scale[co] : 0.f;  // exact scaling
+      split2s(v, h[j], l[j]);
+    }
+    unsigned short *ph = wq + ((((size_t)g * 27 + tap) * 2 + 0) * cout + co) * 8;
+    unsigned short *pl = wq + ((((size_t)g * 27 + tap) * 2 + 1) * cout + co) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ph[j] = h[j]; pl[j] = l[j]; }
+  }
+}
+extern "C" size_t bdm_sparse_conv_fused_weight_elems(int cout, int cin) { return (size_t)((cin + 7) / 8) * 27 * 2 * cout * 8; }
+extern "C" int bdm_sparse_conv_fused_pack_weights(int cout, int cin, const float *w, void *packed, float *scale_ws,
+                                                  float *inv_scale, void *stream) {
+  BDM_REQUIRE(cout >= 1 && cin >= 1 && scale_ws != nullptr && inv_scale != nullptr, "sparse_conv_fused_pack_weights: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sparse_fused_weight_scale_kernel, dim3(cout), dim3(256), 0, s, cout, cin, w, scale_ws, inv_scale);
+  hipLaunchKernelGGL(sparse_fused_pack_kernel, dim3(512), dim3(256), 0, s, cout, cin, w, scale_ws, (unsigned short *)packed);
+  return launch_status("sparse_conv_fused_pack_weights");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the fused convolution
+// ---------------------------------------------------------------------------------------------------
+template <int R, int SX>
+__global__ __launch_bounds__(256) void sparse_conv_fused_kernel(int G, int Cout, int n_max, const float4 *__restrict__ xr,
+                                                                const float *__restrict__ amax,
+                                                                const uint4 *__restrict__ wq,
+                                                                const float *__restrict__ inv_sw,
+                                                                const int *__restrict__ occ_list,
+                                                                const int *__restrict__ n_occ,
+                                                                const float *__restrict__ bias, float *__restrict__ out) {
+  constexpr int R2 = R * R, R3 = R2 * R, NV = SX * R2, LD = 33;
+  extern __shared__ float accs[];  // [NV][LD]
+  __shared__ int s_bound[SX + 3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int x0 = blockIdx.x * SX, co0 = blockIdx.y * 32, bi = blockIdx.z;
+  const int co = co0 + li;
+  const bool co_ok = co < Cout;
+  const int nocc = min(n_occ[bi], n_max);
+  const int *ol = occ_list + (size_t)bi * n_max;
+
+  // plane boundaries of the sorted compact list: s_bound[t] = first row with voxel id >= (x0 - 1 + t) * R2
+  if (tid < SX + 3) {
+    const int plane = x0 - 1 + tid;
+    int lo = 0;
+    if (plane >= R) lo = nocc;
+    else if (plane > 0) {
+      const int key = plane * R2;
+      int hi = nocc;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ol[mid] < key) lo = mid + 1; else hi = mid;
+      }
+    }
+    s_bound[tid] = lo;
+  }
+  for (int e = tid; e < NV * 32; e += 256) {
+    const int c = e & 31, p = e >> 5;
+    accs[p * LD + c] = (bias && co0 + c < Cout) ? bias[co0 + c] : 0.f;
+  }
+  __syncthreads();
+
+  const float sx = act_scale_from_max(*amax);
+  const float post = (co_ok ? inv_sw[co] : 0.f) * (1.0f / sx);  // powers of two: exact
+  const int K16 = (G + 1) >> 1;
+  const float4 *xb = xr + (size_t)bi * G * n_max * 2;
+
+  for (int kx = 0; kx < 3; ++kx) {
+    // input planes [x0 + kx - 1, x0 + SX + kx - 1) reach output planes [x0, x0 + SX) through kernel column kx
+    const int lo = s_bound[kx], hi = s_bound[kx + SX];
+    const int nchunks = (hi - lo + 31) >> 5;
+    for (int c0 = 0; c0 < nchunks; c0 += 4) {
+      const int chunk = c0 + wave;
+      const bool active = chunk < nchunks;
+      const bool multi = nchunks - c0 > 1;  // more than one wave scatters in this round -> phases need barriers
+      f32x16 acc[9];
+      int tgt[16];  // per accumulator row: LDS cell of the centre tap | uy << 16 | uz << 24, or -1
+      if (active) {
+        const int row = lo + chunk * 32 + li;
+        const bool rv = row < hi;
+        const int u = rv ? ol[row] : -1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        // ---- K loop, register double-buffered -------------------------------------------------------------
+        float4 xa[2][2];
+        uint4 wa[2][18];
+        auto load = [&](int ks, int buf) {
+          const int g = 2 * ks + lh;
+          const bool gv = g < G;
+          const size_t xo = ((size_t)(gv ? g : 0) * n_max + (rv ? row : 0)) * 2;
+          const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 p = xb[xo], q = xb[xo + 1];
+          xa[buf][0] = (gv && rv) ? p : z4;
+          xa[buf][1] = (gv && rv) ? q : z4;
+          const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+          const uint4 *wp = wq + (((size_t)(gv ? g : 0) * 27 + kx * 9) * 2) * Cout + (co_ok ? co : 0);
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const uint4 v = wp[(size_t)(t * 2 + s) * Cout];
+              wa[buf][t * 2 + s] = (gv && co_ok) ? v : z;
+            }
+        };
+        auto compute = [&](int buf) {
+          f16x8 ah, al;
+          split_record(xa[buf][0], xa[buf][1], sx, ah, al);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const f16x8 bh = *reinterpret_cast<const f16x8 *>(&wa[buf][t * 2]);
+            const f16x8 bl = *reinterpret_cast<const f16x8 *>(&wa[buf][t * 2 + 1]);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+          }
+        };
+        load(0, 0);
+        for (int ks = 0; ks < K16; ks += 2) {
+          if (ks + 1 < K16) load(ks + 1, 1);
+          compute(0);
+          if (ks + 1 < K16) {
+            if (ks + 2 < K16) load(ks + 2, 0);
+            compute(1);
+          }
+        }
+        // ---- scatter targets of this lane's 16 accumulator rows --------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int m = (i & 3) + 8 * (i >> 2) + 4 * lh;
+          const int um = __shfl(u, m, 64);
+          int t = -1;
+          if (um >= 0) {
+            const int ux = um / R2, uy = (um / R) % R, uz = um % R;
+            const int ox = ux - kx + 1 - x0;
+            if (ox >= 0 && ox < SX) t = ((ox * R + uy) * R + uz) | (uy << 16) | (uz << 24);
+          }
+          tgt[i] = t;
+        }
+      }
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        if (active && co_ok) {
+          const int dy = 1 - t9 / 3, dz = 1 - t9 % 3;  // output cell = input cell + (dy, dz) in (y, z)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int t = tgt[i];
+            const int oy = ((t >> 16) & 0xFF) + dy, oz = ((t >> 24) & 0xFF) + dz;
+            if (t >= 0 && oy >= 0 && oy < R && oz >= 0 && oz < R)
+              atomicAdd(&accs[((t & 0xFFFF) + dy * R + dz) * LD + li], acc[t9][i] * post);
+          }
+        }
+        if (multi) __syncthreads();
+      }
+      if (!multi) __syncthreads();
+    }
+  }
+  __syncthreads();
+  float *ob = out + (size_t)bi * Cout * R3 + (size_t)x0 * R2;
+  for (int e = tid; e < NV * 32; e += 256) {
+    const int c = e / NV, p = e % NV;
+    if (co0 + c < Cout) ob[(size_t)(co0 + c) * R3 + p] = accs[p * LD + c];
+  }
+}
+
+extern "C" int bdm_sparse_conv_fused(int b, int cin, int cout, int r, int n_max, const void *xr, const float *amax,
+                                     const void *packed_w, const float *inv_scale, const int *occ_list, const int *n_occ,
+                                     const float *bias, float *out, void *stream) {
+  BDM_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && n_max >= 1 && amax != nullptr && inv_scale != nullptr,
+              "sparse_conv_fused: bad arguments");
+  if (r != 8 && r != 16 && r != 32) {
+    set_error("sparse_conv_fused: resolution %d unsupported (8, 16, 32)", r);
+    return BDM_ERR_UNSUPPORTED;
+  }
+  if (b == 0) return BDM_OK;
+  const int G = (cin + 7) / 8;
+  hipStream_t s = (hipStream_t)stream;
+#define FUSED_LAUNCH(R, SX)                                                                                          \
+  do {                                                                                                               \
+    const size_t smem = sizeof(float) * (size_t)(SX) * (R) * (R) * 33;                                               \
+    BDM_ALLOW_LDS((sparse_conv_fused_kernel<R, SX>), smem);                                                          \
+    hipLaunchKernelGGL((sparse_conv_fused_kernel<R, SX>), dim3((R) / (SX), cdiv(cout, 32), b), dim3(256), smem, s, G, \
+                       cout, n_max, (const float4 *)xr, amax, (const uint4 *)packed_w, inv_scale, occ_list, n_occ,   \
+                       bias, out);                                                                                   \
+  } while (0)
+  if (r == 32) FUSED_LAUNCH(32, 1);
+  else if (r == 16) FUSED_LAUNCH(16, 2);
+  else FUSED_LAUNCH(8, 4);
+#undef FUSED_LAUNCH
+  return launch_status("sparse_conv_fused");
+}

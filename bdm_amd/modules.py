@@ -162,7 +162,9 @@ class PVConv(nn.Module):
     conv_impl = os.environ.get("BDM_CONV", "fp16x3")
     sparse_first_conv = os.environ.get("BDM_SPARSE_CONV1", "1") == "1"
     sparse_resolutions = {int(v) for v in os.environ.get("BDM_SPARSE_R", "8,16,32").split(",") if v}
-    sparse_gemm = "sparse" if os.environ.get("BDM_SPARSE_GEMM", "bf16x6") == "fp32" else "sparse_s3"
+    # first convolution on the occupied voxels: "fused" (default; sparse_conv_fused.hip: one kernel, fp16x3, accumulators in
+    # LDS) | "bf16x6" (batched GEMM + gather over a 27x-expanded intermediate, sparse_conv.hip) | "fp32" (same, fp32 MFMA)
+    sparse_gemm = {"fp32": "sparse", "bf16x6": "sparse_s3"}.get(os.environ.get("BDM_SPARSE_GEMM", "fused"), "sparse_fused")
 
     def _packed_weight(self, conv, impl):
         key = (id(conv), impl)
@@ -170,7 +172,7 @@ class PVConv(nn.Module):
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
             pack = {"bf16x6": ops.conv3d_s3_pack, "fp16x3": ops.conv3d_h2_pack, "sparse": ops.sparse_conv_pack,
-                    "sparse_s3": ops.sparse_conv_pack_s3,
+                    "sparse_s3": ops.sparse_conv_pack_s3, "sparse_fused": ops.sparse_conv_pack_fused,
                     "fp32": ops.conv3d_pack}[impl]
             hit = (sig, pack(conv.weight.detach()))
             self._packed[key] = hit

@@ -421,6 +421,36 @@ def sparse_conv_pack_s3(weight):
     return ws
 
 
+def sparse_conv_pack_fused(weight):
+    """(Cout, Cin, 3,3,3) fp32 -> (fp16 records [ceil(Cin/8)][27][2][Cout][8], inv_scale (Cout,)) for bdm_sparse_conv_fused."""
+    cout, cin = weight.shape[:2]
+    lib = L.lib()
+    packed = torch.empty(lib.bdm_sparse_conv_fused_weight_elems(cout, cin), dtype=torch.float16, device=weight.device)
+    scale = torch.empty(cout, dtype=torch.float32, device=weight.device)
+    inv_scale = torch.empty(cout, dtype=torch.float32, device=weight.device)
+    L.check(lib.bdm_sparse_conv_fused_pack_weights(cout, cin, L.ptr(weight.contiguous()), L.ptr(packed), L.ptr(scale),
+                                                   L.ptr(inv_scale), L.stream()), "sparse_conv_fused_pack_weights")
+    return packed, inv_scale
+
+
+_amax_rings = {}
+
+
+def _amax_slot(device):
+    """One zeroed float per sparse convolution call (its activation-scale maximum): slots of a per-(device, stream) ring that
+    is refilled with zeros in ONE launch every 256 calls, so the convolution itself needs no memset."""
+    dev = torch.device(device)
+    key = (str(device), torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch._C._cuda_getDevice()))
+    ring = _amax_rings.get(key)
+    if ring is None or ring[1] >= ring[0].shape[0]:
+        # a NEW buffer (not an in-place refill): slots handed out earlier may still be read by enqueued kernels
+        ring = [torch.zeros(256, dtype=torch.float32, device=device), 0]
+        _amax_rings[key] = ring
+    slot = ring[0][ring[1]:ring[1] + 1]
+    ring[1] += 1
+    return slot
+
+
 class VoxelPlan:
     """Everything that depends on (coords, r) only: normalised / integer voxel coordinates, per-voxel point lists,
     occupied-cell compaction and row occupancy.  PVConvs of one level share it (exactly the same values)."""
@@ -464,6 +494,18 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout):
     """Conv3d(k3, p1)(avg_voxelize(features)) on the occupied voxels of `plan`: (B, cout, r^3) fp32."""
     f, B, C, n, bs_f, ld_f = _bcl(features)
     dev, lib, r = f.device, L.lib(), plan.r
+    if isinstance(wt, tuple):  # fused kernel (sparse_conv_pack_fused): GEMM + scatter in one launch, no intermediate
+        packed, inv_scale = wt
+        xr = torch.empty(B, (C + 7) // 8, plan.n_max, 8, dtype=torch.float32, device=dev)
+        amax = _amax_slot(dev)
+        L.check(lib.bdm_sparse_voxel_features_f32(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),
+                                                  L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()),
+                "sparse_voxel_features_f32")
+        out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
+        L.check(lib.bdm_sparse_conv_fused(B, C, cout, r, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(packed), L.ptr(inv_scale),
+                                          L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(bias), L.ptr(out), L.stream()),
+                "sparse_conv_fused")
+        return out
     y = torch.empty(B, plan.n_max, 27 * cout, dtype=torch.float32, device=dev)
     if wt.dtype == torch.bfloat16:  # bf16x6: pre-split operands (sparse_conv_pack_s3)
         xs = torch.empty(B, (C + 7) // 8, 3, plan.n_max, 8, dtype=torch.bfloat16, device=dev)

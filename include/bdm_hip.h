@@ -256,6 +256,26 @@ int bdm_sparse_conv_gemm(int b, int n_max, int cin, int n27, const float *xc, co
 int bdm_sparse_conv_gather(int b, int cout, int r, int n_max, const float *y, const int *occ_index,
                            const unsigned char *rowocc, const float *bias, float *out, void *stream);
 
+/* --- the same first convolution in ONE kernel, no (n_occ x 27*cout) intermediate (sparse_conv_fused.hip; the default) ---
+ *   bdm_sparse_voxel_features_f32  occupied cells' mean features as fp32 records xr (b, ceil(c/8), n_max) x 8 channels,
+ *                                  rows >= n_occ zero; amax[0] (ZERO on entry) receives max |value| of the call
+ *   bdm_sparse_conv_fused_pack_weights  (cout, cin, 3,3,3) fp32 -> [ceil(cin/8)][27][2][cout] records of 8 fp16
+ *                                  (hi / lo of w * 2^e[co]); inv_scale[co] = 2^-e[co]; scale_ws (cout floats) scratch
+ *   bdm_sparse_conv_fused          out (b, cout, r^3) = bias + conv: workgroup = (shape, slab of output x-planes, 32 output
+ *                                  channels) with the slab's accumulators in LDS; occupied cells (sorted by voxel index:
+ *                                  occ_list of bdm_voxelize_plan_full) are multiplied on the matrix cores (fp16x3, activation
+ *                                  scale derived on the device from amax) and scattered tap by tap, phases separated by
+ *                                  barriers: deterministic.  r in {8, 16, 32}. */
+int bdm_sparse_voxel_features_f32(int b, int c, int n, int r, int n_max, const float *features, long long bs_f,
+                                  int ld_f, const int *cnt, const void *plan_workspace, const int *occ_list,
+                                  const int *n_occ, void *xr, float *amax, void *stream);
+size_t bdm_sparse_conv_fused_weight_elems(int cout, int cin);
+int bdm_sparse_conv_fused_pack_weights(int cout, int cin, const float *w, void *packed, float *scale_ws,
+                                       float *inv_scale, void *stream);
+int bdm_sparse_conv_fused(int b, int cin, int cout, int r, int n_max, const void *xr, const float *amax,
+                          const void *packed_w, const float *inv_scale, const int *occ_list, const int *n_occ,
+                          const float *bias, float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * 3. Per-step glue of the coupled DDPM loop
  * ---------------------------------------------------------------------------------- */

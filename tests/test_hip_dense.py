@@ -304,11 +304,43 @@ def test_sparse_first_conv_equals_dense(ops, oracle_ops, cin, cout, r, npts):
     # bf16x6 GEMM on pre-split operands: same bound (fp32-grade products, fp32 accumulation)
     got6 = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack_s3(w.cuda()), bias.cuda(), cout).cpu()
     assert rel(got6, ref) < 2e-6
+    # fused kernel (GEMM + deterministic scatter into LDS accumulators, fp16x3): same bound; bit-reproducible
+    gotf = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack_fused(w.cuda()), bias.cuda(), cout).cpu()
+    assert rel(gotf, ref) < 2e-6
+    again = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack_fused(w.cuda()), bias.cuda(), cout).cpu()
+    assert torch.equal(gotf, again)
     # runs of a concat buffer (strided features) give the same result
     big = torch.randn(B, cin + 6, npts, generator=g).cuda()
     big[:, 3:3 + cin] = f.cuda()
     got2 = ops.sparse_first_conv(big[:, 3:3 + cin], vc.cuda(), r, ops.sparse_conv_pack(w.cuda()), bias.cuda(), cout).cpu()
     assert torch.equal(got, got2)
+    gotf2 = ops.sparse_first_conv(big[:, 3:3 + cin], vc.cuda(), r, ops.sparse_conv_pack_fused(w.cuda()), bias.cuda(), cout).cpu()
+    assert torch.equal(gotf, gotf2)
+
+
+def test_sparse_fused_conv_wide_dynamic_range_and_empty_shape(ops, oracle_ops):
+    """channels of very different magnitude (the activation scale is ONE power of two from max |x|), a shape whose points
+    all fall into a single voxel, batch 16 with 4096 points (the bench's grid)."""
+    B, cin, cout, r, npts = 16, 64, 64, 32, 4096
+    g = torch.Generator().manual_seed(5)
+    vc = (torch.randn(B, 3, npts, generator=g) * r / 8 + r / 2).round().clamp(0, r - 1).to(torch.int32)
+    vc[3] = 31                                           # one occupied voxel, at the grid corner
+    f = torch.randn(B, cin, npts, generator=g)
+    f[:, :8] *= 3000.0                                   # huge channels next to ...
+    f[:, 8:16] *= 1e-4                                   # ... tiny ones
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    got = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack_fused(w.cuda()), bias.cuda(), cout).cpu()
+    for b in (0, 3, 15):
+        vox = oracle_ops.avg_voxelize_forward(f[b:b + 1].contiguous(), vc[b:b + 1].contiguous(), r)[0]
+        ref = TF.conv3d(vox.double().view(1, cin, r, r, r), w.double(), bias.double(), padding=1).float().reshape(1, cout, -1)
+        assert rel(got[b:b + 1], ref) < 2e-6, b
+    # the tiny channels alone: their products sit far below the big ones, yet keep fp32-grade ABSOLUTE accuracy
+    f2 = f.clone(); f2[:, :8] = 0
+    got2 = ops.sparse_first_conv(f2.cuda(), vc.cuda(), r, ops.sparse_conv_pack_fused(w.cuda()), bias.cuda(), cout).cpu()
+    vox = oracle_ops.avg_voxelize_forward(f2[:1].contiguous(), vc[:1].contiguous(), r)[0]
+    ref = TF.conv3d(vox.double().view(1, cin, r, r, r), w.double(), bias.double(), padding=1).float().reshape(1, cout, -1)
+    assert rel(got2[:1], ref) < 2e-6
 
 
 @pytest.mark.parametrize("r,n", [(32, 4096), (16, 1000), (8, 64), (8, 700)])
