@@ -35,16 +35,24 @@ inline int launch_status(const char *what) {
     }                               \
   } while (0)
 
-// Raise a kernel's dynamic-LDS ceiling (up to the CU's 160 KiB); not a stream operation.
+// Raise a kernel's dynamic-LDS ceiling (up to the CU's 160 KiB); not a stream operation.  The attribute is sticky per
+// (kernel, device), and hipFuncSetAttribute is a slow driver call (measured ~0.2 ms: at one call per launch it made every
+// big-LDS kernel host-bound), so each expansion site remembers the size it has already granted on each device.
 #define BDM_ALLOW_LDS(kernel, bytes)                                                                      \
   do {                                                                                                    \
     if ((bytes) > 48 * 1024) {                                                                            \
-      hipError_t e_ = hipFuncSetAttribute((const void *)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                          (int)(bytes));                                                  \
-      if (e_ != hipSuccess) {                                                                             \
-        bdm::set_error("%s: cannot raise the dynamic LDS limit to %d bytes: %s", #kernel, (int)(bytes),   \
-                       hipGetErrorString(e_));                                                            \
-        return BDM_ERR_LAUNCH;                                                                            \
+      static int granted_[16] = {0};                                                                      \
+      int dev_ = 0;                                                                                       \
+      (void)hipGetDevice(&dev_);                                                                          \
+      if (dev_ < 0 || dev_ >= 16 || granted_[dev_] < (int)(bytes)) {                                      \
+        hipError_t e_ = hipFuncSetAttribute((const void *)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                            (int)(bytes));                                                \
+        if (e_ != hipSuccess) {                                                                           \
+          bdm::set_error("%s: cannot raise the dynamic LDS limit to %d bytes: %s", #kernel, (int)(bytes), \
+                         hipGetErrorString(e_));                                                          \
+          return BDM_ERR_LAUNCH;                                                                          \
+        }                                                                                                 \
+        if (dev_ >= 0 && dev_ < 16) granted_[dev_] = (int)(bytes);                                        \
       }                                                                                                   \
     }                                                                                                     \
   } while (0)

@@ -26,6 +26,8 @@
 // call derived on the device from max |x| (bdm_sparse_voxel_features_f32 accumulates it with an integer atomic max --
 // order independent, hence deterministic) and split when the operand is loaded.  fp32-grade: <= 3e-7 relative L2 vs
 // fp64 in tests/test_hip_dense.py.
+#include <stdlib.h>
+
 #include "../../include/bdm_hip.h"
 #include "common.h"
 
@@ -55,6 +57,10 @@ __device__ __forceinline__ void split_record(const float4 &p, const float4 &q, f
   hi = *reinterpret_cast<const f16x8 *>(&ph);
   lo = *reinterpret_cast<const f16x8 *>(&pl);
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter (vmcnt(0)), i.e.
+// it waits for the global loads issued as PREFETCH for later steps and so exposes their whole latency at every barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // power of two s with amax * s in [2^14, 2^15)  (1 when amax is 0 / not finite)
 __device__ __forceinline__ float act_scale_from_max(float amax) {
@@ -192,7 +198,11 @@ __global__ __launch_bounds__(256) void sparse_conv_fused_kernel(int G, int Cout,
                                                                 const int *__restrict__ n_occ,
                                                                 const float *__restrict__ bias, float *__restrict__ out) {
   constexpr int R2 = R * R, R3 = R2 * R, NV = SX * R2, LD = 33;
-  extern __shared__ float accs[];  // [NV][LD]
+  constexpr int WREC = 2 * 18 * 32, WI = (WREC + 255) / 256;  // weight records of one K=16 step: [lh][tap*2+split][32 channels]
+  extern __shared__ __align__(16) float smem[];
+  float *accs = smem;                                            // [NV][LD], then 64 scratch floats (sink of masked-off lanes)
+  constexpr int SINK = NV * LD;
+  uint4 *Ws = reinterpret_cast<uint4 *>(smem + (NV * LD + 64 + 3) / 4 * 4);  // [2][18][32]
   __shared__ int s_bound[SX + 3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int x0 = blockIdx.x * SX, co0 = blockIdx.y * 32, bi = blockIdx.z;
@@ -201,20 +211,16 @@ __global__ __launch_bounds__(256) void sparse_conv_fused_kernel(int G, int Cout,
   const int nocc = min(n_occ[bi], n_max);
   const int *ol = occ_list + (size_t)bi * n_max;
 
-  // plane boundaries of the sorted compact list: s_bound[t] = first row with voxel id >= (x0 - 1 + t) * R2
-  if (tid < SX + 3) {
-    const int plane = x0 - 1 + tid;
-    int lo = 0;
-    if (plane >= R) lo = nocc;
-    else if (plane > 0) {
-      const int key = plane * R2;
-      int hi = nocc;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (ol[mid] < key) lo = mid + 1; else hi = mid;
-      }
+  // plane boundaries of the sorted compact list: s_bound[t] = first row whose voxel lies in plane >= x0 - 1 + t.
+  // One coalesced sweep over the list: a row that starts a new plane records itself for every boundary it crosses.
+  if (tid < SX + 3) s_bound[tid] = (x0 - 1 + tid <= 0) ? 0 : nocc;
+  __syncthreads();
+  for (int row = tid; row < nocc; row += 256) {
+    const int pl = ol[row] / R2, pp = row > 0 ? ol[row - 1] / R2 : -1;
+    if (pl != pp) {
+      const int t_lo = max(pp + 1, x0 - 1) - (x0 - 1), t_hi = min(pl, x0 + SX + 1) - (x0 - 1);
+      for (int t = max(t_lo, 0); t <= t_hi; ++t) s_bound[t] = row;  // planes pp+1 .. pl all start at this row
     }
-    s_bound[tid] = lo;
   }
   for (int e = tid; e < NV * 32; e += 256) {
     const int c = e & 31, p = e >> 5;
@@ -235,94 +241,125 @@ __global__ __launch_bounds__(256) void sparse_conv_fused_kernel(int G, int Cout,
       const int chunk = c0 + wave;
       const bool active = chunk < nchunks;
       const bool multi = nchunks - c0 > 1;  // more than one wave scatters in this round -> phases need barriers
+      const int row = lo + chunk * 32 + li;
+      const bool rv = active && row < hi;
+      const int u = rv ? ol[row] : -1;
       f32x16 acc[9];
-      int tgt[16];  // per accumulator row: LDS cell of the centre tap | uy << 16 | uz << 24, or -1
-      if (active) {
-        const int row = lo + chunk * 32 + li;
-        const bool rv = row < hi;
-        const int u = rv ? ol[row] : -1;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+      for (int t = 0; t < 9; ++t)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        // ---- K loop, register double-buffered -------------------------------------------------------------
-        float4 xa[2][2];
-        uint4 wa[2][18];
-        auto load = [&](int ks, int buf) {
-          const int g = 2 * ks + lh;
-          const bool gv = g < G;
-          const size_t xo = ((size_t)(gv ? g : 0) * n_max + (rv ? row : 0)) * 2;
-          const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          const float4 p = xb[xo], q = xb[xo + 1];
-          xa[buf][0] = (gv && rv) ? p : z4;
-          xa[buf][1] = (gv && rv) ? q : z4;
-          const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-          const uint4 *wp = wq + (((size_t)(gv ? g : 0) * 27 + kx * 9) * 2) * Cout + (co_ok ? co : 0);
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+      // ---- K loop: the step's weight records go through LDS once per workgroup (register-prefetched), the chunk's own
+      //      activation records straight to registers ----------------------------------------------------------------
+      uint4 wreg[WI], wnxt[WI];
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 xc0, xc1, xn0 = z4, xn1 = z4, xm0 = z4, xm1 = z4;
+      auto wload = [&](int ks, uint4 *wdst) {
 #pragma unroll
-          for (int t = 0; t < 9; ++t)
+        for (int i = 0; i < WI; ++i) {
+          const int e = tid + i * 256;
+          const int col = e & 31, ts = (e >> 5) % 18, hh = e / (18 * 32);
+          const int g = 2 * ks + hh;
+          const bool ok = e < WREC && g < G && co0 + col < Cout;
+          const uint4 v = wq[ok ? (((size_t)g * 27 + kx * 9) * 2 + ts) * Cout + co0 + col : 0];
+          const unsigned k = ok ? 0xFFFFFFFFu : 0u;
+          wdst[i] = make_uint4(v.x & k, v.y & k, v.z & k, v.w & k);
+        }
+      };
+      auto xload = [&](int ks, float4 &d0, float4 &d1) {
+        const int g = 2 * ks + lh;
+        const bool ok = rv && g < G;
+        const size_t xo = ((size_t)(ok ? g : 0) * n_max + (ok ? row : 0)) * 2;
+        const float4 p = xb[xo], q = xb[xo + 1];
+        const float m = ok ? 1.f : 0.f;  // (a select on the whole vector made the compiler go through scratch memory)
+        d0 = make_float4(p.x * m, p.y * m, p.z * m, p.w * m);
+        d1 = make_float4(q.x * m, q.y * m, q.z * m, q.w * m);
+      };
+      // loads run TWO steps ahead of the matrix work (one workgroup per CU at r = 32: nothing else hides the latency)
+      wload(0, wreg);
+      xload(0, xc0, xc1);
+      if (K16 > 1) { wload(1, wnxt); xload(1, xn0, xn1); }
+      for (int ks = 0; ks < K16; ++ks) {
+        lds_barrier();  // the previous step's readers are done with Ws
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              const uint4 v = wp[(size_t)(t * 2 + s) * Cout];
-              wa[buf][t * 2 + s] = (gv && co_ok) ? v : z;
-            }
-        };
-        auto compute = [&](int buf) {
+        for (int i = 0; i < WI; ++i)
+          if (tid + i * 256 < WREC) Ws[tid + i * 256] = wreg[i];
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < WI; ++i) wreg[i] = wnxt[i];
+        if (ks + 2 < K16) { wload(ks + 2, wnxt); xload(ks + 2, xm0, xm1); }
+        {  // waves without a chunk multiply zeros: a branch here makes the compiler shuttle the nine accumulators
+           // between the two register files on every iteration (measured: 1.6 us per step)
           f16x8 ah, al;
-          split_record(xa[buf][0], xa[buf][1], sx, ah, al);
+          split_record(xc0, xc1, sx, ah, al);
+          f16x8 bh[9], bl[9];
 #pragma unroll
           for (int t = 0; t < 9; ++t) {
-            const f16x8 bh = *reinterpret_cast<const f16x8 *>(&wa[buf][t * 2]);
-            const f16x8 bl = *reinterpret_cast<const f16x8 *>(&wa[buf][t * 2 + 1]);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+            const uint4 wh = Ws[(lh * 18 + t * 2) * 32 + li], wl = Ws[(lh * 18 + t * 2 + 1) * 32 + li];
+            bh[t] = *reinterpret_cast<const f16x8 *>(&wh);
+            bl[t] = *reinterpret_cast<const f16x8 *>(&wl);
           }
-        };
-        load(0, 0);
-        for (int ks = 0; ks < K16; ks += 2) {
-          if (ks + 1 < K16) load(ks + 1, 1);
-          compute(0);
-          if (ks + 1 < K16) {
-            if (ks + 2 < K16) load(ks + 2, 0);
-            compute(1);
-          }
-        }
-        // ---- scatter targets of this lane's 16 accumulator rows --------------------------------------------
+          // term-major: consecutive MFMAs hit nine independent accumulators (smallest terms first: lo.hi, hi.lo, hi.hi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int m = (i & 3) + 8 * (i >> 2) + 4 * lh;
-          const int um = __shfl(u, m, 64);
-          int t = -1;
-          if (um >= 0) {
-            const int ux = um / R2, uy = (um / R) % R, uz = um % R;
-            const int ox = ux - kx + 1 - x0;
-            if (ox >= 0 && ox < SX) t = ((ox * R + uy) * R + uz) | (uy << 16) | (uz << 24);
-          }
-          tgt[i] = t;
+          for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[t], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t], acc[t], 0, 0, 0);
         }
+        xc0 = xn0; xc1 = xn1;
+        xn0 = xm0; xn1 = xm1;
       }
+      // ---- scatter targets of this lane's 16 accumulator rows: LDS cell of the centre tap | uy << 16 | uz << 24, or -1
+      int tgt[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = (i & 3) + 8 * (i >> 2) + 4 * lh;
+        const int um = __shfl(u, m, 64);
+        int t = -1;
+        if (um >= 0) {
+          const int ux = um / R2, uy = (um / R) % R, uz = um % R;
+          const int ox = ux - kx + 1 - x0;
+          if (ox >= 0 && ox < SX) t = ((ox * R + uy) * R + uz) | (uy << 16) | (uz << 24);
+        }
+        tgt[i] = t;
+      }
+      lds_barrier();  // every wave has left the K loop (Ws is free) before the accumulators are touched
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9) {
         if (active && co_ok) {
           const int dy = 1 - t9 / 3, dz = 1 - t9 % 3;  // output cell = input cell + (dy, dz) in (y, z)
+          // For ONE tap the 32 x 16 (row, lane) targets of a wave -- and those of the other waves -- are distinct cells,
+          // so the read-modify-write needs no atomics: all reads, then all writes.
+          int ad[16];
+          float v[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int t = tgt[i];
             const int oy = ((t >> 16) & 0xFF) + dy, oz = ((t >> 24) & 0xFF) + dz;
-            if (t >= 0 && oy >= 0 && oy < R && oz >= 0 && oz < R)
-              atomicAdd(&accs[((t & 0xFFFF) + dy * R + dz) * LD + li], acc[t9][i] * post);
+            // masked-off rows go to a per-lane sink cell: every lane issues the same 16 reads and 16 writes, no branches
+            ad[i] = (t >= 0 && oy >= 0 && oy < R && oz >= 0 && oz < R) ? ((t & 0xFFFF) + dy * R + dz) * LD + li : SINK + lane;
           }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = accs[ad[i]];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] += acc[t9][i] * post;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) accs[ad[i]] = v[i];
         }
-        if (multi) __syncthreads();
+        if (multi) lds_barrier();
       }
-      if (!multi) __syncthreads();
+      if (!multi) lds_barrier();
     }
   }
   __syncthreads();
   float *ob = out + (size_t)bi * Cout * R3 + (size_t)x0 * R2;
-  for (int e = tid; e < NV * 32; e += 256) {
-    const int c = e / NV, p = e % NV;
-    if (co0 + c < Cout) ob[(size_t)(co0 + c) * R3 + p] = accs[p * LD + c];
+  for (int e = tid; e < NV * 8; e += 256) {  // 4 consecutive cells of one channel per thread: 16-byte stores
+    const int c = e / (NV / 4), p = (e % (NV / 4)) * 4;
+    if (co0 + c < Cout) {
+      const float4 v = make_float4(accs[p * LD + c], accs[(p + 1) * LD + c], accs[(p + 2) * LD + c], accs[(p + 3) * LD + c]);
+      *reinterpret_cast<float4 *>(ob + (size_t)(co0 + c) * R3 + p) = v;
+    }
   }
 }
 
@@ -340,7 +377,7 @@ extern "C" int bdm_sparse_conv_fused(int b, int cin, int cout, int r, int n_max,
   hipStream_t s = (hipStream_t)stream;
 #define FUSED_LAUNCH(R, SX)                                                                                          \
   do {                                                                                                               \
-    const size_t smem = sizeof(float) * (size_t)(SX) * (R) * (R) * 33;                                               \
+    const size_t smem = sizeof(float) * (((size_t)(SX) * (R) * (R) * 33 + 64 + 3) / 4 * 4) + 16 * (size_t)(2 * 18 * 32); \
     BDM_ALLOW_LDS((sparse_conv_fused_kernel<R, SX>), smem);                                                          \
     hipLaunchKernelGGL((sparse_conv_fused_kernel<R, SX>), dim3((R) / (SX), cdiv(cout, 32), b), dim3(256), smem, s, G, \
                        cout, n_max, (const float4 *)xr, amax, (const uint4 *)packed_w, inv_scale, occ_list, n_occ,   \

@@ -162,9 +162,10 @@ class PVConv(nn.Module):
     conv_impl = os.environ.get("BDM_CONV", "fp16x3")
     sparse_first_conv = os.environ.get("BDM_SPARSE_CONV1", "1") == "1"
     sparse_resolutions = {int(v) for v in os.environ.get("BDM_SPARSE_R", "8,16,32").split(",") if v}
-    # first convolution on the occupied voxels: "fused" (default; sparse_conv_fused.hip: one kernel, fp16x3, accumulators in
-    # LDS) | "bf16x6" (batched GEMM + gather over a 27x-expanded intermediate, sparse_conv.hip) | "fp32" (same, fp32 MFMA)
-    sparse_gemm = {"fp32": "sparse", "bf16x6": "sparse_s3"}.get(os.environ.get("BDM_SPARSE_GEMM", "fused"), "sparse_fused")
+    # first convolution on the occupied voxels: "bf16x6" (default: batched GEMM + gather over a 27x-expanded intermediate,
+    # sparse_conv.hip) | "fp32" (same, fp32 MFMA) | "fused" (sparse_conv_fused.hip: one kernel, fp16x3, accumulators in LDS;
+    # correct and deterministic but measured SLOWER on MI355X -- DESIGN.md section 7 -- so it is opt-in)
+    sparse_gemm = {"fp32": "sparse", "bf16x6": "sparse_s3"}.get(os.environ.get("BDM_SPARSE_GEMM", "bf16x6"), "sparse_fused")
 
     def _packed_weight(self, conv, impl):
         key = (id(conv), impl)

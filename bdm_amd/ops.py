@@ -433,6 +433,7 @@ def sparse_conv_pack_fused(weight):
     return packed, inv_scale
 
 
+SPARSE_Y_BYTES = int(float(os.environ.get("BDM_SPARSE_Y_MB", "256")) * 2 ** 20)
 _amax_rings = {}
 
 
@@ -506,24 +507,36 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout):
                                           L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(bias), L.ptr(out), L.stream()),
                 "sparse_conv_fused")
         return out
-    y = torch.empty(B, plan.n_max, 27 * cout, dtype=torch.float32, device=dev)
-    if wt.dtype == torch.bfloat16:  # bf16x6: pre-split operands (sparse_conv_pack_s3)
-        xs = torch.empty(B, (C + 7) // 8, 3, plan.n_max, 8, dtype=torch.bfloat16, device=dev)
-        L.check(lib.bdm_sparse_voxel_features_s3(B, C, n, r, plan.n_max, L.ptr(f), L.c_ll(bs_f), ld_f, L.ptr(plan.cnt),
+    out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
+    # The 27x-expanded intermediate Y (n_occ x 27*cout fp32 per shape) is written by the GEMM and read once by the gather.
+    # Shapes are processed in groups whose Y stays within BDM_SPARSE_Y_MB (default 256 MiB, about the memory-side cache),
+    # reusing ONE Y buffer.  Measured (tools/sparse_bench.py): two groups of 8 at the 64 -> 64 / 32^3 layer: 287 -> 261 us;
+    # smaller groups lose more to the extra launches than they gain.
+    per_shape = plan.n_max * 27 * cout * 4
+    gb = max(1, min(B, SPARSE_Y_BYTES // max(per_shape, 1)))
+    y = torch.empty(gb, plan.n_max, 27 * cout, dtype=torch.float32, device=dev)
+    s3 = wt.dtype == torch.bfloat16  # bf16x6: pre-split operands (sparse_conv_pack_s3)
+    G8 = (C + 7) // 8
+    if s3:
+        xs = torch.empty(B, G8, 3, plan.n_max, 8, dtype=torch.bfloat16, device=dev)
+        L.check(lib.bdm_sparse_voxel_features_s3(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt),
                                                  L.ptr(plan.ws), L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xs), L.stream()),
                 "sparse_voxel_features_s3")
-        L.check(lib.bdm_sparse_conv_gemm_s3(B, plan.n_max, C, 27 * cout, L.ptr(xs), L.ptr(wt), L.ptr(plan.n_occ), L.ptr(y),
-                                            L.stream()), "sparse_conv_gemm_s3")
     else:
-        xc = torch.empty(B, C, plan.n_max, dtype=torch.float32, device=dev)
-        L.check(lib.bdm_sparse_voxel_features(B, C, n, r, plan.n_max, L.ptr(f), L.c_ll(bs_f), ld_f, L.ptr(plan.cnt),
-                                              L.ptr(plan.ws), L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xc), L.stream()),
+        xs = torch.empty(B, C, plan.n_max, dtype=torch.float32, device=dev)
+        L.check(lib.bdm_sparse_voxel_features(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt),
+                                              L.ptr(plan.ws), L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xs), L.stream()),
                 "sparse_voxel_features")
-        L.check(lib.bdm_sparse_conv_gemm(B, plan.n_max, C, 27 * cout, L.ptr(xc), L.ptr(wt), L.ptr(plan.n_occ), L.ptr(y),
-                                         L.stream()), "sparse_conv_gemm")
-    out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
-    L.check(lib.bdm_sparse_conv_gather(B, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index), L.ptr(plan.rowocc), L.ptr(bias),
-                                       L.ptr(out), L.stream()), "sparse_conv_gather")
+    for b0 in range(0, B, gb):
+        nb = min(gb, B - b0)
+        if s3:
+            L.check(lib.bdm_sparse_conv_gemm_s3(nb, plan.n_max, C, 27 * cout, L.ptr(xs[b0:]), L.ptr(wt), L.ptr(plan.n_occ[b0:]),
+                                                L.ptr(y), L.stream()), "sparse_conv_gemm_s3")
+        else:
+            L.check(lib.bdm_sparse_conv_gemm(nb, plan.n_max, C, 27 * cout, L.ptr(xs[b0:]), L.ptr(wt), L.ptr(plan.n_occ[b0:]),
+                                             L.ptr(y), L.stream()), "sparse_conv_gemm")
+        L.check(lib.bdm_sparse_conv_gather(nb, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index[b0:]), L.ptr(plan.rowocc[b0:]),
+                                           L.ptr(bias), L.ptr(out[b0:]), L.stream()), "sparse_conv_gather")
     return out
 
 
