@@ -1,0 +1,218 @@
+"""Live per-kernel-class timing of the C-ABI launches (bench.py's roofline table).
+
+Every kernel of the path is launched through `_lib.lib().<bdm_function>(...)`.  While a `KernelClassProfiler` is
+installed the library handle is a thin proxy: every `every`-th call of each (function, shape signature) is bracketed by
+two HIP events recorded on the stream the launch goes to (torch's current stream at that moment -- the main stream or one
+of the side streams), so durations are measured on the device, inside the timed region, without synchronising anything.
+The algorithmic work of a call (FLOPs for the matrix-core kernels, bytes for the streaming kernels) is computed from its
+arguments with the per-unit formulas of SURVEY.md 8(d) / DESIGN.md section 4, so that each class gets
+
+    share  = its part of the summed kernel time (sampled durations scaled by calls / samples)
+    frac   = achieved algorithmic rate / the peak that bounds it (dense 16-bit MFMA peak / products per fp32 product for
+             the split-precision convolutions and GEMMs, fp32 MFMA peak for fp32-input MFMA, HBM peak for streaming kernels)
+
+Several kernels may sit behind one ABI function (template instantiations chosen by shape); rows are therefore keyed by
+(function, shape signature) and then folded into classes.  Timing a launch with events costs two marker packets on its
+queue; with every = 8 that is ~70 of ~2400 packets per reverse step.
+"""
+import collections
+
+import torch
+
+from . import _lib as L
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+MFMA16_PEAK_TFLOPS = 2500.0      # dense fp16 / bf16 MFMA
+MFMA32_PEAK_TFLOPS = 157.3       # fp32-input MFMA
+
+
+def _f(flops, products):
+    return ("mfma", flops, MFMA16_PEAK_TFLOPS / products)
+
+
+# name -> (class, signature(args) , cost(args) -> ("mfma", flops, peak_tflops) | ("hbm", bytes) | None)
+def _conv_h2(a):
+    b, cin, cout, r = a[0], a[1], a[2], a[3]
+    return _f(2.0 * 27 * cin * cout * r ** 3 * b, 3)
+
+
+def _conv_s3(a):
+    b, cin, cout, r = a[0], a[1], a[2], a[3]
+    return _f(2.0 * 27 * cin * cout * r ** 3 * b, 6)
+
+
+def _conv_f32(a):
+    b, cin, cout, r = a[0], a[1], a[2], a[3]
+    return ("mfma", 2.0 * 27 * cin * cout * r ** 3 * b, MFMA32_PEAK_TFLOPS)
+
+
+def _pw(a):
+    b, m, k, n = a[0], a[1], a[2], a[3]
+    return ("mfma", 2.0 * b * m * k * n, MFMA32_PEAK_TFLOPS)
+
+
+def _attn(a):
+    b, c, l = a[0], a[1], a[2]
+    return _f(4.0 * b * c * l * l, 6) if l > 64 else ("hbm", 4.0 * 4 * b * c * l)
+
+
+SPEC = {
+    # dense 3x3x3 voxel convolutions
+    "bdm_conv3d_3x3x3_h2": ("dense conv3d (fp16x3)", lambda a: a[:4], _conv_h2),
+    "bdm_conv3d_3x3x3_s3": ("dense conv3d (bf16x6)", lambda a: a[:4], _conv_s3),
+    "bdm_conv3d_3x3x3": ("dense conv3d (fp32 MFMA)", lambda a: a[:4], _conv_f32),
+    "bdm_conv3d_3x3x3_sparse": ("dense conv3d (fp32 MFMA)", lambda a: a[:4], _conv_f32),
+    # sparse first convolution: GEMM over n_max rows (upper bound of the occupied rows: FLOPs counted on n_max are an
+    # over-estimate, so no peak fraction is claimed for it), features and gather are streaming kernels
+    "bdm_sparse_conv_gemm_s3": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), None),
+    "bdm_sparse_conv_gemm": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), None),
+    "bdm_sparse_conv_gather": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), None),
+    "bdm_sparse_voxel_features_s3": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), None),
+    "bdm_sparse_voxel_features": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), None),
+    "bdm_sparse_voxel_features_f32": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), None),
+    "bdm_sparse_conv_fused": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), None),
+    # 1x1 convolutions / linear layers
+    "bdm_pointwise_conv": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:4], _pw),
+    # normalisation and operand repacks: 1 read + 1 write of the tensor
+    "bdm_group_norm": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", 8.0 * a[0] * a[1] * a[2])),
+    "bdm_group_norm_to_h2": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", (4.0 + 4.0 + 4.0) * a[0] * a[1] * a[2])),
+    "bdm_group_norm_to_s3": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", (4.0 + 4.0 + 6.0) * a[0] * a[1] * a[2])),
+    "bdm_attention_core": ("attention", lambda a: a[:3], _attn),
+    # point operators (SURVEY.md 8d byte formulas)
+    "bdm_furthest_point_sampling": ("furthest point sampling", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * (3 * a[1] + 4 * a[2]))),
+    "bdm_ball_query": ("ball query + grouping", lambda a: (a[0], a[1], a[2], a[4]),
+                       lambda a: ("hbm", 4.0 * a[0] * (3 * a[1] + 3 * a[2] + a[2] * a[4]))),
+    "bdm_sa_group": ("ball query + grouping", lambda a: a[:5],
+                     lambda a: ("hbm", 4.0 * a[0] * ((3 + a[1]) * a[2] + a[3] * a[4] + (a[1] + 3) * a[3] * a[4]))),
+    "bdm_grouping_forward": ("ball query + grouping", lambda a: a[:5],
+                             lambda a: ("hbm", 4.0 * a[0] * (a[1] * a[2] + a[3] * a[4] + a[1] * a[3] * a[4]))),
+    "bdm_max_over_neighbors": ("ball query + grouping", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] * (a[3] + 1))),
+    "bdm_three_nn_search": ("3-NN interpolation", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 3 * a[1] + 6 * a[2]))),
+    "bdm_three_nn_apply": ("3-NN interpolation", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (a[1] * a[2] + a[1] * a[3] + 6 * a[3]))),
+    "bdm_voxelize_plan_full": ("voxelize / devoxelize", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * (4 * a[1] + 3 * a[2] ** 3))),
+    "bdm_voxel_coords": ("voxelize / devoxelize", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * 9 * a[1])),
+    "bdm_devoxelize_gate_add": ("voxelize / devoxelize", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 10 * a[1] * a[2]))),
+    "bdm_se_gate": ("SE gate", lambda a: (a[0], a[1], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[3])),
+    "bdm_copy_rows": ("concat / broadcast / transpose copies", lambda a: a[:3], lambda a: ("hbm", 8.0 * a[0] * a[1] * a[2])),
+    "bdm_broadcast_rows": ("concat / broadcast / transpose copies", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2])),
+    "bdm_transpose": ("concat / broadcast / transpose copies", lambda a: a[:3], lambda a: ("hbm", 8.0 * a[0] * a[1] * a[2])),
+    "bdm_rasterize_points": ("projection conditioning", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * 4 * a[1])),
+    "bdm_condition_gather": ("projection conditioning", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * a[1] * (2 * a[2] + 7))),
+    "bdm_ddpm_step": ("scheduler step / blend", lambda a: a[:1], lambda a: ("hbm", 16.0 * a[0])),
+    "bdm_ddpm_step_philox": ("scheduler step / blend", lambda a: a[:2], lambda a: ("hbm", 12.0 * a[0] * a[1])),
+    "bdm_pvd_step": ("scheduler step / blend", lambda a: a[:1], lambda a: ("hbm", 16.0 * a[0])),
+    "bdm_pvd_step_philox": ("scheduler step / blend", lambda a: a[:2], lambda a: ("hbm", 12.0 * a[0] * a[1])),
+    "bdm_blend_select": ("scheduler step / blend", lambda a: a[:1], lambda a: ("hbm", (36.0 + 8.0) * a[0])),
+    "bdm_center_points": ("scheduler step / blend", lambda a: a[:2], lambda a: ("hbm", 24.0 * a[0] * a[1])),
+    "bdm_philox_normal": ("scheduler step / blend", lambda a: a[:2], lambda a: ("hbm", 4.0 * a[0] * a[1])),
+    "bdm_philox_bits": ("scheduler step / blend", lambda a: a[:2], lambda a: ("hbm", 8.0 * a[0] * a[1])),
+    "bdm_time_embedding": ("time embedding", lambda a: a[:2], None),
+}
+
+
+def _plain(v):
+    return v.value if hasattr(v, "value") else v
+
+
+class _Proxy:
+    def __init__(self, handle, prof):
+        self.__dict__["_h"], self.__dict__["_p"] = handle, prof
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        host_only = (not name.startswith("bdm_") or name.endswith("_bytes") or name.endswith("_elems")
+                     or name in ("bdm_last_error", "bdm_abi_version"))
+        if host_only:
+            return fn
+        spec = SPEC.get(name, ("other", lambda a: (), None))
+        prof = self._p
+
+        def call(*args):
+            if not prof.enabled or torch.cuda.is_current_stream_capturing():
+                return fn(*args)
+            try:
+                sig = tuple(int(_plain(v)) for v in spec[1](args))
+            except (TypeError, ValueError):
+                sig = ()
+            row = prof.rows[(name, sig)]
+            row[0] += 1
+            if row[0] % prof.every:
+                return fn(*args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            cost = None
+            if spec[2] is not None:
+                try:
+                    cost = spec[2]([_plain(v) for v in args[:8]])
+                except (TypeError, ValueError, IndexError):
+                    cost = None
+            row[1].append((e0, e1, cost))
+            return rc
+        self.__dict__[name] = call  # cache the wrapper
+        return call
+
+
+class KernelClassProfiler:
+    def __init__(self, every=8):
+        self.every, self.enabled = int(every), False
+        self.rows = collections.defaultdict(lambda: [0, []])  # (name, sig) -> [calls, [(e0, e1, cost)]]
+        self._saved = None
+
+    def install(self):
+        handle = L.lib()
+        self._saved = handle
+        L._lib = _Proxy(handle, self)
+        self.enabled = True
+        return self
+
+    def remove(self):
+        self.enabled = False
+        if self._saved is not None:
+            L._lib = self._saved
+            self._saved = None
+
+    def table(self):
+        """(rows, classes): rows = per (function, shape) dicts, classes = per kernel class dicts sorted by time share."""
+        rows = []
+        for (name, sig), (calls, samples) in self.rows.items():
+            if not samples:
+                continue
+            ms = [e0.elapsed_time(e1) for e0, e1, _ in samples]
+            avg_us = 1e3 * sum(ms) / len(ms)
+            cost = samples[0][2]
+            rows.append({"function": name, "shape": list(sig), "class": SPEC.get(name, ("other",))[0], "calls": calls,
+                         "sampled": len(samples), "avg_us": avg_us, "est_total_ms": avg_us * calls / 1e3, "cost": cost})
+        total = sum(r["est_total_ms"] for r in rows) or 1.0
+        classes = {}
+        for r in rows:
+            c = classes.setdefault(r["class"], {"class": r["class"], "est_total_ms": 0.0, "calls": 0, "flops": 0.0, "bytes": 0.0,
+                                                "mfma_ms": 0.0, "hbm_ms": 0.0, "peak_tflops": None})
+            c["est_total_ms"] += r["est_total_ms"]
+            c["calls"] += r["calls"]
+            if r["cost"] is not None:
+                if r["cost"][0] == "mfma":
+                    c["flops"] += r["cost"][1] * r["calls"]
+                    c["mfma_ms"] += r["est_total_ms"]
+                    c["peak_tflops"] = r["cost"][2] if c["peak_tflops"] is None else max(c["peak_tflops"], r["cost"][2])
+                else:
+                    c["bytes"] += r["cost"][1] * r["calls"]
+                    c["hbm_ms"] += r["est_total_ms"]
+        out = []
+        for c in classes.values():
+            d = {"class": c["class"], "share": c["est_total_ms"] / total, "kernel_ms": c["est_total_ms"], "launches": c["calls"]}
+            if c["flops"] > 0 and c["mfma_ms"] > 0 and c["mfma_ms"] >= c["hbm_ms"]:
+                ach = c["flops"] / (c["mfma_ms"] * 1e-3) / 1e12
+                d.update(bound="mfma", achieved=ach, peak=c["peak_tflops"], unit="TFLOP/s", frac=ach / c["peak_tflops"])
+            elif c["bytes"] > 0 and c["hbm_ms"] > 0:
+                ach = c["bytes"] / (c["hbm_ms"] * 1e-3) / 1e9
+                d.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
+            else:
+                d.update(bound=None, achieved=None, peak=None, unit=None, frac=None)
+            out.append(d)
+        out.sort(key=lambda d: -d["share"])
+        for r in rows:
+            r["share"] = r["est_total_ms"] / total
+        rows.sort(key=lambda r: -r["est_total_ms"])
+        return rows, out

@@ -13,11 +13,16 @@ collective on the data path; one barrier + MAX-over-ranks for timing).
         bench.py --gpus N --steps K --warmup W
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel (3x3x3 voxel convolution 64->64 on the 32^3 grid, bf16x6 arithmetic): algorithmic
-                  fp32 FLOPs of the launches timed with HIP events inside the timed region / their summed duration,
-                  vs the dense bf16 matrix peak of MI355X_MICROARCH.md (2.5 PFLOP/s) / 6 partial products.
-  cpu_baseline -- the CPU oracle ("port": oracle/ref_net.py + oracle/pvcnn_ops_ref.c, the reference has no CPU
-                  path) timed on this box's host cores on a bounded sample and extrapolated to a trajectory.
+  roofline       -- the kernel CLASS with the largest share of kernel time (live HIP-event sampling of every 8th launch of
+                    every C-ABI function inside the timed region, bdm_amd/profiling.py): achieved = algorithmic FLOPs (or
+                    bytes) of its launches / their summed duration, against the peak that bounds it (dense 16-bit MFMA peak
+                    / 3 partial products for the fp16x3 convolution); `kernel` names the heaviest (function, shape) row of
+                    the class, whose avg_launch_us is the number to compare with the rocprofv3 summary under profiles/.
+                    `traffic` comes from the committed PMC pass profiles/r02_pmc_traffic.json (same kernel; the JSON records
+                    the commit it was measured at).
+  roofline_table -- every kernel class: share of kernel time, launches, achieved vs peak.
+  cpu_baseline   -- the CPU oracle ("port": oracle/ref_net.py + oracle/pvcnn_ops_ref.c, the reference has no CPU
+                    path) timed on this box's host cores on a bounded sample and extrapolated to a trajectory.
 """
 import argparse
 import json
@@ -35,56 +40,6 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5
 CONV_IMPL = os.environ.get("BDM_CONV", "fp16x3")
 SPLIT_PRODUCTS = 3 if CONV_IMPL == "fp16x3" else 6  # 16-bit MFMA products issued per fp32 multiply-add by the convolution
 MILESTONES = [1000, 968, 936, 872, 128, 64, 32, 0]
-
-
-class ConvTimer:
-    """HIP-event timing of the launches of ONE kernel instantiation -- conv3d_s3_kernel<2,4,32,2,8>, the bf16x6 3x3x3
-    voxel convolution with Cout > 32 on the 32^3 grid -- on the stream they are enqueued on (torch's current stream),
-    sampled every `every`-th launch inside the timed region."""
-
-    def __init__(self, every=8):
-        self.every, self.count, self.pairs = every, 0, []
-
-    def wants(self, cout, r):
-        return cout > 32 and r == 32
-
-    def begin(self, b, cin, cout, r):
-        self.count += 1
-        if self.count % self.every:
-            return None
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        return (e0, e1, 2.0 * 27 * cin * cout * r ** 3 * b)
-
-    def end(self, tok):
-        if tok is not None:
-            tok[1].record()
-            self.pairs.append(tok)
-
-    def summary(self):
-        if not self.pairs:
-            return None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.pairs)
-        fl = sum(f for _, _, f in self.pairs)
-        return dict(launches_timed=len(self.pairs), launches_total=self.count, avg_us=ms * 1e3 / len(self.pairs),
-                    tflops=fl / (ms * 1e-3) / 1e12)
-
-
-def install_conv_timer(timer):
-    from bdm_amd import ops
-    name = "conv3d_h2" if CONV_IMPL == "fp16x3" else "conv3d_s3"
-    raw = getattr(ops, name)
-
-    def timed(x_split, packed_w, bias, cin, cout, r):
-        if timer is not None and timer.wants(cout, r) and not torch.cuda.is_current_stream_capturing():
-            tok = timer.begin((x_split[0] if isinstance(x_split, tuple) else x_split).shape[0], cin, cout, r)
-            y = raw(x_split, packed_w, bias, cin, cout, r)
-            timer.end(tok)
-            return y
-        return raw(x_split, packed_w, bias, cin, cout, r)
-
-    setattr(ops, name, timed)
-    return raw
 
 
 def host_cores():
@@ -208,7 +163,7 @@ def main():
     from bdm_amd.distributed import barrier, init_from_env, max_over_ranks, shard_indices
     from bdm_amd.model import get_model
     from bdm_amd.pvd import prepare_pvd_model
-    from bdm_amd.sampling import bdm_blending, count_forwards
+    from bdm_amd.sampling import batch_streams, bdm_blending, count_forwards
     from bdm_amd.utils.procedural import fill_module_
 
     rank, local_rank, world = init_from_env()
@@ -234,10 +189,14 @@ def main():
     batch = next(iter(SyntheticShapes(shard_indices(total_shapes, rank, world), args.batch, seed=cfg.run.seed,
                                       image_size=224, num_points=args.points))).to(device)
     gen = torch.Generator().manual_seed(cfg.run.seed + rank)
+    cfg.run.rng = "per_shape"  # every draw from the shapes' own Philox streams keyed by (seed, GLOBAL shape index): the
+    counter = [0]              # samples do not depend on the number of ranks
 
     def trajectory():
         model._cond_cache = None  # the hoisted image encoder runs once per trajectory, inside the timed region
-        return bdm_blending(None, batch, cfg, model, pvd_model, generator=gen).points_padded()
+        counter[0] += 1
+        return bdm_blending(None, batch, cfg, model, pvd_model,
+                            streams=batch_streams(cfg, batch, device, sample_idx=counter[0])).points_padded()
 
     # prime allocator / code objects (not a "step": a 2-forward schedule)
     prime_cfg = ProjectConfig()
@@ -248,8 +207,8 @@ def main():
         trajectory()
 
     model.eager_probe_every = 50  # only with BDM_GRAPH=1: every 50th step runs eagerly so that single launches can be timed
-    timer = ConvTimer(every=8)
-    install_conv_timer(timer)
+    from bdm_amd.profiling import KernelClassProfiler
+    prof = KernelClassProfiler(every=8).install()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -258,6 +217,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0, device)
+    prof.remove()
     assert torch.isfinite(out).all()
 
     if rank == 0:
@@ -268,6 +228,7 @@ def main():
             "metric": "sampled shapes/sec (4096 pts, 1000 DDPM steps)", "value": value, "unit": "shapes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rng": "per-shape Philox4x32-10 streams keyed by (seed, global shape index), noise generated inside the step kernels",
             "conv_arithmetic": CONV_IMPL + (" (fp32-grade: operands as two fp16 terms after power-of-two scaling, three partial "
                                                     "products, fp32 accumulate; first conv of each PVConv: sparse, bf16x6)"
                                                     if CONV_IMPL == "fp16x3" else " (fp32-grade: exact 3-way bf16 operand split, "
@@ -279,26 +240,31 @@ def main():
         }
         if args.ddpm_steps != 1000 or args.points != 4096:
             line["invalid"] = "smoke configuration: not the metric's workload"
-        if conv:
-            peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
-            traffic = None  # HBM bytes per launch from the PMC pass committed under profiles/ (separate run, same kernel/shape)
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")))
-                traffic = pm["traffic_mb_per_launch"] * 2 ** 20
+        rows, classes = prof.table()
+        if classes:
+            top = classes[0]
+            top_rows = [r for r in rows if r["class"] == top["class"]]
+            head = top_rows[0]
+            traffic, traffic_commit = None, None
+            try:  # HBM bytes per launch of that kernel from the committed PMC pass (separate rocprofv3 --pmc runs)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+                ent = pm["kernels"].get(f"{head['function']}{tuple(head['shape'])}")
+                if ent:
+                    traffic, traffic_commit = ent["bytes_per_launch"], pm.get("commit")
             except (OSError, KeyError, ValueError):
                 pass
-            line["roofline"] = {"bound": "mfma", "achieved": conv["tflops"], "peak": peak, "unit": "TFLOP/s",
-                                "frac": conv["tflops"] / peak, "traffic": traffic,
-                                "kernel": ("conv3d_h2_kernel<2,2,32,2,8,8> (3x3x3 voxel conv, fp16x3, Cout>32, 32^3 grid)"
-                                           if CONV_IMPL == "fp16x3" else
-                                           "conv3d_s3_kernel<2,4,32,2,8> (3x3x3 voxel conv, bf16x6 split, Cout>32, 32^3 grid)"),
-                                "note": "achieved = ALGORITHMIC fp32 FLOPs (2*27*Cin*Cout*r^3*B) / launch time; every fp32 product is "
-                                        f"{SPLIT_PRODUCTS} 16-bit MFMA products, so peak = 2500 TFLOP/s dense fp16/bf16 / {SPLIT_PRODUCTS}; "
-                                        "the fp32-input MFMA peak would be 157.3 TFLOP/s",
-                                "executed_16bit_tflops": conv["tflops"] * SPLIT_PRODUCTS,
-                                "frac_of_fp32_mfma_peak": conv["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                                "avg_launch_us": conv["avg_us"], "launches_timed": conv["launches_timed"],
-                                "launches_total": conv["launches_total"]}
+            line["roofline"] = {"bound": top["bound"], "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+                                "frac": top["frac"], "traffic": traffic, "traffic_commit": traffic_commit,
+                                "kernel_class": top["class"], "share_of_kernel_time": top["share"],
+                                "kernel": f"{head['function']}{tuple(head['shape'])}", "avg_launch_us": head["avg_us"],
+                                "launches_timed": sum(r["sampled"] for r in top_rows),
+                                "launches_total": sum(r["calls"] for r in top_rows),
+                                "note": "class with the largest share of kernel time; achieved = ALGORITHMIC work of its launches "
+                                        "/ their summed duration (HIP events on the launching stream, every 8th launch); for the "
+                                        "fp16x3 convolution every fp32 product is 3 fp16 MFMA products: peak = 2500 TFLOP/s / 3"}
+            line["roofline_table"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in c.items()} for c in classes]
+            line["roofline_rows"] = [{"kernel": f"{r['function']}{tuple(r['shape'])}", "class": r["class"], "share": round(r["share"], 4),
+                                      "avg_us": round(r["avg_us"], 2), "launches": r["calls"]} for r in rows[:12]]
         # whole-path view: algorithmic FLOPs of SURVEY.md 8d per trajectory
         tflop_per_shape = (pc2_f * 103.64 + pvd_f * 81.22) / 1e3 if args.points == 4096 else None
         if tflop_per_shape:

@@ -19,7 +19,7 @@ from helpers import rel_l2
 import trajectory_case as case
 
 pytestmark = pytest.mark.gpu
-HEAD_SCALE = 0.01
+HEAD_SCALE = 0.1
 NORTH_STAR = 1e-3
 
 
