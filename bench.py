@@ -223,7 +223,6 @@ def main():
     if rank == 0:
         pc2_f, pvd_f, _ = count_forwards(cfg.aux_run.milestones, cfg.aux_run.roll_step)
         value = total_shapes * args.steps / elapsed
-        conv = timer.summary()
         line = {
             "metric": "sampled shapes/sec (4096 pts, 1000 DDPM steps)", "value": value, "unit": "shapes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
