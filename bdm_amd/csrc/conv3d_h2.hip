@@ -287,7 +287,7 @@ extern "C" int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *
 // ---------------------------------------------------------------------------------------------------
 __global__ void to_h2_kernel(int C, int V, int G, int S, const float *__restrict__ x, const double *__restrict__ partial,
                              const float *__restrict__ gamma, const float *__restrict__ beta, float eps, int act,
-                             float act_scale, unsigned short *__restrict__ out) {
+                             float act_scale, unsigned short *__restrict__ out, unsigned *__restrict__ saturated) {
   __shared__ float s_mean[64], s_rstd[64];
   const int bi = blockIdx.z, c8 = blockIdx.y, C8 = gridDim.y;
   const int cg = C / G;
@@ -307,6 +307,7 @@ __global__ void to_h2_kernel(int C, int V, int G, int S, const float *__restrict
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   float val[8];
+  bool sat = false;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int ch = c8 * 8 + j;
@@ -320,8 +321,12 @@ __global__ void to_h2_kernel(int C, int V, int G, int S, const float *__restrict
       }
     }
     val[j] = t * act_scale;  // a power of two: exact
+    sat |= !(fabsf(val[j]) <= 65504.f);  // beyond fp16's range (or NaN): split2 clamps -- the caller must be told
   }
   store_h2(out + ((size_t)bi * C8 + c8) * 2 * (size_t)V * 8, (size_t)v, (size_t)V, val);
+  // one sticky word per layer; an OR is order-independent, and the word is only ever written when something saturated
+  if (saturated != nullptr && __ballot(sat) != 0ull && (threadIdx.x & 63) == __ffsll((long long)__ballot(sat)) - 1)
+    atomicOr(saturated, 1u);
 }
 
 extern "C" int bdm_group_norm_stats(int b, int c, int l, int groups, const float *x, long long bs_x, void *workspace,
@@ -329,7 +334,7 @@ extern "C" int bdm_group_norm_stats(int b, int c, int l, int groups, const float
 
 extern "C" int bdm_group_norm_to_h2(int b, int c, int v, int groups, const float *x, const float *gamma,
                                     const float *beta, float eps, int act, float act_scale, void *out_h2, void *workspace,
-                                    void *stream) {
+                                    unsigned int *saturated, void *stream) {
   BDM_REQUIRE(b >= 0 && c >= 1 && v >= 1, "group_norm_to_h2: bad sizes");
   {
     int ex = 0;
@@ -345,6 +350,7 @@ extern "C" int bdm_group_norm_to_h2(int b, int c, int v, int groups, const float
   }
   dim3 grid(cdiv(v, 256), (c + 7) / 8, b);
   hipLaunchKernelGGL(to_h2_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, v, groups > 0 ? groups : 1, S, x,
-                     groups > 0 ? (const double *)workspace : nullptr, gamma, beta, eps, act, act_scale, (unsigned short *)out_h2);
+                     groups > 0 ? (const double *)workspace : nullptr, gamma, beta, eps, act, act_scale, (unsigned short *)out_h2,
+                     saturated);
   return launch_status("group_norm_to_h2");
 }

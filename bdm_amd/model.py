@@ -290,6 +290,7 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
             return self.tensor_to_point_cloud(x_t, denormalize=True, unscale=True), \
                 [self.tensor_to_point_cloud(o, denormalize=True, unscale=True) for o in all_outputs]
         x_t = self._denoise_loop(x_t, camera, image_rgb, mask, scheduler, ts)
+        ops.poll_h2_saturation()  # fp16x3 accuracy guard: one host check per trajectory
         return self.tensor_to_point_cloud(x_t, denormalize=True, unscale=True)
 
     @torch.no_grad()

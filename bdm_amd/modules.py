@@ -225,8 +225,11 @@ class PVConv(nn.Module):
                 v = ops.conv3d_s3(x3, self._packed_weight(conv1, "bf16x6"), conv1.bias, conv1.in_channels,
                                   conv1.out_channels, r)
             # GroupNorm + Swish fused into the operand split of the second conv
-            if self.conv_impl == "fp16x3":
-                v = ops.conv3d_h2(ops.to_h2(v, gn1, swish=True), self._packed_weight(conv2, "fp16x3"), conv2.bias,
+            if self.conv_impl == "fp16x3" and not getattr(self, "h2_saturated", False):
+                # saturation guard: to_h2 raises this layer's sticky device word when a scaled activation leaves fp16's
+                # range; ops.poll_h2_saturation() (once per trajectory) then routes the layer to bf16x6 and warns
+                sat = ops.saturation_slot(self, v.device) if v.is_cuda else None
+                v = ops.conv3d_h2(ops.to_h2(v, gn1, swish=True, saturated=sat), self._packed_weight(conv2, "fp16x3"), conv2.bias,
                                   conv2.in_channels, conv2.out_channels, r)
             else:
                 v = ops.conv3d_s3(ops.to_s3(v, gn1, swish=True), self._packed_weight(conv2, "bf16x6"), conv2.bias,

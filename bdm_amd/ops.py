@@ -372,9 +372,56 @@ def h2_activation_scale(gn, sigmas=64.0):
     return hit[1]
 
 
-def to_h2(x, gn=None, swish=False, scale=None):
+_sat_registry = {}  # device -> [flags tensor (int32, 256 slots), [weakref(owner) per slot]]
+
+
+def saturation_slot(owner, device):
+    """One sticky device word per fp16x3 layer (`owner` = its PVConv): set by to_h2 when a value left fp16's range."""
+    import weakref
+    key = str(device)
+    reg = _sat_registry.get(key)
+    if reg is None:
+        reg = _sat_registry[key] = [torch.zeros(256, dtype=torch.int32, device=device), []]
+    slots = getattr(owner, "_bdm_sat_slots", None)
+    if slots is None:
+        slots = owner._bdm_sat_slots = {}
+    idx = slots.get(key)
+    if idx is None:
+        if len(reg[1]) >= reg[0].numel():
+            raise L.BdmHipError("more than 256 fp16x3 layers on one device")
+        idx = slots[key] = len(reg[1])
+        reg[1].append(weakref.ref(owner))
+    return reg[0][idx:idx + 1]
+
+
+def poll_h2_saturation():
+    """Host check of the saturation words (ONE small device->host copy; the samplers call it once per trajectory, never per
+    step).  Every flagged layer is switched to the bf16x6 kernels (exact split, no range limit) for all later calls and a
+    warning names it: the trajectory that just finished used clamped activations in that layer."""
+    import warnings
+    hit = []
+    for key, (flags, owners) in _sat_registry.items():
+        if not owners:
+            continue
+        host = flags[:len(owners)].cpu()
+        for i, ref in enumerate(owners):
+            m = ref()
+            if m is not None and int(host[i]) != 0 and not getattr(m, "h2_saturated", False):
+                m.h2_saturated = True
+                hit.append(m)
+        if hit:
+            flags.zero_()
+    if hit:
+        warnings.warn(f"fp16x3 convolution input saturated (|scale * y| > 65504) in {len(hit)} layer(s): "
+                      f"{[getattr(m, 'bdm_name', type(m).__name__) for m in hit]}; the trajectory that just finished used clamped "
+                      "activations there.  These layers now run the bf16x6 kernels (no range limit).", stacklevel=2)
+    return hit
+
+
+def to_h2(x, gn=None, swish=False, scale=None, saturated=None):
     """x (B, C, V) fp32 contiguous -> (H2 tensor (B, ceil(C/8), 2, V, 8) fp16 of scale * [swish(group_norm(x))], 1 / scale).
-    scale: power of two; default from the GroupNorm parameters, or (no GroupNorm: test path, host sync) from max |x|."""
+    scale: power of two; default from the GroupNorm parameters, or (no GroupNorm: test path, host sync) from max |x|.
+    saturated: optional 1-element int32 device tensor, OR-ed with 1 when a scaled value left fp16's range."""
     x = x.contiguous()
     B, C = x.shape[:2]
     V = x.numel() // (B * C)
@@ -384,11 +431,11 @@ def to_h2(x, gn=None, swish=False, scale=None):
         ws = workspace(L.lib().bdm_group_norm_workspace_bytes(B, gn.num_groups), x.device, "gn")
         L.check(L.lib().bdm_group_norm_to_h2(B, C, V, gn.num_groups, L.ptr(x), L.ptr(gn.weight), L.ptr(gn.bias),
                                              L.c_float(gn.eps), 1 if swish else 0, L.c_float(scale), L.ptr(out), L.ptr(ws),
-                                             L.stream()), "group_norm_to_h2")
+                                             L.ptr(saturated), L.stream()), "group_norm_to_h2")
     else:
         scale = _pow2_below(32768.0 / max(float(x.abs().max()), 1e-30)) if scale is None else scale
         L.check(L.lib().bdm_group_norm_to_h2(B, C, V, 0, L.ptr(x), L.ptr(None), L.ptr(None), L.c_float(0.0), 0,
-                                             L.c_float(scale), L.ptr(out), L.ptr(None), L.stream()), "to_h2")
+                                             L.c_float(scale), L.ptr(out), L.ptr(None), L.ptr(saturated), L.stream()), "to_h2")
     return out, 1.0 / scale
 
 

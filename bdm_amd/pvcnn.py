@@ -202,6 +202,9 @@ class PVCNN2Base(nn.Module):
         self.classifier = create_classifier(channels_fp_features, dropout, num_classes, width_multiplier)
         self.embedf = nn.Sequential(nn.Linear(embed_dim, embed_dim), nn.LeakyReLU(0.1, inplace=True),
                                     nn.Linear(embed_dim, embed_dim))
+        for name, m in self.named_modules():
+            if isinstance(m, PVConv):
+                m.bdm_name = name  # for diagnostics (saturation guard)
 
     @torch.no_grad()
     def forward(self, inputs, t):

@@ -15,7 +15,7 @@ import contextlib
 import torch
 
 from . import _lib as L
-from . import rng
+from . import ops, rng
 from .cameras import Pointclouds
 from .pvd import generate_pvd_xyz
 
@@ -25,7 +25,6 @@ DEFAULT_MILESTONES = [1000, 968, 936, 872, 128, 64, 32, 0]
 @torch.no_grad()
 def pvd_prior(pvd_model, points, start_time, end_time):
     """(B, N, 3) -> PVD steps t = start_time-1 ... end_time -> (B, N, 3)."""
-    from . import ops
     pts = ops.transpose12(points.float())
     out = generate_pvd_xyz(pvd_model, pts, start_time, end_time)
     return ops.transpose12(out)
@@ -115,7 +114,9 @@ def bdm_blending(accelerator, batch, cfg, model, pvd_model, generator=None, init
     streams = batch_streams(cfg, batch, device) if streams is None else streams
     sched = model.schedulers_map[cfg.run.diffusion_scheduler]
     with _streams_on(streams, (sched, rng.PC2), (pvd_model.diffusion, None)):
-        return _bdm_blending(batch, cfg, model, pvd_model, generator, init_noise, blend_masks, streams)
+        out = _bdm_blending(batch, cfg, model, pvd_model, generator, init_noise, blend_masks, streams)
+    ops.poll_h2_saturation()  # fp16x3 accuracy guard: one host check per trajectory
+    return out
 
 
 def _bdm_blending(batch, cfg, model, pvd_model, generator, init_noise, blend_masks, streams):
@@ -161,7 +162,9 @@ def bdm_merging(accelerator, batch, cfg, prior_model, recon_model, fusion_model,
     name = cfg.run.diffusion_scheduler
     with _streams_on(streams, (recon_model.schedulers_map[name], rng.PC2), (fusion_model.schedulers_map[name], rng.FUSE),
                      (prior_model.diffusion, None)):
-        return _bdm_merging(batch, cfg, prior_model, recon_model, fusion_model, init_noise, streams)
+        out = _bdm_merging(batch, cfg, prior_model, recon_model, fusion_model, init_noise, streams)
+    ops.poll_h2_saturation()
+    return out
 
 
 def _bdm_merging(batch, cfg, prior_model, recon_model, fusion_model, init_noise, streams):

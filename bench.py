@@ -13,7 +13,7 @@ collective on the data path; one barrier + MAX-over-ranks for timing).
         bench.py --gpus N --steps K --warmup W
 
 Extra objects on the JSON line:
-  roofline       -- the kernel CLASS with the largest share of kernel time (live HIP-event sampling of every 8th launch of
+  roofline       -- the kernel CLASS with the largest share of kernel time (live HIP-event sampling of every 32nd launch of
                     every C-ABI function inside the timed region, bdm_amd/profiling.py): achieved = algorithmic FLOPs (or
                     bytes) of its launches / their summed duration, against the peak that bounds it (dense 16-bit MFMA peak
                     / 3 partial products for the fp16x3 convolution); `kernel` names the heaviest (function, shape) row of
@@ -208,7 +208,7 @@ def main():
 
     model.eager_probe_every = 50  # only with BDM_GRAPH=1: every 50th step runs eagerly so that single launches can be timed
     from bdm_amd.profiling import KernelClassProfiler
-    prof = KernelClassProfiler(every=8).install()
+    prof = KernelClassProfiler(every=32).install()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -239,6 +239,15 @@ def main():
         }
         if args.ddpm_steps != 1000 or args.points != 4096:
             line["invalid"] = "smoke configuration: not the metric's workload"
+        # occupied fraction of the sparse convolutions' rows on the final clouds (after the timed region), per level
+        from bdm_amd import functional as BF, ops as bops, profiling
+        pts = out.transpose(1, 2).contiguous()
+        for r_, n_ in ((32, args.points), (16, 1024), (8, 256), (8, 64)):
+            if pts.shape[2] > n_:
+                pts = BF.furthest_point_sample(pts, n_)
+            bops.clear_plan_cache()
+            plan = bops.voxel_plan(pts, r_)
+            profiling.OCCUPANCY[plan.n_max] = float(plan.n_occ.float().mean()) / plan.n_max
         rows, classes = prof.table()
         if classes:
             top = classes[0]
@@ -259,8 +268,9 @@ def main():
                                 "launches_timed": sum(r["sampled"] for r in top_rows),
                                 "launches_total": sum(r["calls"] for r in top_rows),
                                 "note": "class with the largest share of kernel time; achieved = ALGORITHMIC work of its launches "
-                                        "/ their summed duration (HIP events on the launching stream, every 8th launch); for the "
+                                        "/ their summed duration (HIP events on the launching stream, every 32nd launch); for the "
                                         "fp16x3 convolution every fp32 product is 3 fp16 MFMA products: peak = 2500 TFLOP/s / 3"}
+            line["roofline"]["sparse_rows_occupied_fraction"] = {str(k): round(v, 4) for k, v in profiling.OCCUPANCY.items()}
             line["roofline_table"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in c.items()} for c in classes]
             line["roofline_rows"] = [{"kernel": f"{r['function']}{tuple(r['shape'])}", "class": r["class"], "share": round(r["share"], 4),
                                       "avg_us": round(r["avg_us"], 2), "launches": r["calls"]} for r in rows[:12]]

@@ -221,8 +221,12 @@ int bdm_avg_voxelize_s3(int b, int c, int n, int r, const float *features, long 
 size_t bdm_conv3d_h2_weight_elems(int cout, int cin);
 int bdm_conv3d_h2_pack_weights(int cout, int cin, const float *w, void *packed, float *scale_ws, float *inv_scale,
                                void *stream);
+/* saturated (may be NULL): one device word that is OR-ed with 1 when any scaled value left fp16's range (|act_scale * y| >
+ * 65504, or NaN) and was clamped by the split -- the accuracy guard of the fp16x3 path: the host polls the word once per
+ * trajectory and re-routes that layer to the bf16x6 kernels (bdm_amd/ops.py: poll_h2_saturation). */
 int bdm_group_norm_to_h2(int b, int c, int v, int groups, const float *x, const float *gamma, const float *beta,
-                         float eps, int act, float act_scale, void *out_h2, void *workspace, void *stream);
+                         float eps, int act, float act_scale, void *out_h2, void *workspace,
+                         unsigned int *saturated, void *stream);
 int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale, const void *packed_w,
                         const float *inv_scale, const float *bias, float *y, void *stream);
 
