@@ -60,6 +60,31 @@ extern "C" int bdm_ddpm_step_dev(long long n, const float *x, const float *eps, 
   return launch_status("ddpm_step_dev");
 }
 
+// out = ((c0*x0 + c1*x1) + c2*x2 + c3*x3) / div, left to right, k <= 4 terms: the linear multistep combinations and the
+// transfer step of the PNDM scheduler (diffusers 0.21.0 PNDMScheduler.step_prk / step_plms / _get_prev_sample)
+__global__ void lincomb_kernel(long long n, int k, float c0, float c1, float c2, float c3, const float *__restrict__ x0,
+                               const float *__restrict__ x1, const float *__restrict__ x2, const float *__restrict__ x3,
+                               float div, float *__restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float acc = c0 * x0[i];
+    if (k > 1) acc = acc + c1 * x1[i];
+    if (k > 2) acc = acc + c2 * x2[i];
+    if (k > 3) acc = acc + c3 * x3[i];
+    out[i] = div == 1.0f ? acc : acc / div;
+  }
+}
+extern "C" int bdm_lincomb(long long n, int k, float c0, const float *x0, float c1, const float *x1, float c2,
+                           const float *x2, float c3, const float *x3, float div, float *out, void *stream) {
+  BDM_REQUIRE(n >= 0 && k >= 1 && k <= 4 && x0 != nullptr && (k < 2 || x1) && (k < 3 || x2) && (k < 4 || x3) && div != 0.f,
+              "lincomb: bad arguments");
+  if (n == 0) return BDM_OK;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(lincomb_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, k, c0, c1, c2, c3, x0, x1, x2, x3, div,
+                     out);
+  return launch_status("lincomb");
+}
+
 // x0 = a*x - b*eps ; mean = c1*x0 + c2*x ; out = mean + sigma*z   (sigma = 0 at t == 0)
 __global__ void pvd_step_kernel(long long n, const float *__restrict__ x, const float *__restrict__ eps,
                                 const float *__restrict__ z, float a, float b, float c1, float c2, float sigma,

@@ -280,7 +280,8 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
         B = 1 if image_rgb is None else image_rgb.shape[0]
         device = self.device if image_rgb is None else image_rgb.device
         x_t = torch.randn(B, num_points, 3, device=device)
-        ts = _timestep_list(scheduler, num_inference_steps, num_inference_steps, 0)
+        scheduler.set_timesteps(num_inference_steps)
+        ts = [int(v) for v in scheduler.timesteps]  # ALL entries (model.py:182): PNDM lists more than num_inference_steps
         all_outputs = []
         if return_sample_every_n_steps > 0:
             for i, t in enumerate(ts):

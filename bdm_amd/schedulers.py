@@ -174,16 +174,110 @@ class DDIMScheduler(DDPMScheduler):
         return SimpleNamespace(prev_sample=out) if return_dict else (out,)
 
 
-class _UnsupportedScheduler:
-    """PNDM exists in the reference's schedulers_map (model.py:61) but no BDM recipe selects it; not built."""
+def _lincomb(terms, div=1.0):
+    """(sum_i c_i * x_i) / div for up to four (coefficient, tensor) terms, one launch."""
+    xs = [t.contiguous() for _, t in terms]
+    cs = [float(c) for c, _ in terms] + [0.0] * (4 - len(terms))
+    out = torch.empty_like(xs[0])
+    ps = [L.ptr(x) for x in xs] + [L.ptr(None)] * (4 - len(xs))
+    L.check(L.lib().bdm_lincomb(xs[0].numel(), len(xs), cs[0], ps[0], cs[1], ps[1], cs[2], ps[2], cs[3], ps[3], float(div),
+                                L.ptr(out), L.stream()), "lincomb")
+    return out
 
-    def __init__(self, name):
-        self.name = name
 
-    def __getattr__(self, item):
-        raise NotImplementedError(f"{self.name} scheduler is not implemented on the MI355X path (DDPM and DDIM are)")
+class PNDMScheduler(DDPMScheduler):
+    """diffusers 0.21.0 PNDMScheduler as the reference constructs it (model/model.py:61: beta_start / beta_end /
+    beta_schedule only -> skip_prk_steps=False, set_alpha_to_one=False, epsilon prediction, leading spacing, offset 0).
+    Restated from the published algorithm (Liu et al., "Pseudo Numerical Methods for Diffusion Models on Manifolds",
+    formulas (9), (12), (13)); unpinned against diffusers itself (absent), checked against oracle/ref_sampler.RefPNDM and
+    closed-form properties.  No BDM recipe selects it; it completes the reference's schedulers_map.
+
+      set_timesteps(n): ratio = T // n; base = arange(n) * ratio
+          prk  = the last 4 base steps, each followed by its half step (+ ratio // 2), laid out as 12 Runge-Kutta stages
+          plms = base[:-3] reversed;   timesteps = concat(prk, plms)             (n = 50 -> 59 network evaluations)
+      step: 4-stage Runge-Kutta for the first 12 entries, then the linear multistep formulas of order 1..4 on the stored
+      epsilons; every stage ends in   x_prev = sqrt(a_prev / a_t) x - (a_prev - a_t) e / (a_t sqrt(1 - a_prev) +
+      sqrt(a_t (1 - a_t) a_prev))."""
+    pndm_order = 4
+
+    def __init__(self, *args, skip_prk_steps=False, set_alpha_to_one=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.skip_prk_steps = skip_prk_steps
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.config.skip_prk_steps, self.config.set_alpha_to_one = skip_prk_steps, set_alpha_to_one
+        self._reset()
+
+    def _reset(self):
+        self.cur_model_output, self.counter, self.cur_sample, self.ets = None, 0, None, []
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        if num_inference_steps > self.num_train_timesteps:
+            raise ValueError("num_inference_steps cannot exceed num_train_timesteps")
+        self.num_inference_steps = int(num_inference_steps)
+        ratio = self.num_train_timesteps // self.num_inference_steps
+        base = (np.arange(0, num_inference_steps) * ratio).round().astype(np.int64)
+        self._timesteps = base
+        if self.skip_prk_steps:
+            self.prk_timesteps = np.array([], dtype=np.int64)
+            self.plms_timesteps = np.concatenate([base[:-1], base[-2:-1], base[-1:]])[::-1].copy()
+        else:
+            prk = np.array(base[-self.pndm_order:]).repeat(2) + np.tile(np.array([0, ratio // 2]), self.pndm_order)
+            self.prk_timesteps = (prk[:-1].repeat(2)[1:-1])[::-1].copy()
+            self.plms_timesteps = base[:-3][::-1].copy()
+        self.timesteps = torch.from_numpy(np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64))
+        self._reset()
+
+    def _prev_sample(self, sample, timestep, prev_timestep, model_output):
+        a_t = self.alphas_cumprod[int(timestep)]
+        a_prev = self.alphas_cumprod[int(prev_timestep)] if prev_timestep >= 0 else self.final_alpha_cumprod
+        sample_coeff = (a_prev / a_t) ** 0.5
+        denom = a_t * (1 - a_prev) ** 0.5 + (a_t * (1 - a_t) * a_prev) ** 0.5
+        return _lincomb([(float(sample_coeff), sample), (-float((a_prev - a_t) / denom), model_output)])
+
+    def step(self, model_output, timestep, sample, return_dict=True, **_ignored):
+        if self.num_inference_steps is None:
+            raise ValueError("run set_timesteps first")
+        t, ratio = int(timestep), self.num_train_timesteps // self.num_inference_steps
+        e = model_output.contiguous()
+        if self.counter < len(self.prk_timesteps) and not self.skip_prk_steps:   # ---- Runge-Kutta stage
+            prev_t = t - (0 if self.counter % 2 else ratio // 2)
+            t = int(self.prk_timesteps[self.counter // 4 * 4])
+            stage = self.counter % 4
+            if stage == 0:
+                self.cur_model_output = _lincomb([(1 / 6, e)])
+                self.ets.append(e)
+                self.cur_sample = sample
+            elif stage in (1, 2):
+                self.cur_model_output = _lincomb([(1.0, self.cur_model_output), (1 / 3, e)])
+            else:
+                e = _lincomb([(1.0, self.cur_model_output), (1 / 6, e)])
+                self.cur_model_output = None
+            cur = self.cur_sample if self.cur_sample is not None else sample
+            out = self._prev_sample(cur, t, prev_t, e)
+        else:                                                                     # ---- linear multistep
+            prev_t = t - ratio
+            if self.counter != 1:
+                self.ets = self.ets[-3:]
+                self.ets.append(e)
+            else:
+                prev_t, t = t, t + ratio
+            if len(self.ets) == 1 and self.counter == 0:
+                self.cur_sample = sample
+            elif len(self.ets) == 1 and self.counter == 1:
+                e = _lincomb([(1.0, e), (1.0, self.ets[-1])], div=2.0)
+                sample, self.cur_sample = self.cur_sample, None
+            elif len(self.ets) == 2:
+                e = _lincomb([(3.0, self.ets[-1]), (-1.0, self.ets[-2])], div=2.0)
+            elif len(self.ets) == 3:
+                e = _lincomb([(23.0, self.ets[-1]), (-16.0, self.ets[-2]), (5.0, self.ets[-3])], div=12.0)
+            else:
+                e = _lincomb([(55.0, self.ets[-1]), (-59.0, self.ets[-2]), (37.0, self.ets[-3]), (-9.0, self.ets[-4])], div=24.0)
+            out = self._prev_sample(sample, t, prev_t, e)
+        self.counter += 1
+        return SimpleNamespace(prev_sample=out) if return_dict else (out,)
 
 
 def make_schedulers_map(**scheduler_kwargs):
     return {"ddpm": DDPMScheduler(**scheduler_kwargs, clip_sample=False),
-            "ddim": DDIMScheduler(**scheduler_kwargs, clip_sample=False), "pndm": _UnsupportedScheduler("pndm")}
+            "ddim": DDIMScheduler(**scheduler_kwargs, clip_sample=False),
+            "pndm": PNDMScheduler(**scheduler_kwargs, clip_sample=False)}

@@ -303,6 +303,12 @@ int bdm_ddpm_step_dev(long long n, const float *x, const float *eps, const float
 int bdm_ddim_step(long long n, const float *x, const float *eps, const float *noise, float sqrt_beta_prod,
                   float sqrt_alpha_prod, float coef_x0, float coef_eps, float sigma, float *out, void *stream);
 
+/* out = (c0*x0 [+ c1*x1 [+ c2*x2 [+ c3*x3]]]) / div over n floats, k <= 4 terms, evaluated left to right: the linear
+ * multistep combinations and the transfer step of the PNDM scheduler (diffusers 0.21.0 PNDMScheduler, the reference's
+ * schedulers_map['pndm'], model/model.py:61).  out may alias any input. */
+int bdm_lincomb(long long n, int k, float c0, const float *x0, float c1, const float *x1, float c2,
+                const float *x2, float c3, const float *x3, float div, float *out, void *stream);
+
 /* PVD scheduler step: GaussianDiffusion.p_sample (experiments/pvd/__init__.py:136-224):
  *   x0 = sqrt_recip_abar * x - sqrt_recipm1_abar * eps;  mean = coef1 * x0 + coef2 * x;
  *   out = mean + sigma * noise      (sigma = 0 at t == 0; noise is always drawn, as the reference does) */

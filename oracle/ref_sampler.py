@@ -42,6 +42,71 @@ class RefDDPM:
         return prev
 
 
+class RefPNDM:
+    """diffusers 0.21.0 PNDMScheduler (skip_prk_steps=False, set_alpha_to_one=False, epsilon prediction, leading spacing),
+    restated with torch CPU ops from the published algorithm ("parity unpinned": diffusers absent).  The reference exposes
+    it as schedulers_map['pndm'] (experiments/model/model.py:61)."""
+
+    def __init__(self, beta_start=1e-5, beta_end=8e-3, T=1000):
+        self.T = T
+        self.ac = torch.cumprod(1.0 - torch.linspace(beta_start, beta_end, T, dtype=torch.float32), dim=0)
+        self.final = self.ac[0]
+
+    def set_timesteps(self, n):
+        self.n, ratio = n, self.T // n
+        base = (np.arange(0, n) * ratio).round().astype(np.int64)
+        prk = np.array(base[-4:]).repeat(2) + np.tile(np.array([0, ratio // 2]), 4)
+        self.prk = (prk[:-1].repeat(2)[1:-1])[::-1].copy()
+        self.plms = base[:-3][::-1].copy()
+        self.timesteps = np.concatenate([self.prk, self.plms]).astype(np.int64)
+        self.cur_model_output, self.counter, self.cur_sample, self.ets = 0, 0, None, []
+
+    def _prev(self, sample, t, prev_t, e):
+        a_t = self.ac[t]
+        a_prev = self.ac[prev_t] if prev_t >= 0 else self.final
+        coeff = (a_prev / a_t) ** 0.5
+        denom = a_t * (1 - a_prev) ** 0.5 + (a_t * (1 - a_t) * a_prev) ** 0.5
+        return coeff * sample - (a_prev - a_t) * e / denom
+
+    def step(self, e, t, sample):
+        ratio = self.T // self.n
+        if self.counter < len(self.prk):
+            prev_t = t - (0 if self.counter % 2 else ratio // 2)
+            t = int(self.prk[self.counter // 4 * 4])
+            if self.counter % 4 == 0:
+                self.cur_model_output = self.cur_model_output + 1 / 6 * e
+                self.ets.append(e)
+                self.cur_sample = sample
+            elif (self.counter - 1) % 4 == 0 or (self.counter - 2) % 4 == 0:
+                self.cur_model_output = self.cur_model_output + 1 / 3 * e
+            else:
+                e = self.cur_model_output + 1 / 6 * e
+                self.cur_model_output = 0
+            cur = self.cur_sample if self.cur_sample is not None else sample
+            out = self._prev(cur, t, prev_t, e)
+        else:
+            prev_t = t - ratio
+            if self.counter != 1:
+                self.ets = self.ets[-3:]
+                self.ets.append(e)
+            else:
+                prev_t, t = t, t + ratio
+            if len(self.ets) == 1 and self.counter == 0:
+                self.cur_sample = sample
+            elif len(self.ets) == 1 and self.counter == 1:
+                e = (e + self.ets[-1]) / 2
+                sample, self.cur_sample = self.cur_sample, None
+            elif len(self.ets) == 2:
+                e = (3 * self.ets[-1] - self.ets[-2]) / 2
+            elif len(self.ets) == 3:
+                e = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+            else:
+                e = (1 / 24) * (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4])
+            out = self._prev(sample, t, prev_t, e)
+        self.counter += 1
+        return out
+
+
 class RefPVDDiffusion:
     """pvd/__init__.py:24-68 tables + :196-224 step."""
 

@@ -184,3 +184,34 @@ def test_screen_space_and_pix3d_cameras():
     cam2 = pix3d_camera(torch.eye(3).numpy(), [0.0, 0.0, 2.0], [0.1, 0.0, 0.0], 2.0, (640, 480), (200, 100, 440, 420), 35.0)
     assert torch.allclose(cam2.T, torch.tensor([[0.1, 0.0, 2.0]]))
     assert torch.allclose(cam2.R[0], 2.0 * torch.tensor([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [-1.0, 0.0, 0.0]]).T)
+
+
+def test_pndm_timestep_layout_and_exactness_on_a_consistent_model():
+    """PNDM (the reference's schedulers_map['pndm'], model.py:61): 50 inference steps -> 12 Runge-Kutta stages + 47 linear
+    multistep steps = 59 network evaluations; for a model that always predicts the noise consistent with ONE fixed x0 the
+    transfer formula is exact, so the chain must land on x0 (up to final_alpha_cumprod = alphas_cumprod[0] != 1)."""
+    from oracle.ref_sampler import RefPNDM
+    s = RefPNDM()
+    s.set_timesteps(50)
+    assert len(s.timesteps) == 59
+    assert s.timesteps[:12].tolist() == [980, 970, 970, 960, 960, 950, 950, 940, 940, 930, 930, 920]
+    assert s.timesteps[12:15].tolist() == [920, 900, 880] and s.timesteps[-1] == 0
+    g = torch.Generator().manual_seed(0)
+    x0, z = torch.randn(2, 64, 3, generator=g), torch.randn(2, 64, 3, generator=g)
+    a = s.ac[980]
+    x = a.sqrt() * x0 + (1 - a).sqrt() * z
+
+    def eps_of(x, t):   # the noise that explains x at level t given the fixed x0
+        return (x - s.ac[t].sqrt() * x0) / (1 - s.ac[t]).sqrt()
+    for t in s.timesteps:
+        # PRK stages evaluate the network at the stage's own (t, sample) pair, exactly as the reference's loop does
+        x = s.step(eps_of(x, int(t)), int(t), x)
+    assert float((x - s.final.sqrt() * x0).norm() / x0.norm()) < 0.05
+
+
+def test_pndm_product_scheduler_layout():
+    from bdm_amd.schedulers import make_schedulers_map
+    m = make_schedulers_map(beta_start=1e-5, beta_end=8e-3, beta_schedule="linear")
+    p = m["pndm"]
+    p.set_timesteps(50)
+    assert len(p.timesteps) == 59 and p.timesteps[:4].tolist() == [980, 970, 970, 960]
