@@ -86,6 +86,14 @@ class PointCloudDatasetConfig:  # structured.py:127-140 (+ dataset-specific keys
     root: Optional[str] = None
     r2n2_dir: Optional[str] = None
     category: str = "chair"
+    # ShapeNetR2N2Config / Pix3DConfig keys (structured.py:139-160)
+    pc_dict: Optional[str] = None          # default: pc_dict_v2.json (R2N2) / pix3d.json (Pix3D)
+    split_file: str = "R2N2_split.json"
+    views_rel_path: str = "ShapeNetRendering"
+    which_view_from24: str = "00"
+    mask_images: bool = False
+    start_ratio: float = 0.0
+    processed: bool = True
     num_shapes: int = 16  # synthetic only
 
 
@@ -123,6 +131,8 @@ def parse_overrides(argv, cfg: Optional[ProjectConfig] = None) -> ProjectConfig:
         key, raw = arg.split("=", 1)
         key = key.lstrip("+")
         value = yaml.safe_load(raw) if raw != "" else None
+        if key == "dataset.which_view_from24" and value is not None:
+            value = f"{int(value):02d}" if not isinstance(value, str) else value  # '00' must stay a string
         parts = key.split(".")
         if len(parts) == 1:
             if parts[0] == "dataset":  # config-group selection: dataset=shapenet_r2n2 | pix3d | synthetic

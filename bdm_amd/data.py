@@ -15,6 +15,7 @@ from .cameras import PerspectiveCameras, r2n2_camera
 
 @dataclass
 class FrameData:
+    """The keys of the datasets' sample dict (dataset/shapenet_r2n2.py:508-536); the sampling path reads the first seven."""
     image_rgb: Optional[torch.Tensor] = None
     fg_probability: Optional[torch.Tensor] = None
     camera: Any = None
@@ -22,16 +23,42 @@ class FrameData:
     sequence_name: Optional[List[str]] = None
     sequence_category: Optional[List[str]] = None
     frame_number: Optional[List[int]] = None
+    frame_timestamp: Any = None
+    image_size_hw: Any = None
+    effective_image_size_hw: Any = None
+    image_path: Any = None
+    mask_crop: Any = None
+    depth_path: Any = None
+    depth_map: Any = None
+    depth_mask: Any = None
+    mask_path: Any = None
+    bbox_xywh: Any = None
+    crop_bbox_xywh: Any = None
+    camera_quality_score: Any = None
+    point_cloud_quality_score: Any = None
+    sequence_point_cloud_path: Any = None
+    sequence_point_cloud_idx: Any = None
+    frame_type: Any = None
+    meta: Any = None
 
     def to(self, device):
+        import dataclasses
         cam = self.camera
         if isinstance(cam, (list, tuple)):
             cam = [c.to(device) for c in cam]
         elif cam is not None:
             cam = cam.to(device)
-        return FrameData(self.image_rgb.to(device), self.fg_probability, cam,
-                         None if self.sequence_point_cloud is None else self.sequence_point_cloud.to(device),
-                         self.sequence_name, self.sequence_category, self.frame_number)
+        fg = self.fg_probability.to(device) if torch.is_tensor(self.fg_probability) else self.fg_probability
+        return dataclasses.replace(self, image_rgb=self.image_rgb.to(device), fg_probability=fg, camera=cam,
+                                   sequence_point_cloud=None if self.sequence_point_cloud is None
+                                   else self.sequence_point_cloud.to(device))
+
+    def shape_indices(self):
+        """Global shape indices of the batch (keys of the per-shape random streams): the dataset index when the loader
+        recorded one (meta['dataset_index']), else frame_number (the synthetic shapes number themselves)."""
+        if isinstance(self.meta, dict) and "dataset_index" in self.meta:
+            return [int(v) for v in self.meta["dataset_index"]]
+        return [int(v) for v in self.frame_number]
 
 
 def shape_generator(seed: int, shape_index: int) -> torch.Generator:

@@ -99,10 +99,8 @@ def batch_streams(cfg, batch, device, sample_idx=0):
     configuration asks for the reference's global-generator draws (run.rng = "reference")."""
     if getattr(cfg.run, "rng", "reference") != "per_shape":
         return None
-    if batch.frame_number is None:
-        raise ValueError("run.rng=per_shape needs batch.frame_number (the global shape indices)")
     # run.num_samples > 1: sample k of a shape uses the stream family seed + k * 1000003
-    return rng.ShapeStreams(cfg.run.seed + 1000003 * int(sample_idx), batch.frame_number, device)
+    return rng.ShapeStreams(cfg.run.seed + 1000003 * int(sample_idx), batch.shape_indices(), device)
 
 
 @torch.no_grad()

@@ -41,12 +41,14 @@ def build_models(cfg, device, need_fusion=False):
 
 
 def get_dataloader(cfg, rank, world):
-    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.data import FrameData, SyntheticShapes
     from bdm_amd.distributed import shard_indices
+    if cfg.dataset.type in ("shapenet_r2n2", "pix3d"):  # the reference's loaders (dataset/__init__.py:get_dataset)
+        from bdm_amd.datasets import get_dataset
+        _, val, _ = get_dataset(cfg, rank, world)
+        return (FrameData(**b) for b in val)
     if cfg.dataset.type != "synthetic":
-        raise FileNotFoundError(
-            f"dataset={cfg.dataset.type}: the ShapeNet-R2N2 / Pix3D loaders need the datasets on disk and are a later "
-            "scope row (SURVEY.md 8f-3); use dataset=synthetic")
+        raise NotImplementedError(f"dataset={cfg.dataset.type} (the BDM recipes use shapenet_r2n2 or pix3d; synthetic = benchmark inputs)")
     idx = shard_indices(cfg.dataset.num_shapes, rank, world)
     return SyntheticShapes(idx, cfg.dataloader.batch_size, seed=cfg.run.seed, image_size=cfg.dataset.image_size,
                            num_points=cfg.dataset.max_points, category=cfg.dataset.category)
@@ -73,7 +75,11 @@ def main(argv=None):
     rank, local_rank, world = init_from_env()
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    torch.manual_seed(cfg.run.seed + rank)  # training_utils.py:373-378
+    torch.manual_seed(cfg.run.seed + rank)  # training_utils.py:373-378 (set_seed: python, numpy and torch generators)
+    import random as _random
+    import numpy as _np
+    _random.seed(cfg.run.seed + rank)
+    _np.random.seed(cfg.run.seed + rank)
     if cfg.run.job != "sample_bdm_blending":
         raise ValueError(f"Invalid job: {cfg.run.job}")
     out_root = Path(shared_run_dir(cfg, rank, world)) / "sample_bdm_blending"
