@@ -2,9 +2,9 @@
 
 Same 12 names, argument order and return conventions as the pybind11 module
 `_pvcnn_backend` (reference: experiments/model/pvcnn/modules/functional/src/bindings.cpp:10-37),
-so the reference's functional/*.py wrappers work unchanged against this object.  The five
-backward operators exist in the reference for training only and raise NotImplementedError
-here (out of scope: the hot path is sampling).
+so the reference's functional/*.py wrappers work unchanged against this object, including the five
+gradient operators and the training-mode devoxelisation (csrc/backward_ops.hip; training is outside the
+sampling hot path, they complete the plugin surface).
 Outputs are freshly allocated on the inputs' device (callee allocates, caller owns), as in
 the reference's at::Tensor API; argument errors raise RuntimeError, nothing exits the process.
 """
@@ -110,26 +110,72 @@ class _Backend:
     @staticmethod
     def trilinear_devoxelize_forward(resolution, is_training, coords, features):
         _chk_f(features, "features"); _chk_f(coords, "coords")
-        if is_training:
-            raise NotImplementedError("training mode (saved inds/wgts) is out of scope: sampling only")
         b, c, _ = features.shape
         n = coords.shape[2]
         dev = features.device
         out = torch.empty(b, c, n, dtype=torch.float32, device=dev)
+        if is_training:  # also saves the corner indices / weights for the backward pass
+            inds = torch.empty(b, 8, n, dtype=torch.int32, device=dev)
+            wgts = torch.empty(b, 8, n, dtype=torch.float32, device=dev)
+            L.check(L.lib().bdm_trilinear_devoxelize_forward_training(b, c, n, int(resolution), L.ptr(coords), L.ptr(features),
+                                                                      L.ptr(out), L.ptr(inds), L.ptr(wgts), L.stream()),
+                    "trilinear_devoxelize_forward(training)")
+            return [out, inds, wgts]
         L.check(L.lib().bdm_trilinear_devoxelize_forward(b, c, n, int(resolution), L.ptr(coords), L.ptr(features),
                                                          L.ptr(out), L.stream()), "trilinear_devoxelize_forward")
         # eval mode returns 1-element placeholders (trilinear_devox.cpp:45-53)
         return [out, torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, device=dev)]
 
+    # ---- training half (gradients): sampling.cpp:25-41, grouping.cpp:26-44, neighbor_interpolate.cpp:42-66,
+    #      trilinear_devox.cpp:57-83, vox.cpp:45-69 -------------------------------------------------------------
     @staticmethod
-    def _training_only(*_a, **_k):
-        raise NotImplementedError("backward operators are training-only; the MI355X path covers sampling")
+    def gather_features_backward(grad_y, indices, n):
+        _chk_f(grad_y, "grad_y"); _chk_i(indices, "indices")
+        b, c, m = grad_y.shape
+        gx = torch.empty(b, c, int(n), dtype=torch.float32, device=grad_y.device)
+        L.check(L.lib().bdm_gather_features_backward(b, c, int(n), m, L.ptr(grad_y), L.ptr(indices), L.ptr(gx), L.stream()),
+                "gather_features_backward")
+        return gx
 
-    gather_features_backward = _training_only
-    grouping_backward = _training_only
-    three_nearest_neighbors_interpolate_backward = _training_only
-    trilinear_devoxelize_backward = _training_only
-    avg_voxelize_backward = _training_only
+    @staticmethod
+    def grouping_backward(grad_y, indices, n):
+        _chk_f(grad_y, "grad_y"); _chk_i(indices, "indices")
+        b, c, m, u = grad_y.shape
+        gx = torch.empty(b, c, int(n), dtype=torch.float32, device=grad_y.device)
+        L.check(L.lib().bdm_grouping_backward(b, c, int(n), m, u, L.ptr(grad_y), L.ptr(indices), L.ptr(gx), L.stream()),
+                "grouping_backward")
+        return gx
+
+    @staticmethod
+    def three_nearest_neighbors_interpolate_backward(grad_y, indices, weights, m):
+        _chk_f(grad_y, "grad_y"); _chk_i(indices, "indices"); _chk_f(weights, "weights")
+        b, c, n = grad_y.shape
+        gx = torch.empty(b, c, int(m), dtype=torch.float32, device=grad_y.device)
+        L.check(L.lib().bdm_three_nn_interpolate_backward(b, c, n, int(m), L.ptr(grad_y), L.ptr(indices), L.ptr(weights), L.ptr(gx),
+                                                          L.stream()), "three_nearest_neighbors_interpolate_backward")
+        return gx
+
+    @staticmethod
+    def trilinear_devoxelize_backward(grad_y, indices, weights, resolution):
+        _chk_f(grad_y, "grad_y"); _chk_i(indices, "indices"); _chk_f(weights, "weights")
+        b, c, n = grad_y.shape
+        r = int(resolution)
+        gx = torch.empty(b, c, r ** 3, dtype=torch.float32, device=grad_y.device)
+        L.check(L.lib().bdm_trilinear_devoxelize_backward(b, c, n, r, L.ptr(indices), L.ptr(weights), L.ptr(grad_y), L.ptr(gx),
+                                                          L.stream()), "trilinear_devoxelize_backward")
+        return gx
+
+    @staticmethod
+    def avg_voxelize_backward(grad_y, indices, cnt):
+        _chk_f(grad_y, "grad_y"); _chk_i(indices, "indices"); _chk_i(cnt, "cnt")
+        b, c, s = grad_y.shape
+        n = indices.shape[1]
+        r = round(s ** (1.0 / 3.0))
+        assert r ** 3 == s, "grad_y must be (B, C, r^3)"
+        gx = torch.empty(b, c, n, dtype=torch.float32, device=grad_y.device)
+        L.check(L.lib().bdm_avg_voxelize_backward(b, c, n, r, L.ptr(indices), L.ptr(cnt), L.ptr(grad_y), L.ptr(gx), L.stream()),
+                "avg_voxelize_backward")
+        return gx
 
 
 _backend = _Backend()

@@ -93,6 +93,26 @@ int bdm_avg_voxelize_forward(int b, int c, int n, int r, const float *features, 
 int bdm_trilinear_devoxelize_forward(int b, int c, int n, int r, const float *coords,
                                      const float *grid, float *out, void *stream);
 
+/* --- the training half of the plugin (bindings.cpp:10-37): gradient operators and the training-mode devoxelisation.
+ * Outside the sampling hot path (they serve training_bdm_merging, main_merging.py:242-366); present so that the plugin
+ * surface is complete.  grad_x is fully written by the callee (zero-filled, then accumulated).  Scatter-adds are float
+ * atomics as in the reference (grouping.cu:58-77, neighbor_interpolate.cu:145-170, trilinear_devox.cu:119-162,
+ * sampling.cu:52-66); avg_voxelize_backward (vox.cu:86-110) is a gather. */
+int bdm_gather_features_backward(int b, int c, int n, int m, const float *grad_y, const int *indices,
+                                 float *grad_x, void *stream);
+int bdm_grouping_backward(int b, int c, int n, int m, int u, const float *grad_y, const int *indices,
+                          float *grad_x, void *stream);
+int bdm_three_nn_interpolate_backward(int b, int c, int n, int m, const float *grad_y, const int *indices,
+                                      const float *weights, float *grad_x, void *stream);
+int bdm_trilinear_devoxelize_backward(int b, int c, int n, int r, const int *inds, const float *wgts,
+                                      const float *grad_y, float *grad_x, void *stream);
+int bdm_avg_voxelize_backward(int b, int c, int n, int r, const int *ind, const int *cnt, const float *grad_y,
+                              float *grad_x, void *stream);
+/* trilinear_devoxelize_forward with is_training = true: also returns inds (b,8,n) int32 and wgts (b,8,n), corner order
+ * 000, 001, 010, 011, 100, 101, 110, 111 (trilinear_devox.cu:21-105). */
+int bdm_trilinear_devoxelize_forward_training(int b, int c, int n, int r, const float *coords, const float *grid,
+                                              float *out, int *inds, float *wgts, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * 2. Dense per-point / per-voxel operators of one denoiser forward
  *    (stock nn.Modules in the reference; hand-written gfx950 kernels here)

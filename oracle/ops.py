@@ -100,17 +100,47 @@ def trilinear_devoxelize_forward(resolution, is_training, coords, features):
     b, c, _ = features.shape
     n = coords.shape[2]
     out = torch.zeros(b, c, n)
+    if is_training:
+        inds, wgts = torch.zeros(b, 8, n, dtype=torch.int32), torch.zeros(b, 8, n)
+        lib().oracle_trilinear_devoxelize_training(b, c, n, int(resolution), _fp(coords), _fp(features), _fp(out), _ip(inds), _fp(wgts))
+        return [out, inds, wgts]
     lib().oracle_trilinear_devoxelize(b, c, n, int(resolution), _fp(coords), _fp(features), _fp(out))
     # eval mode returns 1-element placeholders (trilinear_devox.cpp:45-53)
     return [out, torch.zeros(1, dtype=torch.int32), torch.zeros(1)]
 
 
-def _training_only(*_a, **_k):
-    raise NotImplementedError("backward operators are training-only and out of scope (SURVEY.md 8b)")
+def gather_features_backward(grad_y, indices, n):
+    b, c, m = grad_y.shape
+    gx = torch.zeros(b, c, int(n))
+    lib().oracle_gather_features_backward(b, c, int(n), m, _fp(grad_y), _ip(indices), _fp(gx))
+    return gx
 
 
-gather_features_backward = _training_only
-grouping_backward = _training_only
-three_nearest_neighbors_interpolate_backward = _training_only
-trilinear_devoxelize_backward = _training_only
-avg_voxelize_backward = _training_only
+def grouping_backward(grad_y, indices, n):
+    b, c, m, u = grad_y.shape
+    gx = torch.zeros(b, c, int(n))
+    lib().oracle_grouping_backward(b, c, int(n), m, u, _fp(grad_y), _ip(indices), _fp(gx))
+    return gx
+
+
+def three_nearest_neighbors_interpolate_backward(grad_y, indices, weights, m):
+    b, c, n = grad_y.shape
+    gx = torch.zeros(b, c, int(m))
+    lib().oracle_three_nn_interpolate_backward(b, c, n, int(m), _fp(grad_y), _ip(indices), _fp(weights), _fp(gx))
+    return gx
+
+
+def trilinear_devoxelize_backward(grad_y, indices, weights, resolution):
+    b, c, n = grad_y.shape
+    r3 = int(resolution) ** 3
+    gx = torch.zeros(b, c, r3)
+    lib().oracle_trilinear_devoxelize_backward(b, c, n, r3, _ip(indices), _fp(weights), _fp(grad_y), _fp(gx))
+    return gx
+
+
+def avg_voxelize_backward(grad_y, indices, cnt):
+    b, c, s = grad_y.shape
+    n = indices.shape[1]
+    gx = torch.zeros(b, c, n)
+    lib().oracle_avg_voxelize_backward(b, c, n, s, _ip(indices), _ip(cnt), _fp(grad_y), _fp(gx))
+    return gx

@@ -239,3 +239,92 @@ void oracle_trilinear_devoxelize(int b, int c, int n, int r, const float *coords
     }
   }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Training half of the plugin: gradient operators, sequential restatements in the reference's loop order
+ * (grouping.cu:58-77, neighbor_interpolate.cu:145-170, trilinear_devox.cu:119-162, sampling.cu:52-66, vox.cu:86-110)
+ * and the training-mode devoxelisation that saves (inds, wgts) (trilinear_devox.cu:21-105).  The reference accumulates
+ * with float atomicAdd (order left to thread timing); here the additions run in ascending source index.
+ * ------------------------------------------------------------------------------------------------------------- */
+void oracle_gather_features_backward(int b, int c, int n, int m, const float *grad_y, const int *indices, float *grad_x) {
+  memset(grad_x, 0, sizeof(float) * (size_t)b * c * n);
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci)
+      for (int j = 0; j < m; ++j)
+        grad_x[((size_t)bi * c + ci) * n + indices[(size_t)bi * m + j]] += grad_y[((size_t)bi * c + ci) * m + j];
+}
+
+void oracle_grouping_backward(int b, int c, int n, int m, int u, const float *grad_y, const int *indices, float *grad_x) {
+  memset(grad_x, 0, sizeof(float) * (size_t)b * c * n);
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci)
+      for (size_t e = 0; e < (size_t)m * u; ++e)
+        grad_x[((size_t)bi * c + ci) * n + indices[(size_t)bi * m * u + e]] += grad_y[((size_t)bi * c + ci) * m * u + e];
+}
+
+void oracle_three_nn_interpolate_backward(int b, int c, int n, int m, const float *grad_y, const int *indices,
+                                          const float *weights, float *grad_x) {
+  memset(grad_x, 0, sizeof(float) * (size_t)b * c * m);
+  for (int bi = 0; bi < b; ++bi)
+    for (int ci = 0; ci < c; ++ci)
+      for (int j = 0; j < n; ++j) {
+        const float g = grad_y[((size_t)bi * c + ci) * n + j];
+        float *gx = grad_x + ((size_t)bi * c + ci) * m;
+        for (int k = 0; k < 3; ++k)
+          gx[indices[((size_t)bi * 3 + k) * n + j]] += g * weights[((size_t)bi * 3 + k) * n + j];
+      }
+}
+
+void oracle_trilinear_devoxelize_backward(int b, int c, int n, int r3, const int *inds, const float *wgts,
+                                          const float *grad_y, float *grad_x) {
+  memset(grad_x, 0, sizeof(float) * (size_t)b * c * r3);
+  for (int bi = 0; bi < b; ++bi)
+    for (int i = 0; i < n; ++i)
+      for (int ci = 0; ci < c; ++ci) {
+        const float g = grad_y[((size_t)bi * c + ci) * n + i];
+        for (int k = 0; k < 8; ++k)
+          grad_x[((size_t)bi * c + ci) * r3 + inds[((size_t)bi * 8 + k) * n + i]] += wgts[((size_t)bi * 8 + k) * n + i] * g;
+      }
+}
+
+void oracle_avg_voxelize_backward(int b, int c, int n, int r3, const int *ind, const int *cnt, const float *grad_y,
+                                  float *grad_x) {
+  memset(grad_x, 0, sizeof(float) * (size_t)b * c * n);
+  for (int bi = 0; bi < b; ++bi)
+    for (int i = 0; i < n; ++i) {
+      const int pos = ind[(size_t)bi * n + i], cur = cnt[(size_t)bi * r3 + pos];
+      if (cur > 0) {
+        const float inv = (float)(1.0 / (double)(float)cur); /* vox.cu:102 */
+        for (int ci = 0; ci < c; ++ci)
+          grad_x[((size_t)bi * c + ci) * n + i] += grad_y[((size_t)bi * c + ci) * r3 + pos] * inv;
+      }
+    }
+}
+
+/* trilinear_devox.cu:21-105 with is_training = true: corner indices / weights, order 000,001,010,011,100,101,110,111 */
+void oracle_trilinear_devoxelize_training(int b, int c, int n, int r, const float *coords, const float *grid, float *out,
+                                          int *inds, float *wgts) {
+  const int r2 = r * r, r3 = r2 * r;
+  for (int bi = 0; bi < b; ++bi) {
+    const float *px = coords + (size_t)bi * 3 * n, *py = px + n, *pz = py + n;
+    for (int i = 0; i < n; ++i) {
+      const float xl = floorf(px[i]), yl = floorf(py[i]), zl = floorf(pz[i]);
+      const float x1 = px[i] - xl, y1 = py[i] - yl, z1 = pz[i] - zl;
+      const float x0 = 1.0f - x1, y0 = 1.0f - y1, z0 = 1.0f - z1;
+      const float w[8] = {x0 * y0 * z0, x0 * y0 * z1, x0 * y1 * z0, x0 * y1 * z1, x1 * y0 * z0, x1 * y0 * z1, x1 * y1 * z0, x1 * y1 * z1};
+      const int sx = x1 > 0 ? r2 : 0, sy = y1 > 0 ? r : 0, sz = z1 > 0 ? 1 : 0;
+      const int i000 = (int)xl * r2 + (int)yl * r + (int)zl;
+      const int id[8] = {i000, i000 + sz, i000 + sy, i000 + sy + sz, i000 + sx, i000 + sx + sz, i000 + sx + sy, i000 + sx + sy + sz};
+      for (int k = 0; k < 8; ++k) {
+        inds[((size_t)bi * 8 + k) * n + i] = id[k];
+        wgts[((size_t)bi * 8 + k) * n + i] = w[k];
+      }
+      for (int ci = 0; ci < c; ++ci) {
+        const float *g = grid + ((size_t)bi * c + ci) * r3;
+        float acc = w[0] * g[id[0]];
+        for (int k = 1; k < 8; ++k) acc = acc + w[k] * g[id[k]];
+        out[((size_t)bi * c + ci) * n + i] = acc;
+      }
+    }
+  }
+}

@@ -64,3 +64,28 @@ def test_product_does_not_import_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b|from\s+\.\.?oracle|liboracle", src, flags=re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_pvcnn_backend_extension_module_has_the_reference_surface():
+    """The compiled torch extension `_pvcnn_backend` (bdm_amd/csrc/torch_binding.cpp) exposes the 12 names of the
+    reference's bindings.cpp:10-37 and rejects CPU tensors with a RuntimeError as the reference's CHECK_CUDA does."""
+    import importlib
+    import sys
+    import pytest
+    import torch
+    from bdm_amd import _lib
+    if not os.path.exists(os.path.join(os.path.dirname(_lib.SO_PATH), "_pvcnn_backend.so")):
+        _lib.build()
+    sys.path.insert(0, os.path.dirname(_lib.SO_PATH))
+    try:
+        mod = importlib.import_module("_pvcnn_backend")
+    finally:
+        sys.path.pop(0)
+    names = {"gather_features_forward", "gather_features_backward", "furthest_point_sampling", "ball_query", "grouping_forward",
+             "grouping_backward", "three_nearest_neighbors_interpolate_forward", "three_nearest_neighbors_interpolate_backward",
+             "trilinear_devoxelize_forward", "trilinear_devoxelize_backward", "avg_voxelize_forward", "avg_voxelize_backward"}
+    assert names <= set(dir(mod))
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        mod.ball_query(torch.zeros(1, 3, 4), torch.zeros(1, 3, 8), 0.1, 4)
+    with pytest.raises(RuntimeError):
+        mod.furthest_point_sampling(torch.zeros(1, 3, 4), 2)

@@ -155,3 +155,38 @@ def test_known_answer_cases_on_the_hip_backend(hip, case):
     """strict '<', first-hit fill, zero rows, FPS (k mod 512, k) ties, 3-NN ties / clamp, voxel summation order, the
     devoxelisation corner rule: the SAME known answers that pin the oracle, asked of the HIP kernels."""
     getattr(_KA, case)(_HipAsOps(hip))
+
+
+def test_pvcnn_backend_extension_equals_oracle(hip, oracle_ops):
+    """`import _pvcnn_backend` (the reference's module name): same calls the reference's functional/*.py make."""
+    import importlib
+    import os
+    import sys
+    from bdm_amd import _lib
+    sys.path.insert(0, os.path.dirname(_lib.SO_PATH))
+    try:
+        B = importlib.import_module("_pvcnn_backend")
+    finally:
+        sys.path.pop(0)
+    O = oracle_ops
+    pts = cloud(2, 1100, seed=3)
+    idx = B.furthest_point_sampling(pts.cuda(), 130)
+    assert torch.equal(idx.cpu(), O.furthest_point_sampling(pts, 130))
+    ctr = B.gather_features_forward(pts.cuda(), idx)
+    nb = B.ball_query(ctr, pts.cuda(), 0.2, 32)
+    assert torch.equal(nb.cpu(), O.ball_query(ctr.cpu(), pts, 0.2, 32))
+    f = torch.randn(2, 7, 1100, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(B.grouping_forward(f.cuda(), nb).cpu(), O.grouping_forward(f, nb.cpu()))
+    out, i3, w3 = B.three_nearest_neighbors_interpolate_forward(pts.cuda(), ctr, f[:, :, :130].contiguous().cuda())
+    ro, ri, rw = O.three_nearest_neighbors_interpolate_forward(pts, ctr.cpu(), f[:, :, :130].contiguous())
+    assert torch.equal(out.cpu(), ro) and torch.equal(i3.cpu(), ri) and torch.equal(w3.cpu(), rw)
+    vc = torch.randint(0, 8, (2, 3, 1100), generator=torch.Generator().manual_seed(2), dtype=torch.int32)
+    vo, vi, vcnt = B.avg_voxelize_forward(f.cuda(), vc.cuda(), 8)
+    ro, ri, rc = O.avg_voxelize_forward(f, vc, 8)
+    assert torch.equal(vo.cpu(), ro) and torch.equal(vi.cpu(), ri) and torch.equal(vcnt.cpu(), rc)
+    nc = torch.rand(2, 3, 1100, generator=torch.Generator().manual_seed(4)) * 7
+    d_out, d_i, d_w = B.trilinear_devoxelize_forward(8, True, nc.cuda(), vo)
+    ro, ri, rw = O.trilinear_devoxelize_forward(8, True, nc, ro)
+    assert torch.equal(d_out.cpu(), ro) and torch.equal(d_i.cpu(), ri) and torch.equal(d_w.cpu(), rw)
+    gy = torch.randn(2, 7, 1100, generator=torch.Generator().manual_seed(5))
+    assert torch.allclose(B.trilinear_devoxelize_backward(gy.cuda(), d_i, d_w, 8).cpu(), O.trilinear_devoxelize_backward(gy, ri, rw, 8), atol=1e-5)
