@@ -23,6 +23,32 @@ from .pvcnn import PVCNN2_PC2, PVCNN_fuse
 from .schedulers import DDPMScheduler, make_schedulers_map
 
 
+def compute_distance_transform(mask: Tensor):
+    """model_utils.py:13-21: cv2.distanceTransform(1 - m, DIST_L2, DIST_MASK_3) / (image_size / 2), clipped to [0, 1]:
+    distance of every background pixel to the nearest foreground pixel.  cv2 is absent here; its 3x3 DIST_L2 transform is
+    the two-pass chamfer transform with weights a = 0.955 (edge neighbours), b = 1.3693 (diagonal neighbours) in 16-bit
+    fixed point (OpenCV documentation of distanceTransform; "unpinned": restated, checked against the exact Euclidean
+    transform within the chamfer metric's known error in tests/test_sampler_host.py).  Host code, once per image batch."""
+    image_size = mask.shape[-1]
+    HV, DIAG, BIG = int(round(0.955 * 65536)), int(round(1.3693 * 65536)), (2 ** 31 - 1) >> 2
+    outs = []
+    for m in mask.squeeze(1).detach().cpu().numpy().astype(np.uint8):
+        src = 1 - m                                   # zero where the mask is set
+        H, W = src.shape
+        d = np.full((H + 2, W + 2), BIG, dtype=np.int64)
+        d[1:-1, 1:-1] = np.where(src == 0, 0, BIG)
+        for i in range(1, H + 1):                     # forward pass: up-left, up, up-right, left
+            for j in range(1, W + 1):
+                if d[i, j]:
+                    d[i, j] = min(d[i, j], d[i - 1, j - 1] + DIAG, d[i - 1, j] + HV, d[i - 1, j + 1] + DIAG, d[i, j - 1] + HV)
+        for i in range(H, 0, -1):                     # backward pass: right, down-right, down, down-left
+            for j in range(W, 0, -1):
+                if d[i, j]:
+                    d[i, j] = min(d[i, j], d[i, j + 1] + HV, d[i + 1, j + 1] + DIAG, d[i + 1, j] + HV, d[i + 1, j - 1] + DIAG)
+        outs.append(torch.from_numpy((d[1:-1, 1:-1].astype(np.float64) / 65536.0).astype(np.float32) / (image_size / 2)))
+    return torch.stack(outs).unsqueeze(1).clip(0, 1).to(mask.device)
+
+
 class _DeviceMixin:
     @property
     def device(self):
@@ -83,15 +109,18 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
         self.predict_shape, self.predict_color, self.process_color = predict_shape, predict_color, process_color
         self.image_color_channels, self.color_channels = image_color_channels, color_channels
         self.colors_mean, self.colors_std = colors_mean, colors_std
-        if use_global_features or use_mask or use_distance_transform or predict_color or process_color:
-            raise NotImplementedError("the BDM configs use local colours + local features only (config/structured.py:80-84)")
+        if use_global_features or predict_color or process_color:
+            raise NotImplementedError("global features / colour prediction are not used by the BDM recipes (config/structured.py:80-90)")
+        if use_distance_transform and not use_mask:
+            raise ValueError("No mask for distance transform?")  # projection_model.py:119-120
         if raster_points_per_pixel != 1:
             raise NotImplementedError("one point per pixel (projection_model.py:41)")
-        self.use_local_conditioning = use_local_colors or use_local_features
+        self.use_local_conditioning = use_local_colors or use_local_features or use_mask
         self.use_global_conditioning = False
         self.feature_model = FeatureModel(image_size, image_feature_model)
         self.in_channels = 3 + (image_color_channels if use_local_colors else 0) + \
-            (self.feature_model.feature_dim if use_local_features else 0)
+            (self.feature_model.feature_dim if use_local_features else 0) + \
+            ((2 if use_distance_transform else 1) if use_mask else 0)  # projection_model.py:67-77
         self.out_channels = 3
         self.raster_point_radius = raster_point_radius
         self._cond_cache = None
@@ -110,18 +139,34 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
             parts.append(self.normalize(image_rgb))
         if self.use_local_features:
             parts.append(self.feature_model(image_rgb))
+        parts.extend(self._mask_channels(image_rgb, mask))
         return torch.cat(parts, dim=1)
+
+    def _mask_channels(self, image_rgb, mask):
+        """[mask] (+ [distance transform]) as (B, 1, H, W) float tensors (projection_model.py:116-123)."""
+        if not self.use_mask:
+            return []
+        if mask is None:
+            raise ValueError("use_mask=True needs batch.fg_probability")
+        out = [mask.float().to(image_rgb.device)]
+        if self.use_distance_transform:
+            m = (mask > 0.5) if mask.is_floating_point() else mask
+            out.append(compute_distance_transform(m).to(image_rgb.device))
+        return out
 
     def conditioning_image(self, image_rgb, mask=None):
         """Pixel-major (B, H*W, D_cond) conditioning image, computed once per image batch (hoisted)."""
         # The entry holds the image tensor itself and is matched by identity (+ in-place version): a freed batch's
         # address can be handed to the next batch by the caching allocator, so a data_ptr key alone would alias.
         hit = self._cond_cache
-        if hit is None or hit[0] is not image_rgb or hit[1] != image_rgb._version:
+        if hit is None or hit[0] is not image_rgb or hit[1] != image_rgb._version or hit[4] is not mask:
             assert self.use_local_colors and self.use_local_features
             H, W = image_rgb.shape[-2:]
-            hit = (image_rgb, image_rgb._version,
-                   self.feature_model.conditioning_image(image_rgb, self.colors_mean, self.colors_std), (H, W))
+            img = self.feature_model.conditioning_image(image_rgb, self.colors_mean, self.colors_std)   # (B, H*W, 3 + D)
+            extra = self._mask_channels(image_rgb, mask)
+            if extra:  # once per image batch (hoisted): the mask / distance-transform channels join the pixel-major image
+                img = torch.cat([img] + [e.reshape(e.shape[0], H * W, 1) for e in extra], dim=2).contiguous()
+            hit = (image_rgb, image_rgb._version, img, (H, W), mask)
             self._cond_cache = hit
         return hit[2], hit[3]
 

@@ -290,3 +290,33 @@ def test_pndm_scheduler_vs_oracle(hip):
     out = model.forward_sample(num_points=1024, camera=b.camera, image_rgb=b.image_rgb, mask=None, scheduler="pndm",
                                num_inference_steps=10).points_padded()
     assert out.shape == (1, 1024, 3) and bool(torch.isfinite(out).all())
+
+
+def test_mask_and_distance_transform_conditioning(hip):
+    """use_mask / use_distance_transform (projection_model.py:67-77,110-125; off in the BDM recipes): the two extra channels
+    ride on the hoisted conditioning image and reach the points through the same owner-pixel gather."""
+    from bdm_amd.cameras import join_cameras
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.model import compute_distance_transform, get_model
+    from bdm_amd.utils.procedural import fill_module_
+    from oracle import ref_sampler as R, ref_vit
+    cfg = ProjectConfig()
+    cfg.model.use_mask, cfg.model.use_distance_transform = True, True
+    model = fill_module_(get_model(cfg).eval(), seed=6)
+    B, N = 2, 1024
+    batch = next(iter(SyntheticShapes(range(B), B, seed=6, image_size=224, num_points=N)))
+    mask = torch.zeros(B, 1, 224, 224)
+    mask[0, 0, 60:170, 80:150] = 1.0
+    mask[1, 0, 100:130, 20:200] = 1.0
+    x = seeded((B, N, 3), 8, 0.3)
+    local = torch.cat([ref_vit.local_conditioning(model.state_dict(), batch.image_rgb), mask, compute_distance_transform(mask > 0.5)], 1)
+    ref = R.get_input_with_conditioning(x, join_cameras(batch.camera).packed(), local)
+    model = model.cuda()
+    b = batch.to("cuda")
+    got = model.get_input_with_conditioning(x.cuda(), camera=b.camera, image_rgb=b.image_rgb, mask=mask.cuda(), t=None).cpu()
+    assert got.shape == (B, N, 392)
+    assert torch.equal(got[:, :, -2:], ref[:, :, -2:])          # mask + distance transform at the owner pixel: exact
+    assert rel_l2(got, ref) < 1e-4
+    out = model.forward_sample(num_points=N, camera=b.camera, image_rgb=b.image_rgb, mask=mask.cuda(), num_inference_steps=3)
+    assert bool(torch.isfinite(out.points_padded()).all())

@@ -215,3 +215,39 @@ def test_pndm_product_scheduler_layout():
     p = m["pndm"]
     p.set_timesteps(50)
     assert len(p.timesteps) == 59 and p.timesteps[:4].tolist() == [980, 970, 970, 960]
+
+
+def test_distance_transform_chamfer_vs_exact():
+    """compute_distance_transform (model_utils.py:13-21 over cv2's 3x3 DIST_L2 chamfer metric): zero on the mask, grows away
+    from it, within the chamfer-3x3 metric's known relative error (< 6 %) of the exact Euclidean transform, scaled by
+    image_size / 2 and clipped to [0, 1]."""
+    from scipy import ndimage
+    from bdm_amd.model import compute_distance_transform
+    g = torch.Generator().manual_seed(0)
+    m = torch.zeros(2, 1, 48, 48, dtype=torch.bool)
+    m[0, 0, 10:20, 12:30] = True
+    m[1, 0][torch.rand(48, 48, generator=g) > 0.97] = True
+    dt = compute_distance_transform(m)
+    assert dt.shape == (2, 1, 48, 48) and float(dt.min()) == 0.0 and float(dt.max()) <= 1.0
+    assert bool((dt[m] == 0).all())
+    for b in range(2):
+        exact = ndimage.distance_transform_edt(~m[b, 0].numpy()) / 24.0
+        got = dt[b, 0].numpy()
+        sel = exact < 0.95                                     # below the clip
+        assert np.all(np.abs(got[sel] - exact[sel]) <= 0.06 * exact[sel] + 1e-6)
+    # horizontal / vertical neighbours are exactly a = 0.955 pixels away in this metric
+    one = torch.zeros(1, 1, 9, 9, dtype=torch.bool); one[0, 0, 4, 4] = True
+    d1 = compute_distance_transform(one)[0, 0] * (9 / 2)
+    assert abs(float(d1[4, 5]) - 0.955) < 1e-4 and abs(float(d1[5, 5]) - 1.3693) < 1e-4 and abs(float(d1[4, 6]) - 1.91) < 1e-4
+
+
+def test_mask_conditioning_changes_the_input_width():
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.model import get_model
+    cfg = ProjectConfig()
+    base = get_model(cfg).in_channels
+    cfg.model.use_mask, cfg.model.use_distance_transform = True, True
+    m = get_model(cfg)
+    assert (base, m.in_channels) == (390, 392) and m.point_cloud_model.model.in_channels == 392
+    cfg.model.use_distance_transform = False
+    assert get_model(cfg).in_channels == 391
