@@ -381,16 +381,22 @@ def saturation_slot(owner, device):
     key = str(device)
     reg = _sat_registry.get(key)
     if reg is None:
-        reg = _sat_registry[key] = [torch.zeros(256, dtype=torch.int32, device=device), []]
+        reg = _sat_registry[key] = [torch.zeros(1024, dtype=torch.int32, device=device), []]
     slots = getattr(owner, "_bdm_sat_slots", None)
     if slots is None:
         slots = owner._bdm_sat_slots = {}
     idx = slots.get(key)
     if idx is None:
-        if len(reg[1]) >= reg[0].numel():
-            raise L.BdmHipError("more than 256 fp16x3 layers on one device")
-        idx = slots[key] = len(reg[1])
-        reg[1].append(weakref.ref(owner))
+        if len(reg[1]) < reg[0].numel():
+            idx = len(reg[1])
+            reg[1].append(weakref.ref(owner))
+        else:  # recycle the slot of a layer that no longer exists
+            idx = next((i for i, r in enumerate(reg[1]) if r() is None), None)
+            if idx is None:
+                raise L.BdmHipError(f"more than {reg[0].numel()} live fp16x3 layers on one device")
+            reg[0][idx:idx + 1].zero_()
+            reg[1][idx] = weakref.ref(owner)
+        slots[key] = idx
     return reg[0][idx:idx + 1]
 
 
