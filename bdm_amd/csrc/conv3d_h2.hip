@@ -110,7 +110,7 @@ template <int MI, int NI, int R, int TX, int TY, int NW>  // NW waves per workgr
 __global__ __launch_bounds__(NW * 64) void conv3d_h2_kernel(int C8, int Cout, const float4 *__restrict__ x,
                                                         const float4 *__restrict__ wq, const float *__restrict__ inv_scale,
                                                         float x_inv_scale, const float *__restrict__ bias,
-                                                        float *__restrict__ y) {
+                                                        float *__restrict__ y, int gn_cg, double *__restrict__ gn_partial) {
   extern __shared__ __align__(16) float4 smem4[];
   constexpr int BM = 32 * MI;
   constexpr int RSV = R + 2;                 // voxel records per halo row (one zero pad at each end)
@@ -224,6 +224,15 @@ __global__ __launch_bounds__(NW * 64) void conv3d_h2_kernel(int C8, int Cout, co
             acc[mi][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][term == 0 ? 1 : 0], b[q][term == 1 ? 1 : 0], acc[mi][q], 0, 0, 0);
     }
   }
+  // Epilogue: scale + bias + store.  When gn_partial is given, the workgroup also leaves the (sum, sum of squares) of the
+  // values it wrote, per GroupNorm group of its channel tile, as slice blockIdx.x of the group's partials -- the GroupNorm
+  // that follows the convolution (pvconv.py:84) then needs no statistics pass of its own.  Deterministic: fixed order inside
+  // the lane, half-wave butterflies, then a fixed-order sum over waves by one thread per group.
+  float bs[MI][4], bq[MI][4];  // per 4-row block j of this lane: rows p*32 + 8j + 4lh .. +3 (never straddle a group)
+#pragma unroll
+  for (int p = 0; p < MI; ++p)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bs[p][j] = 0.f; bq[p][j] = 0.f; }
 #pragma unroll
   for (int p = 0; p < MI; ++p)
 #pragma unroll
@@ -231,8 +240,52 @@ __global__ __launch_bounds__(NW * 64) void conv3d_h2_kernel(int C8, int Cout, co
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int m = m0 + p * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-        if (m < Cout) yb[(size_t)m * R3 + gvox[q]] = acc[p][q][i] * (inv_scale[m] * x_inv_scale) + (bias ? bias[m] : 0.f);
+        if (m < Cout) {
+          const float v = acc[p][q][i] * (inv_scale[m] * x_inv_scale) + (bias ? bias[m] : 0.f);
+          yb[(size_t)m * R3 + gvox[q]] = v;
+          bs[p][i >> 2] += v;
+          bq[p][i >> 2] += v * v;
+        }
       }
+  if (gn_partial != nullptr) {
+#pragma unroll
+    for (int p = 0; p < MI; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+          bs[p][j] += __shfl_xor(bs[p][j], o, 64);
+          bq[p][j] += __shfl_xor(bq[p][j], o, 64);
+        }
+    __syncthreads();  // the operand tiles are dead: reuse the LDS
+    float *red = reinterpret_cast<float *>(smem4);  // [NW][2][MI][4][2]
+    if (li == 0) {
+#pragma unroll
+      for (int p = 0; p < MI; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          red[((((wave * 2 + lh) * MI + p) * 4 + j) * 2) + 0] = bs[p][j];
+          red[((((wave * 2 + lh) * MI + p) * 4 + j) * 2) + 1] = bq[p][j];
+        }
+    }
+    __syncthreads();
+    const int ngt = BM / gn_cg;  // groups inside this channel tile
+    if (tid < ngt && m0 + tid * gn_cg < Cout) {
+      double a = 0.0, qq = 0.0;
+      for (int w = 0; w < NW; ++w)
+        for (int hh = 0; hh < 2; ++hh)
+          for (int p = 0; p < MI; ++p)
+            for (int j = 0; j < 4; ++j)
+              if ((p * 32 + 8 * j + 4 * hh) / gn_cg == tid) {
+                a += (double)red[((((w * 2 + hh) * MI + p) * 4 + j) * 2) + 0];
+                qq += (double)red[((((w * 2 + hh) * MI + p) * 4 + j) * 2) + 1];
+              }
+      const int G = Cout / gn_cg, g = m0 / gn_cg + tid, S = gridDim.x;
+      double *dst = gn_partial + (((size_t)bi * G + g) * S + blockIdx.x) * 2;
+      dst[0] = a;
+      dst[1] = qq;
+    }
+  }
 }
 
 static int h2_waves() {  // experiment switch: BDM_H2_WAVES=4 selects the 4-wave tiling
@@ -241,9 +294,9 @@ static int h2_waves() {  // experiment switch: BDM_H2_WAVES=4 selects the 4-wave
   return w;
 }
 
-extern "C" int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale,
-                                   const void *packed_w, const float *inv_scale, const float *bias, float *y,
-                                   void *stream) {
+static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale, const void *packed_w,
+                            const float *inv_scale, const float *bias, float *y, int gn_cg, double *gn_partial,
+                            int *slices_out, void *stream) {
   BDM_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && inv_scale != nullptr, "conv3d_h2: bad arguments");
   if (r != 8 && r != 16 && r != 32) {
     set_error("conv3d_h2: resolution %d unsupported (8, 16, 32)", r);
@@ -261,11 +314,17 @@ extern "C" int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *
   const size_t smem = 16 * ((size_t)2 * (tx + 2) * (ty + 2) * (r + 2) + (size_t)H2_PAIRS * 4 * 32 * mi);
   dim3 grid((r / tx) * (r / ty), cdiv(cout, 32 * mi), b);
   hipStream_t s = (hipStream_t)stream;
+  if (gn_partial != nullptr) {
+    BDM_REQUIRE(gn_cg >= 4 && gn_cg % 4 == 0 && (32 * mi) % gn_cg == 0 && cout % gn_cg == 0 && (int)grid.x <= 64,
+                "conv3d_h2: GroupNorm statistics need 4 | channels-per-group | %d and <= 64 spatial tiles (got cg=%d)", 32 * mi, gn_cg);
+    if (slices_out) *slices_out = (int)grid.x;
+  }
 #define H2_LAUNCH(MI, NI, R, TX, TY, NW)                                                                        \
   do {                                                                                                          \
     BDM_ALLOW_LDS((conv3d_h2_kernel<MI, NI, R, TX, TY, NW>), smem);                                             \
     hipLaunchKernelGGL((conv3d_h2_kernel<MI, NI, R, TX, TY, NW>), grid, dim3(NW * 64), smem, s, c8, cout,       \
-                       (const float4 *)x_h2, (const float4 *)packed_w, inv_scale, x_inv_scale, bias, y);        \
+                       (const float4 *)x_h2, (const float4 *)packed_w, inv_scale, x_inv_scale, bias, y, gn_cg,  \
+                       gn_partial);                                                                             \
   } while (0)
   const bool w8 = h2_waves() == 8;
   if (r == 32) {
@@ -279,6 +338,22 @@ extern "C" int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *
   }
 #undef H2_LAUNCH
   return launch_status("conv3d_h2");
+}
+
+extern "C" int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale,
+                                   const void *packed_w, const float *inv_scale, const float *bias, float *y,
+                                   void *stream) {
+  return conv3d_h2_launch(b, cin, cout, r, x_h2, x_inv_scale, packed_w, inv_scale, bias, y, 0, nullptr, nullptr, stream);
+}
+
+// The same convolution, also leaving the GroupNorm(groups) statistics of its OUTPUT as slice partials in `gn_workspace`
+// (layout and size of bdm_group_norm_workspace_bytes(b, groups); *slices_out = slices per (shape, group)).
+extern "C" int bdm_conv3d_3x3x3_h2_gn(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale,
+                                      const void *packed_w, const float *inv_scale, const float *bias, float *y, int groups,
+                                      void *gn_workspace, int *slices_out, void *stream) {
+  BDM_REQUIRE(groups >= 1 && cout % groups == 0 && gn_workspace != nullptr && slices_out != nullptr, "conv3d_h2_gn: bad arguments");
+  return conv3d_h2_launch(b, cin, cout, r, x_h2, x_inv_scale, packed_w, inv_scale, bias, y, cout / groups,
+                          (double *)gn_workspace, slices_out, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -840,6 +840,113 @@ extern "C" int bdm_se_gate(int b, int c, int hidden, int l, const float *x, cons
   return launch_status("se_fc");
 }
 
+// ---- GroupNorm-folded form of the PVConv tail (pvconv.py:84-96 without an attention block) ---------------------------
+// The second convolution leaves its output RAW plus the GroupNorm slice partials (bdm_conv3d_3x3x3_h2_gn).  Instead of a
+// normalise + Swish pass that rewrites the grid, the two consumers apply it on the fly:
+//   row_mean_gn_kernel   per (shape, channel) row: finalise the group's mean / rstd from the partials, store the row's
+//                        affine form (a, b) = (gamma rstd, beta - mean gamma rstd), and reduce mean_l swish(a x + b) for SE;
+//   devox_gn_fused_kernel the trilinear gather evaluates swish(a g + b) at each of the 8 corners.
+// One read of the grid by each consumer, no write: the grid is never rewritten.
+__global__ void row_mean_gn_kernel(int c, int l, int G, int S, const float *__restrict__ x, const double *__restrict__ partial,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                   float *__restrict__ mean, float2 *__restrict__ coef) {
+  const int row = blockIdx.x, bi = row / c, ch = row % c, cg = c / G, g = ch / cg;
+  __shared__ float s_ab[2];
+  __shared__ double sh[16];
+  if (threadIdx.x == 0) {
+    double a = 0.0, q = 0.0;
+    const double *p = partial + ((size_t)bi * G + g) * S * 2;
+    for (int s = 0; s < S; ++s) { a += p[2 * s]; q += p[2 * s + 1]; }
+    const double cnt = (double)cg * l, mu = a / cnt;
+    double var = q / cnt - mu * mu;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float ga = gamma[ch] * rstd, be = beta[ch] - (float)mu * ga;
+    s_ab[0] = ga; s_ab[1] = be;
+    coef[row] = make_float2(ga, be);
+  }
+  __syncthreads();
+  const float ga = s_ab[0], be = s_ab[1];
+  const float *xr = x + (size_t)row * l;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < l; i += blockDim.x) acc += (double)swishf(xr[i] * ga + be);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += sh[w];
+    mean[row] = (float)(a / (double)l);
+  }
+}
+
+extern "C" int bdm_se_gate_gn(int b, int c, int hidden, int l, int groups, const float *x, const void *gn_workspace,
+                              int slices, const float *gamma, const float *beta, float eps, const float *w1,
+                              const float *w2, float *mean_ws, float *coef, float *gate, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && hidden >= 1 && l >= 1 && groups >= 1 && c % groups == 0 && slices >= 1 && slices <= GN_MAX_SLICES &&
+              gn_workspace != nullptr && coef != nullptr, "se_gate_gn: bad arguments");
+  if (b == 0) return BDM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(row_mean_gn_kernel, dim3(b * c), dim3(256), 0, s, c, l, groups, slices, x, (const double *)gn_workspace,
+                     gamma, beta, eps, mean_ws, (float2 *)coef);
+  int rc = launch_status("se_row_mean_gn");
+  if (rc) return rc;
+  if (w1 == nullptr) return BDM_OK;  // no SE block: only the affine forms are wanted
+  hipLaunchKernelGGL(se_fc_kernel, dim3(b), dim3(256), (c + hidden) * sizeof(float), s, c, hidden, mean_ws, w1, w2, gate);
+  return launch_status("se_fc");
+}
+
+__global__ void devox_gn_fused_kernel(int b, int cslots, int pblocks, int c, int n, int r, const float *__restrict__ coords,
+                                      const float *__restrict__ grid, const float2 *__restrict__ coef,
+                                      const float *__restrict__ gate, const float *__restrict__ add, long long bs_a, int ld_a,
+                                      float *__restrict__ out, long long bs_o, int ld_o) {
+#pragma clang fp contract(off)
+  const int span = 8 * pblocks, wg = blockIdx.x;
+  const int unit = (wg / span) * 8 + (wg % span) % 8, pb = (wg % span) / 8;
+  if (unit >= b * cslots) return;
+  const int bi = unit / cslots, c_first = unit % cslots;
+  const int i = pb * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r2 = r * r, r3 = r2 * r;
+  const float *pc = coords + (size_t)bi * 3 * n;
+  const float x = pc[i], y = pc[n + i], z = pc[2 * n + i];
+  const float xl = floorf(x), yl = floorf(y), zl = floorf(z);
+  const float x1 = x - xl, y1 = y - yl, z1 = z - zl;
+  const float x0 = 1.0f - x1, y0 = 1.0f - y1, z0 = 1.0f - z1;
+  const float w000 = x0 * y0 * z0, w001 = x0 * y0 * z1, w010 = x0 * y1 * z0, w011 = x0 * y1 * z1,
+              w100 = x1 * y0 * z0, w101 = x1 * y0 * z1, w110 = x1 * y1 * z0, w111 = x1 * y1 * z1;
+  const int sx = x1 > 0 ? r2 : 0, sy = y1 > 0 ? r : 0, sz = z1 > 0 ? 1 : 0;
+  const int i000 = (int)xl * r2 + (int)yl * r + (int)zl;
+  const int i001 = i000 + sz, i010 = i000 + sy, i011 = i010 + sz;
+  const int i100 = i000 + sx, i101 = i100 + sz, i110 = i100 + sy, i111 = i110 + sz;
+  for (int ci = c_first; ci < c; ci += cslots) {
+    const float *g = grid + ((size_t)bi * c + ci) * r3;
+    const float2 ab = coef[(size_t)bi * c + ci];
+    const float s = gate ? gate[(size_t)bi * c + ci] : 1.0f;
+    // corners with weight 0 (frac == 0 on an axis) alias an in-grid cell: their value is finite and multiplies 0
+    float acc = w000 * (swishf(g[i000] * ab.x + ab.y) * s);
+    acc += w001 * (swishf(g[i001] * ab.x + ab.y) * s);
+    acc += w010 * (swishf(g[i010] * ab.x + ab.y) * s);
+    acc += w011 * (swishf(g[i011] * ab.x + ab.y) * s);
+    acc += w100 * (swishf(g[i100] * ab.x + ab.y) * s);
+    acc += w101 * (swishf(g[i101] * ab.x + ab.y) * s);
+    acc += w110 * (swishf(g[i110] * ab.x + ab.y) * s);
+    acc += w111 * (swishf(g[i111] * ab.x + ab.y) * s);
+    if (add) acc += add[(size_t)bi * bs_a + (size_t)ci * ld_a + i];
+    out[(size_t)bi * bs_o + (size_t)ci * ld_o + i] = acc;
+  }
+}
+extern "C" int bdm_devoxelize_gn_gate_add(int b, int c, int n, int r, const float *coords, const float *grid,
+                                          const float *coef, const float *gate, const float *add, long long bs_a, int ld_a,
+                                          float *out, long long bs_o, int ld_o, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && n >= 1 && r >= 1 && coef != nullptr, "devoxelize_gn_gate_add: bad arguments");
+  if (b == 0) return BDM_OK;
+  const int cslots = c < 64 ? c : 64, pblocks = cdiv(n, 256);
+  hipLaunchKernelGGL(devox_gn_fused_kernel, dim3(cdiv(b * cslots, 8) * 8 * pblocks), dim3(256), 0, (hipStream_t)stream, b, cslots,
+                     pblocks, c, n, r, coords, grid, (const float2 *)coef, gate, add, bs_a, ld_a, out, bs_o, ld_o);
+  return launch_status("devoxelize_gn_gate_add");
+}
+
 // =====================================================================================
 // PVConv tail: out = trilinear_devoxelize(grid * gate) + point_branch   (pvconv.py:95-96)
 // =====================================================================================

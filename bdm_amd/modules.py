@@ -160,6 +160,7 @@ class PVConv(nn.Module):
     #   "bf16x6": exact 3-way bf16 split of both operands, six partial products on the bf16 matrix cores;
     #   "fp32"  : v_mfma_f32_32x32x2_f32 kernels of conv3d.hip (BDM_CONV=fp32).
     conv_impl = os.environ.get("BDM_CONV", "fp16x3")
+    fold_gn2 = os.environ.get("BDM_FOLD_GN2", "1") == "1"  # second GroupNorm folded into its consumers (fp16x3 path)
     sparse_first_conv = os.environ.get("BDM_SPARSE_CONV1", "1") == "1"
     sparse_resolutions = {int(v) for v in os.environ.get("BDM_SPARSE_R", "8,16,32").split(",") if v}
     # first convolution on the occupied voxels: "bf16x6" (default: batched GEMM + gather over a 27x-expanded intermediate,
@@ -229,8 +230,17 @@ class PVConv(nn.Module):
                 # saturation guard: to_h2 raises this layer's sticky device word when a scaled activation leaves fp16's
                 # range; ops.poll_h2_saturation() (once per trajectory) then routes the layer to bf16x6 and warns
                 sat = ops.saturation_slot(self, v.device) if v.is_cuda else None
-                v = ops.conv3d_h2(ops.to_h2(v, gn1, swish=True, saturated=sat), self._packed_weight(conv2, "fp16x3"), conv2.bias,
-                                  conv2.in_channels, conv2.out_channels, r)
+                xh = ops.to_h2(v, gn1, swish=True, saturated=sat)
+                if self.fold_gn2 and att is None and se is not None:
+                    # GroupNorm-folded tail: the convolution leaves the statistics of its output, SE and the devoxelisation
+                    # normalise + Swish on the fly -- the grid is written once (by the convolution) and never rewritten
+                    v, stats = ops.conv3d_h2_gn(xh, self._packed_weight(conv2, "fp16x3"), conv2.bias, conv2.in_channels,
+                                                conv2.out_channels, r, gn2.num_groups)
+                    gate, coef = ops.se_gate_gn(v, stats, gn2, se.fc[0].weight, se.fc[2].weight)
+                    if pf_ready is not None:
+                        pf_ready.wait()
+                    return ops.devoxelize_gn_gate_add(norm_coords, v, coef, r, gate=gate, add=pf), coords, temb
+                v = ops.conv3d_h2(xh, self._packed_weight(conv2, "fp16x3"), conv2.bias, conv2.in_channels, conv2.out_channels, r)
             else:
                 v = ops.conv3d_s3(ops.to_s3(v, gn1, swish=True), self._packed_weight(conv2, "bf16x6"), conv2.bias,
                                   conv2.in_channels, conv2.out_channels, r)

@@ -455,6 +455,48 @@ def conv3d_h2(x_h2, packed, bias, cin, cout, r):
     return y
 
 
+def conv3d_h2_gn(x_h2, packed, bias, cin, cout, r, groups=8):
+    """conv3d_h2 that also leaves the GroupNorm(groups) statistics of its output: (y raw, (partials workspace, slices))."""
+    (xh, x_inv_scale), (packed_w, inv_scale) = x_h2, packed
+    B = xh.shape[0]
+    y = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=xh.device)
+    ws = torch.empty(L.lib().bdm_group_norm_workspace_bytes(B, groups), dtype=torch.uint8, device=xh.device)
+    slices = ctypes.c_int(0)
+    L.check(L.lib().bdm_conv3d_3x3x3_h2_gn(B, cin, cout, int(r), L.ptr(xh), L.c_float(x_inv_scale), L.ptr(packed_w),
+                                           L.ptr(inv_scale), L.ptr(bias), L.ptr(y), groups, L.ptr(ws), ctypes.byref(slices),
+                                           L.stream()), "conv3d_h2_gn")
+    return y, (ws, slices.value)
+
+
+def se_gate_gn(x, stats, gn, w1, w2):
+    """SE gate of swish(group_norm(x)) evaluated from the raw grid x and the producer's statistics: (gate (B,C), coef (B,C,2))."""
+    ws, slices = stats
+    B, C = x.shape[:2]
+    l = x.numel() // (B * C)
+    mean = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    coef = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+    gate = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    L.check(L.lib().bdm_se_gate_gn(B, C, w1.shape[0], l, gn.num_groups, L.ptr(x), L.ptr(ws), slices, L.ptr(gn.weight), L.ptr(gn.bias),
+                                   L.c_float(gn.eps), L.ptr(w1), L.ptr(w2), L.ptr(mean), L.ptr(coef), L.ptr(gate), L.stream()),
+            "se_gate_gn")
+    return gate, coef
+
+
+def devoxelize_gn_gate_add(norm_coords, grid, coef, r, gate=None, add=None):
+    B, C = grid.shape[:2]
+    n = norm_coords.shape[2]
+    out = torch.empty(B, C, n, dtype=torch.float32, device=grid.device)
+    _, _, _, _, bs_o, ld_o = _bcl(out)
+    if add is not None:
+        aa, _, _, _, bs_a, ld_a = _bcl(add)
+        assert aa.data_ptr() == add.data_ptr()
+    else:
+        bs_a, ld_a = 0, 0
+    L.check(L.lib().bdm_devoxelize_gn_gate_add(B, C, n, int(r), L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(gate), L.ptr(add),
+                                               bs_a, ld_a, L.ptr(out), bs_o, ld_o, L.stream()), "devoxelize_gn_gate_add")
+    return out
+
+
 # ---- sparse first convolution of a PVConv (csrc/sparse_conv.hip) ----------------------------------------------------
 def sparse_conv_pack(weight):
     cout, cin = weight.shape[:2]

@@ -250,6 +250,22 @@ int bdm_group_norm_to_h2(int b, int c, int v, int groups, const float *x, const 
 int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale, const void *packed_w,
                         const float *inv_scale, const float *bias, float *y, void *stream);
 
+/* GroupNorm-folded tail of a PVConv without attention (pvconv.py:84-96): the second convolution leaves its output raw and
+ * the GroupNorm(groups) statistics of that output as slice partials (layout / size: bdm_group_norm_workspace_bytes;
+ * *slices_out slices per (shape, group)); the consumers then normalise + Swish on the fly instead of rewriting the grid:
+ *   bdm_se_gate_gn            per (shape, channel): coef (b, c, 2) = (gamma rstd, beta - mean gamma rstd), and the SE gate
+ *                             sigmoid(w2 relu(w1 mean_l swish(coef.x x + coef.y))) (w1 == NULL: only coef is produced)
+ *   bdm_devoxelize_gn_gate_add out = trilinear_devoxelize(swish(coef.x grid + coef.y) * gate) + add */
+int bdm_conv3d_3x3x3_h2_gn(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale, const void *packed_w,
+                           const float *inv_scale, const float *bias, float *y, int groups, void *gn_workspace,
+                           int *slices_out, void *stream);
+int bdm_se_gate_gn(int b, int c, int hidden, int l, int groups, const float *x, const void *gn_workspace, int slices,
+                   const float *gamma, const float *beta, float eps, const float *w1, const float *w2, float *mean_ws,
+                   float *coef, float *gate, void *stream);
+int bdm_devoxelize_gn_gate_add(int b, int c, int n, int r, const float *coords, const float *grid, const float *coef,
+                               const float *gate, const float *add, long long bs_a, int ld_a, float *out,
+                               long long bs_o, int ld_o, void *stream);
+
 /* bf16x6 form of the two steps above (default): operands pre-split into exact bf16 triples ("S3" records of 8
  * channels x 16 bytes), GEMM on v_mfma_f32_32x32x16_bf16 with six partial products per fp32 product.
  *   xs (b, ceil(c/8), 3, n_max) records; ws (ceil(cin/8), 3, 27*cout) records = bdm_sparse_conv_s3_weight_elems bf16. */

@@ -399,3 +399,21 @@ def test_fp16x3_saturation_guard(ops, oracle_ops):
     y1 = pv((f, c, t))[0]                                   # now on the bf16x6 kernels
     assert rel(y1.cpu(), y0.cpu()) < 2e-6
     assert ops.poll_h2_saturation() == []                   # the word was cleared
+
+
+@pytest.mark.parametrize("cin,cout,r,n", [(16, 32, 8, 300), (32, 32, 32, 4096), (64, 64, 32, 2000), (128, 128, 16, 1024), (256, 256, 8, 64)])
+def test_gn2_folded_tail_equals_separate_groupnorm_pass(ops, monkeypatch, cin, cout, r, n):
+    """PVConv tail with the second GroupNorm folded into its consumers (statistics from the convolution's epilogue, normalise +
+    Swish inside the SE reduction and the devoxelisation gather) vs the separate GroupNorm pass: same module output."""
+    from bdm_amd.modules import PVConv
+    from bdm_amd.utils.procedural import fill_module_
+    pv = fill_module_(PVConv(cin, cout, 3, resolution=r, with_se=True, with_se_relu=True).eval(), seed=cin + r).cuda()
+    g = torch.Generator().manual_seed(n)
+    f, c = torch.randn(3, cin, n, generator=g).cuda(), (torch.randn(3, 3, n, generator=g) * 0.3).cuda()
+    t = torch.zeros(3, 8, n, device="cuda")
+    monkeypatch.setattr(PVConv, "fold_gn2", False)
+    ref = pv((f, c, t))[0].clone()
+    monkeypatch.setattr(PVConv, "fold_gn2", True)
+    got = pv((f, c, t))[0]
+    assert rel(got.cpu(), ref.cpu()) < 1e-6
+    assert torch.equal(got, pv((f, c, t))[0])      # deterministic
