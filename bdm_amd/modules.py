@@ -231,7 +231,8 @@ class PVConv(nn.Module):
                 # range; ops.poll_h2_saturation() (once per trajectory) then routes the layer to bf16x6 and warns
                 sat = ops.saturation_slot(self, v.device) if v.is_cuda else None
                 xh = ops.to_h2(v, gn1, swish=True, saturated=sat)
-                if self.fold_gn2 and att is None and se is not None:
+                cg2, tile = conv2.out_channels // gn2.num_groups, (64 if (conv2.out_channels > 32 and r != 8) else 32)
+                if self.fold_gn2 and att is None and se is not None and cg2 in (4, 8, 16, 32) and tile % cg2 == 0:
                     # GroupNorm-folded tail: the convolution leaves the statistics of its output, SE and the devoxelisation
                     # normalise + Swish on the fly -- the grid is written once (by the convolution) and never rewritten
                     v, stats = ops.conv3d_h2_gn(xh, self._packed_weight(conv2, "fp16x3"), conv2.bias, conv2.in_channels,

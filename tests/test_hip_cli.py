@@ -74,7 +74,8 @@ def test_two_ranks_equal_one_rank_with_per_shape_streams(hip, tmp_path):
     big = ["dataset.num_shapes=4"]
     one = _check_tree(_launch(1, tmp_path / "w1", big, 29741), 4, 1024)
     two = _check_tree(_launch(2, tmp_path / "w2", big, 29742), 4, 1024)
-    assert np.array_equal(one, two)
+    diff = np.abs(one - two).reshape(4, -1).max(1)
+    assert np.array_equal(one, two), f"per-shape max |diff| between the 1-rank and the 2-rank run: {diff}"
     # another batch size regroups the shapes: same streams, so the clouds agree up to kernel-variant summation order
     three = _check_tree(_launch(1, tmp_path / "w3", big + ["dataloader.batch_size=4"], 29743), 4, 1024)
     err = np.linalg.norm(three - one) / np.linalg.norm(one)
