@@ -269,17 +269,26 @@ __global__ __launch_bounds__(NW * 64) void conv3d_h2_kernel(int C8, int Cout, co
         }
     }
     __syncthreads();
+    // stage 1: one thread per (half, p, j, statistic) adds the NW waves' values in wave order (NW reads deep, not NW*32)
+    constexpr int NB = 2 * MI * 4 * 2;
+    float *red2 = red + NW * NB;
+    if (tid < NB) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) a += red[w * NB + tid];
+      red2[tid] = a;
+    }
+    __syncthreads();
     const int ngt = BM / gn_cg;  // groups inside this channel tile
     if (tid < ngt && m0 + tid * gn_cg < Cout) {
       double a = 0.0, qq = 0.0;
-      for (int w = 0; w < NW; ++w)
-        for (int hh = 0; hh < 2; ++hh)
-          for (int p = 0; p < MI; ++p)
-            for (int j = 0; j < 4; ++j)
-              if ((p * 32 + 8 * j + 4 * hh) / gn_cg == tid) {
-                a += (double)red[((((w * 2 + hh) * MI + p) * 4 + j) * 2) + 0];
-                qq += (double)red[((((w * 2 + hh) * MI + p) * 4 + j) * 2) + 1];
-              }
+      for (int hh = 0; hh < 2; ++hh)
+        for (int p = 0; p < MI; ++p)
+          for (int j = 0; j < 4; ++j)
+            if ((p * 32 + 8 * j + 4 * hh) / gn_cg == tid) {
+              a += (double)red2[(((hh * MI + p) * 4 + j) * 2) + 0];
+              qq += (double)red2[(((hh * MI + p) * 4 + j) * 2) + 1];
+            }
       const int G = Cout / gn_cg, g = m0 / gn_cg + tid, S = gridDim.x;
       double *dst = gn_partial + (((size_t)bi * G + g) * S + blockIdx.x) * 2;
       dst[0] = a;
