@@ -27,6 +27,32 @@ def init_from_env(backend=None):
     return rank, local_rank, world
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def gpu_turn(device=None):
+    """Test aid for BDM_SHARE_GPU=1 (several ranks driving ONE GPU, used to exercise the multi-rank code on a 1-GPU box):
+    the ranks take turns on the device (an flock'ed file; the GPU is drained before the turn ends).  Measured on MI355X /
+    ROCm 7.2: when two PROCESSES run kernels on the same GPU at the same time, a kernel occasionally returns a wrong
+    64-byte sector (16 consecutive floats of one row; all inputs bit-identical, the same launch alone or in a single
+    process is always right -- tools/determinism_trace.py).  One process per GPU, the production layout, never shares a
+    device, so this only matters for the shared-GPU test mode.  No-op otherwise."""
+    if os.environ.get("BDM_SHARE_GPU") != "1":
+        yield
+        return
+    import fcntl
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"bdm_share_gpu_{os.environ.get('MASTER_PORT', '0')}.lock")
+    with open(path, "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+            if torch.cuda.is_available():
+                torch.cuda.synchronize(device)
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
 def shard_indices(num_shapes, rank, world):
     """Contiguous, balanced shard of global shape indices [0, num_shapes) for `rank`."""
     base, extra = divmod(num_shapes, world)

@@ -69,7 +69,7 @@ def save_outputs(output_dir, batch, clouds, sample_idx, num_samples):
 
 def main(argv=None):
     from bdm_amd.config import parse_overrides
-    from bdm_amd.distributed import barrier, init_from_env, shared_run_dir
+    from bdm_amd.distributed import barrier, gpu_turn, init_from_env, shared_run_dir
     from bdm_amd.sampling import batch_streams, bdm_blending
     cfg = parse_overrides(sys.argv[1:] if argv is None else argv)
     rank, local_rank, world = init_from_env()
@@ -90,8 +90,9 @@ def main(argv=None):
             break
         batch = batch.to(device)
         for sample_idx in range(cfg.run.num_samples):
-            output = bdm_blending(None, batch, cfg, model, pvd_model, generator=generator,
-                                  streams=batch_streams(cfg, batch, device, sample_idx))
+            with gpu_turn(device):  # no-op unless several ranks share one GPU (test aid)
+                output = bdm_blending(None, batch, cfg, model, pvd_model, generator=generator,
+                                      streams=batch_streams(cfg, batch, device, sample_idx))
             save_outputs(out_root, batch, output.points_padded(), sample_idx, cfg.run.num_samples)
     barrier()
     if rank == 0:

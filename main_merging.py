@@ -11,7 +11,7 @@ from main_blending import build_models, get_dataloader, save_outputs
 
 def main(argv=None):
     from bdm_amd.config import parse_overrides
-    from bdm_amd.distributed import barrier, init_from_env, shared_run_dir
+    from bdm_amd.distributed import barrier, gpu_turn, init_from_env, shared_run_dir
     from bdm_amd.sampling import batch_streams, bdm_merging
     cfg = parse_overrides(sys.argv[1:] if argv is None else argv)
     rank, local_rank, world = init_from_env()
@@ -29,8 +29,9 @@ def main(argv=None):
             break
         batch = batch.to(device)
         for sample_idx in range(cfg.run.num_samples):
-            output = bdm_merging(None, batch, cfg, prior_model, recon_model, fusion_model,
-                                 streams=batch_streams(cfg, batch, device, sample_idx))
+            with gpu_turn(device):
+                output = bdm_merging(None, batch, cfg, prior_model, recon_model, fusion_model,
+                                     streams=batch_streams(cfg, batch, device, sample_idx))
             save_outputs(out_root, batch, output.points_padded(), sample_idx, cfg.run.num_samples)
     barrier()
     if rank == 0:
