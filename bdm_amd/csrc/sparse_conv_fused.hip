@@ -389,3 +389,150 @@ extern "C" int bdm_sparse_conv_fused(int b, int cin, int cout, int r, int n_max,
 #undef FUSED_LAUNCH
   return launch_status("sparse_conv_fused");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// fp16x3 form of the batched GEMM of sparse_conv.hip (step 2): Y[b] (n_occ x 27*Cout) = X[b] . W with HALF the matrix work
+// of the bf16x6 GEMM.  A = the fp32 feature records of bdm_sparse_voxel_features_f32, scaled by the power of two derived
+// from amax and split into (hi, lo) fp16 while they are staged into LDS; B = weights packed as [G][2][27*Cout] fp16 records
+// with a per-output-channel scale (column n -> channel n % Cout).  Tile BM x 128 (BM = 128, or 64 for levels with <= 256
+// occupied rows per shape: less padding), K = 32 per stage, register-prefetched.  The gather (step 3) is unchanged.
+// ---------------------------------------------------------------------------------------------------
+__global__ void sparse_gemm_h2_pack_kernel(int cout, int cin, const float *__restrict__ w, const float *__restrict__ scale,
+                                           unsigned short *__restrict__ wq) {
+  const int G = (cin + 7) / 8, n27 = 27 * cout;
+  const long long total = (long long)G * n27;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(e % n27), g = (int)(e / n27), tap = col / cout, co = col % cout;
+    unsigned short h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ci = g * 8 + j;
+      split2s(ci < cin ? w[((size_t)co * cin + ci) * 27 + tap] * scale[co] : 0.f, h[j], l[j]);
+    }
+    unsigned short *ph = wq + (((size_t)g * 2 + 0) * n27 + col) * 8, *pl = wq + (((size_t)g * 2 + 1) * n27 + col) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ph[j] = h[j]; pl[j] = l[j]; }
+  }
+}
+extern "C" size_t bdm_sparse_conv_h2_weight_elems(int cout, int cin) { return (size_t)((cin + 7) / 8) * 2 * 27 * cout * 8; }
+extern "C" int bdm_sparse_conv_pack_weights_h2(int cout, int cin, const float *w, void *packed, float *scale_ws,
+                                               float *inv_scale, void *stream) {
+  BDM_REQUIRE(cout >= 1 && cin >= 1 && scale_ws != nullptr && inv_scale != nullptr, "sparse_conv_pack_weights_h2: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sparse_fused_weight_scale_kernel, dim3(cout), dim3(256), 0, s, cout, cin, w, scale_ws, inv_scale);
+  hipLaunchKernelGGL(sparse_gemm_h2_pack_kernel, dim3(512), dim3(256), 0, s, cout, cin, w, scale_ws, (unsigned short *)packed);
+  return launch_status("sparse_conv_pack_weights_h2");
+}
+
+template <int BM>
+__global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N, int Cout, const float4 *__restrict__ A,
+                                                             const float *__restrict__ amax, const uint4 *__restrict__ Bw,
+                                                             const float *__restrict__ inv_sw, const int *__restrict__ m_count,
+                                                             float *__restrict__ Y) {
+  constexpr int BN = 128, MX = BM / 64, BI = 8 * BN / 256;  // 4 groups x 2 splits per stage
+  __shared__ uint4 As[8 * BM], Bs[8 * BN];  // [group-in-stage][split][row]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;  // 2 x 2 waves: rows wr * (BM/2), columns wc * 64
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, bi = blockIdx.z;
+  if (m_count && m0 >= m_count[bi]) return;  // rows beyond this shape's occupied cells
+  const float sx = act_scale_from_max(*amax);
+  const float4 *Ab = A + (size_t)bi * G * M * 2;
+  f32x16 acc[MX][2];
+#pragma unroll
+  for (int x = 0; x < MX; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  // A stage: 4 groups x BM rows of fp32 records (2 float4 each) -> one thread loads whole records, splits, stores hi / lo
+  constexpr int AR = 4 * BM / 256;  // records per thread per stage
+  float4 ar[AR][2];
+  uint4 br[BI];
+  auto load_stage = [&](int g0) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int e = tid + i * 256, row = e % BM, g = g0 + e / BM;
+      const bool ok = g < G && m0 + row < M;
+      const size_t o = ((size_t)(ok ? g : 0) * M + (ok ? m0 + row : 0)) * 2;
+      const float4 p = Ab[o], q = Ab[o + 1];
+      const float k = ok ? sx : 0.f;
+      ar[i][0] = make_float4(p.x * k, p.y * k, p.z * k, p.w * k);
+      ar[i][1] = make_float4(q.x * k, q.y * k, q.z * k, q.w * k);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int e = tid + i * 256, col = e % BN, gs = e / BN, g = g0 + gs / 2, sp = gs % 2;
+      const bool ok = g < G && n0 + col < N;
+      const uint4 v = Bw[ok ? ((size_t)g * 2 + sp) * N + n0 + col : 0];
+      const unsigned k = ok ? 0xFFFFFFFFu : 0u;
+      br[i] = make_uint4(v.x & k, v.y & k, v.z & k, v.w & k);
+    }
+  };
+  load_stage(0);
+  for (int g0 = 0; g0 < G; g0 += 4) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int e = tid + i * 256, row = e % BM, gs = e / BM;
+      f16x8 hi, lo;
+      split_record(ar[i][0], ar[i][1], 1.0f, hi, lo);
+      As[(gs * 2 + 0) * BM + row] = *reinterpret_cast<const uint4 *>(&hi);
+      As[(gs * 2 + 1) * BM + row] = *reinterpret_cast<const uint4 *>(&lo);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) Bs[tid + i * 256] = br[i];
+    __syncthreads();
+    if (g0 + 4 < G) load_stage(g0 + 4);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      f16x8 a[MX][2], b[2][2];
+#pragma unroll
+      for (int x = 0; x < MX; ++x)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+          a[x][sp] = *reinterpret_cast<const f16x8 *>(&As[((2 * kk + lh) * 2 + sp) * BM + (wr * MX + x) * 32 + li]);
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+          b[y][sp] = *reinterpret_cast<const f16x8 *>(&Bs[((2 * kk + lh) * 2 + sp) * BN + (wc * 2 + y) * 32 + li]);
+      // term-major over the independent accumulators: lo.hi, hi.lo, hi.hi
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int x = 0; x < MX; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y)
+            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[x][term == 0 ? 1 : 0], b[y][term == 1 ? 1 : 0], acc[x][y], 0, 0, 0);
+    }
+  }
+  float *Yb = Y + (size_t)bi * M * N;
+  const float inv_sx = 1.0f / sx;
+#pragma unroll
+  for (int x = 0; x < MX; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int nn = n0 + (wc * 2 + y) * 32 + li;
+      const float post = nn < N ? inv_sw[nn % Cout] * inv_sx : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wr * MX + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && nn < N) Yb[(size_t)m * N + nn] = acc[x][y][r] * post;
+      }
+    }
+}
+
+extern "C" int bdm_sparse_conv_gemm_h2(int b, int n_max, int cin, int cout, const void *xr, const float *amax, const void *packed_w,
+                                       const float *inv_scale, const int *n_occ, float *y, void *stream) {
+  BDM_REQUIRE(b >= 0 && n_max >= 1 && cin >= 1 && cout >= 1 && amax != nullptr && inv_scale != nullptr, "sparse_conv_gemm_h2: bad arguments");
+  if (b == 0) return BDM_OK;
+  const int n27 = 27 * cout, G = (cin + 7) / 8;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_max <= 256)
+    hipLaunchKernelGGL(sparse_gemm_h2_kernel<64>, dim3(cdiv(n27, 128), cdiv(n_max, 64), b), dim3(256), 0, s, n_max, G, n27, cout,
+                       (const float4 *)xr, amax, (const uint4 *)packed_w, inv_scale, n_occ, y);
+  else
+    hipLaunchKernelGGL(sparse_gemm_h2_kernel<128>, dim3(cdiv(n27, 128), cdiv(n_max, 128), b), dim3(256), 0, s, n_max, G, n27, cout,
+                       (const float4 *)xr, amax, (const uint4 *)packed_w, inv_scale, n_occ, y);
+  return launch_status("sparse_conv_gemm_h2");
+}

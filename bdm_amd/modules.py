@@ -163,10 +163,11 @@ class PVConv(nn.Module):
     fold_gn2 = os.environ.get("BDM_FOLD_GN2", "1") == "1"  # second GroupNorm folded into its consumers (fp16x3 path)
     sparse_first_conv = os.environ.get("BDM_SPARSE_CONV1", "1") == "1"
     sparse_resolutions = {int(v) for v in os.environ.get("BDM_SPARSE_R", "8,16,32").split(",") if v}
-    # first convolution on the occupied voxels: "bf16x6" (default: batched GEMM + gather over a 27x-expanded intermediate,
-    # sparse_conv.hip) | "fp32" (same, fp32 MFMA) | "fused" (sparse_conv_fused.hip: one kernel, fp16x3, accumulators in LDS;
-    # correct and deterministic but measured SLOWER on MI355X -- DESIGN.md section 7 -- so it is opt-in)
-    sparse_gemm = {"fp32": "sparse", "bf16x6": "sparse_s3"}.get(os.environ.get("BDM_SPARSE_GEMM", "bf16x6"), "sparse_fused")
+    # first convolution on the occupied voxels: "fp16x3" (default: batched GEMM on two-term fp16 operands, activation scale
+    # from a device-side max, + gather) | "bf16x6" (same structure, exact 3-way bf16 split, twice the matrix work) | "fp32"
+    # (fp32 MFMA) | "fused" (sparse_conv_fused.hip: one kernel, accumulators in LDS; correct and deterministic but measured
+    # SLOWER on MI355X -- DESIGN.md section 7 -- so it is opt-in)
+    sparse_gemm = {"fp32": "sparse", "bf16x6": "sparse_s3", "fused": "sparse_fused"}.get(os.environ.get("BDM_SPARSE_GEMM", "fp16x3"), "sparse_h2")
 
     def _packed_weight(self, conv, impl):
         key = (id(conv), impl)
@@ -174,7 +175,7 @@ class PVConv(nn.Module):
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
             pack = {"bf16x6": ops.conv3d_s3_pack, "fp16x3": ops.conv3d_h2_pack, "sparse": ops.sparse_conv_pack,
-                    "sparse_s3": ops.sparse_conv_pack_s3, "sparse_fused": ops.sparse_conv_pack_fused,
+                    "sparse_s3": ops.sparse_conv_pack_s3, "sparse_fused": ops.sparse_conv_pack_fused, "sparse_h2": ops.sparse_conv_pack_h2,
                     "fp32": ops.conv3d_pack}[impl]
             hit = (sig, pack(conv.weight.detach()))
             self._packed[key] = hit

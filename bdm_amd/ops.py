@@ -590,8 +590,26 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout):
     """Conv3d(k3, p1)(avg_voxelize(features)) on the occupied voxels of `plan`: (B, cout, r^3) fp32."""
     f, B, C, n, bs_f, ld_f = _bcl(features)
     dev, lib, r = f.device, L.lib(), plan.r
+    if isinstance(wt, tuple) and wt[0] == "h2":  # fp16x3 GEMM (sparse_conv_pack_h2) + gather: the default
+        _, packed, inv_scale = wt
+        xr = torch.empty(B, (C + 7) // 8, plan.n_max, 8, dtype=torch.float32, device=dev)
+        amax = _amax_slot(dev)
+        L.check(lib.bdm_sparse_voxel_features_f32(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),
+                                                  L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()),
+                "sparse_voxel_features_f32")
+        out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
+        per_shape = plan.n_max * 27 * cout * 4
+        gb = max(1, min(B, SPARSE_Y_BYTES // max(per_shape, 1)))
+        y = torch.empty(gb, plan.n_max, 27 * cout, dtype=torch.float32, device=dev)
+        for b0 in range(0, B, gb):
+            nb = min(gb, B - b0)
+            L.check(lib.bdm_sparse_conv_gemm_h2(nb, plan.n_max, C, cout, L.ptr(xr[b0:]), L.ptr(amax), L.ptr(packed), L.ptr(inv_scale),
+                                                L.ptr(plan.n_occ[b0:]), L.ptr(y), L.stream()), "sparse_conv_gemm_h2")
+            L.check(lib.bdm_sparse_conv_gather(nb, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index[b0:]), L.ptr(plan.rowocc[b0:]),
+                                               L.ptr(bias), L.ptr(out[b0:]), L.stream()), "sparse_conv_gather")
+        return out
     if isinstance(wt, tuple):  # fused kernel (sparse_conv_pack_fused): GEMM + scatter in one launch, no intermediate
-        packed, inv_scale = wt
+        _, packed, inv_scale = wt
         xr = torch.empty(B, (C + 7) // 8, plan.n_max, 8, dtype=torch.float32, device=dev)
         amax = _amax_slot(dev)
         L.check(lib.bdm_sparse_voxel_features_f32(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),

@@ -304,6 +304,9 @@ def test_sparse_first_conv_equals_dense(ops, oracle_ops, cin, cout, r, npts):
     # bf16x6 GEMM on pre-split operands: same bound (fp32-grade products, fp32 accumulation)
     got6 = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack_s3(w.cuda()), bias.cuda(), cout).cpu()
     assert rel(got6, ref) < 2e-6
+    # fp16x3 GEMM (the default): same bound
+    goth = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack_h2(w.cuda()), bias.cuda(), cout).cpu()
+    assert rel(goth, ref) < 2e-6
     # fused kernel (GEMM + deterministic scatter into LDS accumulators, fp16x3): same bound; bit-reproducible
     gotf = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack_fused(w.cuda()), bias.cuda(), cout).cpu()
     assert rel(gotf, ref) < 2e-6
@@ -331,6 +334,8 @@ def test_sparse_fused_conv_wide_dynamic_range_and_empty_shape(ops, oracle_ops):
     w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
     bias = torch.randn(cout, generator=g)
     got = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack_fused(w.cuda()), bias.cuda(), cout).cpu()
+    goth = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack_h2(w.cuda()), bias.cuda(), cout).cpu()
+    assert rel(goth, got) < 1e-6
     for b in (0, 3, 15):
         vox = oracle_ops.avg_voxelize_forward(f[b:b + 1].contiguous(), vc[b:b + 1].contiguous(), r)[0]
         ref = TF.conv3d(vox.double().view(1, cin, r, r, r), w.double(), bias.double(), padding=1).float().reshape(1, cout, -1)

@@ -32,25 +32,16 @@ for name, cin, cout, r, n in LAYERS:
     f = torch.randn(B, cin, n, generator=g).cuda()
     w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).cuda()
     bias = torch.zeros(cout).cuda()
-    w_old, w_new = ops.sparse_conv_pack_s3(w), ops.sparse_conv_pack_fused(w)
+    w_old, w_new = ops.sparse_conv_pack_s3(w), ops.sparse_conv_pack_h2(w)
     occ = float(plan.n_occ.float().mean())
     a = ops.sparse_first_conv_planned(f, plan, w_old, bias, cout)
     b = ops.sparse_first_conv_planned(f, plan, w_new, bias, cout)
     err = float((a - b).norm() / a.norm())
     t_old = t(lambda: ops.sparse_first_conv_planned(f, plan, w_old, bias, cout))
     t_new = t(lambda: ops.sparse_first_conv_planned(f, plan, w_new, bias, cout))
-    # the fused kernel alone (features precomputed)
-    C = cin
-    xr = torch.empty(B, (C + 7) // 8, plan.n_max, 8, device="cuda")
-    amax = torch.zeros(1, device="cuda")
-    L.check(lib.bdm_sparse_voxel_features_f32(B, C, n, r, plan.n_max, L.ptr(f), C * n, n, L.ptr(plan.cnt), L.ptr(plan.ws),
-                                              L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()))
-    out = torch.empty(B, cout, r ** 3, device="cuda")
-    packed, inv = w_new
-    t_k = t(lambda: L.check(lib.bdm_sparse_conv_fused(B, C, cout, r, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(packed), L.ptr(inv),
-                                                      L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(bias), L.ptr(out), L.stream())))
+    t_k = t_new
     tot_old += MULT[name] * t_old; tot_new += MULT[name] * t_new
     fl = 2 * occ * 27 * cin * cout * B
-    print(f"{name} {cin:4d}->{cout:4d} r={r:2d} n={n:5d} n_occ={occ:7.1f}  old {t_old:7.1f} us  fused {t_new:7.1f} us (kernel {t_k:7.1f} us, "
+    print(f"{name} {cin:4d}->{cout:4d} r={r:2d} n={n:5d} n_occ={occ:7.1f}  bf16x6 {t_old:7.1f} us  fp16x3 {t_new:7.1f} us ("
           f"{fl / t_k / 1e6:6.1f} TF/s alg.)  rel diff {err:.1e}", flush=True)
-print(f"per forward (14 PVConvs): old {tot_old:.0f} us, fused {tot_new:.0f} us")
+print(f"per forward (14 PVConvs): bf16x6 {tot_old:.0f} us, fp16x3 {tot_new:.0f} us")
