@@ -525,7 +525,19 @@ def sparse_conv_pack_fused(weight):
     inv_scale = torch.empty(cout, dtype=torch.float32, device=weight.device)
     L.check(lib.bdm_sparse_conv_fused_pack_weights(cout, cin, L.ptr(weight.contiguous()), L.ptr(packed), L.ptr(scale),
                                                    L.ptr(inv_scale), L.stream()), "sparse_conv_fused_pack_weights")
-    return packed, inv_scale
+    return "fused", packed, inv_scale
+
+
+def sparse_conv_pack_h2(weight):
+    """(Cout, Cin, 3,3,3) fp32 -> ("h2", fp16 records [ceil(Cin/8)][2][27*Cout][8], inv_scale (Cout,)) for bdm_sparse_conv_gemm_h2."""
+    cout, cin = weight.shape[:2]
+    lib = L.lib()
+    packed = torch.empty(lib.bdm_sparse_conv_h2_weight_elems(cout, cin), dtype=torch.float16, device=weight.device)
+    scale = torch.empty(cout, dtype=torch.float32, device=weight.device)
+    inv_scale = torch.empty(cout, dtype=torch.float32, device=weight.device)
+    L.check(lib.bdm_sparse_conv_pack_weights_h2(cout, cin, L.ptr(weight.contiguous()), L.ptr(packed), L.ptr(scale), L.ptr(inv_scale),
+                                                L.stream()), "sparse_conv_pack_weights_h2")
+    return "h2", packed, inv_scale
 
 
 SPARSE_Y_BYTES = int(float(os.environ.get("BDM_SPARSE_Y_MB", "256")) * 2 ** 20)
