@@ -424,8 +424,23 @@ extern "C" int bdm_sparse_conv_pack_weights_h2(int cout, int cin, const float *w
   return launch_status("sparse_conv_pack_weights_h2");
 }
 
+// fp32 records -> (hi, lo) fp16 records of x * 2^e (e from amax), layout [b][g][2][M]: done ONCE per call, so that the
+// GEMM's column tiles do not each repeat the split while staging
+__global__ void sparse_split_h2_kernel(long long rows_total, int M, const float4 *__restrict__ xr, const float *__restrict__ amax,
+                                       uint4 *__restrict__ xh) {
+  const float sx = act_scale_from_max(*amax);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < rows_total; e += (long long)gridDim.x * blockDim.x) {
+    const long long bg = e / M;
+    const int row = (int)(e % M);
+    f16x8 hi, lo;
+    split_record(xr[e * 2], xr[e * 2 + 1], sx, hi, lo);
+    xh[(bg * 2 + 0) * M + row] = *reinterpret_cast<const uint4 *>(&hi);
+    xh[(bg * 2 + 1) * M + row] = *reinterpret_cast<const uint4 *>(&lo);
+  }
+}
+
 template <int BM>
-__global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N, int Cout, const float4 *__restrict__ A,
+__global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N, int Cout, const uint4 *__restrict__ A,
                                                              const float *__restrict__ amax, const uint4 *__restrict__ Bw,
                                                              const float *__restrict__ inv_sw, const int *__restrict__ m_count,
                                                              float *__restrict__ Y) {
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, bi = blockIdx.z;
   if (m_count && m0 >= m_count[bi]) return;  // rows beyond this shape's occupied cells
   const float sx = act_scale_from_max(*amax);
-  const float4 *Ab = A + (size_t)bi * G * M * 2;
+  const uint4 *Ab = A + (size_t)bi * G * 2 * M;
   f32x16 acc[MX][2];
 #pragma unroll
   for (int x = 0; x < MX; ++x)
@@ -444,20 +459,16 @@ __global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-  // A stage: 4 groups x BM rows of fp32 records (2 float4 each) -> one thread loads whole records, splits, stores hi / lo
-  constexpr int AR = 4 * BM / 256;  // records per thread per stage
-  float4 ar[AR][2];
-  uint4 br[BI];
+  constexpr int AI = 8 * BM / 256;
+  uint4 ar[AI], br[BI];
   auto load_stage = [&](int g0) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const int e = tid + i * 256, row = e % BM, g = g0 + e / BM;
+    for (int i = 0; i < AI; ++i) {
+      const int e = tid + i * 256, row = e % BM, gs = e / BM, g = g0 + gs / 2, sp = gs % 2;
       const bool ok = g < G && m0 + row < M;
-      const size_t o = ((size_t)(ok ? g : 0) * M + (ok ? m0 + row : 0)) * 2;
-      const float4 p = Ab[o], q = Ab[o + 1];
-      const float k = ok ? sx : 0.f;
-      ar[i][0] = make_float4(p.x * k, p.y * k, p.z * k, p.w * k);
-      ar[i][1] = make_float4(q.x * k, q.y * k, q.z * k, q.w * k);
+      const uint4 v = Ab[ok ? ((size_t)g * 2 + sp) * M + m0 + row : 0];
+      const unsigned k = ok ? 0xFFFFFFFFu : 0u;
+      ar[i] = make_uint4(v.x & k, v.y & k, v.z & k, v.w & k);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
@@ -472,13 +483,7 @@ __global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N
   for (int g0 = 0; g0 < G; g0 += 4) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const int e = tid + i * 256, row = e % BM, gs = e / BM;
-      f16x8 hi, lo;
-      split_record(ar[i][0], ar[i][1], 1.0f, hi, lo);
-      As[(gs * 2 + 0) * BM + row] = *reinterpret_cast<const uint4 *>(&hi);
-      As[(gs * 2 + 1) * BM + row] = *reinterpret_cast<const uint4 *>(&lo);
-    }
+    for (int i = 0; i < AI; ++i) As[tid + i * 256] = ar[i];
 #pragma unroll
     for (int i = 0; i < BI; ++i) Bs[tid + i * 256] = br[i];
     __syncthreads();
@@ -522,7 +527,19 @@ __global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N
     }
 }
 
-extern "C" int bdm_sparse_conv_gemm_h2(int b, int n_max, int cin, int cout, const void *xr, const float *amax, const void *packed_w,
+// xr (b, G, n_max) fp32 records + amax -> xh (b, G, 2, n_max) fp16 records (hi, lo of x * 2^e)
+extern "C" int bdm_sparse_split_h2(int b, int cin, int n_max, const void *xr, const float *amax, void *xh, void *stream) {
+  BDM_REQUIRE(b >= 0 && cin >= 1 && n_max >= 1 && amax != nullptr, "sparse_split_h2: bad arguments");
+  if (b == 0) return BDM_OK;
+  const long long rows = (long long)b * ((cin + 7) / 8) * n_max;
+  long long grid = (rows + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(sparse_split_h2_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, rows, n_max, (const float4 *)xr,
+                     amax, (uint4 *)xh);
+  return launch_status("sparse_split_h2");
+}
+
+extern "C" int bdm_sparse_conv_gemm_h2(int b, int n_max, int cin, int cout, const void *xh, const float *amax, const void *packed_w,
                                        const float *inv_scale, const int *n_occ, float *y, void *stream) {
   BDM_REQUIRE(b >= 0 && n_max >= 1 && cin >= 1 && cout >= 1 && amax != nullptr && inv_scale != nullptr, "sparse_conv_gemm_h2: bad arguments");
   if (b == 0) return BDM_OK;
@@ -530,9 +547,9 @@ extern "C" int bdm_sparse_conv_gemm_h2(int b, int n_max, int cin, int cout, cons
   hipStream_t s = (hipStream_t)stream;
   if (n_max <= 256)
     hipLaunchKernelGGL(sparse_gemm_h2_kernel<64>, dim3(cdiv(n27, 128), cdiv(n_max, 64), b), dim3(256), 0, s, n_max, G, n27, cout,
-                       (const float4 *)xr, amax, (const uint4 *)packed_w, inv_scale, n_occ, y);
+                       (const uint4 *)xh, amax, (const uint4 *)packed_w, inv_scale, n_occ, y);
   else
     hipLaunchKernelGGL(sparse_gemm_h2_kernel<128>, dim3(cdiv(n27, 128), cdiv(n_max, 128), b), dim3(256), 0, s, n_max, G, n27, cout,
-                       (const float4 *)xr, amax, (const uint4 *)packed_w, inv_scale, n_occ, y);
+                       (const uint4 *)xh, amax, (const uint4 *)packed_w, inv_scale, n_occ, y);
   return launch_status("sparse_conv_gemm_h2");
 }

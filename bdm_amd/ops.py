@@ -609,13 +609,15 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout):
         L.check(lib.bdm_sparse_voxel_features_f32(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),
                                                   L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()),
                 "sparse_voxel_features_f32")
+        xh = torch.empty(B, (C + 7) // 8, 2, plan.n_max, 8, dtype=torch.float16, device=dev)
+        L.check(lib.bdm_sparse_split_h2(B, C, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(xh), L.stream()), "sparse_split_h2")
         out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
         per_shape = plan.n_max * 27 * cout * 4
         gb = max(1, min(B, SPARSE_Y_BYTES // max(per_shape, 1)))
         y = torch.empty(gb, plan.n_max, 27 * cout, dtype=torch.float32, device=dev)
         for b0 in range(0, B, gb):
             nb = min(gb, B - b0)
-            L.check(lib.bdm_sparse_conv_gemm_h2(nb, plan.n_max, C, cout, L.ptr(xr[b0:]), L.ptr(amax), L.ptr(packed), L.ptr(inv_scale),
+            L.check(lib.bdm_sparse_conv_gemm_h2(nb, plan.n_max, C, cout, L.ptr(xh[b0:]), L.ptr(amax), L.ptr(packed), L.ptr(inv_scale),
                                                 L.ptr(plan.n_occ[b0:]), L.ptr(y), L.stream()), "sparse_conv_gemm_h2")
             L.check(lib.bdm_sparse_conv_gather(nb, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index[b0:]), L.ptr(plan.rowocc[b0:]),
                                                L.ptr(bias), L.ptr(out[b0:]), L.stream()), "sparse_conv_gather")

@@ -317,12 +317,14 @@ int bdm_sparse_conv_fused(int b, int cin, int cout, int r, int n_max, const void
                           const float *bias, float *out, void *stream);
 
 /* fp16x3 form of bdm_sparse_conv_gemm_s3 (the default GEMM of the first convolution): half the matrix work.  xr / amax from
- * bdm_sparse_voxel_features_f32; weights [ceil(cin/8)][2][27*cout] fp16 records with per-output-channel scale
+ * bdm_sparse_voxel_features_f32, split once into (hi, lo) fp16 records xh (b, ceil(cin/8), 2, n_max) by bdm_sparse_split_h2;
+ * weights [ceil(cin/8)][2][27*cout] fp16 records with per-output-channel scale
  * (bdm_sparse_conv_pack_weights_h2; inv_scale (cout floats)); y (b, n_max, 27*cout) fp32 as the other GEMM forms. */
 size_t bdm_sparse_conv_h2_weight_elems(int cout, int cin);
 int bdm_sparse_conv_pack_weights_h2(int cout, int cin, const float *w, void *packed, float *scale_ws,
                                     float *inv_scale, void *stream);
-int bdm_sparse_conv_gemm_h2(int b, int n_max, int cin, int cout, const void *xr, const float *amax, const void *packed_w,
+int bdm_sparse_split_h2(int b, int cin, int n_max, const void *xr, const float *amax, void *xh, void *stream);
+int bdm_sparse_conv_gemm_h2(int b, int n_max, int cin, int cout, const void *xh, const float *amax, const void *packed_w,
                             const float *inv_scale, const int *n_occ, float *y, void *stream);
 
 /* ------------------------------------------------------------------------------------
