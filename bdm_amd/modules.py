@@ -219,8 +219,13 @@ class PVConv(nn.Module):
                 # the (coords, r) plan is shared by the PVConvs of one level
                 plan = ops.voxel_plan(coords, r, self.voxelization.eps)
                 norm_coords = plan.norm_coords
-                v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, self.sparse_gemm), conv1.bias,
-                                                  conv1.out_channels)
+                # the fp16x3 GEMM (half the matrix work) wins on the small grids, where the GEMM is matrix-bound and
+                # 64-row tiles cut the padding; on the 16^3 / 32^3 levels the batched GEMM is bound by its 27x-expanded
+                # output and the extra operand split costs more than it saves (measured: tools/sparse_bench.py)
+                impl = self.sparse_gemm
+                if impl == "sparse_h2" and plan.n_max > 256:
+                    impl = "sparse_s3"
+                v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, impl), conv1.bias, conv1.out_channels)
             else:
                 norm_coords, vox_coords = ops.voxel_coords(coords, r, self.voxelization.eps)
                 x3 = ops.avg_voxelize_s3(features, vox_coords, r)
