@@ -139,7 +139,10 @@ __global__ void sparse_vox_features_s3_kernel(int c, int n, int r3, int n_max, i
   const int bi = unit / G, g = unit % G;
   const int k = kb * blockDim.x + threadIdx.x;
   if (k >= n_max) return;
-  const bool live = k < n_occ[bi];
+  const int nocc = n_occ[bi];
+  // rows beyond the GEMM's last (128-row) tile that holds an occupied cell are never read: whole blocks of them are skipped
+  if (kb * (int)blockDim.x >= ((nocc + 127) & ~127)) return;
+  const bool live = k < nocc;
   int cv = 0, s = 0;
   if (live) {
     const int v = occ_list[(size_t)bi * n_max + k];
