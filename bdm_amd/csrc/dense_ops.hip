@@ -906,15 +906,37 @@ extern "C" int bdm_se_gate_gn(int b, int c, int hidden, int l, int groups, const
   return launch_status("se_fc");
 }
 
+__device__ __forceinline__ float se_gate_from_hidden(int ci, int hidden, const float *__restrict__ w2, const float *s_hid) {
+  float a = 0.f;  // same expression (and contraction mode) as se_fc_kernel
+  for (int k = 0; k < hidden; ++k) a += w2[(size_t)ci * hidden + k] * s_hid[k];
+  return 1.0f / (1.0f + expf(-a));
+}
+
+// se_mean != NULL: the SE block's two small FC layers (se.py:8-19) are evaluated HERE from the per-channel means -- every
+// workgroup recomputes the hidden vector (c/8 dot products of length c: a few thousand MACs) instead of a separate launch;
+// same summation order as se_fc_kernel, so the gate is bit-identical to the two-launch form.
 __global__ void devox_gn_fused_kernel(int b, int cslots, int pblocks, int c, int n, int r, const float *__restrict__ coords,
                                       const float *__restrict__ grid, const float2 *__restrict__ coef,
-                                      const float *__restrict__ gate, const float *__restrict__ add, long long bs_a, int ld_a,
+                                      const float *__restrict__ gate, const float *__restrict__ se_mean, int hidden,
+                                      const float *__restrict__ w1, const float *__restrict__ w2,
+                                      const float *__restrict__ add, long long bs_a, int ld_a,
                                       float *__restrict__ out, long long bs_o, int ld_o) {
-#pragma clang fp contract(off)
+  __shared__ float s_hid[64];
   const int span = 8 * pblocks, wg = blockIdx.x;
   const int unit = (wg / span) * 8 + (wg % span) % 8, pb = (wg % span) / 8;
   if (unit >= b * cslots) return;
   const int bi = unit / cslots, c_first = unit % cslots;
+  if (se_mean != nullptr) {  // block-uniform
+    const float *mv = se_mean + (size_t)bi * c;
+    for (int j = threadIdx.x; j < hidden; j += blockDim.x) {
+      float a = 0.f;
+      for (int k = 0; k < c; ++k) a += w1[(size_t)j * c + k] * mv[k];
+      s_hid[j] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+  }
+  {
+#pragma clang fp contract(off)
   const int i = pb * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int r2 = r * r, r3 = r2 * r;
@@ -932,7 +954,8 @@ __global__ void devox_gn_fused_kernel(int b, int cslots, int pblocks, int c, int
   for (int ci = c_first; ci < c; ci += cslots) {
     const float *g = grid + ((size_t)bi * c + ci) * r3;
     const float2 ab = coef[(size_t)bi * c + ci];
-    const float s = gate ? gate[(size_t)bi * c + ci] : 1.0f;
+    float s = gate ? gate[(size_t)bi * c + ci] : 1.0f;
+    if (se_mean != nullptr) s = se_gate_from_hidden(ci, hidden, w2, s_hid);
     // corners with weight 0 (frac == 0 on an axis) alias an in-grid cell: their value is finite and multiplies 0
     float acc = w000 * (swishf(g[i000] * ab.x + ab.y) * s);
     acc += w001 * (swishf(g[i001] * ab.x + ab.y) * s);
@@ -946,15 +969,30 @@ __global__ void devox_gn_fused_kernel(int b, int cslots, int pblocks, int c, int
     out[(size_t)bi * bs_o + (size_t)ci * ld_o + i] = acc;
   }
 }
-extern "C" int bdm_devoxelize_gn_gate_add(int b, int c, int n, int r, const float *coords, const float *grid,
-                                          const float *coef, const float *gate, const float *add, long long bs_a, int ld_a,
-                                          float *out, long long bs_o, int ld_o, void *stream) {
+}
+static int devox_gn_launch(int b, int c, int n, int r, const float *coords, const float *grid, const float *coef,
+                           const float *gate, const float *se_mean, int hidden, const float *w1, const float *w2,
+                           const float *add, long long bs_a, int ld_a, float *out, long long bs_o, int ld_o, void *stream) {
   BDM_REQUIRE(b >= 0 && c >= 1 && n >= 1 && r >= 1 && coef != nullptr, "devoxelize_gn_gate_add: bad arguments");
+  BDM_REQUIRE(se_mean == nullptr || (hidden >= 1 && hidden <= 64 && w1 != nullptr && w2 != nullptr), "devoxelize_gn_se_add: bad SE arguments");
   if (b == 0) return BDM_OK;
   const int cslots = c < 64 ? c : 64, pblocks = cdiv(n, 256);
   hipLaunchKernelGGL(devox_gn_fused_kernel, dim3(cdiv(b * cslots, 8) * 8 * pblocks), dim3(256), 0, (hipStream_t)stream, b, cslots,
-                     pblocks, c, n, r, coords, grid, (const float2 *)coef, gate, add, bs_a, ld_a, out, bs_o, ld_o);
+                     pblocks, c, n, r, coords, grid, (const float2 *)coef, gate, se_mean, hidden, w1, w2, add, bs_a, ld_a, out, bs_o,
+                     ld_o);
   return launch_status("devoxelize_gn_gate_add");
+}
+extern "C" int bdm_devoxelize_gn_gate_add(int b, int c, int n, int r, const float *coords, const float *grid,
+                                          const float *coef, const float *gate, const float *add, long long bs_a, int ld_a,
+                                          float *out, long long bs_o, int ld_o, void *stream) {
+  return devox_gn_launch(b, c, n, r, coords, grid, coef, gate, nullptr, 0, nullptr, nullptr, add, bs_a, ld_a, out, bs_o, ld_o, stream);
+}
+// The same with the SE block's FC layers evaluated inside the kernel from the channel means of bdm_se_gate_gn(w1 = NULL).
+extern "C" int bdm_devoxelize_gn_se_add(int b, int c, int n, int r, const float *coords, const float *grid, const float *coef,
+                                        const float *se_mean, int hidden, const float *w1, const float *w2, const float *add,
+                                        long long bs_a, int ld_a, float *out, long long bs_o, int ld_o, void *stream) {
+  BDM_REQUIRE(se_mean != nullptr, "devoxelize_gn_se_add: se_mean is NULL");
+  return devox_gn_launch(b, c, n, r, coords, grid, coef, nullptr, se_mean, hidden, w1, w2, add, bs_a, ld_a, out, bs_o, ld_o, stream);
 }
 
 // =====================================================================================

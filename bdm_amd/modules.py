@@ -243,7 +243,13 @@ class PVConv(nn.Module):
                     # normalise + Swish on the fly -- the grid is written once (by the convolution) and never rewritten
                     v, stats = ops.conv3d_h2_gn(xh, self._packed_weight(conv2, "fp16x3"), conv2.bias, conv2.in_channels,
                                                 conv2.out_channels, r, gn2.num_groups)
-                    gate, coef = ops.se_gate_gn(v, stats, gn2, se.fc[0].weight, se.fc[2].weight)
+                    w1, w2 = se.fc[0].weight, se.fc[2].weight
+                    if w1.shape[0] <= 64:  # the SE block's FC layers run inside the devoxelisation kernel: one launch less
+                        mean, coef = ops.se_means_gn(v, stats, gn2)
+                        if pf_ready is not None:
+                            pf_ready.wait()
+                        return ops.devoxelize_gn_se_add(norm_coords, v, coef, r, mean, w1, w2, add=pf), coords, temb
+                    gate, coef = ops.se_gate_gn(v, stats, gn2, w1, w2)
                     if pf_ready is not None:
                         pf_ready.wait()
                     return ops.devoxelize_gn_gate_add(norm_coords, v, coef, r, gate=gate, add=pf), coords, temb

@@ -482,6 +482,36 @@ def se_gate_gn(x, stats, gn, w1, w2):
     return gate, coef
 
 
+def se_means_gn(x, stats, gn):
+    """Per-channel means of swish(group_norm(x)) + the rows' affine forms, from the raw grid and the producer's statistics:
+    (mean (B,C), coef (B,C,2)).  The SE block's FC layers are then evaluated inside the devoxelisation kernel."""
+    ws, slices = stats
+    B, C = x.shape[:2]
+    l = x.numel() // (B * C)
+    mean = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    coef = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+    L.check(L.lib().bdm_se_gate_gn(B, C, 1, l, gn.num_groups, L.ptr(x), L.ptr(ws), slices, L.ptr(gn.weight), L.ptr(gn.bias),
+                                   L.c_float(gn.eps), L.ptr(None), L.ptr(None), L.ptr(mean), L.ptr(coef), L.ptr(None), L.stream()),
+            "se_means_gn")
+    return mean, coef
+
+
+def devoxelize_gn_se_add(norm_coords, grid, coef, r, mean, w1, w2, add=None):
+    B, C = grid.shape[:2]
+    n = norm_coords.shape[2]
+    out = torch.empty(B, C, n, dtype=torch.float32, device=grid.device)
+    _, _, _, _, bs_o, ld_o = _bcl(out)
+    if add is not None:
+        aa, _, _, _, bs_a, ld_a = _bcl(add)
+        assert aa.data_ptr() == add.data_ptr()
+    else:
+        bs_a, ld_a = 0, 0
+    L.check(L.lib().bdm_devoxelize_gn_se_add(B, C, n, int(r), L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(mean), w1.shape[0],
+                                             L.ptr(w1), L.ptr(w2), L.ptr(add), bs_a, ld_a, L.ptr(out), bs_o, ld_o, L.stream()),
+            "devoxelize_gn_se_add")
+    return out
+
+
 def devoxelize_gn_gate_add(norm_coords, grid, coef, r, gate=None, add=None):
     B, C = grid.shape[:2]
     n = norm_coords.shape[2]

@@ -265,6 +265,11 @@ int bdm_se_gate_gn(int b, int c, int hidden, int l, int groups, const float *x, 
 int bdm_devoxelize_gn_gate_add(int b, int c, int n, int r, const float *coords, const float *grid, const float *coef,
                                const float *gate, const float *add, long long bs_a, int ld_a, float *out,
                                long long bs_o, int ld_o, void *stream);
+/* the same with the SE gate computed inside the kernel from se_mean (b, c) = the channel means bdm_se_gate_gn(w1 = NULL) left:
+ * one launch less per PVConv, bit-identical gate (same summation order as the separate FC kernel). hidden <= 64. */
+int bdm_devoxelize_gn_se_add(int b, int c, int n, int r, const float *coords, const float *grid, const float *coef,
+                             const float *se_mean, int hidden, const float *w1, const float *w2, const float *add,
+                             long long bs_a, int ld_a, float *out, long long bs_o, int ld_o, void *stream);
 
 /* bf16x6 form of the two steps above (default): operands pre-split into exact bf16 triples ("S3" records of 8
  * channels x 16 bytes), GEMM on v_mfma_f32_32x32x16_bf16 with six partial products per fp32 product.
