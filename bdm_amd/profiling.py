@@ -60,6 +60,7 @@ def _attn(a):
 SPEC = {
     # dense 3x3x3 voxel convolutions
     "bdm_conv3d_3x3x3_h2": ("dense conv3d (fp16x3)", lambda a: a[:4], _conv_h2),
+    "bdm_conv3d_3x3x3_h2_gn": ("dense conv3d (fp16x3)", lambda a: a[:4], _conv_h2),  # + GroupNorm partial sums in the epilogue
     "bdm_conv3d_3x3x3_s3": ("dense conv3d (bf16x6)", lambda a: a[:4], _conv_s3),
     "bdm_conv3d_3x3x3": ("dense conv3d (fp32 MFMA)", lambda a: a[:4], _conv_f32),
     "bdm_conv3d_3x3x3_sparse": ("dense conv3d (fp32 MFMA)", lambda a: a[:4], _conv_f32),
@@ -70,6 +71,9 @@ SPEC = {
     # on the final clouds after the timed region; 1.0 = upper bound when not set).
     "bdm_sparse_conv_gemm_s3": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]),
                                 lambda a: ("mfma_aux", 2.0 * a[0] * a[1] * OCCUPANCY.get(a[1], 1.0) * a[2] * a[3], MFMA16_PEAK_TFLOPS / 6)),
+    "bdm_sparse_conv_gemm_h2": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]),
+                                lambda a: ("mfma_aux", 2.0 * a[0] * a[1] * OCCUPANCY.get(a[1], 1.0) * a[2] * 27 * a[3], MFMA16_PEAK_TFLOPS / 3)),
+    "bdm_sparse_split_h2": ("sparse first conv", lambda a: (a[0], a[1], a[2]), lambda a: ("hbm", 0.0)),
     "bdm_sparse_conv_gemm": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]),
                              lambda a: ("mfma_aux", 2.0 * a[0] * a[1] * OCCUPANCY.get(a[1], 1.0) * a[2] * a[3], MFMA32_PEAK_TFLOPS)),
     "bdm_sparse_conv_gather": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] ** 3)),
@@ -98,6 +102,12 @@ SPEC = {
     "bdm_voxelize_plan_full": ("voxelize / devoxelize", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * (4 * a[1] + 3 * a[2] ** 3))),
     "bdm_voxel_coords": ("voxelize / devoxelize", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * 9 * a[1])),
     "bdm_devoxelize_gate_add": ("voxelize / devoxelize", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 10 * a[1] * a[2]))),
+    # GroupNorm-folded tail of a PVConv: the row means read the conv output once; the devoxelisation reads coords and the
+    # grid's 8 corners per point-channel and reads the point branch / writes the sum
+    "bdm_se_gate_gn": ("SE gate", lambda a: (a[0], a[1], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[3])),
+    "bdm_devoxelize_gn_gate_add": ("voxelize / devoxelize", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 10 * a[1] * a[2]))),
+    "bdm_devoxelize_gn_se_add": ("voxelize / devoxelize", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 10 * a[1] * a[2]))),
+    "bdm_lincomb": ("scheduler step / blend", lambda a: a[:2], lambda a: ("hbm", 4.0 * a[0] * (a[1] + 1))),
     "bdm_se_gate": ("SE gate", lambda a: (a[0], a[1], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[3])),
     "bdm_copy_rows": ("concat / broadcast / transpose copies", lambda a: a[:3], lambda a: ("hbm", 8.0 * a[0] * a[1] * a[2])),
     "bdm_broadcast_rows": ("concat / broadcast / transpose copies", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2])),

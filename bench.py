@@ -256,7 +256,8 @@ def main():
             traffic, traffic_commit = None, None
             try:  # HBM bytes per launch of that kernel from the committed PMC pass (separate rocprofv3 --pmc runs)
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-                ent = pm["kernels"].get(f"{head['function']}{tuple(head['shape'])}")
+                key = f"{head['function']}{tuple(head['shape'])}"
+                ent = pm["kernels"].get(key) or pm["kernels"].get(key.replace("_h2_gn(", "_h2("))  # same kernel + GN epilogue
                 if ent:
                     traffic, traffic_commit = ent["bytes_per_launch"], pm.get("commit")
             except (OSError, KeyError, ValueError):
