@@ -11,7 +11,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libbdm_hip.so")
+SO_PATH = os.environ.get("BDM_LIB_PATH") or os.path.join(_HERE, "libbdm_hip.so")  # BDM_LIB_PATH: A/B timing of two builds
 CSRC = os.path.join(_HERE, "csrc")
 _lib = None
 

@@ -11,6 +11,8 @@
 //   attention cores                          (pvconv.py:40-63)
 // All arithmetic is fp32; contractions use v_mfma_f32_32x32x2_f32 (exact fp32 products, k-ordered
 // fp32 accumulation -- the 1e-3 end-to-end criterion after 1000 steps rules out bf16 here).
+#include <stdlib.h>
+
 #include "../../include/bdm_hip.h"
 #include "common.h"
 
@@ -24,8 +26,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // contiguous point runs (coalesced 16-B loads, conflict-free ds_read_b32), the weight tile is
 // stored k-major in LDS so A-operand reads are conflict-free too.
 // Tile: (32*MI) x (128*NI) per 256-thread workgroup, K chunk 16, 4 waves side by side along N.
-#define PW_BK 16
-template <int MI, int NI, bool ATRANS = false>
+// K chunk BK per barrier pair: 16 for the throughput shapes; 64 for the latency-bound ones (few workgroups, long K), where
+// one chunk in flight per workgroup leaves the global-load latency exposed on every step.  Same k order: same bits.
+template <int MI, int NI, bool ATRANS = false, int BK = 16>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const float *__restrict__ W, int ldw,
                                                       long long bsw, const int *__restrict__ m_count,
                                                       const float *__restrict__ X, long long bsx, int ldx,
@@ -35,8 +38,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
                                                       float *__restrict__ Y, long long bsy, int ldy, int act,
                                                       float slope) {
   constexpr int BM = 32 * MI, BN = 128 * NI, LDA = BM + 4;
-  __shared__ float As[PW_BK * LDA];
-  __shared__ __align__(16) float Bs[PW_BK * BN];
+  __shared__ float As[BK * LDA];
+  __shared__ __align__(16) float Bs[BK * BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, bi = blockIdx.z;
   if (m_count && m0 >= m_count[bi]) return;  // rows beyond this shape's live count (sparse convolution GEMM)
@@ -53,90 +56,143 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-  // register-prefetched staging: the global loads of K-chunk c+1 are in flight during the MFMAs of chunk c
-  constexpr int AI = (BM * PW_BK) / 256, BI = (PW_BK * BN / 4) / 256;
+  // register-prefetched staging: the global loads of K-chunk c+1 are in flight during the MFMAs of chunk c.  The loads
+  // carry no branch and no select: rows >= M and columns >= N are read from a clamped (valid) address -- they only feed
+  // output elements the epilogue never stores -- and k >= K (last chunk) is read clamped and zeroed when the registers go to
+  // LDS.  (A branch or a select on a freshly loaded value makes the wave wait for memory inside the load phase.)
+  constexpr int AI = (BM * BK) / 256, BI = (BK * BN / 4) / 256;
   float ar[AI];
   float4 br[BI];
+  const bool vec_all = vec_ok && (N & 3) == 0;  // every 4-column piece is entirely inside or outside the matrix
+  unsigned a_off[AI], b_col[BI];  // loop-invariant part of each staged element's address
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int e = tid + i * 256, m = ATRANS ? e % BM : e / BK;
+    const int mm = min(m0 + m, M - 1);
+    a_off[i] = ATRANS ? (unsigned)mm : (unsigned)mm * (unsigned)ldw;
+  }
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int e = tid + i * 256, c4 = (e % (BN / 4)) * 4;
+    b_col[i] = (unsigned)(n0 + c4);
+  }
   auto load_chunk = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int e = tid + i * 256;
-      if constexpr (ATRANS) {  // A given as A^T (K x M, row stride ldw): coalesced along m
-        const int m = e % BM, k = e / BM;
-        ar[i] = (m0 + m < M && k0 + k < K) ? W[(size_t)(k0 + k) * ldw + m0 + m] : 0.f;
-      } else {
-        const int m = e >> 4, k = e & 15;
-        ar[i] = (m0 + m < M && k0 + k < K) ? W[(size_t)(m0 + m) * ldw + k0 + k] : 0.f;
+      const int e = tid + i * 256, k = ATRANS ? e / BM : e % BK;
+      const unsigned kk = (unsigned)min(k0 + k, K - 1);
+      ar[i] = W[a_off[i] + (ATRANS ? kk * (unsigned)ldw : kk)];
+    }
+    if (vec_all) {
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        const int e = tid + i * 256, k = e / (BN / 4);
+        const unsigned kk = (unsigned)min(k0 + k, K - 1);
+        br[i] = *reinterpret_cast<const float4 *>(Xb + (kk * (unsigned)ldx + min(b_col[i], (unsigned)(N - 4))));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        const int e = tid + i * 256, k = e / (BN / 4);
+        const float *src = Xb + (unsigned)min(k0 + k, K - 1) * (unsigned)ldx;
+        const unsigned last = (unsigned)(N - 1);
+        br[i] = make_float4(src[min(b_col[i], last)], src[min(b_col[i] + 1, last)], src[min(b_col[i] + 2, last)],
+                            src[min(b_col[i] + 3, last)]);
       }
     }
+  };
+  // operand fragments of 8 MFMA steps (16 k) at a time, read from LDS one group AHEAD of the matrix work: the reads of
+  // group s+1 are issued before the MFMAs of group s, so the dependent MFMA chain never waits for LDS
+  constexpr int NS = BK / 16;
+  float fa[2][8][MI], fb[2][8][NI];
+  auto read_frag = [&](int s, int buf) {
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int e = tid + i * 256, k = e / (BN / 4), c4 = (e % (BN / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + k < K) {
-        const float *src = Xb + (size_t)(k0 + k) * ldx + n0 + c4;
-        if (vec_ok && n0 + c4 + 3 < N) {
-          v = *reinterpret_cast<const float4 *>(src);
-        } else {
-          if (n0 + c4 + 0 < N) v.x = src[0];
-          if (n0 + c4 + 1 < N) v.y = src[1];
-          if (n0 + c4 + 2 < N) v.z = src[2];
-          if (n0 + c4 + 3 < N) v.w = src[3];
-        }
-      }
-      br[i] = v;
+    for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+      for (int x = 0; x < MI; ++x) fa[buf][kk][x] = As[(16 * s + 2 * kk + lh) * LDA + x * 32 + li];
+#pragma unroll
+      for (int y = 0; y < NI; ++y) fb[buf][kk][y] = Bs[(16 * s + 2 * kk + lh) * BN + (wave * NI + y) * 32 + li];
     }
   };
   load_chunk(0);
-  for (int k0 = 0; k0 < K; k0 += PW_BK) {
+  for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int e = tid + i * 256;
-      const int m = ATRANS ? e % BM : e >> 4, k = ATRANS ? e / BM : e & 15;
-      As[k * LDA + m] = ar[i];
+      const int m = ATRANS ? e % BM : e / BK, k = ATRANS ? e / BM : e % BK;
+      As[k * LDA + m] = (k0 + k < K) ? ar[i] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int e = tid + i * 256, k = e / (BN / 4), c4 = (e % (BN / 4)) * 4;
-      *reinterpret_cast<float4 *>(&Bs[k * BN + c4]) = br[i];
+      const bool ok = k0 + k < K;
+      *reinterpret_cast<float4 *>(&Bs[k * BN + c4]) =
+          make_float4(ok ? br[i].x : 0.f, ok ? br[i].y : 0.f, ok ? br[i].z : 0.f, ok ? br[i].w : 0.f);
     }
     __syncthreads();
-    if (k0 + PW_BK < K) load_chunk(k0 + PW_BK);
+    if (k0 + BK < K) load_chunk(k0 + BK);
+    read_frag(0, 0);
 #pragma unroll
-    for (int kk = 0; kk < PW_BK / 2; ++kk) {
-      float a[MI], b[NI];
+    for (int s = 0; s < NS; ++s) {
+      if (s + 1 < NS) read_frag(s + 1, (s + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the next group's LDS reads ABOVE this group's MFMAs
 #pragma unroll
-      for (int x = 0; x < MI; ++x) a[x] = As[(2 * kk + lh) * LDA + x * 32 + li];
+      for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-      for (int y = 0; y < NI; ++y) b[y] = Bs[(2 * kk + lh) * BN + (wave * NI + y) * 32 + li];
+        for (int x = 0; x < MI; ++x)
 #pragma unroll
-      for (int x = 0; x < MI; ++x)
-#pragma unroll
-        for (int y = 0; y < NI; ++y)
-          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+          for (int y = 0; y < NI; ++y)
+            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][kk][x], fb[s & 1][kk][y], acc[x][y], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // ---- epilogue: C/D map  row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+  // ---- epilogue: C/D map  row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31.  The per-row terms (bias, per-shape bias)
+  // and the residual are fetched in batches under workgroup-uniform branches (clamped addresses), then applied.
 #pragma unroll
-  for (int x = 0; x < MI; ++x)
+  for (int x = 0; x < MI; ++x) {
+    float badd[16], bb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) badd[r] = bb[r] = 0.f;
+    if (bias) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) badd[r] = bias[min(m0 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1)];
+    }
+    if (bbias) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bb[r] = bbias[(size_t)bi * ldbb + min(m0 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1)];
+    }
 #pragma unroll
     for (int y = 0; y < NI; ++y) {
       const int n = n0 + (wave * NI + y) * 32 + li;
+      const int nn = min(n, N - 1);
+      float rv[16];
+      if (R) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rv[r] = R[(size_t)bi * bsr + (size_t)min(m0 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1) * ldr + nn];
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < M && n < N) {
-          float v = acc[x][y][r];
-          if (bias) v += bias[m];
-          if (bbias) v += bbias[(size_t)bi * ldbb + m];
-          if (act == 2) v = v > 0.f ? v : v * slope;
-          else if (act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact GELU (timm Mlp)
-          if (R) v += R[(size_t)bi * bsr + (size_t)m * ldr + n];
-          Yb[(size_t)m * ldy + n] = v;
-        }
+        float v = (acc[x][y][r] + badd[r]) + bb[r];  // same order as y = (W x + b) + b_shape
+        if (act == 2) v = v > 0.f ? v : v * slope;
+        else if (act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact GELU (timm Mlp)
+        if (R) v += rv[r];
+        if (m < M && n < N) Yb[(size_t)m * ldy + n] = v;
       }
     }
+  }
+}
+
+// workgroup count below which the long-K shapes take the 64-deep K chunk (BDM_PW_DEEP_BLOCKS overrides; 0 disables)
+static int pw_deep_limit() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("BDM_PW_DEEP_BLOCKS");
+    v = e ? atoi(e) : 1024;
+  }
+  return v;
 }
 
 extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, int ldw, const float *x,
@@ -145,6 +201,8 @@ extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, in
                                   long long bs_y, int ld_y, int act, float slope, void *stream) {
   BDM_REQUIRE(b >= 0 && m >= 1 && k >= 1 && n >= 0, "pointwise_conv: bad sizes m=%d k=%d n=%d", m, k, n);
   BDM_REQUIRE(act == 0 || act == 2 || act == 3, "pointwise_conv: act must be 0 (none), 2 (leaky relu) or 3 (gelu)");
+  BDM_REQUIRE((long long)k * ld_x + n < (1ll << 31) && (long long)m * ldw + k < (1ll << 31),
+              "pointwise_conv: one operand spans more than 2^31 elements");
   if (b == 0 || n == 0) return BDM_OK;
   hipStream_t s = (hipStream_t)stream;
 #define PW_LAUNCH(MI, NI)                                                                                   \
@@ -153,16 +211,24 @@ extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, in
                      y, bs_y, ld_y, act, slope)
   // biggest tile that still gives the 256 CUs two workgroups each; small problems (the 16..256-point levels) are
   // latency-bound and prefer many small tiles over operand reuse
+#define PW_LAUNCH_DEEP(MI, NI)                                                                                          \
+  hipLaunchKernelGGL((pw_gemm_kernel<MI, NI, false, 64>), dim3(cdiv(n, 128 * NI), cdiv(m, 32 * MI), b), dim3(256), 0, s, \
+                     m, k, n, w, ldw, 0ll, (const int *)nullptr, x, bs_x, ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r,   \
+                     y, bs_y, ld_y, act, slope)
   auto blocks = [&](int mi, int ni) { return (long long)cdiv(n, 128 * ni) * cdiv(m, 32 * mi) * b; };
+  const int deep_limit = pw_deep_limit();
   if (m <= 32) {
-    if (n <= 128 || blocks(1, 2) < 512) PW_LAUNCH(1, 1); else PW_LAUNCH(1, 2);
+    if (n <= 128 || blocks(1, 2) < 512) {
+      if (k >= 128 && blocks(1, 1) < deep_limit) PW_LAUNCH_DEEP(1, 1); else PW_LAUNCH(1, 1);
+    } else PW_LAUNCH(1, 2);
   } else if (n > 128 && blocks(2, 2) >= 512) {
     PW_LAUNCH(2, 2);
   } else if (blocks(2, 1) >= 512) {
-    PW_LAUNCH(2, 1);
+    if (k >= 128 && blocks(2, 1) < deep_limit) PW_LAUNCH_DEEP(2, 1); else PW_LAUNCH(2, 1);
   } else {
-    PW_LAUNCH(1, 1);
+    if (k >= 128 && blocks(1, 1) < deep_limit) PW_LAUNCH_DEEP(1, 1); else PW_LAUNCH(1, 1);
   }
+#undef PW_LAUNCH_DEEP
 #undef PW_LAUNCH
   return launch_status("pointwise_conv");
 }
