@@ -184,8 +184,15 @@ class PVConv(nn.Module):
     # The point branch (1x1 conv + GroupNorm + Swish on the N points) does not depend on the voxel branch: it is enqueued on
     # a second stream and joined before the devoxelisation adds it, so its small, latency-bound kernels run beside the
     # voxel convolutions instead of after them (BDM_POINT_STREAM=0: serial).
+    se_in_devox = os.environ.get("BDM_SE_IN_DEVOX", "0") == "1"
     point_stream = os.environ.get("BDM_POINT_STREAM", "1") == "1"
     _streams = {}
+
+    def voxel_plan_args(self):
+        """(resolution, eps) of the ops.voxel_plan this module's forward will ask for, or None when it voxelises densely."""
+        if self.conv_impl in ("bf16x6", "fp16x3") and self.sparse_first_conv and self.resolution in self.sparse_resolutions:
+            return self.resolution, self.voxelization.eps
+        return None
 
     def _point_branch(self, features):
         if not (self.point_stream and features.is_cuda and features.shape[0] * features.shape[2] >= 8192):
@@ -244,7 +251,10 @@ class PVConv(nn.Module):
                     v, stats = ops.conv3d_h2_gn(xh, self._packed_weight(conv2, "fp16x3"), conv2.bias, conv2.in_channels,
                                                 conv2.out_channels, r, gn2.num_groups)
                     w1, w2 = se.fc[0].weight, se.fc[2].weight
-                    if w1.shape[0] <= 64:  # the SE block's FC layers run inside the devoxelisation kernel: one launch less
+                    if self.se_in_devox and w1.shape[0] <= 64:
+                        # SE block's FC layers inside the devoxelisation kernel: one launch less, but every workgroup re-reads
+                        # w1 / w2 (measured at B=16: devoxelisation 325 -> 650 us per forward for 100 us of se_fc saved), so
+                        # this is only worth it where the forward is launch-bound (opt-in: BDM_SE_IN_DEVOX=1)
                         mean, coef = ops.se_means_gn(v, stats, gn2)
                         if pf_ready is not None:
                             pf_ready.wait()

@@ -592,7 +592,8 @@ def _amax_slot(device):
 class VoxelPlan:
     """Everything that depends on (coords, r) only: normalised / integer voxel coordinates, per-voxel point lists,
     occupied-cell compaction and row occupancy.  PVConvs of one level share it (exactly the same values)."""
-    __slots__ = ("r", "n", "n_max", "norm_coords", "vox_coords", "ind", "cnt", "ws", "occ_index", "occ_list", "n_occ", "rowocc")
+    __slots__ = ("r", "n", "n_max", "norm_coords", "vox_coords", "ind", "cnt", "ws", "occ_index", "occ_list", "n_occ", "rowocc",
+                 "ready", "stream")
 
 
 _plan_cache = {}
@@ -606,12 +607,18 @@ def voxel_plan(coords, r, eps=0.0):
     key = (coords.data_ptr(), coords._version, tuple(coords.shape), int(r))
     p = _plan_cache.get(key)
     if p is not None:
+        ready = getattr(p, "ready", None)
+        if ready is not None:  # planned ahead on a side stream (pvcnn.plan_sampling_chain): the current stream waits for it
+            if torch.cuda.current_stream(coords.device) != getattr(p, "stream", None):
+                ready.wait()
+                p.ready = None
         return p
     lib = L.lib()
     B, _, n = coords.shape
     dev = coords.device
     r3 = r ** 3
     p = VoxelPlan()
+    p.ready = None
     p.r, p.n, p.n_max = int(r), n, min(n, r3)
     p.norm_coords, p.vox_coords = voxel_coords(coords, r, eps)
     p.ind = torch.empty(B, n, dtype=torch.int32, device=dev)
@@ -624,6 +631,7 @@ def voxel_plan(coords, r, eps=0.0):
     L.check(lib.bdm_voxelize_plan_full(B, n, r, p.n_max, L.ptr(p.vox_coords), L.ptr(p.ind), L.ptr(p.cnt), L.ptr(p.ws),
                                        L.ptr(p.occ_index), L.ptr(p.occ_list), L.ptr(p.n_occ), L.ptr(p.rowocc), L.stream()),
             "voxelize_plan_full")
+    p.stream = torch.cuda.current_stream(dev) if coords.is_cuda else None
     _plan_cache[key] = p
     return p
 
@@ -703,6 +711,7 @@ def sparse_first_conv(features, vox_coords, r, wt, bias, cout):
     B, _, n = vox_coords.shape
     dev, lib, r3 = vox_coords.device, L.lib(), r ** 3
     p = VoxelPlan()
+    p.ready = None
     p.r, p.n, p.n_max = int(r), n, min(n, r3)
     p.norm_coords, p.vox_coords = None, vox_coords
     p.ind = torch.empty(B, n, dtype=torch.int32, device=dev)

@@ -117,6 +117,7 @@ def embed_time(embedf, t, embed_dim, n):
 
 _side_streams = {}
 SIDE_STREAM = os.environ.get("BDM_SIDE_STREAM", "1") == "1"  # sampler chain on its own stream (0: inline, for experiments)
+SIDE_PLAN = os.environ.get("BDM_SIDE_PLAN", "1") == "1"  # voxel plans of levels 1.. on the sampler's side stream
 SIDE_STREAM_MIN_POINTS = 8192  # B * N below which the streams are not used (measured: tools/time_loop.py at B=1, N=1024)
 
 
@@ -131,13 +132,22 @@ def plan_sampling_chain(sa_layers, coords):
     side.wait_stream(cur)
     with torch.cuda.stream(side):
         c = coords
-        for blocks in sa_layers:
+        for li, blocks in enumerate(sa_layers):
             sa = blocks[-1] if isinstance(blocks, nn.Sequential) else blocks
             centers, idx = sa.plan(c)
             ev = torch.cuda.Event()
             ev.record(side)
             sa._planned = (centers, idx, ev, c)
             c = centers
+            # the voxel plan of the NEXT level's PVConvs (sort of the centres into cells, occupied-cell lists) is geometry
+            # too: one single-workgroup-per-shape kernel that would otherwise sit on the main stream's critical path
+            nxt = sa_layers[li + 1] if li + 1 < len(sa_layers) else None
+            pv = nxt[0] if isinstance(nxt, nn.Sequential) and hasattr(nxt[0], "voxel_plan_args") else None
+            args = pv.voxel_plan_args() if (pv is not None and SIDE_PLAN) else None
+            if args is not None:
+                plan = ops.voxel_plan(c, *args)
+                plan.ready = torch.cuda.Event()
+                plan.ready.record(side)
 
 
 def encode(sa_layers, global_att, inputs, t_emb):

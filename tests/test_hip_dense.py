@@ -419,6 +419,9 @@ def test_gn2_folded_tail_equals_separate_groupnorm_pass(ops, monkeypatch, cin, c
     monkeypatch.setattr(PVConv, "fold_gn2", False)
     ref = pv((f, c, t))[0].clone()
     monkeypatch.setattr(PVConv, "fold_gn2", True)
-    got = pv((f, c, t))[0]
+    monkeypatch.setattr(PVConv, "se_in_devox", False)
+    got = pv((f, c, t))[0].clone()
     assert rel(got.cpu(), ref.cpu()) < 1e-6
     assert torch.equal(got, pv((f, c, t))[0])      # deterministic
+    monkeypatch.setattr(PVConv, "se_in_devox", True)  # opt-in: SE block's FC layers inside the devoxelisation kernel
+    assert torch.equal(pv((f, c, t))[0], got)      # same summation order as the separate FC kernel: same bits
