@@ -107,7 +107,7 @@ extern "C" int bdm_conv3d_h2_pack_weights(int cout, int cin, const float *w, voi
 // the convolution
 // ---------------------------------------------------------------------------------------------------
 template <int MI, int NI, int R, int TX, int TY, int NW>  // NW waves per workgroup; NI * NW column blocks of 32 voxels
-__global__ __launch_bounds__(NW * 64) void conv3d_h2_kernel(int C8, int Cout, const float4 *__restrict__ x,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void conv3d_h2_kernel(int C8, int Cout, const float4 *__restrict__ x,
                                                         const float4 *__restrict__ wq, const float *__restrict__ inv_scale,
                                                         float x_inv_scale, const float *__restrict__ bias,
                                                         float *__restrict__ y, int gn_cg, double *__restrict__ gn_partial) {
@@ -152,23 +152,27 @@ __global__ __launch_bounds__(NW * 64) void conv3d_h2_kernel(int C8, int Cout, co
 
   for (int e = tid; e < 2 * HALO; e += NT) Xs[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  float4 xr[XI], wr[WI];
+  // (staging registers are native vectors: an array of HIP float4 structs loaded unconditionally ends up in scratch memory)
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v xr[XI], wr[WI];
+  // Branch-free, select-free loads: out-of-range pieces read a clamped (valid) address and are simply never stored
+  // (halo cells outside the grid keep the zeros written above; weight rows >= Cout only feed output rows that are never
+  // written).  A branch or a select on a freshly loaded value makes the wave wait for memory inside the load phase.
   auto load_chunk = [&](int c8) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int e = tid + i * NT;
       const int z = e % R, row = (e / R) % ROWS, s = e / (R * ROWS);
       const int gx = X0 + row / (TY + 2) - 1, gy = Y0 + row % (TY + 2) - 1;
-      xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < XV && gx >= 0 && gx < R && gy >= 0 && gy < R)
-        xr[i] = xb[((size_t)c8 * 2 + s) * R3 + (gx * R + gy) * R + z];
+      const bool ok = e < XV && gx >= 0 && gx < R && gy >= 0 && gy < R;
+      xr[i] = *reinterpret_cast<const f32x4v *>(&xb[ok ? (unsigned)((c8 * 2 + s) * R3 + (gx * R + gy) * R + z) : 0u]);
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       const int e = tid + i * NT;
       const int m = e % BM, psh = e / BM;  // psh = (p*2 + s)*2 + h
-      wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < WV && m0 + m < Cout) wr[i] = wq[((size_t)c8 * (H2_PAIRS * 4) + psh) * Cout + m0 + m];
+      const bool ok = e < WV && m0 + m < Cout;
+      wr[i] = *reinterpret_cast<const f32x4v *>(&wq[ok ? (unsigned)((c8 * (H2_PAIRS * 4) + psh) * Cout + m0 + m) : 0u]);
     }
   };
   auto store_chunk = [&]() {
@@ -177,12 +181,12 @@ __global__ __launch_bounds__(NW * 64) void conv3d_h2_kernel(int C8, int Cout, co
       const int e = tid + i * NT;
       const int z = e % R, row = (e / R) % ROWS, s = e / (R * ROWS);
       const int gx = X0 + row / (TY + 2) - 1, gy = Y0 + row % (TY + 2) - 1;
-      if (e < XV && gx >= 0 && gx < R && gy >= 0 && gy < R) Xs[s * HALO + row * RSV + 1 + z] = xr[i];
+      if (e < XV && gx >= 0 && gx < R && gy >= 0 && gy < R) *reinterpret_cast<f32x4v *>(&Xs[s * HALO + row * RSV + 1 + z]) = xr[i];
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       const int e = tid + i * NT;
-      if (e < WV) Ws[e] = wr[i];
+      if (e < WV) *reinterpret_cast<f32x4v *>(&Ws[e]) = wr[i];
     }
   };
 
@@ -192,27 +196,34 @@ __global__ __launch_bounds__(NW * 64) void conv3d_h2_kernel(int C8, int Cout, co
     store_chunk();
     __syncthreads();
     if (c8 + 1 < C8) load_chunk(c8 + 1);
-#pragma unroll
-    for (int p = 0; p < H2_PAIRS; ++p) {
+    // Operand fragments of tap pair p + 1 are read from LDS BEFORE the matrix work of pair p is issued (two register
+    // buffers, scheduling barriers keep the order): the MFMAs never wait for an LDS read issued just ahead of them.
+    f16x8 fa[2][MI][2], fb[2][NI][2];
+    auto read_pair = [&](int p, int buf) {
       // tap of this lane half: 2p + lh  (compile-time pair, run-time half -> select between two constants)
       const int t0 = 2 * p, t1 = (2 * p + 1 < 27) ? 2 * p + 1 : 26;
       const int off0 = ((t0 / 9 - 1) * (TY + 2) + ((t0 / 3) % 3 - 1)) * RSV + (t0 % 3 - 1);
       const int off1 = ((t1 / 9 - 1) * (TY + 2) + ((t1 / 3) % 3 - 1)) * RSV + (t1 % 3 - 1);
       const int toff = lh ? off1 : off0;
-      f16x8 a[MI][2], b[NI][2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const float4 t = Ws[((p * 2 + s) * 2 + lh) * BM + mi * 32 + li];
-          a[mi][s] = *reinterpret_cast<const f16x8 *>(&t);
+          fa[buf][mi][s] = *reinterpret_cast<const f16x8 *>(&t);
         }
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
           const float4 t = Xs[s * HALO + lbase[q] + toff];
-          b[q][s] = *reinterpret_cast<const f16x8 *>(&t);
+          fb[buf][q][s] = *reinterpret_cast<const f16x8 *>(&t);
         }
       }
+    };
+    read_pair(0, 0);
+#pragma unroll
+    for (int p = 0; p < H2_PAIRS; ++p) {
+      if (p + 1 < H2_PAIRS) read_pair(p + 1, (p + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
       // smallest terms first: lo.hi, hi.lo, hi.hi (lo.lo <= 2^-24 |a b| is dropped).  Term-major order: the MI*NI
       // accumulators are independent, so no MFMA waits on the one issued just before it.
 #pragma unroll
@@ -221,7 +232,9 @@ __global__ __launch_bounds__(NW * 64) void conv3d_h2_kernel(int C8, int Cout, co
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int q = 0; q < NI; ++q)
-            acc[mi][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][term == 0 ? 1 : 0], b[q][term == 1 ? 1 : 0], acc[mi][q], 0, 0, 0);
+            acc[mi][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[p & 1][mi][term == 0 ? 1 : 0], fb[p & 1][q][term == 1 ? 1 : 0],
+                                                               acc[mi][q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // Epilogue: scale + bias + store.  When gn_partial is given, the workgroup also leaves the (sum, sum of squares) of the
