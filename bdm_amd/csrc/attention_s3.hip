@@ -117,21 +117,21 @@ __global__ __launch_bounds__(256) void attn_flash_s3_kernel(int C, int L, int Lp
   float run_max = -INFINITY, run_sum = 0.f;
 
   // register-prefetched tile staging: the loads of step j0 + 32 are in flight during the MFMAs of step j0
-  uint4 kr[KI], vr[VI];
+  // native-vector staging registers; loads without branch or select on the loaded value (either makes the wave wait for
+  // memory inside the load phase): keys beyond L read a clamped address -- their scores are overwritten with -inf below,
+  // so their probabilities are exactly 0 whatever was read -- and pieces beyond the tile are never stored
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  u32x4v kr[KI], vr[VI];
   auto load_tile = [&](int j0) {
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
-      const int e = tid + i * 256, key = e & 31, cs = e >> 5;
-      const bool ok = e < KT && j0 + key < L;
-      const uint4 u = kb[ok ? (size_t)cs * L + j0 + key : 0];
-      kr[i] = make_uint4(ok ? u.x : 0u, ok ? u.y : 0u, ok ? u.z : 0u, ok ? u.w : 0u);
+      const int e = tid + i * 256, key = e & 31, cs = min(e >> 5, KT / 32 - 1);
+      kr[i] = *reinterpret_cast<const u32x4v *>(&kb[(size_t)cs * L + min(j0 + key, L - 1)]);
     }
 #pragma unroll
     for (int i = 0; i < VI; ++i) {
-      const int e = tid + i * 256, piece = e & 3, rowi = e >> 2;
-      const bool ok = e < VT && j0 + piece * 8 < Lp;
-      const uint4 u = *reinterpret_cast<const uint4 *>(vb + (ok ? (size_t)rowi * Lp + j0 + piece * 8 : 0));
-      vr[i] = make_uint4(ok ? u.x : 0u, ok ? u.y : 0u, ok ? u.z : 0u, ok ? u.w : 0u);
+      const int e = tid + i * 256, piece = e & 3, rowi = min(e >> 2, VT / 4 - 1);
+      vr[i] = *reinterpret_cast<const u32x4v *>(vb + ((size_t)rowi * Lp + min(j0 + piece * 8, Lp - 8)));
     }
   };
   load_tile(0);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void attn_flash_s3_kernel(int C, int L, int Lp
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
       const int e = tid + i * 256;
-      if (e < KT) Ksh[e] = kr[i];
+      if (e < KT) *reinterpret_cast<u32x4v *>(&Ksh[e]) = kr[i];
     }
 #pragma unroll
     for (int i = 0; i < VI; ++i) {

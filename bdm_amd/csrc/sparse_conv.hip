@@ -219,30 +219,38 @@ __global__ __launch_bounds__(256) void sparse_gemm_s3_kernel(int M, int G, int N
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-  uint4 ar[AI], br[BI];
+  // Staging registers are native vectors and the loads carry neither a branch nor a select on the loaded value (either
+  // makes the wave wait for memory inside the load phase, i.e. no prefetch): rows >= M / columns >= N read a clamped
+  // address and only feed outputs that are never stored; the channel groups >= G of the last stage are zeroed when the
+  // registers go to LDS.
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  u32x4v ar[AI], br[BI];
   auto load_stage = [&](int g0) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int e = tid + i * 256, row = e % BM, gs = e / BM, g = g0 + gs / 3, sp = gs % 3;
-      const bool ok = g < G && m0 + row < M;  // branch-free: load a valid record, then select (keeps ar[] in registers)
-      const uint4 v = Ab[ok ? ((size_t)g * 3 + sp) * M + m0 + row : 0];
-      ar[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+      const int e = tid + i * 256, row = e % BM, gs = e / BM, g = min(g0 + gs / 3, G - 1), sp = gs % 3;
+      ar[i] = *reinterpret_cast<const u32x4v *>(&Ab[(unsigned)((g * 3 + sp) * M + min(m0 + row, M - 1))]);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int e = tid + i * 256, col = e % BN, gs = e / BN, g = g0 + gs / 3, sp = gs % 3;
-      const bool ok = g < G && n0 + col < N;
-      const uint4 v = Bw[ok ? ((size_t)g * 3 + sp) * N + n0 + col : 0];
-      br[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+      const int e = tid + i * 256, col = e % BN, gs = e / BN, g = min(g0 + gs / 3, G - 1), sp = gs % 3;
+      br[i] = *reinterpret_cast<const u32x4v *>(&Bw[(unsigned)((g * 3 + sp) * N + min(n0 + col, N - 1))]);
     }
   };
   load_stage(0);
   for (int g0 = 0; g0 < G; g0 += 4) {
     __syncthreads();
+    const u32x4v zero = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int i = 0; i < AI; ++i) As[tid + i * 256] = ar[i];
+    for (int i = 0; i < AI; ++i) {
+      const int e = tid + i * 256, gs = e / BM;
+      *reinterpret_cast<u32x4v *>(&As[e]) = (g0 + gs / 3 < G) ? ar[i] : zero;
+    }
 #pragma unroll
-    for (int i = 0; i < BI; ++i) Bs[tid + i * 256] = br[i];
+    for (int i = 0; i < BI; ++i) {
+      const int e = tid + i * 256, gs = e / BN;
+      *reinterpret_cast<u32x4v *>(&Bs[e]) = (g0 + gs / 3 < G) ? br[i] : zero;
+    }
     __syncthreads();
     if (g0 + 4 < G) load_stage(g0 + 4);
 #pragma unroll

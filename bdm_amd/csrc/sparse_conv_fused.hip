@@ -460,32 +460,36 @@ __global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
   constexpr int AI = 8 * BM / 256;
-  uint4 ar[AI], br[BI];
+  // native-vector staging registers, loads without branch or select (see sparse_gemm_s3_kernel): rows / columns beyond the
+  // matrix read a clamped address, channel groups >= G are zeroed on the way to LDS
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  u32x4v ar[AI], br[BI];
   auto load_stage = [&](int g0) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int e = tid + i * 256, row = e % BM, gs = e / BM, g = g0 + gs / 2, sp = gs % 2;
-      const bool ok = g < G && m0 + row < M;
-      const uint4 v = Ab[ok ? ((size_t)g * 2 + sp) * M + m0 + row : 0];
-      const unsigned k = ok ? 0xFFFFFFFFu : 0u;
-      ar[i] = make_uint4(v.x & k, v.y & k, v.z & k, v.w & k);
+      const int e = tid + i * 256, row = e % BM, gs = e / BM, g = min(g0 + gs / 2, G - 1), sp = gs % 2;
+      ar[i] = *reinterpret_cast<const u32x4v *>(&Ab[(unsigned)((g * 2 + sp) * M + min(m0 + row, M - 1))]);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int e = tid + i * 256, col = e % BN, gs = e / BN, g = g0 + gs / 2, sp = gs % 2;
-      const bool ok = g < G && n0 + col < N;
-      const uint4 v = Bw[ok ? ((size_t)g * 2 + sp) * N + n0 + col : 0];
-      const unsigned k = ok ? 0xFFFFFFFFu : 0u;
-      br[i] = make_uint4(v.x & k, v.y & k, v.z & k, v.w & k);
+      const int e = tid + i * 256, col = e % BN, gs = e / BN, g = min(g0 + gs / 2, G - 1), sp = gs % 2;
+      br[i] = *reinterpret_cast<const u32x4v *>(&Bw[(unsigned)((g * 2 + sp) * N + min(n0 + col, N - 1))]);
     }
   };
   load_stage(0);
   for (int g0 = 0; g0 < G; g0 += 4) {
     __syncthreads();
+    const u32x4v zero = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int i = 0; i < AI; ++i) As[tid + i * 256] = ar[i];
+    for (int i = 0; i < AI; ++i) {
+      const int e = tid + i * 256, gs = e / BM;
+      *reinterpret_cast<u32x4v *>(&As[e]) = (g0 + gs / 2 < G) ? ar[i] : zero;
+    }
 #pragma unroll
-    for (int i = 0; i < BI; ++i) Bs[tid + i * 256] = br[i];
+    for (int i = 0; i < BI; ++i) {
+      const int e = tid + i * 256, gs = e / BN;
+      *reinterpret_cast<u32x4v *>(&Bs[e]) = (g0 + gs / 2 < G) ? br[i] : zero;
+    }
     __syncthreads();
     if (g0 + 4 < G) load_stage(g0 + 4);
 #pragma unroll
