@@ -18,6 +18,7 @@
 
 using namespace bdm;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ float swishf(float x) { return x / (1.0f + expf(-x)); }
 
 // =====================================================================================
 // Pointwise convolution = batched GEMM  Y[b] = W (M x K) * X[b] (K x N) + bias
@@ -28,7 +29,21 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // Tile: (32*MI) x (128*NI) per 256-thread workgroup, K chunk 16, 4 waves side by side along N.
 // K chunk BK per barrier pair: 16 for the throughput shapes; 64 for the latency-bound ones (few workgroups, long K), where
 // one chunk in flight per workgroup leaves the global-load latency exposed on every step.  Same k order: same bits.
-template <int MI, int NI, bool ATRANS = false, int BK = 16>
+// GroupNorm folding around a 1x1 convolution (SharedMLP = [conv -> GroupNorm(8) -> Swish]*): the GEMM can (a) leave the
+// (sum, sum of squares) of the values it writes, per GroupNorm group, as slice partials -- the normalisation that follows then
+// needs no statistics pass -- and (b) take its INPUT as the raw output of such a convolution plus that convolution's partials,
+// applying normalise + Swish while the operand goes to LDS -- the normalised tensor is never written.  Deterministic: fixed
+// summation orders everywhere (no float atomics).
+struct PwGn {
+  const double *in_partial;  // (b, in_G, in_S, 2) or NULL
+  int in_S, in_G;
+  const float *in_gamma, *in_beta;
+  float in_eps;
+  double *out_partial;       // (b, M / out_cg, S_out, 2) or NULL;  S_out = gridDim.x * max(1, out_cg / BM)
+  int out_cg;
+};
+
+template <int MI, int NI, bool ATRANS = false, int BK = 16, bool FOLD = false>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const float *__restrict__ W, int ldw,
                                                       long long bsw, const int *__restrict__ m_count,
                                                       const float *__restrict__ X, long long bsx, int ldx,
@@ -36,13 +51,41 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
                                                       const float *__restrict__ bbias, int ldbb,
                                                       const float *__restrict__ R, long long bsr, int ldr,
                                                       float *__restrict__ Y, long long bsy, int ldy, int act,
-                                                      float slope) {
+                                                      float slope, PwGn gn) {
   constexpr int BM = 32 * MI, BN = 128 * NI, LDA = BM + 4;
   __shared__ float As[BK * LDA];
   __shared__ __align__(16) float Bs[BK * BN];
+  __shared__ float2 coef_s[FOLD ? 1024 : 1];  // per input channel: swish(coef.x * x + coef.y) = Swish(GroupNorm(x))
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, bi = blockIdx.z;
   if (m_count && m0 >= m_count[bi]) return;  // rows beyond this shape's live count (sparse convolution GEMM)
+  if constexpr (FOLD) {
+    // statistics of the input's groups from the producer's slice partials: 32 lanes per group (<= 8 groups), each lane adds
+    // slices l, l + 32, ... in order, then a fixed butterfly
+    __shared__ float s_mr[16];
+    const int g = tid >> 5, l = tid & 31, cgi = K / gn.in_G;
+    double a = 0.0, q = 0.0;
+    if (g < gn.in_G) {
+      const double *pp = gn.in_partial + ((size_t)bi * gn.in_G + g) * gn.in_S * 2;
+      for (int sl = l; sl < gn.in_S; sl += 32) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
+    }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    if (l == 0 && g < gn.in_G) {
+      const double cnt = (double)cgi * N, mean = a / cnt;
+      double var = q / cnt - mean * mean;
+      if (var < 0) var = 0;
+      s_mr[2 * g] = (float)mean;
+      s_mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)gn.in_eps));
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+      const int gk = k / cgi;
+      const float ak = gn.in_gamma[k] * s_mr[2 * gk + 1];
+      coef_s[k] = make_float2(ak, gn.in_beta[k] - s_mr[2 * gk] * ak);
+    }
+    // (visible to every wave after the first barrier of the K loop)
+  }
   W += (size_t)bi * bsw;
   const float *Xb = X + (size_t)bi * bsx;
   float *Yb = Y + (size_t)bi * bsy;
@@ -127,8 +170,12 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
     for (int i = 0; i < BI; ++i) {
       const int e = tid + i * 256, k = e / (BN / 4), c4 = (e % (BN / 4)) * 4;
       const bool ok = k0 + k < K;
-      *reinterpret_cast<float4 *>(&Bs[k * BN + c4]) =
-          make_float4(ok ? br[i].x : 0.f, ok ? br[i].y : 0.f, ok ? br[i].z : 0.f, ok ? br[i].w : 0.f);
+      float4 v = br[i];
+      if constexpr (FOLD) {
+        const float2 cf = coef_s[min(k0 + k, K - 1)];
+        v = make_float4(swishf(cf.x * v.x + cf.y), swishf(cf.x * v.y + cf.y), swishf(cf.x * v.z + cf.y), swishf(cf.x * v.w + cf.y));
+      }
+      *reinterpret_cast<float4 *>(&Bs[k * BN + c4]) = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     }
     __syncthreads();
     if (k0 + BK < K) load_chunk(k0 + BK);
@@ -149,6 +196,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
   }
   // ---- epilogue: C/D map  row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31.  The per-row terms (bias, per-shape bias)
   // and the residual are fetched in batches under workgroup-uniform branches (clamped addresses), then applied.
+  float bs[MI][4], bq[MI][4];  // GroupNorm partials of this lane's 4-row blocks j: rows x*32 + 8j + 4lh .. +3
+#pragma unroll
+  for (int x = 0; x < MI; ++x)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bs[x][j] = 0.f; bq[x][j] = 0.f; }
 #pragma unroll
   for (int x = 0; x < MI; ++x) {
     float badd[16], bb[16];
@@ -179,8 +231,57 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
         if (act == 2) v = v > 0.f ? v : v * slope;
         else if (act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // exact GELU (timm Mlp)
         if (R) v += rv[r];
-        if (m < M && n < N) Yb[(size_t)m * ldy + n] = v;
+        if (m < M && n < N) {
+          Yb[(size_t)m * ldy + n] = v;
+          bs[x][r >> 2] += v;
+          bq[x][r >> 2] += v * v;
+        }
       }
+    }
+  }
+  if (gn.out_partial != nullptr) {
+    // (sum, sum of squares) of the tile per GroupNorm group: fixed order inside the lane, half-wave butterflies, the four
+    // waves added in wave order, then the 4-row blocks of a group in fp64 by one thread per group
+#pragma unroll
+    for (int x = 0; x < MI; ++x)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+          bs[x][j] += __shfl_xor(bs[x][j], o, 64);
+          bq[x][j] += __shfl_xor(bq[x][j], o, 64);
+        }
+    __syncthreads();  // the operand tiles are dead: reuse Bs
+    constexpr int NB = 2 * MI * 4 * 2;  // [lh][x][j][stat]
+    float *red = Bs;                    // [4 waves][NB], then [NB]
+    if (li == 0) {
+#pragma unroll
+      for (int x = 0; x < MI; ++x)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          red[wave * NB + ((lh * MI + x) * 4 + j) * 2 + 0] = bs[x][j];
+          red[wave * NB + ((lh * MI + x) * 4 + j) * 2 + 1] = bq[x][j];
+        }
+    }
+    __syncthreads();
+    if (tid < NB) red[4 * NB + tid] = ((red[tid] + red[NB + tid]) + red[2 * NB + tid]) + red[3 * NB + tid];
+    __syncthreads();
+    const int cg = gn.out_cg, G = M / cg;
+    const int ngt = cg >= BM ? 1 : BM / cg;      // groups inside this row tile
+    const int rt = cg >= BM ? cg / BM : 1;       // row tiles per group
+    if (tid < ngt && m0 + tid * cg < M) {
+      double a = 0.0, qq = 0.0;
+      for (int hh = 0; hh < 2; ++hh)
+        for (int x = 0; x < MI; ++x)
+          for (int j = 0; j < 4; ++j)
+            if (cg >= BM || (x * 32 + 8 * j + 4 * hh) / cg == tid) {
+              a += (double)red[4 * NB + ((hh * MI + x) * 4 + j) * 2 + 0];
+              qq += (double)red[4 * NB + ((hh * MI + x) * 4 + j) * 2 + 1];
+            }
+      const int g = m0 / cg + tid, S = gridDim.x * rt, sl = blockIdx.x * rt + (int)(blockIdx.y % rt);
+      double *dst = gn.out_partial + (((size_t)bi * G + g) * S + sl) * 2;
+      dst[0] = a;
+      dst[1] = qq;
     }
   }
 }
@@ -195,6 +296,45 @@ static int pw_deep_limit() {
   return v;
 }
 
+// biggest tile that still gives the 256 CUs two workgroups each; small problems (the 16..256-point levels) are latency-bound
+// and prefer many small tiles over operand reuse, and take the 64-deep K chunk when K is long
+static void pw_tile(int b, int m, int k, int n, int *mi, int *ni, int *bk) {
+  auto blocks = [&](int a, int c) { return (long long)cdiv(n, 128 * c) * cdiv(m, 32 * a) * b; };
+  const int deep_limit = pw_deep_limit();
+  *bk = 16;
+  if (m <= 32) {
+    if (n <= 128 || blocks(1, 2) < 512) { *mi = 1; *ni = 1; if (k >= 128 && blocks(1, 1) < deep_limit) *bk = 64; }
+    else { *mi = 1; *ni = 2; }
+  } else if (n > 128 && blocks(2, 2) >= 512) {
+    *mi = 2; *ni = 2;
+  } else if (blocks(2, 1) >= 512) {
+    *mi = 2; *ni = 1; if (k >= 128 && blocks(2, 1) < deep_limit) *bk = 64;
+  } else {
+    *mi = 1; *ni = 1; if (k >= 128 && blocks(1, 1) < deep_limit) *bk = 64;
+  }
+}
+
+// tile choice + launch, shared by the plain and the GroupNorm-folded entry points.  *bm_out = rows of the chosen tile,
+// *gx_out = column tiles (the GroupNorm slice count derives from both)
+template <bool FOLD>
+static void pw_dispatch(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x, int ld_x,
+                        const float *bias, const float *batch_bias, int ld_bb, const float *residual, long long bs_r, int ld_r,
+                        float *y, long long bs_y, int ld_y, int act, float slope, PwGn gn, hipStream_t s) {
+#define PW_LAUNCH(MI, NI, BK)                                                                                             \
+  hipLaunchKernelGGL((pw_gemm_kernel<MI, NI, false, BK, FOLD>), dim3(cdiv(n, 128 * NI), cdiv(m, 32 * MI), b), dim3(256), 0, s, \
+                     m, k, n, w, ldw, 0ll, (const int *)nullptr, x, bs_x, ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r,   \
+                     y, bs_y, ld_y, act, slope, gn)
+  int mi, ni, bk;
+  pw_tile(b, m, k, n, &mi, &ni, &bk);
+  if (mi == 1 && ni == 1 && bk == 16) PW_LAUNCH(1, 1, 16);
+  else if (mi == 1 && ni == 1) PW_LAUNCH(1, 1, 64);
+  else if (mi == 1 && ni == 2) PW_LAUNCH(1, 2, 16);
+  else if (mi == 2 && ni == 2) PW_LAUNCH(2, 2, 16);
+  else if (bk == 16) PW_LAUNCH(2, 1, 16);
+  else PW_LAUNCH(2, 1, 64);
+#undef PW_LAUNCH
+}
+
 extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, int ldw, const float *x,
                                   long long bs_x, int ld_x, const float *bias, const float *batch_bias,
                                   int ld_bb, const float *residual, long long bs_r, int ld_r, float *y,
@@ -204,33 +344,46 @@ extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, in
   BDM_REQUIRE((long long)k * ld_x + n < (1ll << 31) && (long long)m * ldw + k < (1ll << 31),
               "pointwise_conv: one operand spans more than 2^31 elements");
   if (b == 0 || n == 0) return BDM_OK;
-  hipStream_t s = (hipStream_t)stream;
-#define PW_LAUNCH(MI, NI)                                                                                   \
-  hipLaunchKernelGGL((pw_gemm_kernel<MI, NI>), dim3(cdiv(n, 128 * NI), cdiv(m, 32 * MI), b), dim3(256), 0, s, \
-                     m, k, n, w, ldw, 0ll, (const int *)nullptr, x, bs_x, ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r,  \
-                     y, bs_y, ld_y, act, slope)
-  // biggest tile that still gives the 256 CUs two workgroups each; small problems (the 16..256-point levels) are
-  // latency-bound and prefer many small tiles over operand reuse
-#define PW_LAUNCH_DEEP(MI, NI)                                                                                          \
-  hipLaunchKernelGGL((pw_gemm_kernel<MI, NI, false, 64>), dim3(cdiv(n, 128 * NI), cdiv(m, 32 * MI), b), dim3(256), 0, s, \
-                     m, k, n, w, ldw, 0ll, (const int *)nullptr, x, bs_x, ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r,   \
-                     y, bs_y, ld_y, act, slope)
-  auto blocks = [&](int mi, int ni) { return (long long)cdiv(n, 128 * ni) * cdiv(m, 32 * mi) * b; };
-  const int deep_limit = pw_deep_limit();
-  if (m <= 32) {
-    if (n <= 128 || blocks(1, 2) < 512) {
-      if (k >= 128 && blocks(1, 1) < deep_limit) PW_LAUNCH_DEEP(1, 1); else PW_LAUNCH(1, 1);
-    } else PW_LAUNCH(1, 2);
-  } else if (n > 128 && blocks(2, 2) >= 512) {
-    PW_LAUNCH(2, 2);
-  } else if (blocks(2, 1) >= 512) {
-    if (k >= 128 && blocks(2, 1) < deep_limit) PW_LAUNCH_DEEP(2, 1); else PW_LAUNCH(2, 1);
-  } else {
-    if (k >= 128 && blocks(1, 1) < deep_limit) PW_LAUNCH_DEEP(1, 1); else PW_LAUNCH(1, 1);
-  }
-#undef PW_LAUNCH_DEEP
-#undef PW_LAUNCH
+  pw_dispatch<false>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r, y, bs_y, ld_y, act, slope,
+                     PwGn{}, (hipStream_t)stream);
   return launch_status("pointwise_conv");
+}
+
+// slices per (shape, group) the GroupNorm-folded convolution below writes for an (m x n) output in `groups` groups
+extern "C" int bdm_pointwise_conv_gn_slices(int b, int m, int k, int n, int groups) {
+  if (groups < 1 || m % groups) return 0;
+  int mi, ni, bk;
+  pw_tile(b, m, k, n, &mi, &ni, &bk);
+  const int cg = m / groups, bm = 32 * mi;
+  return cdiv(n, 128 * ni) * (cg >= bm ? cg / bm : 1);
+}
+
+extern "C" int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x,
+                                     int ld_x, const float *bias, float *y, long long bs_y, int ld_y, const void *in_partial,
+                                     int in_slices, int in_groups, const float *in_gamma, const float *in_beta, float in_eps,
+                                     int out_groups, void *out_partial, void *stream) {
+  BDM_REQUIRE(b >= 0 && m >= 1 && k >= 1 && n >= 1, "pointwise_conv_gn: bad sizes m=%d k=%d n=%d", m, k, n);
+  BDM_REQUIRE((long long)k * ld_x + n < (1ll << 31) && (long long)m * ldw + k < (1ll << 31),
+              "pointwise_conv_gn: one operand spans more than 2^31 elements");
+  PwGn gn{};
+  if (in_partial != nullptr) {
+    BDM_REQUIRE(in_groups >= 1 && in_groups <= 8 && k % in_groups == 0 && k <= 1024 && in_slices >= 1 && in_gamma && in_beta,
+                "pointwise_conv_gn: input fold needs <= 8 groups dividing k <= 1024 (k=%d groups=%d)", k, in_groups);
+    gn.in_partial = (const double *)in_partial;
+    gn.in_S = in_slices; gn.in_G = in_groups; gn.in_gamma = in_gamma; gn.in_beta = in_beta; gn.in_eps = in_eps;
+  }
+  if (out_partial != nullptr) {
+    const int cg = out_groups >= 1 && m % out_groups == 0 ? m / out_groups : 0;
+    BDM_REQUIRE(cg >= 4 && (cg & (cg - 1)) == 0, "pointwise_conv_gn: output statistics need a power-of-two >= 4 channels per group "
+                "(m=%d groups=%d)", m, out_groups);
+    gn.out_partial = (double *)out_partial; gn.out_cg = cg;
+  }
+  if (b == 0) return BDM_OK;
+  if (in_partial != nullptr)
+    pw_dispatch<true>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, nullptr, 0, nullptr, 0ll, 0, y, bs_y, ld_y, 0, 0.f, gn, (hipStream_t)stream);
+  else
+    pw_dispatch<false>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, nullptr, 0, nullptr, 0ll, 0, y, bs_y, ld_y, 0, 0.f, gn, (hipStream_t)stream);
+  return launch_status("pointwise_conv_gn");
 }
 
 // Sparse first-convolution GEMM (sparse_conv.hip): Y[b] (n_max x n27) = Xc[b]^T (n_max x cin) . Wt (cin x n27), rows
@@ -242,7 +395,7 @@ extern "C" int bdm_sparse_conv_gemm(int b, int n_max, int cin, int n27, const fl
   hipLaunchKernelGGL((pw_gemm_kernel<2, 2, true>), dim3(cdiv(n27, 256), cdiv(n_max, 64), b), dim3(256), 0,
                      (hipStream_t)stream, n_max, cin, n27, xc, n_max, (long long)cin * n_max, n_occ, wt, 0ll, n27,
                      (const float *)nullptr, (const float *)nullptr, 0, (const float *)nullptr, 0ll, 0, y,
-                     (long long)n_max * n27, n27, 0, 0.f);
+                     (long long)n_max * n27, n27, 0, 0.f, PwGn{});
   return launch_status("sparse_conv_gemm");
 }
 
@@ -252,7 +405,6 @@ extern "C" int bdm_sparse_conv_gemm(int b, int n_max, int cin, int n27, const fl
 // Two launches: slice-partial (sum, sumsq) in fp64, then normalise; the second kernel re-reduces
 // the S partials in a fixed order, so results are run-to-run deterministic.
 #define GN_MAX_SLICES 64
-__device__ __forceinline__ float swishf(float x) { return x / (1.0f + expf(-x)); }
 
 __global__ void gn_stats_kernel(int cg, int L, const float *__restrict__ x, long long bs, int ld,
                                 const float *__restrict__ res, long long bs_r, int ld_r, int G,
@@ -533,6 +685,55 @@ extern "C" int bdm_max_over_neighbors(int b, int c, int m, int u, const float *x
   dim3 grid(cdiv(m, 64), c < 256 ? c : 256, b);
   hipLaunchKernelGGL(max_u_kernel, grid, dim3(64), 0, (hipStream_t)stream, c, m, u, x, y, bs_y, ld_y);
   return launch_status("max_over_neighbors");
+}
+
+// The same reduction over Swish(GroupNorm(x)) with x the RAW output of the SA MLP's last convolution and the GroupNorm
+// statistics taken from that convolution's slice partials (bdm_pointwise_conv_gn): the normalised (B, C, M, U) tensor is
+// never written.  Swish is not monotonic, so every element is transformed before the maximum.
+__global__ void max_u_gn_kernel(int c, int m, int u, int G, int S, const float *__restrict__ x,
+                                const double *__restrict__ partial, const float *__restrict__ gamma,
+                                const float *__restrict__ beta, float eps, float *__restrict__ y, long long bs_y, int ld_y) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x;
+  const int bi = blockIdx.z, cg = c / G;
+  for (int ci = blockIdx.y; ci < c; ci += gridDim.y) {
+    const int g = ci / cg;
+    const double *pp = partial + ((size_t)bi * G + g) * S * 2;
+    double a = 0.0, q = 0.0;
+    for (int sl = lane; sl < S; sl += 64) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    const double cnt = (double)cg * m * u, mean = a / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0) var = 0;
+    const float ca = gamma[ci] * (float)(1.0 / sqrt(var + (double)eps)), cb = beta[ci] - (float)mean * ca;
+    if (j < m) {
+      const float *row = x + (((size_t)bi * c + ci) * m + j) * u;
+      float v = swishf(ca * row[0] + cb);
+      if ((u & 3) == 0) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(row);
+        for (int qd = 0; qd < u / 4; ++qd) {
+          const float4 t = r4[qd];
+          v = fmaxf(v, fmaxf(fmaxf(swishf(ca * t.x + cb), swishf(ca * t.y + cb)), fmaxf(swishf(ca * t.z + cb), swishf(ca * t.w + cb))));
+        }
+      } else {
+        for (int qd = 1; qd < u; ++qd) v = fmaxf(v, swishf(ca * row[qd] + cb));
+      }
+      y[(size_t)bi * bs_y + (size_t)ci * ld_y + j] = v;
+    }
+  }
+}
+
+extern "C" int bdm_max_over_neighbors_gn(int b, int c, int m, int u, const float *x, const void *in_partial, int in_slices,
+                                         int groups, const float *gamma, const float *beta, float eps, float *y, long long bs_y,
+                                         int ld_y, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && m >= 1 && u >= 1, "max_over_neighbors_gn: bad sizes");
+  BDM_REQUIRE(in_partial != nullptr && in_slices >= 1 && groups >= 1 && c % groups == 0 && gamma && beta,
+              "max_over_neighbors_gn: bad GroupNorm arguments");
+  if (b == 0) return BDM_OK;
+  dim3 grid(cdiv(m, 64), c < 256 ? c : 256, b);
+  hipLaunchKernelGGL(max_u_gn_kernel, grid, dim3(64), 0, (hipStream_t)stream, c, m, u, groups, in_slices, x,
+                     (const double *)in_partial, gamma, beta, eps, y, bs_y, ld_y);
+  return launch_status("max_over_neighbors_gn");
 }
 
 // =====================================================================================

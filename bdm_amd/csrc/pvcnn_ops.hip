@@ -31,7 +31,7 @@ void set_error(const char *fmt, ...) {
 }  // namespace bdm
 
 extern "C" const char *bdm_last_error(void) { return bdm::g_err; }
-extern "C" int bdm_abi_version(void) { return 2; }
+extern "C" int bdm_abi_version(void) { return 3; }
 
 using namespace bdm;
 

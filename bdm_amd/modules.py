@@ -46,14 +46,34 @@ class SharedMLP(nn.Module):
             in_channels = oc
         self.layers = nn.Sequential(*layers)
 
-    def run(self, x, out_last=None):
+    # GroupNorm folding (BDM_FOLD_GN_MLP=0 disables): a layer's convolution leaves the GroupNorm statistics of its output
+    # and the NEXT consumer (the next layer's convolution, or the caller's max over neighbours with fold_last) normalises +
+    # Swishes on the fly -- no GroupNorm pass, the normalised tensor is never written
+    fold_gn = os.environ.get("BDM_FOLD_GN_MLP", "1") == "1"
+
+    def run(self, x, out_last=None, fold_last=False):
+        """-> activations; with fold_last -> (raw output of the last convolution, (stats, gn) | None): the caller applies the
+        last GroupNorm + Swish inside its own consumer kernel (None: already applied)."""
         n = len(self.layers) // 3
+        pending = None
         for i in range(n):
             conv, gn = self.layers[3 * i], self.layers[3 * i + 1]
-            dst = out_last if (i == n - 1) else None
-            x = ops.pointwise_conv(x, conv.weight, conv.bias, out=dst)
-            ops.group_norm_(x, gn.weight, gn.bias, gn.num_groups, gn.eps, swish=True)
-        return x
+            last = i == n - 1
+            dst = out_last if last else None
+            defer = (self.fold_gn and x.is_cuda and (not last or fold_last) and ops.gn_foldable(conv.out_channels, gn.num_groups))
+            if defer or pending is not None:
+                r = ops.pointwise_conv_gn(x, conv.weight, conv.bias, out=dst, fold_in=pending,
+                                          out_groups=gn.num_groups if defer else None)
+                if defer:
+                    x, stats = r
+                    pending = (stats, gn)
+                else:
+                    x, pending = r, None
+                    ops.group_norm_(x, gn.weight, gn.bias, gn.num_groups, gn.eps, swish=True)
+            else:
+                x = ops.pointwise_conv(x, conv.weight, conv.bias, out=dst)
+                ops.group_norm_(x, gn.weight, gn.bias, gn.num_groups, gn.eps, swish=True)
+        return (x, pending) if fold_last else x
 
     def forward(self, inputs):
         if isinstance(inputs, (list, tuple)):
@@ -372,8 +392,8 @@ class PointNetSAModule(nn.Module):
         else:
             centers_coords, idx = self.plan(coords)
         grouped, g_t = self.groupers[0](coords, centers_coords, temb, features, neighbor_indices=idx)
-        h = self.mlps[0].run(grouped)
-        out = ops.max_over_neighbors(h)
+        h, pending = self.mlps[0].run(grouped, fold_last=True)
+        out = ops.max_over_neighbors(h, fold=pending)
         if g_t.stride(2) == 0 and g_t.stride(3) == 0:
             temb_out = g_t[:, :, 0, 0][:, :, None].expand(-1, -1, self.num_centers)
         else:

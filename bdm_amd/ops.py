@@ -74,6 +74,44 @@ def pointwise_conv(x, weight, bias=None, out=None, batch_bias=None, act=0, slope
     return out
 
 
+def gn_foldable(channels, groups):
+    """Can bdm_pointwise_conv_gn leave / take GroupNorm(groups) statistics for a `channels`-wide tensor?"""
+    cg = channels // groups if groups and channels % groups == 0 else 0
+    return groups <= 8 and cg >= 4 and (cg & (cg - 1)) == 0 and channels <= 1024
+
+
+def pointwise_conv_gn(x, weight, bias=None, out=None, fold_in=None, out_groups=None):
+    """1x1 convolution with GroupNorm folding (bdm_pointwise_conv_gn).  fold_in = (stats, gn) of a previous call: x is that
+    call's raw output and Swish(GroupNorm(x)) is applied on the fly.  out_groups: also return the statistics of the output
+    -> (y, (partial, slices, groups)).  shared_mlp.py:25-30."""
+    x, B, K, n, bs_x, ld_x = _bcl(x)
+    M = weight.shape[0]
+    w = weight.reshape(M, -1)
+    assert w.shape[1] == K, f"weight expects {w.shape[1]} channels, input has {K}"
+    w = w if w.is_contiguous() else w.contiguous()
+    if out is None:
+        out = torch.empty((B, M) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    o, Bo, Mo, no, bs_y, ld_y = _bcl(out)
+    assert o.data_ptr() == out.data_ptr() and (Bo, Mo, no) == (B, M, n), "out must be a dense-row view of matching shape"
+    lib = L.lib()
+    in_p, in_s, in_g, in_gamma, in_beta, in_eps = None, 0, 0, None, None, 0.0
+    if fold_in is not None:
+        (in_p, in_s, in_g), gn = fold_in
+        assert gn.num_groups == in_g and gn.weight.shape[0] == K
+        in_gamma, in_beta, in_eps = gn.weight, gn.bias, gn.eps
+    stats, out_p, og = None, None, 0
+    if out_groups:
+        og = int(out_groups)
+        slices = lib.bdm_pointwise_conv_gn_slices(B, M, K, n, og)
+        assert slices > 0
+        out_p = torch.empty(B * og * slices * 2, dtype=torch.float64, device=x.device)
+        stats = (out_p, slices, og)
+    L.check(lib.bdm_pointwise_conv_gn(B, M, K, n, L.ptr(w), K, L.ptr(x), L.c_ll(bs_x), ld_x, L.ptr(bias), L.ptr(out), L.c_ll(bs_y),
+                                      ld_y, L.ptr(in_p), in_s, in_g, L.ptr(in_gamma), L.ptr(in_beta), L.c_float(in_eps), og,
+                                      L.ptr(out_p), L.stream()), "pointwise_conv_gn")
+    return (out, stats) if out_groups else out
+
+
 def group_norm_(x, gamma, beta, groups=8, eps=1e-5, swish=False, residual=None, out=None):
     """GroupNorm(groups) [+residual first] [+Swish]; in place unless `out` is given."""
     xx, B, C, l, bs_x, ld_x = _bcl(x)
@@ -93,12 +131,19 @@ def group_norm_(x, gamma, beta, groups=8, eps=1e-5, swish=False, residual=None, 
     return out
 
 
-def max_over_neighbors(x, out=None):
+def max_over_neighbors(x, out=None, fold=None):
+    """max over the neighbour axis; fold = (stats, gn): x is a raw convolution output, Swish(GroupNorm(x)) is applied on the fly."""
     B, C, M, U = x.shape
     x = x.contiguous()
     if out is None:
         out = torch.empty(B, C, M, dtype=torch.float32, device=x.device)
     _, _, _, _, bs_y, ld_y = _bcl(out)
+    if fold is not None:
+        (p, slices, groups), gn = fold
+        L.check(L.lib().bdm_max_over_neighbors_gn(B, C, M, U, L.ptr(x), L.ptr(p), slices, groups, L.ptr(gn.weight), L.ptr(gn.bias),
+                                                  L.c_float(gn.eps), L.ptr(out), L.c_ll(bs_y), ld_y, L.stream()),
+                "max_over_neighbors_gn")
+        return out
     L.check(L.lib().bdm_max_over_neighbors(B, C, M, U, L.ptr(x), L.ptr(out), L.c_ll(bs_y), ld_y, L.stream()),
             "max_over_neighbors")
     return out

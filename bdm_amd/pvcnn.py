@@ -104,8 +104,10 @@ def run_blocks(blocks, inputs):
 
 
 def run_classifier(classifier, features):
-    h = classifier[0].run(features)
+    h, pending = classifier[0].run(features, fold_last=True)
     last = classifier[-1]
+    if pending is not None:  # GroupNorm + Swish of the hidden layer applied inside the last convolution (dropout is identity)
+        return ops.pointwise_conv_gn(h, last.weight, last.bias, fold_in=pending)
     return ops.pointwise_conv(h, last.weight, last.bias)
 
 

@@ -142,6 +142,24 @@ int bdm_group_norm(int b, int c, int l, int groups, const float *x, long long bs
                    void *workspace, void *stream);
 
 /* features.max(dim=-1) over the neighbour axis (pointnet.py:86): x (b,c,m,u) -> y (b,c,m) strided. */
+/* SharedMLP = [Conv k=1 -> GroupNorm(8) -> Swish]* (modules/shared_mlp.py:25-30) without a pass per GroupNorm.
+ *   bdm_pointwise_conv_gn: y = W x' + bias with
+ *     x' = x, or (in_partial != NULL) x' = Swish(GroupNorm(x)) applied while the operand is staged, the statistics of x taken
+ *          from the slice partials in_partial (b, in_groups, in_slices, 2 doubles) its producer left (in_groups <= 8, k <= 1024);
+ *     and (out_partial != NULL) the (sum, sum of squares) of y per (shape, group of m / out_groups channels) written as
+ *          bdm_pointwise_conv_gn_slices(b, m, k, n, out_groups) slices per (shape, group) into out_partial
+ *          (b, out_groups, slices, 2 doubles); channels per group must be a power of two >= 4.
+ *   bdm_max_over_neighbors_gn: max over the neighbour axis of Swish(GroupNorm(x)), statistics from such partials
+ *     (pointnet.py:86 after the last MLP layer).
+ * Deterministic (fixed summation orders, no float atomics). */
+int bdm_pointwise_conv_gn_slices(int b, int m, int k, int n, int groups);
+int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x, int ld_x,
+                          const float *bias, float *y, long long bs_y, int ld_y, const void *in_partial, int in_slices,
+                          int in_groups, const float *in_gamma, const float *in_beta, float in_eps, int out_groups,
+                          void *out_partial, void *stream);
+int bdm_max_over_neighbors_gn(int b, int c, int m, int u, const float *x, const void *in_partial, int in_slices, int groups,
+                              const float *gamma, const float *beta, float eps, float *y, long long bs_y, int ld_y,
+                              void *stream);
 int bdm_max_over_neighbors(int b, int c, int m, int u, const float *x, float *y, long long bs_y,
                            int ld_y, void *stream);
 
