@@ -83,6 +83,7 @@ SPEC = {
     "bdm_sparse_conv_fused": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[2] * a[3] ** 3)),
     # 1x1 convolutions / linear layers
     "bdm_pointwise_conv": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:4], _pw),
+    "bdm_pointwise_conv_gn": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:4], _pw),  # + GroupNorm statistics / folded input GroupNorm
     # normalisation and operand repacks: 1 read + 1 write of the tensor
     "bdm_group_norm": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", 8.0 * a[0] * a[1] * a[2])),
     "bdm_group_norm_to_h2": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", (4.0 + 4.0 + 4.0) * a[0] * a[1] * a[2])),
@@ -97,6 +98,7 @@ SPEC = {
     "bdm_grouping_forward": ("ball query + grouping", lambda a: a[:5],
                              lambda a: ("hbm", 4.0 * a[0] * (a[1] * a[2] + a[3] * a[4] + a[1] * a[3] * a[4]))),
     "bdm_max_over_neighbors": ("ball query + grouping", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] * (a[3] + 1))),
+    "bdm_max_over_neighbors_gn": ("ball query + grouping", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] * (a[3] + 1))),
     "bdm_three_nn_search": ("3-NN interpolation", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 3 * a[1] + 6 * a[2]))),
     "bdm_three_nn_apply": ("3-NN interpolation", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (a[1] * a[2] + a[1] * a[3] + 6 * a[3]))),
     "bdm_voxelize_plan_full": ("voxelize / devoxelize", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * (4 * a[1] + 3 * a[2] ** 3))),
