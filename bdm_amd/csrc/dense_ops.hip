@@ -879,6 +879,31 @@ extern "C" int bdm_copy_rows(int b, int c, int l, const float *x, long long bs_x
   return launch_status("copy_rows");
 }
 
+// torch.cat([a, b], dim=1) in ONE launch; each part is either a (c, l) row block (ld > 0) or a point-invariant column
+// (ld == 0: element (shape, channel) at x[shape * bs + channel], broadcast along l) -- pvcnn.py:100-108 cat([features, temb])
+__global__ void concat2_rows_kernel(int l, int c0, const float *__restrict__ x0, long long bs0, int ld0, int c1,
+                                    const float *__restrict__ x1, long long bs1, int ld1, float *__restrict__ y, long long bs_y,
+                                    int ld_y) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (col >= l) return;
+  for (int ci = blockIdx.y; ci < c0 + c1; ci += gridDim.y) {
+    float v;
+    if (ci < c0) v = ld0 ? x0[(size_t)bi * bs0 + (size_t)ci * ld0 + col] : x0[(size_t)bi * bs0 + ci];
+    else v = ld1 ? x1[(size_t)bi * bs1 + (size_t)(ci - c0) * ld1 + col] : x1[(size_t)bi * bs1 + (ci - c0)];
+    y[(size_t)bi * bs_y + (size_t)ci * ld_y + col] = v;
+  }
+}
+extern "C" int bdm_concat2_rows(int b, int l, int c0, const float *x0, long long bs_0, int ld_0, int c1, const float *x1,
+                                long long bs_1, int ld_1, float *y, long long bs_y, int ld_y, void *stream) {
+  BDM_REQUIRE(b >= 0 && l >= 1 && c0 >= 0 && c1 >= 0 && c0 + c1 >= 1, "concat2_rows: bad sizes");
+  if (b == 0) return BDM_OK;
+  const int c = c0 + c1;
+  hipLaunchKernelGGL(concat2_rows_kernel, dim3(cdiv(l, 256), c < 64 ? c : 64, b), dim3(256), 0, (hipStream_t)stream, l, c0, x0,
+                     bs_0, ld_0, c1, x1, bs_1, ld_1, y, bs_y, ld_y);
+  return launch_status("concat2_rows");
+}
+
 // (B, N, C) point-major  ->  (B, C, N) channel-first  (point_cloud_model.py:65 `inputs.transpose(1, 2)`)
 __global__ void transpose_kernel(int rows, int cols, const float *__restrict__ x, float *__restrict__ y) {
   __shared__ float tile[32][33];
@@ -1107,6 +1132,14 @@ extern "C" int bdm_se_gate(int b, int c, int hidden, int l, const float *x, cons
   return launch_status("se_fc");
 }
 
+// statistics of a second tensor (the PVConv's point branch, raw output of its 1x1 convolution) to turn into affine forms
+struct GnFold {
+  const double *partial;  // (b, G, S, 2) or NULL
+  int S, G, l;            // slices, groups, row length (points)
+  const float *gamma, *beta;
+  float eps;
+};
+
 // ---- GroupNorm-folded form of the PVConv tail (pvconv.py:84-96 without an attention block) ---------------------------
 // The second convolution leaves its output RAW plus the GroupNorm slice partials (bdm_conv3d_3x3x3_h2_gn).  Instead of a
 // normalise + Swish pass that rewrites the grid, the two consumers apply it on the fly:
@@ -1116,10 +1149,22 @@ extern "C" int bdm_se_gate(int b, int c, int hidden, int l, const float *x, cons
 // One read of the grid by each consumer, no write: the grid is never rewritten.
 __global__ void row_mean_gn_kernel(int c, int l, int G, int S, const float *__restrict__ x, const double *__restrict__ partial,
                                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                   float *__restrict__ mean, float2 *__restrict__ coef) {
+                                   float *__restrict__ mean, float2 *__restrict__ coef, GnFold pf, float2 *__restrict__ pf_coef) {
   const int row = blockIdx.x, bi = row / c, ch = row % c, cg = c / G, g = ch / cg;
   __shared__ float s_ab[2];
   __shared__ double sh[16];
+  if (threadIdx.x == 64 && pf.partial != nullptr) {
+    // the point branch's GroupNorm (same channel count): its affine form for this row, applied by the devoxelisation kernel
+    const int cgp = c / pf.G, gp = ch / cgp;
+    double a = 0.0, q = 0.0;
+    const double *p = pf.partial + ((size_t)bi * pf.G + gp) * pf.S * 2;
+    for (int s = 0; s < pf.S; ++s) { a += p[2 * s]; q += p[2 * s + 1]; }
+    const double cnt = (double)cgp * pf.l, mu = a / cnt;
+    double var = q / cnt - mu * mu;
+    if (var < 0) var = 0;
+    const float ga = pf.gamma[ch] * (float)(1.0 / sqrt(var + (double)pf.eps));
+    pf_coef[row] = make_float2(ga, pf.beta[ch] - (float)mu * ga);
+  }
   if (threadIdx.x == 0) {
     double a = 0.0, q = 0.0;
     const double *p = partial + ((size_t)bi * G + g) * S * 2;
@@ -1157,20 +1202,40 @@ __global__ void row_mean_gn_kernel(int c, int l, int G, int S, const float *__re
   }
 }
 
-extern "C" int bdm_se_gate_gn(int b, int c, int hidden, int l, int groups, const float *x, const void *gn_workspace,
-                              int slices, const float *gamma, const float *beta, float eps, const float *w1,
-                              const float *w2, float *mean_ws, float *coef, float *gate, void *stream) {
+static int se_gate_gn_impl(int b, int c, int hidden, int l, int groups, const float *x, const void *gn_workspace, int slices,
+                           const float *gamma, const float *beta, float eps, const float *w1, const float *w2, float *mean_ws,
+                           float *coef, float *gate, GnFold pf, float *pf_coef, void *stream) {
   BDM_REQUIRE(b >= 0 && c >= 1 && hidden >= 1 && l >= 1 && groups >= 1 && c % groups == 0 && slices >= 1 && slices <= GN_MAX_SLICES &&
               gn_workspace != nullptr && coef != nullptr, "se_gate_gn: bad arguments");
   if (b == 0) return BDM_OK;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(row_mean_gn_kernel, dim3(b * c), dim3(256), 0, s, c, l, groups, slices, x, (const double *)gn_workspace,
-                     gamma, beta, eps, mean_ws, (float2 *)coef);
+                     gamma, beta, eps, mean_ws, (float2 *)coef, pf, (float2 *)pf_coef);
   int rc = launch_status("se_row_mean_gn");
   if (rc) return rc;
   if (w1 == nullptr) return BDM_OK;  // no SE block: only the affine forms are wanted
   hipLaunchKernelGGL(se_fc_kernel, dim3(b), dim3(256), (c + hidden) * sizeof(float), s, c, hidden, mean_ws, w1, w2, gate);
   return launch_status("se_fc");
+}
+extern "C" int bdm_se_gate_gn(int b, int c, int hidden, int l, int groups, const float *x, const void *gn_workspace,
+                              int slices, const float *gamma, const float *beta, float eps, const float *w1,
+                              const float *w2, float *mean_ws, float *coef, float *gate, void *stream) {
+  return se_gate_gn_impl(b, c, hidden, l, groups, x, gn_workspace, slices, gamma, beta, eps, w1, w2, mean_ws, coef, gate, GnFold{},
+                         nullptr, stream);
+}
+// The same, and also the affine forms pf_coef (b, c, 2) of the POINT BRANCH's GroupNorm(pf_groups) from the slice partials its
+// 1x1 convolution left (bdm_pointwise_conv_gn; n points per row): bdm_devoxelize_gn_gate_add_pf then normalises + Swishes the
+// raw point-branch rows while adding them, and the branch needs no GroupNorm launch of its own.
+extern "C" int bdm_se_gate_gn_pf(int b, int c, int hidden, int l, int groups, const float *x, const void *gn_workspace,
+                                 int slices, const float *gamma, const float *beta, float eps, const float *w1,
+                                 const float *w2, float *mean_ws, float *coef, float *gate, const void *pf_partial,
+                                 int pf_slices, int pf_groups, int pf_n, const float *pf_gamma, const float *pf_beta,
+                                 float pf_eps, float *pf_coef, void *stream) {
+  BDM_REQUIRE(pf_partial != nullptr && pf_slices >= 1 && pf_groups >= 1 && c % pf_groups == 0 && pf_n >= 1 && pf_gamma && pf_beta &&
+              pf_coef, "se_gate_gn_pf: bad point-branch arguments");
+  GnFold pf{(const double *)pf_partial, pf_slices, pf_groups, pf_n, pf_gamma, pf_beta, pf_eps};
+  return se_gate_gn_impl(b, c, hidden, l, groups, x, gn_workspace, slices, gamma, beta, eps, w1, w2, mean_ws, coef, gate, pf, pf_coef,
+                         stream);
 }
 
 __device__ __forceinline__ float se_gate_from_hidden(int ci, int hidden, const float *__restrict__ w2, const float *s_hid) {
@@ -1187,7 +1252,7 @@ __global__ void devox_gn_fused_kernel(int b, int cslots, int pblocks, int c, int
                                       const float *__restrict__ gate, const float *__restrict__ se_mean, int hidden,
                                       const float *__restrict__ w1, const float *__restrict__ w2,
                                       const float *__restrict__ add, long long bs_a, int ld_a,
-                                      float *__restrict__ out, long long bs_o, int ld_o) {
+                                      const float2 *__restrict__ add_coef, float *__restrict__ out, long long bs_o, int ld_o) {
   __shared__ float s_hid[64];
   const int span = 8 * pblocks, wg = blockIdx.x;
   const int unit = (wg / span) * 8 + (wg % span) % 8, pb = (wg % span) / 8;
@@ -1232,34 +1297,52 @@ __global__ void devox_gn_fused_kernel(int b, int cslots, int pblocks, int c, int
     acc += w101 * (swishf(g[i101] * ab.x + ab.y) * s);
     acc += w110 * (swishf(g[i110] * ab.x + ab.y) * s);
     acc += w111 * (swishf(g[i111] * ab.x + ab.y) * s);
-    if (add) acc += add[(size_t)bi * bs_a + (size_t)ci * ld_a + i];
+    if (add) {
+      float av = add[(size_t)bi * bs_a + (size_t)ci * ld_a + i];
+      if (add_coef) {  // raw point-branch convolution output: its GroupNorm + Swish applied here
+        const float2 pc2 = add_coef[(size_t)bi * c + ci];
+        av = swishf(av * pc2.x + pc2.y);
+      }
+      acc += av;
+    }
     out[(size_t)bi * bs_o + (size_t)ci * ld_o + i] = acc;
   }
 }
 }
 static int devox_gn_launch(int b, int c, int n, int r, const float *coords, const float *grid, const float *coef,
                            const float *gate, const float *se_mean, int hidden, const float *w1, const float *w2,
-                           const float *add, long long bs_a, int ld_a, float *out, long long bs_o, int ld_o, void *stream) {
+                           const float *add, long long bs_a, int ld_a, const float *add_coef, float *out, long long bs_o, int ld_o,
+                           void *stream) {
   BDM_REQUIRE(b >= 0 && c >= 1 && n >= 1 && r >= 1 && coef != nullptr, "devoxelize_gn_gate_add: bad arguments");
   BDM_REQUIRE(se_mean == nullptr || (hidden >= 1 && hidden <= 64 && w1 != nullptr && w2 != nullptr), "devoxelize_gn_se_add: bad SE arguments");
   if (b == 0) return BDM_OK;
   const int cslots = c < 64 ? c : 64, pblocks = cdiv(n, 256);
   hipLaunchKernelGGL(devox_gn_fused_kernel, dim3(cdiv(b * cslots, 8) * 8 * pblocks), dim3(256), 0, (hipStream_t)stream, b, cslots,
-                     pblocks, c, n, r, coords, grid, (const float2 *)coef, gate, se_mean, hidden, w1, w2, add, bs_a, ld_a, out, bs_o,
-                     ld_o);
+                     pblocks, c, n, r, coords, grid, (const float2 *)coef, gate, se_mean, hidden, w1, w2, add, bs_a, ld_a,
+                     (const float2 *)add_coef, out, bs_o, ld_o);
   return launch_status("devoxelize_gn_gate_add");
 }
 extern "C" int bdm_devoxelize_gn_gate_add(int b, int c, int n, int r, const float *coords, const float *grid,
                                           const float *coef, const float *gate, const float *add, long long bs_a, int ld_a,
                                           float *out, long long bs_o, int ld_o, void *stream) {
-  return devox_gn_launch(b, c, n, r, coords, grid, coef, gate, nullptr, 0, nullptr, nullptr, add, bs_a, ld_a, out, bs_o, ld_o, stream);
+  return devox_gn_launch(b, c, n, r, coords, grid, coef, gate, nullptr, 0, nullptr, nullptr, add, bs_a, ld_a, nullptr, out, bs_o, ld_o,
+                         stream);
+}
+// add = RAW output of the point branch's 1x1 convolution, add_coef (b, c, 2) = its GroupNorm's affine forms (bdm_se_gate_gn_pf)
+extern "C" int bdm_devoxelize_gn_gate_add_pf(int b, int c, int n, int r, const float *coords, const float *grid,
+                                             const float *coef, const float *gate, const float *add, long long bs_a, int ld_a,
+                                             const float *add_coef, float *out, long long bs_o, int ld_o, void *stream) {
+  BDM_REQUIRE(add != nullptr && add_coef != nullptr, "devoxelize_gn_gate_add_pf: add / add_coef is NULL");
+  return devox_gn_launch(b, c, n, r, coords, grid, coef, gate, nullptr, 0, nullptr, nullptr, add, bs_a, ld_a, add_coef, out, bs_o, ld_o,
+                         stream);
 }
 // The same with the SE block's FC layers evaluated inside the kernel from the channel means of bdm_se_gate_gn(w1 = NULL).
 extern "C" int bdm_devoxelize_gn_se_add(int b, int c, int n, int r, const float *coords, const float *grid, const float *coef,
                                         const float *se_mean, int hidden, const float *w1, const float *w2, const float *add,
                                         long long bs_a, int ld_a, float *out, long long bs_o, int ld_o, void *stream) {
   BDM_REQUIRE(se_mean != nullptr, "devoxelize_gn_se_add: se_mean is NULL");
-  return devox_gn_launch(b, c, n, r, coords, grid, coef, nullptr, se_mean, hidden, w1, w2, add, bs_a, ld_a, out, bs_o, ld_o, stream);
+  return devox_gn_launch(b, c, n, r, coords, grid, coef, nullptr, se_mean, hidden, w1, w2, add, bs_a, ld_a, nullptr, out, bs_o, ld_o,
+                         stream);
 }
 
 // =====================================================================================

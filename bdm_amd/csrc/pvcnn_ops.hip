@@ -504,6 +504,50 @@ extern "C" int bdm_three_nn_apply(int b, int c, int m, int n, const float *featu
   return launch_status("three_nn_apply");
 }
 
+// PointNetFPModule input assembly in ONE launch (pointnet.py:104-112): out0 = cat[interpolate(centers_features), skip],
+// out1 = interpolate(centers_temb), all three with the same (indices, weights).  Channel index space of the grid's y axis:
+// [0, c_a) interpolated features, [c_a, c_a + c_s) skip rows (plain copy), [c_a + c_s, c_a + c_s + c_t) interpolated t_emb.
+__global__ void fp_assemble_kernel(int n, int c_a, const float *__restrict__ fa, long long bs_a, int ld_a, int c_s,
+                                   const float *__restrict__ fs, long long bs_s, int ld_s, int c_t,
+                                   const float *__restrict__ ft, long long bs_t, int ld_t, const int *__restrict__ indices,
+                                   const float *__restrict__ weights, float *__restrict__ out0, long long bs_0, int ld_0,
+                                   float *__restrict__ out1, long long bs_1, int ld_1) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.z;
+  if (j >= n) return;
+  const int *id = indices + (size_t)bi * 3 * n;
+  const float *w = weights + (size_t)bi * 3 * n;
+  const int i0 = id[j], i1 = id[n + j], i2 = id[2 * n + j];
+  const float w0 = w[j], w1 = w[n + j], w2 = w[2 * n + j];
+  for (int ci = blockIdx.y; ci < c_a + c_s + c_t; ci += gridDim.y) {
+    if (ci < c_a) {
+      const float *fr = fa + (size_t)bi * bs_a + (size_t)ci * ld_a;
+      out0[(size_t)bi * bs_0 + (size_t)ci * ld_0 + j] =
+          __fadd_rn(__fadd_rn(__fmul_rn(fr[i0], w0), __fmul_rn(fr[i1], w1)), __fmul_rn(fr[i2], w2));
+    } else if (ci < c_a + c_s) {
+      out0[(size_t)bi * bs_0 + (size_t)ci * ld_0 + j] = fs[(size_t)bi * bs_s + (size_t)(ci - c_a) * ld_s + j];
+    } else {
+      const int ct = ci - c_a - c_s;
+      const float *fr = ft + (size_t)bi * bs_t + (size_t)ct * ld_t;
+      out1[(size_t)bi * bs_1 + (size_t)ct * ld_1 + j] =
+          __fadd_rn(__fadd_rn(__fmul_rn(fr[i0], w0), __fmul_rn(fr[i1], w1)), __fmul_rn(fr[i2], w2));
+    }
+  }
+}
+
+extern "C" int bdm_fp_assemble(int b, int m, int n, const int *indices, const float *weights, int c_a, const float *fa,
+                               long long bs_a, int ld_a, int c_s, const float *fs, long long bs_s, int ld_s, int c_t,
+                               const float *ft, long long bs_t, int ld_t, float *out0, long long bs_0, int ld_0, float *out1,
+                               long long bs_1, int ld_1, void *stream) {
+  BDM_REQUIRE(b >= 0 && m >= 1 && n >= 0 && c_a >= 0 && c_s >= 0 && c_t >= 0, "fp_assemble: bad sizes");
+  if (b == 0 || n == 0 || c_a + c_s + c_t == 0) return BDM_OK;
+  const int c = c_a + c_s + c_t;
+  dim3 grid(cdiv(n, 256), c < 64 ? c : 64, b);
+  hipLaunchKernelGGL(fp_assemble_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, c_a, fa, bs_a, ld_a, c_s, fs, bs_s, ld_s, c_t,
+                     ft, bs_t, ld_t, indices, weights, out0, bs_0, ld_0, out1, bs_1, ld_1);
+  return launch_status("fp_assemble");
+}
+
 extern "C" int bdm_three_nn_interpolate_forward(int b, int c, int m, int n, const float *points,
                                                 const float *centers, const float *features, float *out,
                                                 int *indices, float *weights, void *stream) {

@@ -205,6 +205,7 @@ class PVConv(nn.Module):
     # a second stream and joined before the devoxelisation adds it, so its small, latency-bound kernels run beside the
     # voxel convolutions instead of after them (BDM_POINT_STREAM=0: serial).
     se_in_devox = os.environ.get("BDM_SE_IN_DEVOX", "0") == "1"
+    fold_pf = os.environ.get("BDM_FOLD_PF", "1") == "1"  # point branch's GroupNorm folded into the devoxelisation kernel
     point_stream = os.environ.get("BDM_POINT_STREAM", "1") == "1"
     _streams = {}
 
@@ -214,19 +215,26 @@ class PVConv(nn.Module):
             return self.resolution, self.voxelization.eps
         return None
 
-    def _point_branch(self, features):
-        if not (self.point_stream and features.is_cuda and features.shape[0] * features.shape[2] >= 8192):
+    def _point_branch(self, features, fold=False):
+        """-> (activations, event | None, pending): with fold the LAST GroupNorm + Swish of the branch is left to the caller
+        (pending = (stats, gn), activations = raw convolution output; None when the layer cannot be folded)."""
+        def run():
+            if fold:
+                return self.point_features.run(features, fold_last=True)
             return self.point_features.run(features), None
+        if not (self.point_stream and features.is_cuda and features.shape[0] * features.shape[2] >= 8192):
+            pf, pending = run()
+            return pf, None, pending
         dev = features.device
         side = PVConv._streams.get(dev)
         if side is None:
             side = PVConv._streams[dev] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            pf = self.point_features.run(features)
+            pf, pending = run()
             ev = torch.cuda.Event()
             ev.record(side)
-        return pf, ev
+        return pf, ev, pending
 
     def forward(self, inputs):
         features, coords, temb = inputs
@@ -239,7 +247,11 @@ class PVConv(nn.Module):
         se = next((m for m in rest if isinstance(m, SE3d)), None)
 
         features = ops.materialize(features)
-        pf, pf_ready = self._point_branch(features)
+        cg2_, tile_ = conv2.out_channels // gn2.num_groups, (64 if (conv2.out_channels > 32 and r != 8) else 32)
+        folded_tail = (self.conv_impl == "fp16x3" and not getattr(self, "h2_saturated", False) and self.fold_gn2 and att is None
+                       and se is not None and cg2_ in (4, 8, 16, 32) and tile_ % cg2_ == 0)
+        # with the folded tail the branch's GroupNorm + Swish is applied by the devoxelisation kernel (one launch less)
+        pf, pf_ready, pf_pending = self._point_branch(features, fold=folded_tail and self.fold_pf and not self.se_in_devox)
         if self.conv_impl in ("bf16x6", "fp16x3"):
             if self.sparse_first_conv and r in self.sparse_resolutions:
                 # conv1 sees the freshly voxelised cloud: evaluate it on the occupied cells only (sparse_conv.hip);
@@ -279,6 +291,11 @@ class PVConv(nn.Module):
                         if pf_ready is not None:
                             pf_ready.wait()
                         return ops.devoxelize_gn_se_add(norm_coords, v, coef, r, mean, w1, w2, add=pf), coords, temb
+                    if pf_pending is not None:
+                        if pf_ready is not None:
+                            pf_ready.wait()  # the branch's statistics are read by the SE kernel
+                        gate, coef, pf_coef = ops.se_gate_gn(v, stats, gn2, w1, w2, pf=pf_pending, n_points=pf.shape[2])
+                        return ops.devoxelize_gn_gate_add(norm_coords, v, coef, r, gate=gate, add=pf, add_coef=pf_coef), coords, temb
                     gate, coef = ops.se_gate_gn(v, stats, gn2, w1, w2)
                     if pf_ready is not None:
                         pf_ready.wait()
@@ -424,20 +441,22 @@ class PointNetFPModule(nn.Module):
         # one search serves both tensors (the reference searches twice, pointnet.py:107-108: same result)
         L.check(L.lib().bdm_three_nn_search(B, m, n, L.ptr(pc), L.ptr(cc), L.ptr(idx), L.ptr(w), L.stream()), "three_nn_search")
 
-        def apply(src, dst):
-            s, _, C, _, bs_f, ld_f = ops._bcl(src)
-            _, _, _, _, bs_o, ld_o = ops._bcl(dst)
-            L.check(L.lib().bdm_three_nn_apply(B, C, m, n, L.ptr(s), L.c_ll(bs_f), ld_f, L.ptr(idx), L.ptr(w), L.ptr(dst),
-                                               L.c_ll(bs_o), ld_o, L.stream()), "three_nn_apply")
-
         cf = ops.materialize(centers_features)
         c_int = cf.shape[1]
         c_skip = 0 if points_features is None else points_features.shape[1]
         buf = torch.empty(B, c_int + c_skip, n, dtype=torch.float32, device=dev)
-        apply(cf, buf[:, :c_int])
-        if c_skip:
-            ops.copy_rows(points_features, buf[:, c_int:])
         t_src = ops.materialize(temb)
         interpolated_temb = torch.empty(B, t_src.shape[1], n, dtype=torch.float32, device=dev)
-        apply(t_src, interpolated_temb)
+        # interpolated features, skip features and interpolated t_emb written by ONE launch
+        fa, _, _, _, bs_a, ld_a = ops._bcl(cf)
+        ft, _, c_t, _, bs_t, ld_t = ops._bcl(t_src)
+        if c_skip:
+            fs, _, _, _, bs_s, ld_s = ops._bcl(points_features)
+        else:
+            fs, bs_s, ld_s = None, 0, 0
+        _, _, _, _, bs_0, ld_0 = ops._bcl(buf)
+        _, _, _, _, bs_1, ld_1 = ops._bcl(interpolated_temb)
+        L.check(L.lib().bdm_fp_assemble(B, m, n, L.ptr(idx), L.ptr(w), c_int, L.ptr(fa), L.c_ll(bs_a), ld_a, c_skip, L.ptr(fs),
+                                        L.c_ll(bs_s), ld_s, c_t, L.ptr(ft), L.c_ll(bs_t), ld_t, L.ptr(buf), L.c_ll(bs_0), ld_0,
+                                        L.ptr(interpolated_temb), L.c_ll(bs_1), ld_1, L.stream()), "fp_assemble")
         return self.mlp.run(buf), points_coords, interpolated_temb

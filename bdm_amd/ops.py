@@ -199,6 +199,21 @@ def cat_channels(parts):
     parts = [p for p in parts if p.shape[1] > 0]
     B, l = parts[0].shape[0], parts[0].shape[2]
     out = torch.empty(B, sum(p.shape[1] for p in parts), l, dtype=torch.float32, device=parts[0].device)
+    if len(parts) == 2:  # the denoisers' cat([features, temb]): one launch
+        desc = []
+        for p in parts:
+            if is_point_invariant(p):
+                v = p[:, :, 0]
+                v = v if v.stride(1) == 1 else v.contiguous()
+                desc.append((v, p.shape[1], v.stride(0), 0))
+            else:
+                x, _, C, _, bs_x, ld_x = _bcl(p)
+                desc.append((x, C, bs_x, ld_x))
+        _, _, _, _, bs_y, ld_y = _bcl(out)
+        (x0, c0_, bs0, ld0), (x1, c1_, bs1, ld1) = desc
+        L.check(L.lib().bdm_concat2_rows(B, l, c0_, L.ptr(x0), L.c_ll(bs0), ld0, c1_, L.ptr(x1), L.c_ll(bs1), ld1, L.ptr(out),
+                                         L.c_ll(bs_y), ld_y, L.stream()), "concat2_rows")
+        return out
     c0 = 0
     for p in parts:
         dst = out[:, c0:c0 + p.shape[1], :]
@@ -513,14 +528,23 @@ def conv3d_h2_gn(x_h2, packed, bias, cin, cout, r, groups=8):
     return y, (ws, slices.value)
 
 
-def se_gate_gn(x, stats, gn, w1, w2):
-    """SE gate of swish(group_norm(x)) evaluated from the raw grid x and the producer's statistics: (gate (B,C), coef (B,C,2))."""
+def se_gate_gn(x, stats, gn, w1, w2, pf=None, n_points=0):
+    """SE gate of swish(group_norm(x)) evaluated from the raw grid x and the producer's statistics: (gate (B,C), coef (B,C,2)).
+    pf = ((partial, slices, groups), gn) of the PVConv's point branch: also returns that GroupNorm's affine forms (B,C,2)."""
     ws, slices = stats
     B, C = x.shape[:2]
     l = x.numel() // (B * C)
     mean = torch.empty(B, C, dtype=torch.float32, device=x.device)
     coef = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
     gate = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    if pf is not None:
+        (pp, ps, pg), pgn = pf
+        pf_coef = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+        L.check(L.lib().bdm_se_gate_gn_pf(B, C, w1.shape[0], l, gn.num_groups, L.ptr(x), L.ptr(ws), slices, L.ptr(gn.weight),
+                                          L.ptr(gn.bias), L.c_float(gn.eps), L.ptr(w1), L.ptr(w2), L.ptr(mean), L.ptr(coef), L.ptr(gate),
+                                          L.ptr(pp), ps, pg, int(n_points), L.ptr(pgn.weight), L.ptr(pgn.bias), L.c_float(pgn.eps),
+                                          L.ptr(pf_coef), L.stream()), "se_gate_gn_pf")
+        return gate, coef, pf_coef
     L.check(L.lib().bdm_se_gate_gn(B, C, w1.shape[0], l, gn.num_groups, L.ptr(x), L.ptr(ws), slices, L.ptr(gn.weight), L.ptr(gn.bias),
                                    L.c_float(gn.eps), L.ptr(w1), L.ptr(w2), L.ptr(mean), L.ptr(coef), L.ptr(gate), L.stream()),
             "se_gate_gn")
@@ -557,7 +581,7 @@ def devoxelize_gn_se_add(norm_coords, grid, coef, r, mean, w1, w2, add=None):
     return out
 
 
-def devoxelize_gn_gate_add(norm_coords, grid, coef, r, gate=None, add=None):
+def devoxelize_gn_gate_add(norm_coords, grid, coef, r, gate=None, add=None, add_coef=None):
     B, C = grid.shape[:2]
     n = norm_coords.shape[2]
     out = torch.empty(B, C, n, dtype=torch.float32, device=grid.device)
@@ -567,6 +591,11 @@ def devoxelize_gn_gate_add(norm_coords, grid, coef, r, gate=None, add=None):
         assert aa.data_ptr() == add.data_ptr()
     else:
         bs_a, ld_a = 0, 0
+    if add_coef is not None:  # add is the point branch's raw convolution output; its GroupNorm + Swish is applied in the kernel
+        L.check(L.lib().bdm_devoxelize_gn_gate_add_pf(B, C, n, int(r), L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(gate),
+                                                      L.ptr(add), bs_a, ld_a, L.ptr(add_coef), L.ptr(out), bs_o, ld_o, L.stream()),
+                "devoxelize_gn_gate_add_pf")
+        return out
     L.check(L.lib().bdm_devoxelize_gn_gate_add(B, C, n, int(r), L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(gate), L.ptr(add),
                                                bs_a, ld_a, L.ptr(out), bs_o, ld_o, L.stream()), "devoxelize_gn_gate_add")
     return out

@@ -91,6 +91,7 @@ SPEC = {
     "bdm_attention_core": ("attention", lambda a: a[:3], _attn),
     # point operators (SURVEY.md 8d byte formulas)
     "bdm_furthest_point_sampling": ("furthest point sampling", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * (3 * a[1] + 4 * a[2]))),
+    "bdm_gather_features_forward": ("furthest point sampling", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (2 * a[1] * a[3] + a[3]))),
     "bdm_ball_query": ("ball query + grouping", lambda a: (a[0], a[1], a[2], a[4]),
                        lambda a: ("hbm", 4.0 * a[0] * (3 * a[1] + 3 * a[2] + a[2] * a[4]))),
     "bdm_sa_group": ("ball query + grouping", lambda a: a[:5],
@@ -101,6 +102,8 @@ SPEC = {
     "bdm_max_over_neighbors_gn": ("ball query + grouping", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] * (a[3] + 1))),
     "bdm_three_nn_search": ("3-NN interpolation", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 3 * a[1] + 6 * a[2]))),
     "bdm_three_nn_apply": ("3-NN interpolation", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (a[1] * a[2] + a[1] * a[3] + 6 * a[3]))),
+    "bdm_fp_assemble": ("3-NN interpolation", lambda a: (a[0], a[1], a[2], a[5], a[9], a[13]),
+                        lambda a: ("hbm", 4.0 * a[0] * ((a[5] + a[13]) * (a[1] + a[2]) + 2 * a[9] * a[2] + 6 * a[2]))),
     "bdm_voxelize_plan_full": ("voxelize / devoxelize", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * (4 * a[1] + 3 * a[2] ** 3))),
     "bdm_voxel_coords": ("voxelize / devoxelize", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * 9 * a[1])),
     "bdm_devoxelize_gate_add": ("voxelize / devoxelize", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 10 * a[1] * a[2]))),
@@ -108,10 +111,13 @@ SPEC = {
     # grid's 8 corners per point-channel and reads the point branch / writes the sum
     "bdm_se_gate_gn": ("SE gate", lambda a: (a[0], a[1], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[3])),
     "bdm_devoxelize_gn_gate_add": ("voxelize / devoxelize", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 10 * a[1] * a[2]))),
+    "bdm_se_gate_gn_pf": ("SE gate", lambda a: (a[0], a[1], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[3])),
+    "bdm_devoxelize_gn_gate_add_pf": ("voxelize / devoxelize", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 10 * a[1] * a[2]))),
     "bdm_devoxelize_gn_se_add": ("voxelize / devoxelize", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 10 * a[1] * a[2]))),
     "bdm_lincomb": ("scheduler step / blend", lambda a: a[:2], lambda a: ("hbm", 4.0 * a[0] * (a[1] + 1))),
     "bdm_se_gate": ("SE gate", lambda a: (a[0], a[1], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[3])),
     "bdm_copy_rows": ("concat / broadcast / transpose copies", lambda a: a[:3], lambda a: ("hbm", 8.0 * a[0] * a[1] * a[2])),
+    "bdm_concat2_rows": ("concat / broadcast / transpose copies", lambda a: (a[0], a[1], a[2], a[6]), lambda a: ("hbm", 4.0 * a[0] * a[1] * (2 * a[2] + a[6]))),
     "bdm_broadcast_rows": ("concat / broadcast / transpose copies", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2])),
     "bdm_transpose": ("concat / broadcast / transpose copies", lambda a: a[:3], lambda a: ("hbm", 8.0 * a[0] * a[1] * a[2])),
     "bdm_rasterize_points": ("projection conditioning", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * 4 * a[1])),
@@ -138,7 +144,7 @@ class _Proxy:
 
     def __getattr__(self, name):
         fn = getattr(self._h, name)
-        host_only = (not name.startswith("bdm_") or name.endswith("_bytes") or name.endswith("_elems")
+        host_only = (not name.startswith("bdm_") or name.endswith("_bytes") or name.endswith("_elems") or name.endswith("_slices")
                      or name in ("bdm_last_error", "bdm_abi_version"))
         if host_only:
             return fn

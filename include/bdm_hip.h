@@ -67,6 +67,12 @@ int bdm_grouping_forward(int b, int c, int n, int m, int u, const float *feature
 /* three_nearest_neighbors_interpolate_forward (neighbor_interpolate.cpp:6-40,
  * neighbor_interpolate.cu:20-129).  points (b,3,n), centers (b,3,m), features (b,c,m)
  * -> out (b,c,n), indices (b,3,n) int32, weights (b,3,n). */
+/* PointNetFPModule input assembly in one launch (pointnet.py:104-112): out0 = cat[interpolate(fa), fs] (c_a + c_s rows),
+ * out1 = interpolate(ft) (c_t rows), with the (indices, weights) of bdm_three_nn_search.  Same arithmetic as
+ * bdm_three_nn_apply (three products, two adds, no contraction). */
+int bdm_fp_assemble(int b, int m, int n, const int *indices, const float *weights, int c_a, const float *fa, long long bs_a,
+                    int ld_a, int c_s, const float *fs, long long bs_s, int ld_s, int c_t, const float *ft, long long bs_t,
+                    int ld_t, float *out0, long long bs_0, int ld_0, float *out1, long long bs_1, int ld_1, void *stream);
 int bdm_three_nn_interpolate_forward(int b, int c, int m, int n, const float *points,
                                      const float *centers, const float *features, float *out,
                                      int *indices, float *weights, void *stream);
@@ -176,6 +182,10 @@ int bdm_sa_group(int b, int c, int n, int m, int u, const float *coords, const f
 int bdm_broadcast_rows(int b, int c, int l, const float *v, int ld_v, float *y, long long bs_y,
                        int ld_y, void *stream);
 /* strided row copy (building torch.cat operands in place) */
+/* torch.cat([x0, x1], dim=1) in one launch.  A part with ld == 0 is a point-invariant column: element (shape, channel) at
+ * x[shape * bs + channel], broadcast along l (the time embedding before the first SA level). */
+int bdm_concat2_rows(int b, int l, int c0, const float *x0, long long bs_0, int ld_0, int c1, const float *x1, long long bs_1,
+                     int ld_1, float *y, long long bs_y, int ld_y, void *stream);
 int bdm_copy_rows(int b, int c, int l, const float *x, long long bs_x, int ld_x, float *y,
                   long long bs_y, int ld_y, void *stream);
 /* (b, rows, cols) -> (b, cols, rows): PointCloudModel.forward's transposes (point_cloud_model.py:65). */
@@ -283,6 +293,17 @@ int bdm_se_gate_gn(int b, int c, int hidden, int l, int groups, const float *x, 
 int bdm_devoxelize_gn_gate_add(int b, int c, int n, int r, const float *coords, const float *grid, const float *coef,
                                const float *gate, const float *add, long long bs_a, int ld_a, float *out,
                                long long bs_o, int ld_o, void *stream);
+/* Point branch of the PVConv folded in as well: bdm_se_gate_gn_pf also turns the slice partials that the branch's 1x1
+ * convolution left (bdm_pointwise_conv_gn; pf_groups groups over the same c channels, pf_n points per row) into affine forms
+ * pf_coef (b, c, 2), and bdm_devoxelize_gn_gate_add_pf adds Swish(pf_coef.x add + pf_coef.y) with add the RAW convolution
+ * output -- the branch's GroupNorm needs no launch of its own. */
+int bdm_se_gate_gn_pf(int b, int c, int hidden, int l, int groups, const float *x, const void *gn_workspace, int slices,
+                      const float *gamma, const float *beta, float eps, const float *w1, const float *w2, float *mean_ws,
+                      float *coef, float *gate, const void *pf_partial, int pf_slices, int pf_groups, int pf_n,
+                      const float *pf_gamma, const float *pf_beta, float pf_eps, float *pf_coef, void *stream);
+int bdm_devoxelize_gn_gate_add_pf(int b, int c, int n, int r, const float *coords, const float *grid, const float *coef,
+                                  const float *gate, const float *add, long long bs_a, int ld_a, const float *add_coef,
+                                  float *out, long long bs_o, int ld_o, void *stream);
 /* the same with the SE gate computed inside the kernel from se_mean (b, c) = the channel means bdm_se_gate_gn(w1 = NULL) left:
  * one launch less per PVConv, bit-identical gate (same summation order as the separate FC kernel). hidden <= 64. */
 int bdm_devoxelize_gn_se_add(int b, int c, int n, int r, const float *coords, const float *grid, const float *coef,

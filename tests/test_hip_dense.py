@@ -420,11 +420,17 @@ def test_gn2_folded_tail_equals_separate_groupnorm_pass(ops, monkeypatch, cin, c
     ref = pv((f, c, t))[0].clone()
     monkeypatch.setattr(PVConv, "fold_gn2", True)
     monkeypatch.setattr(PVConv, "se_in_devox", False)
+    monkeypatch.setattr(PVConv, "fold_pf", False)
     got = pv((f, c, t))[0].clone()
     assert rel(got.cpu(), ref.cpu()) < 1e-6
     assert torch.equal(got, pv((f, c, t))[0])      # deterministic
     monkeypatch.setattr(PVConv, "se_in_devox", True)  # opt-in: SE block's FC layers inside the devoxelisation kernel
     assert torch.equal(pv((f, c, t))[0], got)      # same summation order as the separate FC kernel: same bits
+    monkeypatch.setattr(PVConv, "se_in_devox", False)
+    monkeypatch.setattr(PVConv, "fold_pf", True)   # default: the point branch's GroupNorm + Swish inside the devoxelisation kernel
+    got_pf = pv((f, c, t))[0].clone()
+    assert rel(got_pf.cpu(), ref.cpu()) < 1e-6
+    assert torch.equal(got_pf, pv((f, c, t))[0])   # deterministic
 
 
 @pytest.mark.parametrize("chans,shape", [((35, 32, 64), (2, 1024, 32)), ((67, 64, 128), (3, 256, 32)), ((131, 128, 256), (2, 64, 32)),
