@@ -12,6 +12,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <stdlib.h>
+
 #include "../../include/bdm_hip.h"
 #include "common.h"
 
@@ -650,6 +652,123 @@ __global__ void vox_plan_kernel(int n, int r, const int *__restrict__ coords, in
   }
 }
 
+// The same plan for the 32^3 grids with EIGHT workgroups per shape instead of one (the single-workgroup form walks 32 768
+// counters with 1 024 threads, 32 serial cells per thread and several dependent passes: ~140 us on the critical path of every
+// forward).  Workgroup s owns the cells [s * CS, (s + 1) * CS); it needs two numbers from the other slabs -- the points and
+// the occupied cells that precede its range -- and derives both by itself from the coordinates (every workgroup reads all n
+// points: 48 KB) and a whole-grid occupancy bitset in LDS, so the slabs never communicate.  Same outputs, bit for bit.
+template <int CS>  // cells per slab
+__global__ __launch_bounds__(1024) void vox_plan_slab_kernel(int n, int r, int slabs, const int *__restrict__ coords,
+                                                             int *__restrict__ ind, int *__restrict__ cnt,
+                                                             int *__restrict__ start, int *__restrict__ sorted, int n_max,
+                                                             int *__restrict__ occ_index, int *__restrict__ occ_list,
+                                                             int *__restrict__ n_occ, unsigned char *__restrict__ rowocc) {
+  extern __shared__ int slab_smem[];
+  constexpr int T = 1024, PER = CS / T;  // cells per thread (contiguous run)
+  static_assert(CS % T == 0 && PER >= 1, "slab size must be a multiple of the workgroup size");
+  const int r2 = r * r, r3 = r2 * r;
+  int *lcnt = slab_smem;                                   // [CS] counters, then cursors
+  unsigned *bits = reinterpret_cast<unsigned *>(lcnt + CS);  // [r3 / 32] occupancy of the whole grid
+  int *lbeg = reinterpret_cast<int *>(bits + r3 / 32);     // [CS] slab-local start of each cell's list
+  int *lst = lbeg + CS;                                    // [n] the slab's points grouped by cell (unordered inside a cell)
+  __shared__ int red[16], red2[16];
+  const int bi = blockIdx.x / slabs, sl = blockIdx.x % slabs, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo_cell = sl * CS;
+  const int *vx = coords + (size_t)bi * 3 * n, *vy = vx + n, *vz = vy + n;
+  int *id = ind + (size_t)bi * n;
+  int *gc = cnt + (size_t)bi * r3, *gs = start + (size_t)bi * r3, *so = sorted + (size_t)bi * n;
+
+  for (int v = tid; v < CS; v += T) lcnt[v] = 0;
+  for (int w = tid; w < r3 / 32; w += T) bits[w] = 0u;
+  __syncthreads();
+  int before = 0;  // points whose cell precedes this slab
+  for (int i = tid; i < n; i += T) {
+    const int v = vx[i] * r2 + vy[i] * r + vz[i];
+    if (sl == 0) id[i] = v;
+    atomicOr(&bits[v >> 5], 1u << (v & 31));
+    before += v < lo_cell;
+    if (v >= lo_cell && v < lo_cell + CS) atomicAdd(&lcnt[v - lo_cell], 1);
+  }
+  // block sums: `before`, and (after the barrier) the occupied cells preceding the slab / in the whole grid
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (lane == 0) red[wave] = before;
+  __syncthreads();
+  int occ_before = 0, occ_total = 0;
+  for (int w = tid; w < r3 / 32; w += T) {
+    const int pc = __popc(bits[w]);
+    occ_total += pc;
+    occ_before += (w < lo_cell / 32) ? pc : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { occ_before += __shfl_xor(occ_before, o, 64); occ_total += __shfl_xor(occ_total, o, 64); }
+  __shared__ int red3[16];
+  if (lane == 0) { red2[wave] = occ_before; red3[wave] = occ_total; }
+  __syncthreads();
+  int point_base = 0, occ_base = 0, occ_all = 0;
+  for (int w = 0; w < T / 64; ++w) { point_base += red[w]; occ_base += red2[w]; occ_all += red3[w]; }
+  if (sl == 0 && tid == 0 && n_occ != nullptr) n_occ[bi] = occ_all;
+  __syncthreads();  // red / red2 are reused below
+
+  // exclusive scans over the slab's cells (points and occupied cells): each thread owns PER contiguous cells
+  int cv[PER], local = 0, olocal = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { cv[j] = lcnt[tid * PER + j]; local += cv[j]; olocal += cv[j] > 0; }
+  int incl = local, oincl = olocal;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t1 = __shfl_up(incl, o, 64), t2 = __shfl_up(oincl, o, 64);
+    if (lane >= o) { incl += t1; oincl += t2; }
+  }
+  if (lane == 63) { red[wave] = incl; red2[wave] = oincl; }
+  __syncthreads();
+  int woff = 0, owoff = 0;
+  for (int w = 0; w < wave; ++w) { woff += red[w]; owoff += red2[w]; }
+  int run = woff + incl - local;            // slab-local start of this thread's first cell
+  int orun = occ_base + owoff + oincl - olocal;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int v = lo_cell + tid * PER + j;
+    gc[v] = cv[j];
+    gs[v] = point_base + run;
+    lcnt[tid * PER + j] = run;  // cursor for the fill below
+    lbeg[tid * PER + j] = run;
+    if (occ_index != nullptr) {
+      if (cv[j] > 0) { occ_index[(size_t)bi * r3 + v] = orun; occ_list[(size_t)bi * n_max + orun] = v; ++orun; }
+      else occ_index[(size_t)bi * r3 + v] = -1;
+    }
+    run += cv[j];
+  }
+  if (rowocc != nullptr) {  // a grid row = r consecutive cells; r / PER threads share one row
+    const int any = local > 0;
+    // rows of the slab: one ballot per wave covers 64 * PER cells = 64 * PER / r rows
+    const unsigned long long m = __ballot(any);
+    constexpr int TPR_MAX = 64;
+    const int tpr = r / PER;  // threads per row (8 for r = 32, PER = 4)
+    if (tpr <= TPR_MAX && (lane % tpr) == 0) {
+      const unsigned long long rowmask = ((tpr == 64 ? ~0ull : ((1ull << tpr) - 1ull)) << lane);
+      const int row = (lo_cell + tid * PER) / r;
+      rowocc[(size_t)bi * r2 + row] = (m & rowmask) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  // unordered fill of the slab's per-cell lists, then rank-within-list placement (ascending point index inside a cell)
+  for (int i = tid; i < n; i += T) {
+    const int v = vx[i] * r2 + vy[i] * r + vz[i];
+    if (v >= lo_cell && v < lo_cell + CS) lst[atomicAdd(&lcnt[v - lo_cell], 1)] = i;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += T) {
+    const int v = vx[i] * r2 + vy[i] * r + vz[i];
+    if (v >= lo_cell && v < lo_cell + CS) {
+      const int s0 = lbeg[v - lo_cell], cvv = lcnt[v - lo_cell] - s0;  // cursor after the fill = end of the cell's list
+      int rank = 0;
+      for (int q = 0; q < cvv; ++q) rank += lst[s0 + q] < i;
+      so[point_base + s0 + rank] = i;
+    }
+  }
+}
+
 __global__ void vox_reduce_kernel(int c, int n, int r3, const float *__restrict__ feat,
                                   const int *__restrict__ cnt, const int *__restrict__ start,
                                   const int *__restrict__ sorted, float *__restrict__ out) {
@@ -666,6 +785,12 @@ __global__ void vox_reduce_kernel(int c, int n, int r3, const float *__restrict_
     for (int q = 0; q < cv; ++q) acc = __fadd_rn(acc, __fmul_rn(f[so[q]], inv));
     out[((size_t)bi * c + ci) * r3 + v] = acc;
   }
+}
+
+// BDM_VOX_PLAN_SLABS=0 keeps the one-workgroup-per-shape plan kernel at 32^3 (read per call: tests flip it)
+static bool vox_plan_slabs() {
+  const char *e = getenv("BDM_VOX_PLAN_SLABS");
+  return !(e && e[0] == '0');
 }
 
 extern "C" int bdm_voxelize_plan(int b, int n, int r, const int *coords, int *ind, int *cnt, void *workspace,
@@ -689,6 +814,13 @@ extern "C" int bdm_voxelize_plan_full(int b, int n, int r, int n_max, const int 
   if (b == 0) return BDM_OK;
   const int r3 = r * r * r;
   VoxWs w = vox_ws(workspace, b, n, r3);
+  if (r == 32 && n <= 24576 && vox_plan_slabs()) {  // eight workgroups per shape (LDS: 2 x 16 KB counters / starts + 4 KB bitset + 4 n bytes)
+    const size_t sm = sizeof(int) * (2 * 4096 + (size_t)r3 / 32 + (size_t)n);
+    BDM_ALLOW_LDS(vox_plan_slab_kernel<4096>, sm);
+    hipLaunchKernelGGL(vox_plan_slab_kernel<4096>, dim3(b * 8), dim3(1024), sm, (hipStream_t)stream, n, r, 8, coords, ind, cnt,
+                       w.start, w.sorted, n_max, occ_index, occ_list, n_occ, rowocc);
+    return launch_status("vox_plan_full");
+  }
   const size_t smem = (size_t)r3 * sizeof(int);
   BDM_ALLOW_LDS(vox_plan_kernel, smem);
   hipLaunchKernelGGL(vox_plan_kernel, dim3(b), dim3(1024), smem, (hipStream_t)stream, n, r, coords, ind, cnt, w.start,

@@ -190,3 +190,28 @@ def test_pvcnn_backend_extension_equals_oracle(hip, oracle_ops):
     assert torch.equal(d_out.cpu(), ro) and torch.equal(d_i.cpu(), ri) and torch.equal(d_w.cpu(), rw)
     gy = torch.randn(2, 7, 1100, generator=torch.Generator().manual_seed(5))
     assert torch.allclose(B.trilinear_devoxelize_backward(gy.cuda(), d_i, d_w, 8).cpu(), O.trilinear_devoxelize_backward(gy, ri, rw, 8), atol=1e-5)
+
+
+@pytest.mark.parametrize("n,scale", [(4096, 0.5), (4096, 0.05), (8192, 0.4), (16384, 0.6), (1000, 1.5)])
+def test_voxel_plan_eight_slab_kernel_equals_one_workgroup_kernel(monkeypatch, n, scale):
+    """32^3 plan with eight workgroups per shape (each owns 4096 cells and derives the preceding points / occupied cells by
+    itself) vs the one-workgroup-per-shape kernel: every output identical, also on a cloud squeezed into a few cells."""
+    from bdm_amd import ops
+    g = torch.Generator().manual_seed(n)
+    coords = (torch.randn(3, 3, n, generator=g) * scale).cuda()
+    fields = ("vox_coords", "ind", "cnt", "occ_index", "n_occ", "rowocc")
+    plans = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BDM_VOX_PLAN_SLABS", flag)
+        ops.clear_plan_cache()
+        p = ops.voxel_plan(coords, 32)
+        torch.cuda.synchronize()
+        nb = p.ws.numel() // 4
+        ws = p.ws.view(torch.int32)
+        start, sorted_ = ws[:3 * 32768].clone(), ws[nb - 3 * n:].clone()     # VoxWs: start | tmp | sorted
+        occ = [p.occ_list[b, :int(p.n_occ[b])].clone() for b in range(3)]
+        plans.append(([getattr(p, f).clone() for f in fields], start, sorted_, occ))
+    for a, b in zip(plans[0][0], plans[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(plans[0][1], plans[1][1]) and torch.equal(plans[0][2], plans[1][2])
+    assert all(torch.equal(x, y) for x, y in zip(plans[0][3], plans[1][3]))
