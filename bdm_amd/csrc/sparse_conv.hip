@@ -156,11 +156,24 @@ __global__ void sparse_vox_features_s3_kernel(int c, int n, int r3, int n_max, i
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int q = 0; q < cv; ++q) {
-    const int p = so[q];
+  // four points of the cell at a time: their indices, then their 32 feature values, are fetched as independent loads (a
+  // point-at-a-time loop pays two dependent round trips per point); the sums keep the list order
+  for (int q0 = 0; q0 < cv; q0 += 4) {
+    int p[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < nch) acc[j] = acc[j] + fb[(size_t)j * ld_f + p] * inv;
+    for (int u = 0; u < 4; ++u) p[u] = so[min(q0 + u, cv - 1)];
+    float v[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[u][j] = fb[(size_t)min(j, nch - 1) * ld_f + p[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (q0 + u < cv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nch) acc[j] = acc[j] + v[u][j] * inv;
+      }
   }
   store_s3(xs + ((size_t)bi * G + g) * 3 * (size_t)n_max * 8, (size_t)k, (size_t)n_max, acc);
 }

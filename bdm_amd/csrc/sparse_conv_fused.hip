@@ -99,11 +99,22 @@ __global__ void sparse_vox_features_f32_kernel(int c, int n, int r3, int n_max, 
     const float inv = cv > 0 ? (float)(1.0 / (double)(float)cv) : 0.f;
     const float *fb = feat + (size_t)bi * bs_f + (size_t)g * 8 * ld_f;
     const int nch = min(8, c - g * 8);
-    for (int q = 0; q < cv; ++q) {
-      const int p = so[q];
+    for (int q0 = 0; q0 < cv; q0 += 4) {  // four points at a time, independent loads, list order kept (see sparse_conv.hip)
+      int p[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (j < nch) acc[j] = acc[j] + fb[(size_t)j * ld_f + p] * inv;
+      for (int u = 0; u < 4; ++u) p[u] = so[min(q0 + u, cv - 1)];
+      float v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[u][j] = fb[(size_t)min(j, nch - 1) * ld_f + p[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q0 + u < cv) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < nch) acc[j] = acc[j] + v[u][j] * inv;
+        }
     }
   }
   float m = 0.f;
