@@ -213,10 +213,20 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
             raise ValueError(f"{hw=} and {image_rgb.shape=}")
         pix = self.surface_projection_indices(x_t[:, :, :3], camera, hw)
         C = feat.shape[2]
+        if CHANNEL_FIRST_CONDITIONING:
+            # written channel-first and returned as its (B, N, 3 + C) transposed VIEW: the reference's shape and values, and the
+            # denoiser's `inputs.transpose(1, 2)` (point_cloud_model.py:65) becomes free (ops.transpose12 sees the view)
+            out = torch.empty(B, 3 + C, N, dtype=torch.float32, device=x_t.device)
+            L.check(L.lib().bdm_condition_gather_cf(B, N, C, hw[0] * hw[1], L.ptr(x_t), L.ptr(feat), L.ptr(pix), L.ptr(out),
+                                                    L.stream()), "condition_gather_cf")
+            return out.transpose(1, 2)
         out = torch.empty(B, N, 3 + C, dtype=torch.float32, device=x_t.device)
         L.check(L.lib().bdm_condition_gather(B, N, C, hw[0] * hw[1], L.ptr(x_t), L.ptr(feat), L.ptr(pix), L.ptr(out),
                                              L.stream()), "condition_gather")
         return out
+
+
+CHANNEL_FIRST_CONDITIONING = os.environ.get("BDM_CONDITION_CF", "1") == "1"
 
 
 def _timestep_list(scheduler, num_inference_steps, start_time, end_time):

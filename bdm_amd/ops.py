@@ -227,6 +227,8 @@ def cat_channels(parts):
 
 def transpose12(x):
     """(B, R, C) -> (B, C, R) contiguous."""
+    if x.dim() == 3 and not x.is_contiguous() and x.transpose(1, 2).is_contiguous():
+        return x.transpose(1, 2)  # already stored the other way round (model.get_input_with_conditioning): no copy
     x = x.contiguous()
     B, R, C = x.shape
     out = torch.empty(B, C, R, dtype=torch.float32, device=x.device)

@@ -452,6 +452,9 @@ int bdm_rasterize_points(int b, int n, int h, int w, float radius, const float *
  * feature_image is stored pixel-major (b, h*w, c). */
 int bdm_condition_gather(int b, int n, int c, int hw, const float *x_t, const float *feature_image,
                          const int *pix_of_point, float *out, void *stream);
+/* the same, written channel-first: out (b, 3 + c, n) -- the layout the denoiser consumes (no transpose pass) */
+int bdm_condition_gather_cf(int b, int n, int c, int hw, const float *x_t, const float *feature_image,
+                            const int *pix_of_point, float *out, void *stream);
 
 /* Quality metrics of the evaluation scripts (evaluation/evaluation_cd.py:111-131, evaluation_f1.py:90-110):
  * out (b, n) = min over the m target points of the squared distance; src (b,n,3), tgt (b,m,3) point-major. */
