@@ -280,6 +280,8 @@ def main():
         if tflop_per_shape:
             line["path_tflops"] = value * tflop_per_shape
             line["path_frac_of_fp32_mfma_peak"] = value * tflop_per_shape / (FP32_MFMA_PEAK_TFLOPS * world)
+            # against the ceiling the split-precision kernels can reach: dense 16-bit MFMA peak / 3 products per fp32 product
+            line["path_frac_of_fp16x3_peak"] = value * tflop_per_shape / (BF16_MFMA_PEAK_TFLOPS / 3 * world)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(model, pvd_model, args.points)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
