@@ -13,6 +13,8 @@
 //   3. an output-stationary gather: every output cell sums, in fixed tap order 0..26, the Y rows of its occupied
 //      neighbours (occ_index lookup); rows whose 3x3 neighbourhood of grid rows is empty are pure bias.
 // Deterministic (no atomics); differs from the dense kernel only in fp32 summation order.
+#include <stdlib.h>
+
 #include "../../include/bdm_hip.h"
 #include "common.h"
 #include "s3_split.h"
@@ -392,6 +394,7 @@ __global__ __launch_bounds__(256) void sparse_gather_kernel(int cout, int r, int
 // Same sums in the same order, with more memory parallelism (Cout % 4 == 0): a lane owns (cell z, 4 channels) and
 // reads its cell's occupied taps as 16-byte pieces of the Y rows, four loads in flight; a wave therefore works on
 // 64 / (Cout/4) cells at once instead of one, and issues a quarter of the load instructions.
+template <int GU>  // row reads in flight per lane
 __global__ __launch_bounds__(256) void sparse_gather_v4_kernel(int cout, int r, int n_max, const float *__restrict__ y,
                                                                const int *__restrict__ occ_index,
                                                                const unsigned char *__restrict__ rowocc,
@@ -440,9 +443,9 @@ __global__ __launch_bounds__(256) void sparse_gather_v4_kernel(int cout, int r, 
     unsigned mask = zmask[z];
     float4 acc = bias ? make_float4(bias[co], bias[co + 1], bias[co + 2], bias[co + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     while (mask) {
-      float4 v[4];
+      float4 v[GU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < GU; ++u) {
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (mask) {
           const int t = __ffs((int)mask) - 1;
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(256) void sparse_gather_v4_kernel(int cout, int r, 
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      for (int u = 0; u < GU; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
     float *tp = tile + z * ldt + co;
     tp[0] = acc.x; tp[1] = acc.y; tp[2] = acc.z; tp[3] = acc.w;
@@ -470,8 +473,14 @@ extern "C" int bdm_sparse_conv_gather(int b, int cout, int r, int n_max, const f
   if (b == 0) return BDM_OK;
   const size_t smem = sizeof(float) * (size_t)r * (cout + 1) + sizeof(int) * 9 * (size_t)(r + 2);
   if ((cout & 3) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0) {
-    hipLaunchKernelGGL(sparse_gather_v4_kernel, dim3(r * r, b), dim3(256), smem + sizeof(unsigned) * r, (hipStream_t)stream,
-                       cout, r, n_max, y, occ_index, rowocc, bias, out);
+    static int gu = 0;  // BDM_GATHER_INFLIGHT=4|8 (experiment switch)
+    if (!gu) { const char *e = getenv("BDM_GATHER_INFLIGHT"); gu = (e && e[0] == '4') ? 4 : 8; }
+    if (gu == 8)
+      hipLaunchKernelGGL(sparse_gather_v4_kernel<8>, dim3(r * r, b), dim3(256), smem + sizeof(unsigned) * r, (hipStream_t)stream,
+                         cout, r, n_max, y, occ_index, rowocc, bias, out);
+    else
+      hipLaunchKernelGGL(sparse_gather_v4_kernel<4>, dim3(r * r, b), dim3(256), smem + sizeof(unsigned) * r, (hipStream_t)stream,
+                         cout, r, n_max, y, occ_index, rowocc, bias, out);
     return launch_status("sparse_conv_gather");
   }
   hipLaunchKernelGGL(sparse_gather_kernel, dim3(r * r, b), dim3(256), smem, (hipStream_t)stream, cout, r, n_max, y,
