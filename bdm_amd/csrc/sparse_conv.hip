@@ -180,6 +180,135 @@ __global__ void sparse_vox_features_s3_kernel(int c, int n, int r3, int n_max, i
   store_s3(xs + ((size_t)bi * G + g) * 3 * (size_t)n_max * 8, (size_t)k, (size_t)n_max, acc);
 }
 
+// LDS-cached form of the feature gather (n <= 4096 points): one workgroup per (shape, channel group) first copies the
+// group's 8 feature rows (8 x 4n bytes, coalesced) into LDS and then gathers from LDS.  The global-memory form above issues
+// one scattered 4-byte load per (point, channel): the working set of the waves resident on a CU (128 KB per unit) thrashes the
+// vector L1 (PMC: 30 % hit rate, 38 M L1->L2 requests for 102 MB of features at the 390-channel level) and the kernel is
+// bound by the texture-address unit (81 % of its wave cycles are issue stalls).  Same sums in the same order: same bits.
+//   OUT = 0: bf16-triple records (sparse_gemm_s3);  OUT = 1: fp32 records + max |value| (sparse_gemm_h2 path)
+// With few channel groups (32-channel layers: 4 groups x 16 shapes = 64 units) `ksplit` workgroups share a unit, each with
+// its own copy of the rows and a slice of `cells_per` cells.
+template <int OUT>
+__global__ __launch_bounds__(1024) void sparse_vox_features_lds_kernel(int c, int n, int r3, int n_max, int G, int ksplit,
+                                                                       int cells_per,
+                                                                       const float *__restrict__ feat, long long bs_f, int ld_f,
+                                                                       const int *__restrict__ cnt, const int *__restrict__ start,
+                                                                       const int *__restrict__ sorted,
+                                                                       const int *__restrict__ occ_list,
+                                                                       const int *__restrict__ n_occ, void *__restrict__ outp,
+                                                                       unsigned *__restrict__ amax) {
+#pragma clang fp contract(off)  // same arithmetic as vox_reduce_kernel: the values equal the dense grid's bit for bit
+  extern __shared__ float frows[];  // [8][n]
+  constexpr int CPT = 4;            // cells per thread: n_max <= 4 * blockDim.x
+  const int unit = blockIdx.x / ksplit, k0 = (blockIdx.x % ksplit) * cells_per, bi = unit / G, g = unit % G;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int nocc = min(n_occ[bi], n_max);
+  // rows the consumers read: the GEMM's last 128-row tile that holds an occupied cell (S3) / every row (fp32 records: split pass)
+  const int lim = min(OUT == 0 ? min((nocc + 127) & ~127, n_max) : n_max, k0 + cells_per);
+  if (k0 >= lim) return;  // nothing to write in this slice
+  const int nch = min(8, c - g * 8);
+  // the cells' point lists (two dependent index loads) are fetched while the rows stream into LDS
+  int cs[CPT], cc[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int k = k0 + tid + i * T;
+    cs[i] = 0; cc[i] = 0;
+    if (k < nocc && k < lim) {
+      const int v = occ_list[(size_t)bi * n_max + k];
+      cc[i] = cnt[(size_t)bi * r3 + v];
+      cs[i] = start[(size_t)bi * r3 + v];
+    }
+  }
+  const float *fb = feat + (size_t)bi * bs_f + (size_t)g * 8 * ld_f;
+  if ((n & 3) == 0 && (ld_f & 3) == 0 && ((reinterpret_cast<size_t>(fb) & 15) == 0)) {  // 16-byte row pieces
+    const int n4 = n >> 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 *src = reinterpret_cast<const float4 *>(fb + (size_t)min(j, nch - 1) * ld_f);
+      float4 *dst = reinterpret_cast<float4 *>(frows + j * n);
+      for (int p = tid; p < n4; p += T) {
+        const float4 v = src[p];
+        dst[p] = j < nch ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  } else {
+    for (int j = 0; j < 8; ++j)
+      for (int p = tid; p < n; p += T) frows[j * n + p] = j < nch ? fb[(size_t)j * ld_f + p] : 0.f;
+  }
+  __syncthreads();
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int k = k0 + tid + i * T;
+    if (k >= lim) continue;
+    const int cv = cc[i];
+    const int *so = sorted + (size_t)bi * n + cs[i];
+    const float inv = cv > 0 ? (float)(1.0 / (double)(float)cv) : 0.f;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int q0 = 0; q0 < cv; q0 += 4) {
+      int p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = so[min(q0 + u, cv - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q0 + u < cv) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = acc[j] + frows[j * n + p[u]] * inv;  // rows >= nch hold zeros
+        }
+    }
+    if (OUT == 0) {
+      store_s3(reinterpret_cast<unsigned short *>(outp) + ((size_t)bi * G + g) * 3 * (size_t)n_max * 8, (size_t)k, (size_t)n_max, acc);
+    } else {
+      float4 *o = reinterpret_cast<float4 *>(outp) + (((size_t)bi * G + g) * n_max + k) * 2;
+      o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(acc[j]));
+    }
+  }
+  if (OUT == 1) {
+    m = wave_max(m);
+    if ((tid & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));  // non-negative floats order as unsigned ints
+  }
+}
+
+// shared launcher (also used by bdm_sparse_voxel_features_f32 in sparse_conv_fused.hip); false: shape not covered
+bool bdm_sparse_features_lds_launch(int out_kind, int b, int c, int n, int r3, int n_max, const float *features, long long bs_f,
+                                    int ld_f, const int *cnt, const int *start, const int *sorted, const int *occ_list,
+                                    const int *n_occ, void *out, unsigned *amax, hipStream_t stream, int *rc) {
+  const char *sel = getenv("BDM_FEATURES_LDS");  // BDM_FEATURES_LDS=0 keeps the global-memory gather (read per call: tests flip it)
+  if ((sel && sel[0] == '0') || n > 4096 || n_max > 4096) return false;
+  const int G = (c + 7) / 8, units = b * G;
+  // workgroups per unit: every extra one refills the rows, which costs more than the parallelism gains (measured: 32-channel
+  // layer at 32^3, 8 slices: 132 -> 207 us); BDM_FEATURES_KSPLIT overrides for experiments
+  static int ks_env = -1;
+  if (ks_env < 0) { const char *e = getenv("BDM_FEATURES_KSPLIT"); ks_env = e ? atoi(e) : 0; }
+  int ksplit = ks_env > 0 ? ks_env : 1;
+  ksplit = ksplit < 1 ? 1 : (ksplit > 8 ? 8 : ksplit);
+  const int cells_per = ((n_max + ksplit - 1) / ksplit + 63) & ~63;
+  const int T = cells_per > 1024 ? 1024 : 256;  // 4 cells per thread cover the slice
+  const size_t smem = sizeof(float) * 8 * (size_t)n;
+  *rc = BDM_OK;
+  if (out_kind == 0) {
+    if (smem > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)sparse_vox_features_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return false;
+    }
+    hipLaunchKernelGGL(sparse_vox_features_lds_kernel<0>, dim3(units * ksplit), dim3(T), smem, stream, c, n, r3, n_max, G, ksplit,
+                       cells_per, features, bs_f, ld_f, cnt, start, sorted, occ_list, n_occ, out, amax);
+  } else {
+    if (smem > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)sparse_vox_features_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return false;
+    }
+    hipLaunchKernelGGL(sparse_vox_features_lds_kernel<1>, dim3(units * ksplit), dim3(T), smem, stream, c, n, r3, n_max, G, ksplit,
+                       cells_per, features, bs_f, ld_f, cnt, start, sorted, occ_list, n_occ, out, amax);
+  }
+  return true;
+}
+
 extern "C" int bdm_sparse_voxel_features_s3(int b, int c, int n, int r, int n_max, const float *features, long long bs_f,
                                             int ld_f, const int *cnt, const void *plan_workspace, const int *occ_list,
                                             const int *n_occ, void *xs, void *stream) {
@@ -187,6 +316,10 @@ extern "C" int bdm_sparse_voxel_features_s3(int b, int c, int n, int r, int n_ma
   if (b == 0) return BDM_OK;
   const int r3 = r * r * r;
   VoxWs w = vox_ws(const_cast<void *>(plan_workspace), b, n, r3);
+  int rc_lds = BDM_OK;
+  if (bdm_sparse_features_lds_launch(0, b, c, n, r3, n_max, features, bs_f, ld_f, cnt, w.start, w.sorted, occ_list, n_occ, xs, nullptr,
+                                     (hipStream_t)stream, &rc_lds))
+    return launch_status("sparse_voxel_features_s3");
   const int G = (c + 7) / 8, units = b * G, kblocks = cdiv(n_max, 128);
   hipLaunchKernelGGL(sparse_vox_features_s3_kernel, dim3(cdiv(units, 8) * 8 * kblocks), dim3(128), 0, (hipStream_t)stream, c,
                      n, r3, n_max, G, units, kblocks, features, bs_f, ld_f, cnt, w.start, w.sorted, occ_list, n_occ,

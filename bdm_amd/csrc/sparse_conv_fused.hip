@@ -36,6 +36,11 @@ using namespace bdm;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
+// LDS-cached feature gather shared with sparse_conv.hip (defined there)
+bool bdm_sparse_features_lds_launch(int out_kind, int b, int c, int n, int r3, int n_max, const float *features, long long bs_f,
+                                    int ld_f, const int *cnt, const int *start, const int *sorted, const int *occ_list,
+                                    const int *n_occ, void *out, unsigned *amax, hipStream_t stream, int *rc);
+
 namespace {
 
 __device__ __forceinline__ void split2s(float v, unsigned short &h, unsigned short &l) {
@@ -136,6 +141,10 @@ extern "C" int bdm_sparse_voxel_features_f32(int b, int c, int n, int r, int n_m
   if (b == 0) return BDM_OK;
   const int r3 = r * r * r;
   VoxWs w = vox_ws(const_cast<void *>(plan_workspace), b, n, r3);
+  int rc_lds = BDM_OK;
+  if (bdm_sparse_features_lds_launch(1, b, c, n, r3, n_max, features, bs_f, ld_f, cnt, w.start, w.sorted, occ_list, n_occ, xr,
+                                     (unsigned *)amax, (hipStream_t)stream, &rc_lds))
+    return launch_status("sparse_voxel_features_f32");
   const int G = (c + 7) / 8, units = b * G, kblocks = cdiv(n_max, 128);
   hipLaunchKernelGGL(sparse_vox_features_f32_kernel, dim3(cdiv(units, 8) * 8 * kblocks), dim3(128), 0, (hipStream_t)stream, c,
                      n, r3, n_max, G, units, kblocks, features, bs_f, ld_f, cnt, w.start, w.sorted, occ_list, n_occ,

@@ -456,3 +456,25 @@ def test_shared_mlp_groupnorm_folding_equals_separate_passes(ops, monkeypatch, c
         assert rel(out.cpu(), ops.max_over_neighbors(ref).cpu()) < 2e-6
         h2, p2 = mlp.run(x, fold_last=True)
         assert torch.equal(ops.max_over_neighbors(h2, fold=p2), out)   # deterministic
+
+
+@pytest.mark.parametrize("cin,r,n,scale", [(390, 32, 4096, 0.5), (64, 32, 4096, 0.1), (128, 16, 1024, 0.5), (192, 8, 256, 0.5), (256, 8, 64, 0.5),
+                                           (13, 16, 700, 0.3)])
+def test_sparse_feature_gather_from_lds_equals_global_gather(ops, monkeypatch, cin, r, n, scale):
+    """LDS-cached feature gather (rows copied to LDS once per (shape, channel group)) vs the scattered global loads: the
+    sparse first convolution's output is bit-identical for both GEMM arithmetics."""
+    g = torch.Generator().manual_seed(cin + n)
+    f = torch.randn(3, cin, n, generator=g).cuda()
+    c = (torch.randn(3, 3, n, generator=g) * scale).cuda()
+    cout = 32
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    ops.clear_plan_cache()
+    plan = ops.voxel_plan(c, r)
+    for pack in (ops.sparse_conv_pack_s3, ops.sparse_conv_pack_h2):
+        wt = pack(w)
+        monkeypatch.setenv("BDM_FEATURES_LDS", "0")
+        ref = ops.sparse_first_conv_planned(f, plan, wt, b, cout).clone()
+        monkeypatch.delenv("BDM_FEATURES_LDS")
+        got = ops.sparse_first_conv_planned(f, plan, wt, b, cout)
+        assert torch.equal(got, ref)
