@@ -1309,6 +1309,76 @@ __global__ void devox_gn_fused_kernel(int b, int cslots, int pblocks, int c, int
   }
 }
 }
+// LDS-cached form: one workgroup per (shape, `cpw` channels) first evaluates val[v] = swish(a grid[v] + b) * gate for the whole
+// channel grid into LDS (coalesced 16-byte reads, the transcendental once per CELL instead of once per (point, corner)), then
+// every point gathers its 8 corners from LDS.  The global-memory form above issues 8 scattered 4-byte loads per (point, channel)
+// and is bound by the texture-address unit (PMC: 57 % of its wave cycles are issue stalls).  Same expressions in the same
+// order: bit-identical output.
+__global__ __launch_bounds__(1024) void devox_gn_lds_kernel(int c, int n, int r, int cpw, const float *__restrict__ coords,
+                                                            const float *__restrict__ grid, const float2 *__restrict__ coef,
+                                                            const float *__restrict__ gate, const float *__restrict__ add,
+                                                            long long bs_a, int ld_a, const float2 *__restrict__ add_coef,
+                                                            float *__restrict__ out, long long bs_o, int ld_o) {
+  extern __shared__ __align__(16) float vals[];  // [cpw][r3]
+  const int r2 = r * r, r3 = r2 * r, tid = threadIdx.x, T = blockDim.x;
+  const int groups = (c + cpw - 1) / cpw, bi = blockIdx.x / groups, c0 = (blockIdx.x % groups) * cpw;
+  const int nc = min(cpw, c - c0);
+  {
+#pragma clang fp contract(off)
+    for (int cl = 0; cl < nc; ++cl) {
+      const int ci = c0 + cl;
+      const float2 ab = coef[(size_t)bi * c + ci];
+      const float s = gate ? gate[(size_t)bi * c + ci] : 1.0f;
+      const float4 *g4 = reinterpret_cast<const float4 *>(grid + ((size_t)bi * c + ci) * r3);
+      float4 *v4 = reinterpret_cast<float4 *>(vals + (size_t)cl * r3);
+      for (int e = tid; e < r3 / 4; e += T) {
+        const float4 g = g4[e];
+        v4[e] = make_float4(swishf(g.x * ab.x + ab.y) * s, swishf(g.y * ab.x + ab.y) * s, swishf(g.z * ab.x + ab.y) * s,
+                            swishf(g.w * ab.x + ab.y) * s);
+      }
+    }
+  }
+  __syncthreads();
+  {
+#pragma clang fp contract(off)
+    const float *pc = coords + (size_t)bi * 3 * n;
+    for (int i = tid; i < n; i += T) {
+      const float x = pc[i], y = pc[n + i], z = pc[2 * n + i];
+      const float xl = floorf(x), yl = floorf(y), zl = floorf(z);
+      const float x1 = x - xl, y1 = y - yl, z1 = z - zl;
+      const float x0 = 1.0f - x1, y0 = 1.0f - y1, z0 = 1.0f - z1;
+      const float w000 = x0 * y0 * z0, w001 = x0 * y0 * z1, w010 = x0 * y1 * z0, w011 = x0 * y1 * z1,
+                  w100 = x1 * y0 * z0, w101 = x1 * y0 * z1, w110 = x1 * y1 * z0, w111 = x1 * y1 * z1;
+      const int sx = x1 > 0 ? r2 : 0, sy = y1 > 0 ? r : 0, sz = z1 > 0 ? 1 : 0;
+      const int i000 = (int)xl * r2 + (int)yl * r + (int)zl;
+      const int i001 = i000 + sz, i010 = i000 + sy, i011 = i010 + sz;
+      const int i100 = i000 + sx, i101 = i100 + sz, i110 = i100 + sy, i111 = i110 + sz;
+      for (int cl = 0; cl < nc; ++cl) {
+        const int ci = c0 + cl;
+        const float *v = vals + (size_t)cl * r3;
+        // corners with weight 0 (frac == 0 on an axis) alias an in-grid cell: their value is finite and multiplies 0
+        float acc = w000 * v[i000];
+        acc += w001 * v[i001];
+        acc += w010 * v[i010];
+        acc += w011 * v[i011];
+        acc += w100 * v[i100];
+        acc += w101 * v[i101];
+        acc += w110 * v[i110];
+        acc += w111 * v[i111];
+        if (add) {
+          float av = add[(size_t)bi * bs_a + (size_t)ci * ld_a + i];
+          if (add_coef) {
+            const float2 pc2 = add_coef[(size_t)bi * c + ci];
+            av = swishf(av * pc2.x + pc2.y);
+          }
+          acc += av;
+        }
+        out[(size_t)bi * bs_o + (size_t)ci * ld_o + i] = acc;
+      }
+    }
+  }
+}
+
 static int devox_gn_launch(int b, int c, int n, int r, const float *coords, const float *grid, const float *coef,
                            const float *gate, const float *se_mean, int hidden, const float *w1, const float *w2,
                            const float *add, long long bs_a, int ld_a, const float *add_coef, float *out, long long bs_o, int ld_o,
@@ -1316,6 +1386,23 @@ static int devox_gn_launch(int b, int c, int n, int r, const float *coords, cons
   BDM_REQUIRE(b >= 0 && c >= 1 && n >= 1 && r >= 1 && coef != nullptr, "devoxelize_gn_gate_add: bad arguments");
   BDM_REQUIRE(se_mean == nullptr || (hidden >= 1 && hidden <= 64 && w1 != nullptr && w2 != nullptr), "devoxelize_gn_se_add: bad SE arguments");
   if (b == 0) return BDM_OK;
+  const char *lsel = getenv("BDM_DEVOX_LDS");  // BDM_DEVOX_LDS=0 keeps the global-memory gather (read per call: tests flip it)
+  const int r3 = r * r * r;
+  // measured per shape at B = 16 (tools/forward_rows.py): the LDS form wins at 16^3 (29.5 -> 21.9 us) and at 32^3 with >= 64
+  // channels (70.5 -> 64.8 us); at 8^3 and for the 32-channel 32^3 layers it has too few workgroups and loses.
+  // BDM_DEVOX_LDS=1 forces it for every shape that fits (tests), =0 disables it.
+  const bool lds_fits = se_mean == nullptr && (r3 & 3) == 0 && r3 <= 32768 && ((reinterpret_cast<size_t>(grid) & 15) == 0);
+  const bool lds_pays = r == 16 || (r == 32 && (long long)b * c >= 1024);
+  if (lds_fits && !(lsel && lsel[0] == '0') && (lds_pays || (lsel && lsel[0] == '1'))) {
+    int cpw = 8192 / r3;  // channels per workgroup: 32 KB of LDS for the small grids, one channel (128 KB) at 32^3
+    cpw = cpw < 1 ? 1 : (cpw > c ? c : cpw);
+    const size_t smem = sizeof(float) * (size_t)cpw * r3;
+    BDM_ALLOW_LDS(devox_gn_lds_kernel, smem);
+    const int T = n >= 2048 ? 1024 : (n >= 512 ? 512 : 256);
+    hipLaunchKernelGGL(devox_gn_lds_kernel, dim3(b * cdiv(c, cpw)), dim3(T), smem, (hipStream_t)stream, c, n, r, cpw, coords, grid,
+                       (const float2 *)coef, gate, add, bs_a, ld_a, (const float2 *)add_coef, out, bs_o, ld_o);
+    return launch_status("devoxelize_gn_gate_add");
+  }
   const int cslots = c < 64 ? c : 64, pblocks = cdiv(n, 256);
   hipLaunchKernelGGL(devox_gn_fused_kernel, dim3(cdiv(b * cslots, 8) * 8 * pblocks), dim3(256), 0, (hipStream_t)stream, b, cslots,
                      pblocks, c, n, r, coords, grid, (const float2 *)coef, gate, se_mean, hidden, w1, w2, add, bs_a, ld_a,

@@ -478,3 +478,19 @@ def test_sparse_feature_gather_from_lds_equals_global_gather(ops, monkeypatch, c
         monkeypatch.delenv("BDM_FEATURES_LDS")
         got = ops.sparse_first_conv_planned(f, plan, wt, b, cout)
         assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("cin,cout,r,n", [(32, 32, 32, 4096), (64, 64, 32, 3000), (128, 128, 16, 1024), (256, 256, 8, 256), (16, 32, 8, 300)])
+def test_devoxelisation_from_lds_equals_global_gather(ops, monkeypatch, cin, cout, r, n):
+    """GroupNorm-folded devoxelisation with the channel grid evaluated once into LDS vs eight scattered loads per (point,
+    channel): bit-identical PVConv output."""
+    from bdm_amd.modules import PVConv
+    from bdm_amd.utils.procedural import fill_module_
+    pv = fill_module_(PVConv(cin, cout, 3, resolution=r, with_se=True, with_se_relu=True).eval(), seed=cin + r).cuda()
+    g = torch.Generator().manual_seed(n)
+    f, c = torch.randn(3, cin, n, generator=g).cuda(), (torch.randn(3, 3, n, generator=g) * 0.3).cuda()
+    t = torch.zeros(3, 8, n, device="cuda")
+    monkeypatch.setenv("BDM_DEVOX_LDS", "0")
+    ref = pv((f, c, t))[0].clone()
+    monkeypatch.setenv("BDM_DEVOX_LDS", "1")     # forced for every shape (the default picks it where it is faster)
+    assert torch.equal(pv((f, c, t))[0], ref)
