@@ -690,10 +690,14 @@ extern "C" int bdm_max_over_neighbors(int b, int c, int m, int u, const float *x
 // The same reduction over Swish(GroupNorm(x)) with x the RAW output of the SA MLP's last convolution and the GroupNorm
 // statistics taken from that convolution's slice partials (bdm_pointwise_conv_gn): the normalised (B, C, M, U) tensor is
 // never written.  Swish is not monotonic, so every element is transformed before the maximum.
-__global__ void max_u_gn_kernel(int c, int m, int u, int G, int S, const float *__restrict__ x,
+__global__ void max_u_gn_kernel(int c, int m, int u, int lpr, int G, int S, const float *__restrict__ x,
                                 const double *__restrict__ partial, const float *__restrict__ gamma,
                                 const float *__restrict__ beta, float eps, float *__restrict__ y, long long bs_y, int ld_y) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x;
+  // u / 4 lanes share a row (one 16-byte piece each: the wave reads whole 128-byte lines), then a butterfly maximum; rows that
+  // are not a multiple of 4 long (or longer than 256) take one lane per row (lpr = lanes per row, a power of two)
+  const int lane = threadIdx.x;
+  const int rpw = 64 / lpr, sub = lane % lpr;
+  const int j = blockIdx.x * rpw + lane / lpr;
   const int bi = blockIdx.z, cg = c / G;
   for (int ci = blockIdx.y; ci < c; ci += gridDim.y) {
     const int g = ci / cg;
@@ -706,20 +710,17 @@ __global__ void max_u_gn_kernel(int c, int m, int u, int G, int S, const float *
     double var = q / cnt - mean * mean;
     if (var < 0) var = 0;
     const float ca = gamma[ci] * (float)(1.0 / sqrt(var + (double)eps)), cb = beta[ci] - (float)mean * ca;
-    if (j < m) {
-      const float *row = x + (((size_t)bi * c + ci) * m + j) * u;
-      float v = swishf(ca * row[0] + cb);
-      if ((u & 3) == 0) {
-        const float4 *r4 = reinterpret_cast<const float4 *>(row);
-        for (int qd = 0; qd < u / 4; ++qd) {
-          const float4 t = r4[qd];
-          v = fmaxf(v, fmaxf(fmaxf(swishf(ca * t.x + cb), swishf(ca * t.y + cb)), fmaxf(swishf(ca * t.z + cb), swishf(ca * t.w + cb))));
-        }
-      } else {
-        for (int qd = 1; qd < u; ++qd) v = fmaxf(v, swishf(ca * row[qd] + cb));
-      }
-      y[(size_t)bi * bs_y + (size_t)ci * ld_y + j] = v;
+    const float *row = x + (((size_t)bi * c + ci) * m + min(j, m - 1)) * u;
+    float v;
+    if (lpr > 1) {
+      const float4 t = reinterpret_cast<const float4 *>(row)[sub];
+      v = fmaxf(fmaxf(swishf(ca * t.x + cb), swishf(ca * t.y + cb)), fmaxf(swishf(ca * t.z + cb), swishf(ca * t.w + cb)));
+      for (int o = 1; o < lpr; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    } else {
+      v = swishf(ca * row[0] + cb);
+      for (int qd = 1; qd < u; ++qd) v = fmaxf(v, swishf(ca * row[qd] + cb));
     }
+    if (j < m && sub == 0) y[(size_t)bi * bs_y + (size_t)ci * ld_y + j] = v;
   }
 }
 
@@ -730,8 +731,10 @@ extern "C" int bdm_max_over_neighbors_gn(int b, int c, int m, int u, const float
   BDM_REQUIRE(in_partial != nullptr && in_slices >= 1 && groups >= 1 && c % groups == 0 && gamma && beta,
               "max_over_neighbors_gn: bad GroupNorm arguments");
   if (b == 0) return BDM_OK;
-  dim3 grid(cdiv(m, 64), c < 256 ? c : 256, b);
-  hipLaunchKernelGGL(max_u_gn_kernel, grid, dim3(64), 0, (hipStream_t)stream, c, m, u, groups, in_slices, x,
+  const int lpr = ((u & 3) == 0 && u <= 256 && ((u / 4) & (u / 4 - 1)) == 0 && ((reinterpret_cast<size_t>(x) & 15) == 0)) ? u / 4 : 1;
+  BDM_REQUIRE(lpr == 1 || (u & 3) == 0, "max_over_neighbors_gn: internal");
+  dim3 grid(cdiv(m, 64 / lpr), c < 256 ? c : 256, b);
+  hipLaunchKernelGGL(max_u_gn_kernel, grid, dim3(64), 0, (hipStream_t)stream, c, m, u, lpr, groups, in_slices, x,
                      (const double *)in_partial, gamma, beta, eps, y, bs_y, ld_y);
   return launch_status("max_over_neighbors_gn");
 }

@@ -170,7 +170,7 @@ class _Proxy:
             cost = None
             if spec[2] is not None:
                 try:
-                    cost = spec[2]([_plain(v) for v in args[:8]])
+                    cost = spec[2]([_plain(v) for v in args[:16]])
                 except (TypeError, ValueError, IndexError):
                     cost = None
             row[1].append((e0, e1, cost))
