@@ -696,8 +696,7 @@ __global__ void max_u_gn_kernel(int c, int m, int u, int lpr, int G, int S, cons
   // u / 4 lanes share a row (one 16-byte piece each: the wave reads whole 128-byte lines), then a butterfly maximum; rows that
   // are not a multiple of 4 long (or longer than 256) take one lane per row (lpr = lanes per row, a power of two)
   const int lane = threadIdx.x;
-  const int rpw = 64 / lpr, sub = lane % lpr;
-  const int j = blockIdx.x * rpw + lane / lpr;
+  const int rpw = 64 / lpr, sub = lane % lpr;  // a workgroup (one wave) covers 64 rows in lpr passes of rpw rows
   const int bi = blockIdx.z, cg = c / G;
   for (int ci = blockIdx.y; ci < c; ci += gridDim.y) {
     const int g = ci / cg;
@@ -710,17 +709,22 @@ __global__ void max_u_gn_kernel(int c, int m, int u, int lpr, int G, int S, cons
     double var = q / cnt - mean * mean;
     if (var < 0) var = 0;
     const float ca = gamma[ci] * (float)(1.0 / sqrt(var + (double)eps)), cb = beta[ci] - (float)mean * ca;
-    const float *row = x + (((size_t)bi * c + ci) * m + min(j, m - 1)) * u;
-    float v;
+    const float *xb = x + ((size_t)bi * c + ci) * m * u;
     if (lpr > 1) {
-      const float4 t = reinterpret_cast<const float4 *>(row)[sub];
-      v = fmaxf(fmaxf(swishf(ca * t.x + cb), swishf(ca * t.y + cb)), fmaxf(swishf(ca * t.z + cb), swishf(ca * t.w + cb)));
-      for (int o = 1; o < lpr; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+      for (int it = 0; it < lpr; ++it) {
+        const int j = blockIdx.x * 64 + it * rpw + lane / lpr;
+        const float4 t = reinterpret_cast<const float4 *>(xb + (size_t)min(j, m - 1) * u)[sub];
+        float v = fmaxf(fmaxf(swishf(ca * t.x + cb), swishf(ca * t.y + cb)), fmaxf(swishf(ca * t.z + cb), swishf(ca * t.w + cb)));
+        for (int o = 1; o < lpr; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        if (j < m && sub == 0) y[(size_t)bi * bs_y + (size_t)ci * ld_y + j] = v;
+      }
     } else {
-      v = swishf(ca * row[0] + cb);
+      const int j = blockIdx.x * 64 + lane;
+      const float *row = xb + (size_t)min(j, m - 1) * u;
+      float v = swishf(ca * row[0] + cb);
       for (int qd = 1; qd < u; ++qd) v = fmaxf(v, swishf(ca * row[qd] + cb));
+      if (j < m) y[(size_t)bi * bs_y + (size_t)ci * ld_y + j] = v;
     }
-    if (j < m && sub == 0) y[(size_t)bi * bs_y + (size_t)ci * ld_y + j] = v;
   }
 }
 
@@ -733,7 +737,7 @@ extern "C" int bdm_max_over_neighbors_gn(int b, int c, int m, int u, const float
   if (b == 0) return BDM_OK;
   const int lpr = ((u & 3) == 0 && u <= 256 && ((u / 4) & (u / 4 - 1)) == 0 && ((reinterpret_cast<size_t>(x) & 15) == 0)) ? u / 4 : 1;
   BDM_REQUIRE(lpr == 1 || (u & 3) == 0, "max_over_neighbors_gn: internal");
-  dim3 grid(cdiv(m, 64 / lpr), c < 256 ? c : 256, b);
+  dim3 grid(cdiv(m, 64), c < 256 ? c : 256, b);
   hipLaunchKernelGGL(max_u_gn_kernel, grid, dim3(64), 0, (hipStream_t)stream, c, m, u, lpr, groups, in_slices, x,
                      (const double *)in_partial, gamma, beta, eps, y, bs_y, ld_y);
   return launch_status("max_over_neighbors_gn");
