@@ -539,13 +539,19 @@ __global__ __launch_bounds__(256) void sparse_gather_v4_kernel(int cout, int r, 
   int *nbr = reinterpret_cast<int *>(tile + r * ldt);  // nbr[t9][1 + z], -1 = empty / outside the grid
   unsigned *zmask = reinterpret_cast<unsigned *>(nbr + 9 * rs);
   float *ob = out + (size_t)bi * cout * r3;
-  const unsigned char *ro = rowocc + (size_t)bi * r2;
-  bool any = false;
-#pragma unroll
-  for (int t9 = 0; t9 < 9; ++t9) {
+  // neighbour rows straight from occ_index (-1 for an empty cell): no dependent look at the row-occupancy bytes first, and the
+  // "nothing under this row's stencils" test comes out of the same barrier
+  const int *oi = occ_index + (size_t)bi * r3;
+  int mine = 0;
+  for (int e = tid; e < 9 * rs; e += 256) {
+    const int t9 = e / rs, zz = e % rs - 1;
     const int gx = x + t9 / 3 - 1, gy = yy + t9 % 3 - 1;
-    if (gx >= 0 && gx < r && gy >= 0 && gy < r) any |= ro[gx * r + gy] != 0;
+    int k = -1;
+    if (gx >= 0 && gx < r && gy >= 0 && gy < r && zz >= 0 && zz < r) k = oi[(gx * r + gy) * r + zz];
+    nbr[e] = k;
+    mine |= k >= 0;
   }
+  const int any = __syncthreads_or(mine);
   if (!any) {  // no occupied cell anywhere under this row's 3x3x3 stencils: pure bias
     for (int e = tid; e < cout * r; e += 256) {
       const int co = e / r, z = e % r;
@@ -553,15 +559,6 @@ __global__ __launch_bounds__(256) void sparse_gather_v4_kernel(int cout, int r, 
     }
     return;
   }
-  const int *oi = occ_index + (size_t)bi * r3;
-  for (int e = tid; e < 9 * rs; e += 256) {
-    const int t9 = e / rs, zz = e % rs - 1;
-    const int gx = x + t9 / 3 - 1, gy = yy + t9 % 3 - 1;
-    int k = -1;
-    if (gx >= 0 && gx < r && gy >= 0 && gy < r && zz >= 0 && zz < r && ro[gx * r + gy]) k = oi[(gx * r + gy) * r + zz];
-    nbr[e] = k;
-  }
-  __syncthreads();
   if (tid < r) {
     unsigned mk = 0u;
 #pragma unroll
