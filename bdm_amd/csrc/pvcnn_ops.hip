@@ -521,6 +521,7 @@ __global__ void fp_assemble_kernel(int n, int c_a, const float *__restrict__ fa,
   const float *w = weights + (size_t)bi * 3 * n;
   const int i0 = id[j], i1 = id[n + j], i2 = id[2 * n + j];
   const float w0 = w[j], w1 = w[n + j], w2 = w[2 * n + j];
+#pragma unroll 4
   for (int ci = blockIdx.y; ci < c_a + c_s + c_t; ci += gridDim.y) {
     if (ci < c_a) {
       const float *fr = fa + (size_t)bi * bs_a + (size_t)ci * ld_a;
