@@ -41,6 +41,10 @@ struct PwGn {
   float in_eps;
   double *out_partial;       // (b, M / out_cg, S_out, 2) or NULL;  S_out = gridDim.x * max(1, out_cg / BM)
   int out_cg;
+  // second source of the K axis: rows k >= k1 of the operand come from x2 (torch.cat([x, x2], dim=1) without the copy)
+  const float *x2;
+  long long bsx2;
+  int ldx2, k1;
 };
 
 template <int MI, int NI, bool ATRANS = false, int BK = 16, bool FOLD = false>
@@ -88,8 +92,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
   }
   W += (size_t)bi * bsw;
   const float *Xb = X + (size_t)bi * bsx;
+  const float *X2b = gn.x2 ? gn.x2 + (size_t)bi * gn.bsx2 : nullptr;
+  const int k1 = X2b ? gn.k1 : K;  // rows [k1, K) live in X2b
   float *Yb = Y + (size_t)bi * bsy;
-  const bool vec_ok = ((ldx & 3) == 0) && ((((uintptr_t)Xb) & 15) == 0);
+  const bool vec_ok = ((ldx & 3) == 0) && ((((uintptr_t)Xb) & 15) == 0) &&
+                      (!X2b || (((gn.ldx2 & 3) == 0) && ((((uintptr_t)X2b) & 15) == 0)));
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -130,14 +137,16 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
 #pragma unroll
       for (int i = 0; i < BI; ++i) {
         const int e = tid + i * 256, k = e / (BN / 4);
-        const unsigned kk = (unsigned)min(k0 + k, K - 1);
-        br[i] = *reinterpret_cast<const float4 *>(Xb + (kk * (unsigned)ldx + min(b_col[i], (unsigned)(N - 4))));
+        const int kk = min(k0 + k, K - 1);
+        const float *rowp = kk < k1 ? Xb + (unsigned)kk * (unsigned)ldx : X2b + (unsigned)(kk - k1) * (unsigned)gn.ldx2;
+        br[i] = *reinterpret_cast<const float4 *>(rowp + min(b_col[i], (unsigned)(N - 4)));
       }
     } else {
 #pragma unroll
       for (int i = 0; i < BI; ++i) {
         const int e = tid + i * 256, k = e / (BN / 4);
-        const float *src = Xb + (unsigned)min(k0 + k, K - 1) * (unsigned)ldx;
+        const int kk = min(k0 + k, K - 1);
+        const float *src = kk < k1 ? Xb + (unsigned)kk * (unsigned)ldx : X2b + (unsigned)(kk - k1) * (unsigned)gn.ldx2;
         const unsigned last = (unsigned)(N - 1);
         br[i] = make_float4(src[min(b_col[i], last)], src[min(b_col[i] + 1, last)], src[min(b_col[i] + 2, last)],
                             src[min(b_col[i] + 3, last)]);
@@ -359,13 +368,19 @@ extern "C" int bdm_pointwise_conv_gn_slices(int b, int m, int k, int n, int grou
 }
 
 extern "C" int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x,
-                                     int ld_x, const float *bias, float *y, long long bs_y, int ld_y, const void *in_partial,
-                                     int in_slices, int in_groups, const float *in_gamma, const float *in_beta, float in_eps,
-                                     int out_groups, void *out_partial, void *stream) {
+                                     int ld_x, const float *x2, long long bs_x2, int ld_x2, int k1, const float *bias, float *y,
+                                     long long bs_y, int ld_y, const void *in_partial, int in_slices, int in_groups,
+                                     const float *in_gamma, const float *in_beta, float in_eps, int out_groups,
+                                     void *out_partial, void *stream) {
   BDM_REQUIRE(b >= 0 && m >= 1 && k >= 1 && n >= 1, "pointwise_conv_gn: bad sizes m=%d k=%d n=%d", m, k, n);
   BDM_REQUIRE((long long)k * ld_x + n < (1ll << 31) && (long long)m * ldw + k < (1ll << 31),
               "pointwise_conv_gn: one operand spans more than 2^31 elements");
   PwGn gn{};
+  if (x2 != nullptr) {
+    BDM_REQUIRE(k1 >= 1 && k1 < k && (long long)(k - k1) * ld_x2 + n < (1ll << 31) && in_partial == nullptr,
+                "pointwise_conv_gn: second source needs 1 <= k1 < k and no input fold (k=%d k1=%d)", k, k1);
+    gn.x2 = x2; gn.bsx2 = bs_x2; gn.ldx2 = ld_x2; gn.k1 = k1;
+  }
   if (in_partial != nullptr) {
     BDM_REQUIRE(in_groups >= 1 && in_groups <= 8 && k % in_groups == 0 && k <= 1024 && in_slices >= 1 && in_gamma && in_beta,
                 "pointwise_conv_gn: input fold needs <= 8 groups dividing k <= 1024 (k=%d groups=%d)", k, in_groups);

@@ -51,9 +51,10 @@ class SharedMLP(nn.Module):
     # Swishes on the fly -- no GroupNorm pass, the normalised tensor is never written
     fold_gn = os.environ.get("BDM_FOLD_GN_MLP", "1") == "1"
 
-    def run(self, x, out_last=None, fold_last=False):
+    def run(self, x, out_last=None, fold_last=False, x2=None):
         """-> activations; with fold_last -> (raw output of the last convolution, (stats, gn) | None): the caller applies the
-        last GroupNorm + Swish inside its own consumer kernel (None: already applied)."""
+        last GroupNorm + Swish inside its own consumer kernel (None: already applied).  x2: the input is cat([x, x2], dim=1),
+        read in place by the first convolution."""
         n = len(self.layers) // 3
         pending = None
         for i in range(n):
@@ -61,9 +62,10 @@ class SharedMLP(nn.Module):
             last = i == n - 1
             dst = out_last if last else None
             defer = (self.fold_gn and x.is_cuda and (not last or fold_last) and ops.gn_foldable(conv.out_channels, gn.num_groups))
-            if defer or pending is not None:
+            second = x2 if i == 0 else None
+            if defer or pending is not None or second is not None:
                 r = ops.pointwise_conv_gn(x, conv.weight, conv.bias, out=dst, fold_in=pending,
-                                          out_groups=gn.num_groups if defer else None)
+                                          out_groups=gn.num_groups if defer else None, x2=second)
                 if defer:
                     x, stats = r
                     pending = (stats, gn)
@@ -420,6 +422,7 @@ class PointNetSAModule(nn.Module):
 
 class PointNetFPModule(nn.Module):
     """pointnet.py:96-113."""
+    two_source = os.environ.get("BDM_FP_TWO_SOURCE", "1") == "1"  # skip features read in place by the MLP's first convolution
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
@@ -444,6 +447,9 @@ class PointNetFPModule(nn.Module):
         cf = ops.materialize(centers_features)
         c_int = cf.shape[1]
         c_skip = 0 if points_features is None else points_features.shape[1]
+        two_source = self.two_source and c_skip > 0 and dev.type == "cuda"
+        if two_source:  # the skip rows stay where they are: the MLP's first convolution reads cat([interpolated, skip]) in place
+            skip_src, c_skip = points_features, 0
         buf = torch.empty(B, c_int + c_skip, n, dtype=torch.float32, device=dev)
         t_src = ops.materialize(temb)
         interpolated_temb = torch.empty(B, t_src.shape[1], n, dtype=torch.float32, device=dev)
@@ -459,4 +465,6 @@ class PointNetFPModule(nn.Module):
         L.check(L.lib().bdm_fp_assemble(B, m, n, L.ptr(idx), L.ptr(w), c_int, L.ptr(fa), L.c_ll(bs_a), ld_a, c_skip, L.ptr(fs),
                                         L.c_ll(bs_s), ld_s, c_t, L.ptr(ft), L.c_ll(bs_t), ld_t, L.ptr(buf), L.c_ll(bs_0), ld_0,
                                         L.ptr(interpolated_temb), L.c_ll(bs_1), ld_1, L.stream()), "fp_assemble")
+        if two_source:
+            return self.mlp.run(buf, x2=skip_src), points_coords, interpolated_temb
         return self.mlp.run(buf), points_coords, interpolated_temb

@@ -80,11 +80,16 @@ def gn_foldable(channels, groups):
     return groups <= 8 and cg >= 4 and (cg & (cg - 1)) == 0 and channels <= 1024
 
 
-def pointwise_conv_gn(x, weight, bias=None, out=None, fold_in=None, out_groups=None):
+def pointwise_conv_gn(x, weight, bias=None, out=None, fold_in=None, out_groups=None, x2=None):
     """1x1 convolution with GroupNorm folding (bdm_pointwise_conv_gn).  fold_in = (stats, gn) of a previous call: x is that
     call's raw output and Swish(GroupNorm(x)) is applied on the fly.  out_groups: also return the statistics of the output
     -> (y, (partial, slices, groups)).  shared_mlp.py:25-30."""
     x, B, K, n, bs_x, ld_x = _bcl(x)
+    k1, x2p, bs_x2, ld_x2 = 0, None, 0, 0
+    if x2 is not None:  # the operand is cat([x, x2], dim=1), read in place
+        x2p, B2, K2, n2, bs_x2, ld_x2 = _bcl(x2)
+        assert (B2, n2) == (B, n)
+        k1, K = K, K + K2
     M = weight.shape[0]
     w = weight.reshape(M, -1)
     assert w.shape[1] == K, f"weight expects {w.shape[1]} channels, input has {K}"
@@ -106,8 +111,8 @@ def pointwise_conv_gn(x, weight, bias=None, out=None, fold_in=None, out_groups=N
         assert slices > 0
         out_p = torch.empty(B * og * slices * 2, dtype=torch.float64, device=x.device)
         stats = (out_p, slices, og)
-    L.check(lib.bdm_pointwise_conv_gn(B, M, K, n, L.ptr(w), K, L.ptr(x), L.c_ll(bs_x), ld_x, L.ptr(bias), L.ptr(out), L.c_ll(bs_y),
-                                      ld_y, L.ptr(in_p), in_s, in_g, L.ptr(in_gamma), L.ptr(in_beta), L.c_float(in_eps), og,
+    L.check(lib.bdm_pointwise_conv_gn(B, M, K, n, L.ptr(w), K, L.ptr(x), L.c_ll(bs_x), ld_x, L.ptr(x2p), L.c_ll(bs_x2), ld_x2, k1,
+                                      L.ptr(bias), L.ptr(out), L.c_ll(bs_y), ld_y, L.ptr(in_p), in_s, in_g, L.ptr(in_gamma), L.ptr(in_beta), L.c_float(in_eps), og,
                                       L.ptr(out_p), L.stream()), "pointwise_conv_gn")
     return (out, stats) if out_groups else out
 

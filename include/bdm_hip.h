@@ -152,6 +152,8 @@ int bdm_group_norm(int b, int c, int l, int groups, const float *x, long long bs
  *   bdm_pointwise_conv_gn: y = W x' + bias with
  *     x' = x, or (in_partial != NULL) x' = Swish(GroupNorm(x)) applied while the operand is staged, the statistics of x taken
  *          from the slice partials in_partial (b, in_groups, in_slices, 2 doubles) its producer left (in_groups <= 8, k <= 1024);
+ *     x2 != NULL: the operand is torch.cat([x (k1 rows), x2 (k - k1 rows)], dim=1) read in place (pointnet.py:108-110, the skip
+ *          features of an FP module are never copied next to the interpolated ones);
  *     and (out_partial != NULL) the (sum, sum of squares) of y per (shape, group of m / out_groups channels) written as
  *          bdm_pointwise_conv_gn_slices(b, m, k, n, out_groups) slices per (shape, group) into out_partial
  *          (b, out_groups, slices, 2 doubles); channels per group must be a power of two >= 4.
@@ -160,9 +162,9 @@ int bdm_group_norm(int b, int c, int l, int groups, const float *x, long long bs
  * Deterministic (fixed summation orders, no float atomics). */
 int bdm_pointwise_conv_gn_slices(int b, int m, int k, int n, int groups);
 int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x, int ld_x,
-                          const float *bias, float *y, long long bs_y, int ld_y, const void *in_partial, int in_slices,
-                          int in_groups, const float *in_gamma, const float *in_beta, float in_eps, int out_groups,
-                          void *out_partial, void *stream);
+                          const float *x2, long long bs_x2, int ld_x2, int k1, const float *bias, float *y, long long bs_y,
+                          int ld_y, const void *in_partial, int in_slices, int in_groups, const float *in_gamma,
+                          const float *in_beta, float in_eps, int out_groups, void *out_partial, void *stream);
 int bdm_max_over_neighbors_gn(int b, int c, int m, int u, const float *x, const void *in_partial, int in_slices, int groups,
                               const float *gamma, const float *beta, float eps, float *y, long long bs_y, int ld_y,
                               void *stream);
