@@ -426,6 +426,80 @@ __global__ void to_h2_kernel(int C, int V, int G, int S, const float *__restrict
     atomicOr(saturated, 1u);
 }
 
+// The same split with the GroupNorm statistics taken from MANY slice partials (the sparse gather leaves r*r per (shape, group)):
+// fat workgroups (8 channels x VB voxels) reduce their group's partials once, in parallel and in a fixed order (thread t adds
+// slices t, t + 256, ...; half-wave... whole-wave butterfly; waves added in order), then stream VB voxels.
+template <int VB>
+__global__ __launch_bounds__(256) void to_h2_stats_kernel(int C, int V, int G, int S, const float *__restrict__ x,
+                                                          const double *__restrict__ partial, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps, int act, float act_scale,
+                                                          unsigned short *__restrict__ out, unsigned *__restrict__ saturated) {
+  __shared__ float s_mean[2], s_rstd[2];
+  __shared__ double s_red[2][4][2];
+  const int bi = blockIdx.z, c8 = blockIdx.y, C8 = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = C / G;
+  const int g_lo = (c8 * 8) / cg, g_hi = min((c8 * 8 + 7) / cg, G - 1);  // the block's 8 channels touch <= 2 groups (cg >= 4)
+  for (int gi = g_lo; gi <= g_hi; ++gi) {
+    const double *pp = partial + ((size_t)bi * G + gi) * S * 2;
+    double a = 0.0, q = 0.0;
+    for (int sl = tid; sl < S; sl += 256) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    if (lane == 0) { s_red[gi - g_lo][wave][0] = a; s_red[gi - g_lo][wave][1] = q; }
+  }
+  __syncthreads();
+  if (tid <= g_hi - g_lo) {
+    const double a = ((s_red[tid][0][0] + s_red[tid][1][0]) + s_red[tid][2][0]) + s_red[tid][3][0];
+    const double q = ((s_red[tid][0][1] + s_red[tid][1][1]) + s_red[tid][2][1]) + s_red[tid][3][1];
+    const double cnt = (double)cg * V, mean = a / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0) var = 0;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  bool sat = false;
+#pragma unroll 2
+  for (int it = 0; it < VB / 256; ++it) {
+    const int v = blockIdx.x * VB + it * 256 + tid;
+    if (v >= V) break;
+    float val[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = c8 * 8 + j;
+      float t = 0.f;
+      if (ch < C) {
+        t = x[((size_t)bi * C + ch) * V + v];
+        const int g = ch / cg - g_lo;
+        t = (t - s_mean[g]) * s_rstd[g] * gamma[ch] + beta[ch];
+        if (act == 1) t = t / (1.0f + expf(-t));
+      }
+      val[j] = t * act_scale;  // a power of two: exact
+      sat |= !(fabsf(val[j]) <= 65504.f);
+    }
+    store_h2(out + ((size_t)bi * C8 + c8) * 2 * (size_t)V * 8, (size_t)v, (size_t)V, val);
+  }
+  if (saturated != nullptr && __ballot(sat) != 0ull && lane == __ffsll((long long)__ballot(sat)) - 1) atomicOr(saturated, 1u);
+}
+
+extern "C" int bdm_group_norm_to_h2_stats(int b, int c, int v, int groups, const float *x, const float *gamma,
+                                          const float *beta, float eps, int act, float act_scale, void *out_h2,
+                                          const void *partial, int slices, unsigned int *saturated, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && v >= 1 && groups >= 1 && c % groups == 0 && (c / groups) >= 4 && partial != nullptr && slices >= 1,
+              "group_norm_to_h2_stats: bad arguments");
+  {
+    int ex = 0;
+    BDM_REQUIRE(act_scale > 0.f && act_scale < INFINITY && frexpf(act_scale, &ex) == 0.5f,
+                "group_norm_to_h2_stats: act_scale must be a power of two (got %g)", (double)act_scale);
+  }
+  if (b == 0) return BDM_OK;
+  constexpr int VB = 1024;
+  dim3 grid(cdiv(v, VB), (c + 7) / 8, b);
+  hipLaunchKernelGGL(to_h2_stats_kernel<VB>, grid, dim3(256), 0, (hipStream_t)stream, c, v, groups, slices, x,
+                     (const double *)partial, gamma, beta, eps, act, act_scale, (unsigned short *)out_h2, saturated);
+  return launch_status("group_norm_to_h2_stats");
+}
+
 extern "C" int bdm_group_norm_stats(int b, int c, int l, int groups, const float *x, long long bs_x, void *workspace,
                                     int *slices_out, void *stream);
 

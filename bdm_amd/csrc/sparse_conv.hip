@@ -531,13 +531,15 @@ template <int GU>  // row reads in flight per lane
 __global__ __launch_bounds__(256) void sparse_gather_v4_kernel(int cout, int r, int n_max, const float *__restrict__ y,
                                                                const int *__restrict__ occ_index,
                                                                const unsigned char *__restrict__ rowocc,
-                                                               const float *__restrict__ bias, float *__restrict__ out) {
-  extern __shared__ float tile[];  // [r][cout + 1] floats, 9 * (r + 2) neighbour indices, r tap masks
+                                                               const float *__restrict__ bias, float *__restrict__ out,
+                                                               int gn_cg, double *__restrict__ gn_partial) {
+  extern __shared__ float tile[];  // [r][cout + 1] floats, 9 * (r + 2) neighbour indices, r tap masks, [256][2] GroupNorm partials
   const int row = blockIdx.x, bi = blockIdx.y, x = row / r, yy = row % r;
   const int r2 = r * r, r3 = r2 * r, tid = threadIdx.x;
   const int ldt = cout + 1, rs = r + 2;
   int *nbr = reinterpret_cast<int *>(tile + r * ldt);  // nbr[t9][1 + z], -1 = empty / outside the grid
   unsigned *zmask = reinterpret_cast<unsigned *>(nbr + 9 * rs);
+  float *red = reinterpret_cast<float *>(zmask + r);
   float *ob = out + (size_t)bi * cout * r3;
   // neighbour rows straight from occ_index (-1 for an empty cell): no dependent look at the row-occupancy bytes first, and the
   // "nothing under this row's stencils" test comes out of the same barrier
@@ -557,6 +559,16 @@ __global__ __launch_bounds__(256) void sparse_gather_v4_kernel(int cout, int r, 
       const int co = e / r, z = e % r;
       ob[(size_t)co * r3 + row * r + z] = bias ? bias[co] : 0.f;
     }
+    if (gn_partial != nullptr && tid < cout / gn_cg) {  // this row's share of the GroupNorm statistics: r cells of bias
+      double a = 0.0, q = 0.0;
+      for (int j = 0; j < gn_cg; ++j) {
+        const double bv = bias ? (double)bias[tid * gn_cg + j] : 0.0;
+        a += bv; q += bv * bv;
+      }
+      double *dst = gn_partial + (((size_t)bi * (cout / gn_cg) + tid) * r2 + row) * 2;
+      dst[0] = a * r;
+      dst[1] = q * r;
+    }
     return;
   }
   if (tid < r) {
@@ -568,6 +580,7 @@ __global__ __launch_bounds__(256) void sparse_gather_v4_kernel(int cout, int r, 
   __syncthreads();
   const float *yb = y + (size_t)bi * n_max * 27 * cout;
   const int c4n = cout >> 2;
+  float gs = 0.f, gq = 0.f;  // GroupNorm partials of this thread's items
   for (int item = tid; item < r * c4n; item += 256) {
     const int z = item / c4n, co = (item % c4n) * 4;
     unsigned mask = zmask[z];
@@ -589,31 +602,71 @@ __global__ __launch_bounds__(256) void sparse_gather_v4_kernel(int cout, int r, 
     }
     float *tp = tile + z * ldt + co;
     tp[0] = acc.x; tp[1] = acc.y; tp[2] = acc.z; tp[3] = acc.w;
+    gs += (acc.x + acc.y) + (acc.z + acc.w);
+    gq += (acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w);
+  }
+  if (gn_partial != nullptr) {
+    // GroupNorm(cout / gn_cg groups) statistics of this row of the output.  A thread's items all lie in ONE group (256 is a
+    // multiple of cout / 4 and gn_cg of 4).  Lane l of a wave holds channel quad l % c4n: butterflies over the lane bits that
+    // enumerate copies of a quad (>= c4n) and quads of one group (< gn_cg / 4) leave each group's wave sum in its first lane;
+    // the four waves are then added in order, in fp64 -- a fixed order, deterministic.
+    const int lane = tid & 63, wave = tid >> 6, q4 = gn_cg >> 2;
+    for (int o = c4n; o < 64; o <<= 1) { gs += __shfl_xor(gs, o, 64); gq += __shfl_xor(gq, o, 64); }
+    for (int o = 1; o < q4 && o < 64; o <<= 1) { gs += __shfl_xor(gs, o, 64); gq += __shfl_xor(gq, o, 64); }
+    const int lq = lane % c4n;
+    if (lane < c4n && (lq % q4) == 0) { red[(wave * 64 + lq / q4) * 2] = gs; red[(wave * 64 + lq / q4) * 2 + 1] = gq; }
   }
   __syncthreads();
   for (int e = tid; e < cout * r; e += 256) {
     const int co = e / r, z = e % r;
     ob[(size_t)co * r3 + row * r + z] = tile[z * ldt + co];
   }
+  if (gn_partial != nullptr && tid < cout / gn_cg) {
+    double a = 0.0, q = 0.0;
+    for (int w = 0; w < 4; ++w) { a += (double)red[(w * 64 + tid) * 2]; q += (double)red[(w * 64 + tid) * 2 + 1]; }
+    double *dst = gn_partial + (((size_t)bi * (cout / gn_cg) + tid) * r2 + row) * 2;
+    dst[0] = a;
+    dst[1] = q;
+  }
 }
 
-extern "C" int bdm_sparse_conv_gather(int b, int cout, int r, int n_max, const float *y, const int *occ_index,
-                                      const unsigned char *rowocc, const float *bias, float *out, void *stream) {
+static int sparse_gather_launch(int b, int cout, int r, int n_max, const float *y, const int *occ_index,
+                                const unsigned char *rowocc, const float *bias, float *out, int gn_cg, double *gn_partial,
+                                void *stream) {
   BDM_REQUIRE(b >= 0 && cout >= 1 && r >= 1 && n_max >= 1, "sparse_conv_gather: bad sizes");
   if (b == 0) return BDM_OK;
   const size_t smem = sizeof(float) * (size_t)r * (cout + 1) + sizeof(int) * 9 * (size_t)(r + 2);
   if ((cout & 3) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0) {
     static int gu = 0;  // BDM_GATHER_INFLIGHT=4|8 (experiment switch)
     if (!gu) { const char *e = getenv("BDM_GATHER_INFLIGHT"); gu = (e && e[0] == '4') ? 4 : 8; }
+    const size_t sm4 = smem + sizeof(unsigned) * r + sizeof(float) * 512;
     if (gu == 8)
-      hipLaunchKernelGGL(sparse_gather_v4_kernel<8>, dim3(r * r, b), dim3(256), smem + sizeof(unsigned) * r, (hipStream_t)stream,
-                         cout, r, n_max, y, occ_index, rowocc, bias, out);
+      hipLaunchKernelGGL(sparse_gather_v4_kernel<8>, dim3(r * r, b), dim3(256), sm4, (hipStream_t)stream, cout, r, n_max, y,
+                         occ_index, rowocc, bias, out, gn_cg, gn_partial);
     else
-      hipLaunchKernelGGL(sparse_gather_v4_kernel<4>, dim3(r * r, b), dim3(256), smem + sizeof(unsigned) * r, (hipStream_t)stream,
-                         cout, r, n_max, y, occ_index, rowocc, bias, out);
+      hipLaunchKernelGGL(sparse_gather_v4_kernel<4>, dim3(r * r, b), dim3(256), sm4, (hipStream_t)stream, cout, r, n_max, y,
+                         occ_index, rowocc, bias, out, gn_cg, gn_partial);
     return launch_status("sparse_conv_gather");
   }
+  BDM_REQUIRE(gn_partial == nullptr, "sparse_conv_gather_gn: needs cout %% 4 == 0 and a 16-byte aligned intermediate");
   hipLaunchKernelGGL(sparse_gather_kernel, dim3(r * r, b), dim3(256), smem, (hipStream_t)stream, cout, r, n_max, y,
                      occ_index, rowocc, bias, out);
   return launch_status("sparse_conv_gather");
+}
+
+extern "C" int bdm_sparse_conv_gather(int b, int cout, int r, int n_max, const float *y, const int *occ_index,
+                                      const unsigned char *rowocc, const float *bias, float *out, void *stream) {
+  return sparse_gather_launch(b, cout, r, n_max, y, occ_index, rowocc, bias, out, 0, nullptr, stream);
+}
+
+// The same gather, also leaving the GroupNorm(groups) statistics of its OUTPUT: r*r slice partials per (shape, group) in
+// gn_partial (b, groups, r*r, 2 doubles) -- slice = grid row (x, y).  bdm_group_norm_to_h2_stats consumes them, so the first
+// GroupNorm of a PVConv (pvconv.py:80) needs no statistics pass over the grid.
+extern "C" int bdm_sparse_conv_gather_gn(int b, int cout, int r, int n_max, const float *y, const int *occ_index,
+                                         const unsigned char *rowocc, const float *bias, float *out, int groups,
+                                         void *gn_partial, void *stream) {
+  const int cg = groups >= 1 && cout % groups == 0 ? cout / groups : 0;
+  BDM_REQUIRE(gn_partial != nullptr && cg >= 4 && cg % 4 == 0 && (cout & 3) == 0 && 256 % (cout / 4) == 0 && groups <= 64,
+              "sparse_conv_gather_gn: needs 4 | channels per group and (cout / 4) | 256 (cout=%d groups=%d)", cout, groups);
+  return sparse_gather_launch(b, cout, r, n_max, y, occ_index, rowocc, bias, out, cg, (double *)gn_partial, stream);
 }

@@ -207,6 +207,7 @@ class PVConv(nn.Module):
     # a second stream and joined before the devoxelisation adds it, so its small, latency-bound kernels run beside the
     # voxel convolutions instead of after them (BDM_POINT_STREAM=0: serial).
     se_in_devox = os.environ.get("BDM_SE_IN_DEVOX", "0") == "1"
+    fold_gn1 = os.environ.get("BDM_FOLD_GN1", "1") == "1"  # GroupNorm-1 statistics from the sparse gather's epilogue
     fold_pf = os.environ.get("BDM_FOLD_PF", "1") == "1"  # point branch's GroupNorm folded into the devoxelisation kernel
     point_stream = os.environ.get("BDM_POINT_STREAM", "1") == "1"
     _streams = {}
@@ -249,6 +250,7 @@ class PVConv(nn.Module):
         se = next((m for m in rest if isinstance(m, SE3d)), None)
 
         features = ops.materialize(features)
+        gn1_stats = None
         cg2_, tile_ = conv2.out_channels // gn2.num_groups, (64 if (conv2.out_channels > 32 and r != 8) else 32)
         folded_tail = (self.conv_impl == "fp16x3" and not getattr(self, "h2_saturated", False) and self.fold_gn2 and att is None
                        and se is not None and cg2_ in (4, 8, 16, 32) and tile_ % cg2_ == 0)
@@ -266,7 +268,13 @@ class PVConv(nn.Module):
                 impl = self.sparse_gemm
                 if impl == "sparse_h2" and plan.n_max > 256:
                     impl = "sparse_s3"
-                v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, impl), conv1.bias, conv1.out_channels)
+                # with the fp16x3 second convolution the gather also leaves GroupNorm-1's statistics (no pass over the grid for them)
+                want_stats = (self.fold_gn1 and self.conv_impl == "fp16x3" and not getattr(self, "h2_saturated", False)
+                              and impl != "sparse_fused")
+                v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, impl), conv1.bias, conv1.out_channels,
+                                                  gn_groups=gn1.num_groups if want_stats else None)
+                if want_stats:
+                    v, gn1_stats = v
             else:
                 norm_coords, vox_coords = ops.voxel_coords(coords, r, self.voxelization.eps)
                 x3 = ops.avg_voxelize_s3(features, vox_coords, r)
@@ -277,7 +285,7 @@ class PVConv(nn.Module):
                 # saturation guard: to_h2 raises this layer's sticky device word when a scaled activation leaves fp16's
                 # range; ops.poll_h2_saturation() (once per trajectory) then routes the layer to bf16x6 and warns
                 sat = ops.saturation_slot(self, v.device) if v.is_cuda else None
-                xh = ops.to_h2(v, gn1, swish=True, saturated=sat)
+                xh = ops.to_h2(v, gn1, swish=True, saturated=sat, stats=gn1_stats)
                 cg2, tile = conv2.out_channels // gn2.num_groups, (64 if (conv2.out_channels > 32 and r != 8) else 32)
                 if self.fold_gn2 and att is None and se is not None and cg2 in (4, 8, 16, 32) and tile % cg2 == 0:
                     # GroupNorm-folded tail: the convolution leaves the statistics of its output, SE and the devoxelisation

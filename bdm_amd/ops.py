@@ -491,7 +491,7 @@ def poll_h2_saturation():
     return hit
 
 
-def to_h2(x, gn=None, swish=False, scale=None, saturated=None):
+def to_h2(x, gn=None, swish=False, scale=None, saturated=None, stats=None):
     """x (B, C, V) fp32 contiguous -> (H2 tensor (B, ceil(C/8), 2, V, 8) fp16 of scale * [swish(group_norm(x))], 1 / scale).
     scale: power of two; default from the GroupNorm parameters, or (no GroupNorm: test path, host sync) from max |x|.
     saturated: optional 1-element int32 device tensor, OR-ed with 1 when a scaled value left fp16's range."""
@@ -499,7 +499,14 @@ def to_h2(x, gn=None, swish=False, scale=None, saturated=None):
     B, C = x.shape[:2]
     V = x.numel() // (B * C)
     out = torch.empty(B, (C + 7) // 8, 2, V, 8, dtype=torch.float16, device=x.device)
-    if gn is not None:
+    if gn is not None and stats is not None:  # statistics left by the producer (sparse gather): no pass over x for them
+        scale = h2_activation_scale(gn) if scale is None else scale
+        partial, slices, groups = stats
+        assert groups == gn.num_groups
+        L.check(L.lib().bdm_group_norm_to_h2_stats(B, C, V, groups, L.ptr(x), L.ptr(gn.weight), L.ptr(gn.bias), L.c_float(gn.eps),
+                                                   1 if swish else 0, L.c_float(scale), L.ptr(out), L.ptr(partial), slices,
+                                                   L.ptr(saturated), L.stream()), "group_norm_to_h2_stats")
+    elif gn is not None:
         scale = h2_activation_scale(gn) if scale is None else scale
         ws = workspace(L.lib().bdm_group_norm_workspace_bytes(B, gn.num_groups), x.device, "gn")
         L.check(L.lib().bdm_group_norm_to_h2(B, C, V, gn.num_groups, L.ptr(x), L.ptr(gn.weight), L.ptr(gn.bias),
@@ -717,8 +724,26 @@ def voxel_plan(coords, r, eps=0.0):
     return p
 
 
-def sparse_first_conv_planned(features, plan, wt, bias, cout):
-    """Conv3d(k3, p1)(avg_voxelize(features)) on the occupied voxels of `plan`: (B, cout, r^3) fp32."""
+def gather_gn_ok(cout, groups):
+    cg = cout // groups if groups and cout % groups == 0 else 0
+    return cg >= 4 and cg % 4 == 0 and cout % 4 == 0 and 256 % (cout // 4) == 0
+
+
+def _gather(lib, nb, cout, r, plan, b0, y, bias, out, gn):
+    """sparse gather of one shape group; gn = (partial (B, G, r*r, 2) fp64, groups) also leaves the output's GroupNorm partials"""
+    if gn is None:
+        L.check(lib.bdm_sparse_conv_gather(nb, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index[b0:]), L.ptr(plan.rowocc[b0:]),
+                                           L.ptr(bias), L.ptr(out[b0:]), L.stream()), "sparse_conv_gather")
+    else:
+        partial, groups = gn
+        L.check(lib.bdm_sparse_conv_gather_gn(nb, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index[b0:]), L.ptr(plan.rowocc[b0:]),
+                                              L.ptr(bias), L.ptr(out[b0:]), groups, L.ptr(partial[b0:]), L.stream()),
+                "sparse_conv_gather_gn")
+
+
+def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None):
+    """Conv3d(k3, p1)(avg_voxelize(features)) on the occupied voxels of `plan`: (B, cout, r^3) fp32.
+    gn_groups: also return the GroupNorm(gn_groups) statistics of the output as (partial, slices = r*r, groups) -> (out, stats)."""
     f, B, C, n, bs_f, ld_f = _bcl(features)
     dev, lib, r = f.device, L.lib(), plan.r
     if isinstance(wt, tuple) and wt[0] == "h2":  # fp16x3 GEMM (sparse_conv_pack_h2) + gather: the default
@@ -734,13 +759,16 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout):
         per_shape = plan.n_max * 27 * cout * 4
         gb = max(1, min(B, SPARSE_Y_BYTES // max(per_shape, 1)))
         y = torch.empty(gb, plan.n_max, 27 * cout, dtype=torch.float32, device=dev)
+        gn, stats = None, None
+        if gn_groups and gather_gn_ok(cout, gn_groups):
+            partial = torch.empty(B, gn_groups, r * r, 2, dtype=torch.float64, device=dev)
+            gn, stats = (partial, int(gn_groups)), (partial, r * r, int(gn_groups))
         for b0 in range(0, B, gb):
             nb = min(gb, B - b0)
             L.check(lib.bdm_sparse_conv_gemm_h2(nb, plan.n_max, C, cout, L.ptr(xh[b0:]), L.ptr(amax), L.ptr(packed), L.ptr(inv_scale),
                                                 L.ptr(plan.n_occ[b0:]), L.ptr(y), L.stream()), "sparse_conv_gemm_h2")
-            L.check(lib.bdm_sparse_conv_gather(nb, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index[b0:]), L.ptr(plan.rowocc[b0:]),
-                                               L.ptr(bias), L.ptr(out[b0:]), L.stream()), "sparse_conv_gather")
-        return out
+            _gather(lib, nb, cout, r, plan, b0, y, bias, out, gn)
+        return (out, stats) if gn_groups else out
     if isinstance(wt, tuple):  # fused kernel (sparse_conv_pack_fused): GEMM + scatter in one launch, no intermediate
         _, packed, inv_scale = wt
         xr = torch.empty(B, (C + 7) // 8, plan.n_max, 8, dtype=torch.float32, device=dev)
@@ -752,7 +780,7 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout):
         L.check(lib.bdm_sparse_conv_fused(B, C, cout, r, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(packed), L.ptr(inv_scale),
                                           L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(bias), L.ptr(out), L.stream()),
                 "sparse_conv_fused")
-        return out
+        return (out, None) if gn_groups else out
     out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
     # The 27x-expanded intermediate Y (n_occ x 27*cout fp32 per shape) is written by the GEMM and read once by the gather.
     # Shapes are processed in groups whose Y stays within BDM_SPARSE_Y_MB (default 256 MiB, about the memory-side cache),
@@ -773,6 +801,10 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout):
         L.check(lib.bdm_sparse_voxel_features(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt),
                                               L.ptr(plan.ws), L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xs), L.stream()),
                 "sparse_voxel_features")
+    gn, stats = None, None
+    if gn_groups and gather_gn_ok(cout, gn_groups):
+        partial = torch.empty(B, gn_groups, r * r, 2, dtype=torch.float64, device=dev)
+        gn, stats = (partial, int(gn_groups)), (partial, r * r, int(gn_groups))
     for b0 in range(0, B, gb):
         nb = min(gb, B - b0)
         if s3:
@@ -781,9 +813,8 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout):
         else:
             L.check(lib.bdm_sparse_conv_gemm(nb, plan.n_max, C, 27 * cout, L.ptr(xs[b0:]), L.ptr(wt), L.ptr(plan.n_occ[b0:]),
                                              L.ptr(y), L.stream()), "sparse_conv_gemm")
-        L.check(lib.bdm_sparse_conv_gather(nb, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index[b0:]), L.ptr(plan.rowocc[b0:]),
-                                           L.ptr(bias), L.ptr(out[b0:]), L.stream()), "sparse_conv_gather")
-    return out
+        _gather(lib, nb, cout, r, plan, b0, y, bias, out, gn)
+    return (out, stats) if gn_groups else out
 
 
 def sparse_first_conv(features, vox_coords, r, wt, bias, cout):

@@ -77,6 +77,7 @@ SPEC = {
     "bdm_sparse_conv_gemm": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]),
                              lambda a: ("mfma_aux", 2.0 * a[0] * a[1] * OCCUPANCY.get(a[1], 1.0) * a[2] * a[3], MFMA32_PEAK_TFLOPS)),
     "bdm_sparse_conv_gather": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] ** 3)),
+    "bdm_sparse_conv_gather_gn": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] ** 3)),
     "bdm_sparse_voxel_features_s3": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2])),
     "bdm_sparse_voxel_features": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2])),
     "bdm_sparse_voxel_features_f32": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2])),
@@ -87,6 +88,7 @@ SPEC = {
     # normalisation and operand repacks: 1 read + 1 write of the tensor
     "bdm_group_norm": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", 8.0 * a[0] * a[1] * a[2])),
     "bdm_group_norm_to_h2": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", (4.0 + 4.0 + 4.0) * a[0] * a[1] * a[2])),
+    "bdm_group_norm_to_h2_stats": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", (4.0 + 4.0) * a[0] * a[1] * a[2])),
     "bdm_group_norm_to_s3": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", (4.0 + 4.0 + 6.0) * a[0] * a[1] * a[2])),
     "bdm_attention_core": ("attention", lambda a: a[:3], _attn),
     # point operators (SURVEY.md 8d byte formulas)

@@ -277,6 +277,11 @@ int bdm_conv3d_h2_pack_weights(int cout, int cin, const float *w, void *packed, 
 int bdm_group_norm_to_h2(int b, int c, int v, int groups, const float *x, const float *gamma, const float *beta,
                          float eps, int act, float act_scale, void *out_h2, void *workspace,
                          unsigned int *saturated, void *stream);
+/* bdm_group_norm_to_h2 with the statistics given as `slices` slice partials per (shape, group) (b, groups, slices, 2 doubles)
+ * instead of a statistics pass over x; channels per group >= 4 */
+int bdm_group_norm_to_h2_stats(int b, int c, int v, int groups, const float *x, const float *gamma, const float *beta,
+                               float eps, int act, float act_scale, void *out_h2, const void *partial, int slices,
+                               unsigned int *saturated, void *stream);
 int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale, const void *packed_w,
                         const float *inv_scale, const float *bias, float *y, void *stream);
 
@@ -341,6 +346,11 @@ int bdm_sparse_conv_gemm(int b, int n_max, int cin, int n27, const float *xc, co
                          const int *n_occ, float *y, void *stream);
 int bdm_sparse_conv_gather(int b, int cout, int r, int n_max, const float *y, const int *occ_index,
                            const unsigned char *rowocc, const float *bias, float *out, void *stream);
+/* the same gather + the GroupNorm(groups) statistics of its output as r*r slice partials per (shape, group):
+ * gn_partial (b, groups, r*r, 2 doubles); consumed by bdm_group_norm_to_h2_stats */
+int bdm_sparse_conv_gather_gn(int b, int cout, int r, int n_max, const float *y, const int *occ_index,
+                              const unsigned char *rowocc, const float *bias, float *out, int groups, void *gn_partial,
+                              void *stream);
 
 /* --- the same first convolution in ONE kernel, no (n_occ x 27*cout) intermediate (sparse_conv_fused.hip; the default) ---
  *   bdm_sparse_voxel_features_f32  occupied cells' mean features as fp32 records xr (b, ceil(c/8), n_max) x 8 channels,

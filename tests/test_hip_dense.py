@@ -494,3 +494,22 @@ def test_devoxelisation_from_lds_equals_global_gather(ops, monkeypatch, cin, cou
     ref = pv((f, c, t))[0].clone()
     monkeypatch.setenv("BDM_DEVOX_LDS", "1")     # forced for every shape (the default picks it where it is faster)
     assert torch.equal(pv((f, c, t))[0], ref)
+
+
+@pytest.mark.parametrize("cin,cout,r,n", [(32, 32, 32, 4096), (64, 64, 32, 2500), (128, 128, 16, 1024), (256, 256, 8, 256), (192, 128, 8, 64)])
+def test_groupnorm1_statistics_from_the_gather_epilogue(ops, monkeypatch, cin, cout, r, n):
+    """First GroupNorm of a PVConv with its statistics left by the sparse gather (r*r slice partials per group, reduced in
+    parallel by the operand-split kernel) vs a statistics pass over the grid: same module output, deterministic; rows whose
+    stencils see no occupied cell (pure bias) are counted too (scale 0.2: most of the 32^3 grid is empty)."""
+    from bdm_amd.modules import PVConv
+    from bdm_amd.utils.procedural import fill_module_
+    pv = fill_module_(PVConv(cin, cout, 3, resolution=r, with_se=True, with_se_relu=True).eval(), seed=cin + r).cuda()
+    g = torch.Generator().manual_seed(n)
+    f, c = torch.randn(3, cin, n, generator=g).cuda(), (torch.randn(3, 3, n, generator=g) * 0.2).cuda()
+    t = torch.zeros(3, 8, n, device="cuda")
+    monkeypatch.setattr(PVConv, "fold_gn1", False)
+    ref = pv((f, c, t))[0].clone()
+    monkeypatch.setattr(PVConv, "fold_gn1", True)
+    got = pv((f, c, t))[0].clone()
+    assert rel(got.cpu(), ref.cpu()) < 1e-6
+    assert torch.equal(got, pv((f, c, t))[0])
