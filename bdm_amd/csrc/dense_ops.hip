@@ -307,15 +307,22 @@ static int pw_deep_limit() {
 
 // biggest tile that still gives the 256 CUs two workgroups each; small problems (the 16..256-point levels) are latency-bound
 // and prefer many small tiles over operand reuse, and take the 64-deep K chunk when K is long
+// K chunk of the 256-column tiles (BDM_PW_WIDE_BK=16|32): 32 halves the barrier pairs of the short-K layers
+static int pw_wide_bk() {
+  static int v = 0;
+  if (!v) { const char *e = getenv("BDM_PW_WIDE_BK"); v = (e && atoi(e) == 16) ? 16 : 32; }
+  return v;
+}
+
 static void pw_tile(int b, int m, int k, int n, int *mi, int *ni, int *bk) {
   auto blocks = [&](int a, int c) { return (long long)cdiv(n, 128 * c) * cdiv(m, 32 * a) * b; };
   const int deep_limit = pw_deep_limit();
   *bk = 16;
   if (m <= 32) {
     if (n <= 128 || blocks(1, 2) < 512) { *mi = 1; *ni = 1; if (k >= 128 && blocks(1, 1) < deep_limit) *bk = 64; }
-    else { *mi = 1; *ni = 2; }
+    else { *mi = 1; *ni = 2; *bk = pw_wide_bk(); }
   } else if (n > 128 && blocks(2, 2) >= 512) {
-    *mi = 2; *ni = 2;
+    *mi = 2; *ni = 2; *bk = pw_wide_bk();
   } else if (blocks(2, 1) >= 512) {
     *mi = 2; *ni = 1; if (k >= 128 && blocks(2, 1) < deep_limit) *bk = 64;
   } else {
@@ -337,8 +344,10 @@ static void pw_dispatch(int b, int m, int k, int n, const float *w, int ldw, con
   pw_tile(b, m, k, n, &mi, &ni, &bk);
   if (mi == 1 && ni == 1 && bk == 16) PW_LAUNCH(1, 1, 16);
   else if (mi == 1 && ni == 1) PW_LAUNCH(1, 1, 64);
-  else if (mi == 1 && ni == 2) PW_LAUNCH(1, 2, 16);
-  else if (mi == 2 && ni == 2) PW_LAUNCH(2, 2, 16);
+  else if (mi == 1 && ni == 2 && bk == 16) PW_LAUNCH(1, 2, 16);
+  else if (mi == 1 && ni == 2) PW_LAUNCH(1, 2, 32);
+  else if (mi == 2 && ni == 2 && bk == 16) PW_LAUNCH(2, 2, 16);
+  else if (mi == 2 && ni == 2) PW_LAUNCH(2, 2, 32);
   else if (bk == 16) PW_LAUNCH(2, 1, 16);
   else PW_LAUNCH(2, 1, 64);
 #undef PW_LAUNCH

@@ -257,7 +257,8 @@ def main():
             try:  # HBM bytes per launch of that kernel from the committed PMC pass (separate rocprofv3 --pmc runs)
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
                 key = f"{head['function']}{tuple(head['shape'])}"
-                ent = pm["kernels"].get(key) or pm["kernels"].get(key.replace("_h2_gn(", "_h2("))  # same kernel + GN epilogue
+                ent = (pm["kernels"].get(key) or pm["kernels"].get(key.replace("_h2_gn(", "_h2("))  # same kernels + GN epilogue
+                       or pm["kernels"].get(key.replace("_gather_gn(", "_gather(")))
                 if ent:
                     traffic, traffic_commit = ent["bytes_per_launch"], pm.get("commit")
             except (OSError, KeyError, ValueError):
