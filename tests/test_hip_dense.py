@@ -513,3 +513,49 @@ def test_groupnorm1_statistics_from_the_gather_epilogue(ops, monkeypatch, cin, c
     got = pv((f, c, t))[0].clone()
     assert rel(got.cpu(), ref.cpu()) < 1e-6
     assert torch.equal(got, pv((f, c, t))[0])
+
+
+def test_concat2_rows_fp_assemble_two_source_gemm_and_channel_first_gather(ops):
+    """Direct checks of the launch-merging entry points against their unmerged forms (bit-exact: same arithmetic)."""
+    from bdm_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    B, n, m = 3, 700, 96
+    # torch.cat([a, v broadcast], dim=1) in one launch
+    a = torch.randn(B, 37, n, generator=g).cuda()
+    v = torch.randn(B, 9, generator=g).cuda()
+    got = ops.cat_channels([a, v[:, :, None].expand(-1, -1, n)])
+    assert torch.equal(got, torch.cat([a, v[:, :, None].expand(-1, -1, n)], 1))
+    got = ops.cat_channels([a[:, 5:20], a[:, 1:3]])                       # strided row views
+    assert torch.equal(got, torch.cat([a[:, 5:20], a[:, 1:3]], 1))
+    # FP-module assembly vs three separate launches
+    pc, cc = torch.randn(B, 3, n, generator=g).cuda(), torch.randn(B, 3, m, generator=g).cuda()
+    fa, fs, ft = torch.randn(B, 21, m, generator=g).cuda(), torch.randn(B, 13, n, generator=g).cuda(), torch.randn(B, 8, m, generator=g).cuda()
+    idx = torch.empty(B, 3, n, dtype=torch.int32, device="cuda")
+    w = torch.empty(B, 3, n, dtype=torch.float32, device="cuda")
+    lib = L.lib()
+    L.check(lib.bdm_three_nn_search(B, m, n, L.ptr(pc), L.ptr(cc), L.ptr(idx), L.ptr(w), L.stream()), "search")
+    ref0, ref1 = torch.empty(B, 34, n, device="cuda"), torch.empty(B, 8, n, device="cuda")
+    L.check(lib.bdm_three_nn_apply(B, 21, m, n, L.ptr(fa), L.c_ll(21 * m), m, L.ptr(idx), L.ptr(w), L.ptr(ref0), L.c_ll(34 * n), n, L.stream()), "a")
+    ref0[:, 21:] = fs
+    L.check(lib.bdm_three_nn_apply(B, 8, m, n, L.ptr(ft), L.c_ll(8 * m), m, L.ptr(idx), L.ptr(w), L.ptr(ref1), L.c_ll(8 * n), n, L.stream()), "b")
+    out0, out1 = torch.empty_like(ref0), torch.empty_like(ref1)
+    L.check(lib.bdm_fp_assemble(B, m, n, L.ptr(idx), L.ptr(w), 21, L.ptr(fa), L.c_ll(21 * m), m, 13, L.ptr(fs), L.c_ll(13 * n), n, 8,
+                                L.ptr(ft), L.c_ll(8 * m), m, L.ptr(out0), L.c_ll(34 * n), n, L.ptr(out1), L.c_ll(8 * n), n, L.stream()), "fp")
+    assert torch.equal(out0, ref0) and torch.equal(out1, ref1)
+    # 1x1 convolution over cat([x, x2]) read in place vs over the concatenated copy (same k order: same bits)
+    x1, x2 = torch.randn(B, 40, n, generator=g).cuda(), torch.randn(B, 67, n, generator=g).cuda()
+    wt, bias = (torch.randn(48, 107, generator=g) / 10).cuda(), torch.randn(48, generator=g).cuda()
+    ref = ops.pointwise_conv(torch.cat([x1, x2], 1), wt, bias)
+    assert torch.equal(ops.pointwise_conv_gn(x1, wt, bias, x2=x2), ref)
+    big = torch.randn(B, 120, n, generator=g).cuda()
+    assert torch.equal(ops.pointwise_conv_gn(x1, wt, bias, x2=big[:, 3:70]), ops.pointwise_conv(torch.cat([x1, big[:, 3:70]], 1), wt, bias))
+    # conditioning gather written channel-first == the point-major gather transposed
+    C, HW = 29, 50
+    xt = torch.randn(B, n, 3, generator=g).cuda()
+    feat = torch.randn(B, HW, C, generator=g).cuda()
+    pix = torch.randint(-1, HW, (B, n), generator=g, dtype=torch.int32).cuda()
+    pm, cf = torch.empty(B, n, 3 + C, device="cuda"), torch.empty(B, 3 + C, n, device="cuda")
+    L.check(lib.bdm_condition_gather(B, n, C, HW, L.ptr(xt), L.ptr(feat), L.ptr(pix), L.ptr(pm), L.stream()), "pm")
+    L.check(lib.bdm_condition_gather_cf(B, n, C, HW, L.ptr(xt), L.ptr(feat), L.ptr(pix), L.ptr(cf), L.stream()), "cf")
+    assert torch.equal(cf.transpose(1, 2), pm)
+    assert ops.transpose12(cf.transpose(1, 2)).data_ptr() == cf.data_ptr()   # the denoiser's input transpose is a view
