@@ -1,0 +1,260 @@
+// attention_h2.hip -- flash attention on the fp16 matrix cores at fp32-grade accuracy ("fp16x3"), half the matrix work of the
+// bf16x6 kernel of attention_s3.hip (same geometry, same online softmax, same register-resident probability tile).
+//
+// An fp32 operand times a power of two is stored as hi + lo (two fp16 terms, 22 signed bits); a product is
+// lo.hi + hi.lo + hi.hi accumulated in fp32 (lo.lo <= 2^-22 relative is dropped).  fp16 has a narrow exponent range, so every
+// tensor gets ONE power-of-two scale from its max |value| (amax[0..2] for q, k, v: left by the projection GEMM's epilogue,
+// bdm_pointwise_conv_gn, as bit patterns of non-negative floats -- an integer atomicMax, order independent): the scaled
+// operands sit in [2^14, 2^15) at the top, the scales are divided out exactly (q.k scale inside the exponential's constant,
+// v and probability scales at the final normalisation).  Probabilities (in [0, 1]) are scaled by 2^14 before their split.
+#include "../../include/bdm_hip.h"
+#include "common.h"
+
+using namespace bdm;
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+namespace {
+
+__device__ __forceinline__ float h2_scale_from_max(float amax) {  // power of two s with amax * s in [2^14, 2^15)
+  if (!(amax > 0.f) || !(amax < INFINITY)) return 1.f;
+  int ex;
+  (void)frexpf(amax, &ex);
+  return ldexpf(1.f, 15 - ex);
+}
+
+__device__ __forceinline__ void split2h(float v, unsigned short &h, unsigned short &l) {
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  h = __builtin_bit_cast(unsigned short, hi);
+  l = __builtin_bit_cast(unsigned short, lo);
+}
+
+__device__ __forceinline__ uint4 pack8(const unsigned short x[8]) {
+  return make_uint4(x[0] | (x[1] << 16), x[2] | (x[3] << 16), x[4] | (x[5] << 16), x[6] | (x[7] << 16));
+}
+
+__device__ __forceinline__ f16x8 as_f16x8(uint4 u) { return __builtin_bit_cast(f16x8, u); }
+
+}  // namespace
+
+// q or k: (C, L) fp32 rows of stride ld -> records [c8][split][l] of 8 channels x fp16
+__global__ void attn_split_qk_h2_kernel(int C, int L, const float *__restrict__ q, const float *__restrict__ k, long long bs,
+                                        int ld, const float *__restrict__ amax, uint4 *__restrict__ qs, uint4 *__restrict__ ks) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x, c8 = blockIdx.y, C8 = gridDim.y, bi = blockIdx.z >> 1, which = blockIdx.z & 1;
+  if (l >= L) return;
+  const float s = h2_scale_from_max(amax[which]);
+  const float *src = (which ? k : q) + (size_t)bi * bs;
+  uint4 *dst = (which ? ks : qs) + ((size_t)bi * C8 + c8) * 2 * (size_t)L;
+  unsigned short h[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c8 * 8 + j;
+    split2h(c < C ? src[(size_t)c * ld + l] * s : 0.f, h[j], lo[j]);
+  }
+  dst[l] = pack8(h);
+  dst[(size_t)L + l] = pack8(lo);
+}
+
+// v: (C, L) fp32 -> planes [split][c][Lp] fp16 with the KEY index contiguous, zero for c >= C and l >= L
+__global__ void attn_split_v_h2_kernel(int C, int CP, int L, int Lp, const float *__restrict__ v, long long bs, int ld,
+                                       const float *__restrict__ amax, unsigned short *__restrict__ vt) {
+  const int l0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8, c = blockIdx.y, bi = blockIdx.z;
+  if (l0 >= Lp) return;
+  const float s = h2_scale_from_max(amax[2]);
+  unsigned short h[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split2h((c < C && l0 + j < L) ? v[(size_t)bi * bs + (size_t)c * ld + l0 + j] * s : 0.f, h[j], lo[j]);
+  unsigned short *base = vt + (size_t)bi * 2 * CP * Lp;
+  *reinterpret_cast<uint4 *>(base + ((size_t)0 * CP + c) * Lp + l0) = pack8(h);
+  *reinterpret_cast<uint4 *>(base + ((size_t)1 * CP + c) * Lp + l0) = pack8(lo);
+}
+
+#define VROW_H2 36  // fp16 per V row in LDS: 32 keys + 4 pad
+
+template <int CB>  // channel blocks of 32 (C <= 32 * CB)
+__global__ __launch_bounds__(256) void attn_flash_h2_kernel(int C, int L, int Lp, const uint4 *__restrict__ qs,
+                                                            const uint4 *__restrict__ ks,
+                                                            const unsigned short *__restrict__ vt,
+                                                            const float *__restrict__ amax, float *__restrict__ out,
+                                                            long long bs_o, int ld_o) {
+  constexpr int C8 = 4 * CB, CP = 32 * CB, KT = C8 * 2 * 32, VT = 2 * CP * 4;  // uint4 items per K / V tile
+  constexpr int KI = (KT + 255) / 256, VI = (VT + 255) / 256;
+  __shared__ uint4 Ksh[KT];                                       // [c8][split][key]
+  __shared__ __align__(16) unsigned short Vsh[2 * CP * VROW_H2];  // [split][c][VROW_H2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int bi = blockIdx.y;
+  const int i0 = (blockIdx.x * 4 + wave) * 32;  // this wave's first query
+  const uint4 *qb = qs + (size_t)bi * C8 * 2 * L, *kb = ks + (size_t)bi * C8 * 2 * L;
+  const unsigned short *vb = vt + (size_t)bi * 2 * CP * Lp;
+  const float sq = h2_scale_from_max(amax[0]), sk = h2_scale_from_max(amax[1]), sv = h2_scale_from_max(amax[2]);
+  // exp(x) = 2^(x log2 e): the q.k scale (a power of two, exact) is divided out inside the constant
+  const float ec = 1.44269504088896340736f / (sq * sk);
+
+  f16x8 qreg[2 * CB][2];
+#pragma unroll
+  for (int s = 0; s < 2 * CB; ++s)
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) qreg[s][sp] = as_f16x8(qb[((size_t)(2 * s + lh) * 2 + sp) * L + min(i0 + li, L - 1)]);
+  f32x16 o[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
+  float run_max = -INFINITY, run_sum = 0.f;
+
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  u32x4v kr[KI], vr[VI];
+  auto load_tile = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int e = tid + i * 256, key = e & 31, cs = min(e >> 5, KT / 32 - 1);
+      kr[i] = *reinterpret_cast<const u32x4v *>(&kb[(size_t)cs * L + min(j0 + key, L - 1)]);
+    }
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+      const int e = tid + i * 256, piece = e & 3, rowi = min(e >> 2, VT / 4 - 1);
+      vr[i] = *reinterpret_cast<const u32x4v *>(vb + ((size_t)rowi * Lp + min(j0 + piece * 8, Lp - 8)));
+    }
+  };
+  load_tile(0);
+  for (int j0 = 0; j0 < L; j0 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int e = tid + i * 256;
+      if (e < KT) *reinterpret_cast<u32x4v *>(&Ksh[e]) = kr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+      const int e = tid + i * 256, piece = e & 3, rowi = e >> 2;
+      if (e < VT) {
+        uint2 *d = reinterpret_cast<uint2 *>(Vsh + rowi * VROW_H2 + piece * 8);
+        d[0] = make_uint2(vr[i].x, vr[i].y);
+        d[1] = make_uint2(vr[i].z, vr[i].w);
+      }
+    }
+    __syncthreads();
+    if (j0 + 32 < L) load_tile(j0 + 32);
+
+    // S^T[j][i] = sum_c k[c][j] q[c][i]  (scaled by sq * sk); two accumulators: even / odd 16-channel steps
+    f32x16 st, st2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; st2[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 2 * CB; ++s) {
+      const f16x8 ah = as_f16x8(Ksh[((2 * s + lh) * 2 + 0) * 32 + li]), al = as_f16x8(Ksh[((2 * s + lh) * 2 + 1) * 32 + li]);
+      if (s & 1) {
+        st2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qreg[s][0], st2, 0, 0, 0);
+        st2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qreg[s][1], st2, 0, 0, 0);
+        st2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qreg[s][0], st2, 0, 0, 0);
+      } else {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qreg[s][0], st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qreg[s][1], st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qreg[s][0], st, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] += st2[r];
+    if (j0 + 32 > L) {  // only the last tile can hold keys beyond L (uniform branch)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (j0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= L) st[r] = -INFINITY;
+    }
+    float tile_max = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile_max = fmaxf(tile_max, st[r]);
+    tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 32, 64));
+    const float new_max = fmaxf(run_max, tile_max);
+    const float corr = __builtin_amdgcn_exp2f((run_max - new_max) * ec);  // exp(-inf) = 0 on the first tile
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] = __builtin_amdgcn_exp2f((st[r] - new_max) * ec);
+      psum += st[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    run_sum = run_sum * corr + psum;
+    run_max = new_max;
+
+    // P (x 2^14) as B operand: registers 8jj .. 8jj+7 -> the 8 k-slots of MFMA jj, split into fp16 pairs
+    f16x8 pb[2][2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      unsigned short h[8], lo[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) split2h(st[8 * jj + i] * 16384.f, h[i], lo[i]);
+      pb[jj][0] = as_f16x8(pack8(h));
+      pb[jj][1] = as_f16x8(pack8(lo));
+    }
+    const bool rescale = __any(corr != 1.0f);  // the running maximum moves in the first few tiles only
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      f32x16 acc = o[cb];
+      if (rescale) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= corr;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        f16x8 a[2];
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          const unsigned short *rowp = Vsh + (sp * CP + cb * 32 + li) * VROW_H2 + 16 * jj + 4 * lh;
+          const uint2 p0 = *reinterpret_cast<const uint2 *>(rowp), p1 = *reinterpret_cast<const uint2 *>(rowp + 8);
+          a[sp] = as_f16x8(make_uint4(p0.x, p0.y, p1.x, p1.y));
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], pb[jj][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], pb[jj][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], pb[jj][0], acc, 0, 0, 0);
+      }
+      o[cb] = acc;
+    }
+  }
+  const float inv = 1.0f / (run_sum * 16384.f * sv);  // sv and 2^14 are powers of two
+  float *ob = out + (size_t)bi * bs_o;
+  if (i0 + li < L) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (c < C) ob[(size_t)c * ld_o + i0 + li] = o[cb][r] * inv;
+      }
+  }
+}
+
+static inline int attn_cp(int c) { return c <= 32 ? 32 : 64; }
+static inline int attn_lp(int l) { return (l + 7) / 8 * 8; }
+
+extern "C" size_t bdm_attention_h2_workspace_bytes(int b, int c, int l) {
+  if (l <= 64 || c > 64) return 0;
+  const size_t cp = attn_cp(c), qk = (size_t)(cp / 8) * 2 * l * 16, v = 2 * cp * (size_t)attn_lp(l) * 2;
+  return (size_t)b * (2 * qk + v) + 64;
+}
+
+// out (b, c, l) = softmax_keys(q^T k) applied to v, for q, k, v (b, c, l) rows of stride ld_qkv; amax[0..2] = max |q|, |k|, |v| over
+// the whole call (bit patterns of non-negative floats, e.g. from bdm_pointwise_conv_gn's amax output).  64 < l, c <= 64.
+extern "C" int bdm_attention_core_h2(int b, int c, int l, const float *q, const float *k, const float *v, long long bs_qkv,
+                                     int ld_qkv, const float *amax, float *out, long long bs_o, int ld_o, void *workspace,
+                                     void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && c <= 64 && l > 64 && amax != nullptr && workspace != nullptr, "attention_core_h2: bad arguments");
+  if (b == 0) return BDM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int cp = attn_cp(c), c8 = cp / 8, lp = attn_lp(l);
+  const size_t qk_rec = (size_t)b * c8 * 2 * l;
+  uint4 *qs = reinterpret_cast<uint4 *>((reinterpret_cast<size_t>(workspace) + 15) & ~(size_t)15);
+  uint4 *ks = qs + qk_rec;
+  unsigned short *vt = reinterpret_cast<unsigned short *>(ks + qk_rec);
+  hipLaunchKernelGGL(attn_split_qk_h2_kernel, dim3(cdiv(l, 128), c8, 2 * b), dim3(128), 0, s, c, l, q, k, bs_qkv, ld_qkv, amax, qs, ks);
+  hipLaunchKernelGGL(attn_split_v_h2_kernel, dim3(cdiv(lp / 8, 64), cp, b), dim3(64), 0, s, c, cp, l, lp, v, bs_qkv, ld_qkv, amax, vt);
+  dim3 grid(cdiv(l, 128), b);
+  if (cp == 32)
+    hipLaunchKernelGGL(attn_flash_h2_kernel<1>, grid, dim3(256), 0, s, c, l, lp, (const uint4 *)qs, (const uint4 *)ks, vt, amax, out,
+                       bs_o, ld_o);
+  else
+    hipLaunchKernelGGL(attn_flash_h2_kernel<2>, grid, dim3(256), 0, s, c, l, lp, (const uint4 *)qs, (const uint4 *)ks, vt, amax, out,
+                       bs_o, ld_o);
+  return launch_status("attention_core_h2");
+}

@@ -45,6 +45,10 @@ struct PwGn {
   const float *x2;
   long long bsx2;
   int ldx2, k1;
+  // max |y| per block of `amax_rows` output rows (amax_rows % 32 == 0), over the whole call: bit patterns of non-negative
+  // floats combined with an integer atomicMax (order independent).  Zero on entry.  Feeds the fp16x3 attention's scales.
+  unsigned *amax;
+  int amax_rows;
 };
 
 template <int MI, int NI, bool ATRANS = false, int BK = 16, bool FOLD = false>
@@ -206,10 +210,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
   // ---- epilogue: C/D map  row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31.  The per-row terms (bias, per-shape bias)
   // and the residual are fetched in batches under workgroup-uniform branches (clamped addresses), then applied.
   float bs[MI][4], bq[MI][4];  // GroupNorm partials of this lane's 4-row blocks j: rows x*32 + 8j + 4lh .. +3
+  float am[MI];                // max |y| of this lane's part of row block x
 #pragma unroll
-  for (int x = 0; x < MI; ++x)
+  for (int x = 0; x < MI; ++x) {
+    am[x] = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { bs[x][j] = 0.f; bq[x][j] = 0.f; }
+  }
 #pragma unroll
   for (int x = 0; x < MI; ++x) {
     float badd[16], bb[16];
@@ -244,8 +251,16 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
           Yb[(size_t)m * ldy + n] = v;
           bs[x][r >> 2] += v;
           bq[x][r >> 2] += v * v;
+          am[x] = fmaxf(am[x], fabsf(v));
         }
       }
+    }
+  }
+  if (gn.amax != nullptr) {
+#pragma unroll
+    for (int x = 0; x < MI; ++x) {
+      const float mx = wave_max(am[x]);
+      if (lane == 0 && m0 + x * 32 < M && mx > 0.f) atomicMax(gn.amax + (m0 + x * 32) / gn.amax_rows, __float_as_uint(mx));
     }
   }
   if (gn.out_partial != nullptr) {
@@ -381,7 +396,7 @@ extern "C" int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w,
                                      int ld_x, const float *x2, long long bs_x2, int ld_x2, int k1, const float *bias, float *y,
                                      long long bs_y, int ld_y, const void *in_partial, int in_slices, int in_groups,
                                      const float *in_gamma, const float *in_beta, float in_eps, int out_groups,
-                                     void *out_partial, void *stream) {
+                                     void *out_partial, float *amax, int amax_rows, void *stream) {
   BDM_REQUIRE(b >= 0 && m >= 1 && k >= 1 && n >= 1, "pointwise_conv_gn: bad sizes m=%d k=%d n=%d", m, k, n);
   BDM_REQUIRE((long long)k * ld_x + n < (1ll << 31) && (long long)m * ldw + k < (1ll << 31),
               "pointwise_conv_gn: one operand spans more than 2^31 elements");
@@ -396,6 +411,10 @@ extern "C" int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w,
                 "pointwise_conv_gn: input fold needs <= 8 groups dividing k <= 1024 (k=%d groups=%d)", k, in_groups);
     gn.in_partial = (const double *)in_partial;
     gn.in_S = in_slices; gn.in_G = in_groups; gn.in_gamma = in_gamma; gn.in_beta = in_beta; gn.in_eps = in_eps;
+  }
+  if (amax != nullptr) {
+    BDM_REQUIRE(amax_rows >= 32 && amax_rows % 32 == 0, "pointwise_conv_gn: amax_rows must be a multiple of 32 (got %d)", amax_rows);
+    gn.amax = (unsigned *)amax; gn.amax_rows = amax_rows;
   }
   if (out_partial != nullptr) {
     const int cg = out_groups >= 1 && m % out_groups == 0 ? m / out_groups : 0;

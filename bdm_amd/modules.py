@@ -144,8 +144,14 @@ class Attention(nn.Module):
         B, C = x.shape[:2]
         flat = x.reshape(B, C, -1)
         w, b = self._qkv_params()
-        qkv = ops.pointwise_conv(flat, w, b)
-        h = ops.attention_core(qkv, C)
+        if flat.is_cuda and ops.attention_h2_ok(C, flat.shape[2]):
+            # fp16x3 attention: the projection GEMM leaves max |q|, |k|, |v| (the operands' power-of-two scales)
+            amax = ops.amax_slots(flat.device, 3)
+            qkv = ops.pointwise_conv_gn(flat, w, b, amax=amax, amax_rows=C)
+            h = ops.attention_core(qkv, C, amax=amax)
+        else:
+            qkv = ops.pointwise_conv(flat, w, b)
+            h = ops.attention_core(qkv, C)
         h = ops.pointwise_conv(h, self.out.weight, self.out.bias)
         ops.group_norm_(h, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, swish=True,
                         residual=flat)

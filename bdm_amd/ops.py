@@ -80,7 +80,7 @@ def gn_foldable(channels, groups):
     return groups <= 8 and cg >= 4 and (cg & (cg - 1)) == 0 and channels <= 1024
 
 
-def pointwise_conv_gn(x, weight, bias=None, out=None, fold_in=None, out_groups=None, x2=None):
+def pointwise_conv_gn(x, weight, bias=None, out=None, fold_in=None, out_groups=None, x2=None, amax=None, amax_rows=0):
     """1x1 convolution with GroupNorm folding (bdm_pointwise_conv_gn).  fold_in = (stats, gn) of a previous call: x is that
     call's raw output and Swish(GroupNorm(x)) is applied on the fly.  out_groups: also return the statistics of the output
     -> (y, (partial, slices, groups)).  shared_mlp.py:25-30."""
@@ -113,7 +113,7 @@ def pointwise_conv_gn(x, weight, bias=None, out=None, fold_in=None, out_groups=N
         stats = (out_p, slices, og)
     L.check(lib.bdm_pointwise_conv_gn(B, M, K, n, L.ptr(w), K, L.ptr(x), L.c_ll(bs_x), ld_x, L.ptr(x2p), L.c_ll(bs_x2), ld_x2, k1,
                                       L.ptr(bias), L.ptr(out), L.c_ll(bs_y), ld_y, L.ptr(in_p), in_s, in_g, L.ptr(in_gamma), L.ptr(in_beta), L.c_float(in_eps), og,
-                                      L.ptr(out_p), L.stream()), "pointwise_conv_gn")
+                                      L.ptr(out_p), L.ptr(amax), int(amax_rows), L.stream()), "pointwise_conv_gn")
     return (out, stats) if out_groups else out
 
 
@@ -324,16 +324,38 @@ def devoxelize_gate_add(norm_coords, grid, r, gate=None, add=None, out=None):
     return out
 
 
-ATTENTION_IMPL = os.environ.get("BDM_ATTENTION", "bf16x6")  # "fp32": the fp32-input MFMA flash kernel
+ATTENTION_IMPL = os.environ.get("BDM_ATTENTION", "fp16x3")  # "bf16x6": six-product kernel; "fp32": the fp32-input MFMA flash kernel
 
 
-def attention_core(qkv, C, impl=None):
-    """qkv (B, 3C, L): rows [0,C) = q, [C,2C) = k, [2C,3C) = v  ->  (B, C, L)."""
+def amax_slots(device, n):
+    """n zeroed floats (consecutive slots of the per-stream ring of _amax_slot)"""
+    while True:
+        first = _amax_slot(device)
+        ring = _amax_rings[(str(device), torch._C._cuda_getCurrentRawStream(first.device.index))]
+        if ring[1] - 1 + n <= ring[0].shape[0]:
+            start = ring[1] - 1
+            ring[1] = start + n
+            return ring[0][start:start + n]
+        ring[1] = ring[0].shape[0]  # not enough room left in this ring: take a fresh one
+
+
+def attention_h2_ok(C, l):
+    return ATTENTION_IMPL == "fp16x3" and l > 64 and C <= 64 and C % 32 == 0
+
+
+def attention_core(qkv, C, impl=None, amax=None):
+    """qkv (B, 3C, L): rows [0,C) = q, [C,2C) = k, [2C,3C) = v  ->  (B, C, L).  amax (3 floats: max |q|, |k|, |v| of the call,
+    from pointwise_conv_gn) selects the fp16x3 kernel."""
     B, _, l = qkv.shape
     out = torch.empty(B, C, l, dtype=torch.float32, device=qkv.device)
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     lib = L.lib()
-    nbytes = lib.bdm_attention_workspace_bytes(B, C, l) if (impl or ATTENTION_IMPL) == "bf16x6" else 0
+    if amax is not None:
+        ws = workspace(lib.bdm_attention_h2_workspace_bytes(B, C, l), qkv.device, "attention_h2")
+        L.check(lib.bdm_attention_core_h2(B, C, l, L.ptr(q), L.ptr(k), L.ptr(v), L.c_ll(qkv.stride(0)), qkv.stride(1), L.ptr(amax),
+                                          L.ptr(out), L.c_ll(C * l), l, L.ptr(ws), L.stream()), "attention_core_h2")
+        return out
+    nbytes = lib.bdm_attention_workspace_bytes(B, C, l) if (impl or ATTENTION_IMPL) in ("bf16x6", "fp16x3") else 0
     ws = workspace(nbytes, qkv.device, "attention") if nbytes else None
     L.check(lib.bdm_attention_core(B, C, l, L.ptr(q), L.ptr(k), L.ptr(v), L.c_ll(qkv.stride(0)), qkv.stride(1),
                                    L.ptr(out), L.c_ll(C * l), l, L.ptr(ws), L.stream()), "attention_core")

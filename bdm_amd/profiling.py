@@ -91,6 +91,7 @@ SPEC = {
     "bdm_group_norm_to_h2_stats": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", (4.0 + 4.0) * a[0] * a[1] * a[2])),
     "bdm_group_norm_to_s3": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", (4.0 + 4.0 + 6.0) * a[0] * a[1] * a[2])),
     "bdm_attention_core": ("attention", lambda a: a[:3], _attn),
+    "bdm_attention_core_h2": ("attention", lambda a: a[:3], lambda a: _f(4.0 * a[0] * a[1] * a[2] * a[2], 3)),
     # point operators (SURVEY.md 8d byte formulas)
     "bdm_furthest_point_sampling": ("furthest point sampling", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * (3 * a[1] + 4 * a[2]))),
     "bdm_gather_features_forward": ("furthest point sampling", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (2 * a[1] * a[3] + a[3]))),

@@ -152,6 +152,8 @@ int bdm_group_norm(int b, int c, int l, int groups, const float *x, long long bs
  *   bdm_pointwise_conv_gn: y = W x' + bias with
  *     x' = x, or (in_partial != NULL) x' = Swish(GroupNorm(x)) applied while the operand is staged, the statistics of x taken
  *          from the slice partials in_partial (b, in_groups, in_slices, 2 doubles) its producer left (in_groups <= 8, k <= 1024);
+ *     amax != NULL: amax[i] (ZERO on entry) receives max |y| over rows [i * amax_rows, (i + 1) * amax_rows) of the whole call
+ *          (amax_rows % 32 == 0): the scales of the fp16x3 attention, bdm_attention_core_h2;
  *     x2 != NULL: the operand is torch.cat([x (k1 rows), x2 (k - k1 rows)], dim=1) read in place (pointnet.py:108-110, the skip
  *          features of an FP module are never copied next to the interpolated ones);
  *     and (out_partial != NULL) the (sum, sum of squares) of y per (shape, group of m / out_groups channels) written as
@@ -164,7 +166,8 @@ int bdm_pointwise_conv_gn_slices(int b, int m, int k, int n, int groups);
 int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x, int ld_x,
                           const float *x2, long long bs_x2, int ld_x2, int k1, const float *bias, float *y, long long bs_y,
                           int ld_y, const void *in_partial, int in_slices, int in_groups, const float *in_gamma,
-                          const float *in_beta, float in_eps, int out_groups, void *out_partial, void *stream);
+                          const float *in_beta, float in_eps, int out_groups, void *out_partial, float *amax, int amax_rows,
+                          void *stream);
 int bdm_max_over_neighbors_gn(int b, int c, int m, int u, const float *x, const void *in_partial, int in_slices, int groups,
                               const float *gamma, const float *beta, float eps, float *y, long long bs_y, int ld_y,
                               void *stream);
@@ -224,6 +227,12 @@ size_t bdm_attention_workspace_bytes(int b, int c, int l);
 int bdm_attention_core(int b, int c, int l, const float *q, const float *k, const float *v,
                        long long bs_qkv, int ld_qkv, float *out, long long bs_o, int ld_o,
                        void *workspace, void *stream);
+/* fp16x3 form (half the matrix work of the bf16x6 kernel behind bdm_attention_core): needs amax[0..2] = max |q|, |k|, |v| of the
+ * call (the projection GEMM leaves them: bdm_pointwise_conv_gn amax) and a workspace of bdm_attention_h2_workspace_bytes;
+ * 64 < l, c <= 64 */
+size_t bdm_attention_h2_workspace_bytes(int b, int c, int l);
+int bdm_attention_core_h2(int b, int c, int l, const float *q, const float *k, const float *v, long long bs_qkv, int ld_qkv,
+                          const float *amax, float *out, long long bs_o, int ld_o, void *workspace, void *stream);
 
 /* nn.Conv3d(cin, cout, 3, padding=1) on (b, cin, r, r, r), r in {8, 16, 32} (pvconv.py:75-85).
  * packed_w = bdm_conv3d_pack_weights(w) : [27][cin][cout] from the module's (cout, cin, 3, 3, 3). */

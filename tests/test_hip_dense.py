@@ -102,6 +102,44 @@ def test_attention_core(ops, B, C, L):
     for impl in ("bf16x6", "fp32"):
         got = ops.attention_core(qkv.cuda(), C, impl=impl).cpu()
         assert rel(got, ref) < 5e-6, impl
+    if L > 64 and C <= 64:  # fp16x3 kernel: scales from max |q|, |k|, |v| (here computed on the host; the projection GEMM leaves them)
+        for scale in (1.0, 1e-4, 300.0):   # tensors far below / above fp16's comfortable range: the scales absorb it
+            qs = qkv.clone()
+            qs[:, 2 * C:] *= scale         # v
+            qs[:, :C] *= min(scale, 4.0)   # q (a large q.k would make the softmax one-hot: keep it moderate)
+            qd, kd, vd = qs[:, :C].double(), qs[:, C:2 * C].double(), qs[:, 2 * C:].double()
+            refs = torch.matmul(vd, torch.softmax(torch.matmul(qd.permute(0, 2, 1), kd), -1).permute(0, 2, 1)).float()
+            amax = torch.stack([qs[:, :C].abs().max(), qs[:, C:2 * C].abs().max(), qs[:, 2 * C:].abs().max()]).float().cuda()
+            got = ops.attention_core(qs.cuda(), C, amax=amax).cpu()
+            assert rel(got, refs) < 5e-6, ("fp16x3", scale)
+
+
+def test_projection_gemm_leaves_operand_maxima_for_the_fp16x3_attention(ops):
+    """bdm_pointwise_conv_gn amax output: max |y| per block of amax_rows rows over the whole call, and the Attention module on
+    the fp16x3 path vs the bf16x6 path."""
+    g = torch.Generator().manual_seed(3)
+    B, C, L = 3, 64, 1000
+    x = torch.randn(B, C, L, generator=g).cuda()
+    w, b = (torch.randn(3 * C, C, generator=g) / 8).cuda(), torch.randn(3 * C, generator=g).cuda()
+    amax = ops.amax_slots(x.device, 3)
+    y = ops.pointwise_conv_gn(x, w, b, amax=amax, amax_rows=C)
+    assert torch.equal(y, ops.pointwise_conv(x, w, b))
+    want = torch.stack([y[:, i * C:(i + 1) * C].abs().max() for i in range(3)])
+    assert torch.equal(amax, want)
+    from bdm_amd.modules import Attention
+    from bdm_amd.utils.procedural import fill_module_
+    att = fill_module_(Attention(64, 8, D=3).eval(), seed=2).cuda()
+    v = torch.randn(2, 64, 16, 16, 16, generator=g).cuda()
+    import bdm_amd.ops as O
+    old_impl = O.ATTENTION_IMPL
+    try:
+        O.ATTENTION_IMPL = "bf16x6"
+        ref = att(v).clone()
+        O.ATTENTION_IMPL = "fp16x3"
+        got = att(v)
+    finally:
+        O.ATTENTION_IMPL = old_impl
+    assert rel(got.cpu(), ref.cpu()) < 2e-6
 
 
 def test_small_ops(ops):
