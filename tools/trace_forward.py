@@ -9,7 +9,7 @@ from bdm_amd.model import get_model
 from bdm_amd.pvd import prepare_pvd_model
 from bdm_amd.utils.procedural import fill_module_
 
-B, N = 16, 4096
+B, N = int(os.environ.get("TB", 16)), int(os.environ.get("TN", 4096))
 which = sys.argv[1] if len(sys.argv) > 1 else "pc2"
 cfg = ProjectConfig(); cfg.dataset.max_points = N
 model = fill_module_(get_model(cfg).eval(), seed=1).cuda()
