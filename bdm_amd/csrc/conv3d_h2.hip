@@ -329,9 +329,11 @@ static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, f
   // tile = TX x TY grid rows x R cells = NI * NW column blocks of 32 voxels; 8 waves (two per SIMD) with NI = 2 keep the
   // matrix pipe fed while the other wave of the SIMD waits on LDS (measured vs 4 waves with NI = 4)
   int tx, ty, mi;
+  static int r8_small = -1;  // BDM_H2_R8_SMALL=1: 8^3 grids with 128-voxel tiles and 4 waves (twice the workgroups, out of phase)
+  if (r8_small < 0) { const char *e = getenv("BDM_H2_R8_SMALL"); r8_small = (e && e[0] == '1') ? 1 : 0; }
   if (r == 32) { tx = 2; ty = 8; }
   else if (r == 16) { tx = 2; ty = 16; }
-  else { tx = 4; ty = 8; }
+  else { tx = r8_small ? 2 : 4; ty = 8; }
   mi = (cout > 32 && r != 8) ? 2 : 1;
   const size_t smem = 16 * ((size_t)2 * (tx + 2) * (ty + 2) * (r + 2) + (size_t)H2_PAIRS * 4 * 32 * mi);
   dim3 grid((r / tx) * (r / ty), cdiv(cout, 32 * mi), b);
@@ -356,7 +358,8 @@ static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, f
     if (mi == 2) { if (w8) H2_LAUNCH(2, 2, 16, 2, 16, 8); else H2_LAUNCH(2, 4, 16, 2, 16, 4); }
     else { if (w8) H2_LAUNCH(1, 2, 16, 2, 16, 8); else H2_LAUNCH(1, 4, 16, 2, 16, 4); }
   } else {
-    if (w8) H2_LAUNCH(1, 1, 8, 4, 8, 8); else H2_LAUNCH(1, 2, 8, 4, 8, 4);
+    if (r8_small) H2_LAUNCH(1, 1, 8, 2, 8, 4);
+    else if (w8) H2_LAUNCH(1, 1, 8, 4, 8, 8); else H2_LAUNCH(1, 2, 8, 4, 8, 4);
   }
 #undef H2_LAUNCH
   return launch_status("conv3d_h2");
