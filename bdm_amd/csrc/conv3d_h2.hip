@@ -329,8 +329,11 @@ static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, f
   // tile = TX x TY grid rows x R cells = NI * NW column blocks of 32 voxels; 8 waves (two per SIMD) with NI = 2 keep the
   // matrix pipe fed while the other wave of the SIMD waits on LDS (measured vs 4 waves with NI = 4)
   int tx, ty, mi;
-  static int r8_small = -1;  // BDM_H2_R8_SMALL=1: 8^3 grids with 128-voxel tiles and 4 waves (twice the workgroups, out of phase)
-  if (r8_small < 0) { const char *e = getenv("BDM_H2_R8_SMALL"); r8_small = (e && e[0] == '1') ? 1 : 0; }
+  // 8^3 grids: 128-voxel tiles with 4 waves double the workgroup count; they win when the 256-voxel tiling cannot fill the chip
+  // (128 -> 128 at B = 16: 40.6 -> 30.4 us) and lose when it can (256 -> 256: 96 -> 114 us).  BDM_H2_R8_SMALL=0|1 overrides.
+  static int r8_env = -2;
+  if (r8_env == -2) { const char *e = getenv("BDM_H2_R8_SMALL"); r8_env = e ? (e[0] == '1' ? 1 : 0) : -1; }
+  const bool r8_small = r == 8 && (r8_env >= 0 ? r8_env == 1 : (long long)b * 2 * cdiv(cout, 32) < 256);
   if (r == 32) { tx = 2; ty = 8; }
   else if (r == 16) { tx = 2; ty = 16; }
   else { tx = r8_small ? 2 : 4; ty = 8; }
