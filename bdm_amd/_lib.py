@@ -87,18 +87,20 @@ def check(rc: int, what: str = ""):
 
 
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: no CPU path."""
+    """Device pointer of a tensor as a plain int (None -> NULL).  Refuses host tensors: no CPU path.  Every function has its
+    argtypes declared from the header (lib()), so ints and None convert to void* without a ctypes object per argument --
+    with ~1300 pointer arguments per denoiser forward that object construction was a measurable part of the enqueue time."""
     if t is None:
-        return ctypes.c_void_p(0)
+        return None
     if not t.is_cuda:
         raise BdmHipError("bdm_amd operators run on a HIP device only; got a CPU tensor (no CPU fallback)")
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 def stream():
     """hipStream_t of torch's current stream on the current device (the raw C accessors: `torch.cuda.current_stream()`
     costs ~8 us of Python per call, which at ~300 launches per denoiser forward was a quarter of the enqueue time)."""
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def f32(t):
@@ -111,6 +113,7 @@ def i32(t):
     return (t if t.dtype == torch.int32 else t.int()).contiguous()
 
 
-c_float = ctypes.c_float
-c_int = ctypes.c_int
-c_ll = ctypes.c_longlong
+# argument "casts" kept for readability at the call sites; the declared argtypes do the conversion
+c_float = float
+c_int = int
+c_ll = int
