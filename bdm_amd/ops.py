@@ -20,6 +20,9 @@ def _bcl(t):
     if t.dtype != torch.float32:
         raise L.BdmHipError(f"expected float32, got {t.dtype}")
     B, C = t.shape[0], t.shape[1]
+    if B * C > 0 and t.is_contiguous():  # the common case, without the stride walk below
+        l = t.numel() // (B * C)
+        return t, B, C, l, C * l, l
     l = 1
     for s in t.shape[2:]:
         l *= s
