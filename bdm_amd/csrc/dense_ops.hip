@@ -257,11 +257,22 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
     }
   }
   if (gn.amax != nullptr) {
+    // one atomic per (workgroup, row block) at most: waves combine through LDS, and a device-scope look at the slot first
+    // skips the atomic once larger maxima have been published (thousands of same-address atomics cost this GEMM 60 us)
+    __syncthreads();  // the operand tiles are dead: reuse As
 #pragma unroll
     for (int x = 0; x < MI; ++x) {
       const float mx = wave_max(am[x]);
-      if (lane == 0 && m0 + x * 32 < M && mx > 0.f) atomicMax(gn.amax + (m0 + x * 32) / gn.amax_rows, __float_as_uint(mx));
+      if (lane == 0) As[x * 4 + wave] = mx;
     }
+    __syncthreads();
+    if (tid < MI && m0 + tid * 32 < M) {
+      const float mx = fmaxf(fmaxf(As[tid * 4], As[tid * 4 + 1]), fmaxf(As[tid * 4 + 2], As[tid * 4 + 3]));
+      unsigned *slot = gn.amax + (m0 + tid * 32) / gn.amax_rows;
+      if (mx > 0.f && __float_as_uint(mx) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(slot, __float_as_uint(mx));
+    }
+    __syncthreads();
   }
   if (gn.out_partial != nullptr) {
     // (sum, sum of squares) of the tile per GroupNorm group: fixed order inside the lane, half-wave butterflies, the four
