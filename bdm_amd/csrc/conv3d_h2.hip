@@ -420,7 +420,7 @@ __global__ void to_h2_kernel(int C, int V, int G, int S, const float *__restrict
       if (partial) {
         const int g = ch / cg;
         t = (t - s_mean[g]) * s_rstd[g] * gamma[ch] + beta[ch];
-        if (act == 1) t = t / (1.0f + expf(-t));
+        if (act == 1) t = swishf(t);
       }
     }
     val[j] = t * act_scale;  // a power of two: exact
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void to_h2_stats_kernel(int C, int V, int G, i
         t = x[((size_t)bi * C + ch) * V + v];
         const int g = ch / cg - g_lo;
         t = (t - s_mean[g]) * s_rstd[g] * gamma[ch] + beta[ch];
-        if (act == 1) t = t / (1.0f + expf(-t));
+        if (act == 1) t = swishf(t);
       }
       val[j] = t * act_scale;  // a power of two: exact
       sat |= !(fabsf(val[j]) <= 65504.f);

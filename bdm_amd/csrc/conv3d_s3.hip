@@ -256,7 +256,7 @@ __global__ void to_s3_kernel(int C, int V, int G, int S, const float *__restrict
       if (partial) {
         const int g = ch / cg;
         t = (t - s_mean[g]) * s_rstd[g] * gamma[ch] + beta[ch];
-        if (act == 1) t = t / (1.0f + expf(-t));
+        if (act == 1) t = swishf(t);
       }
     }
     val[j] = t;

@@ -18,7 +18,6 @@
 
 using namespace bdm;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-__device__ __forceinline__ float swishf(float x) { return x / (1.0f + expf(-x)); }
 
 // =====================================================================================
 // Pointwise convolution = batched GEMM  Y[b] = W (M x K) * X[b] (K x N) + bias
