@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       for (int hh = 0; hh < 2; ++hh)
         for (int p = 0; p < MI; ++p)
           for (int j = 0; j < 4; ++j)
-            if ((p * 32 + 8 * j + 4 * hh) / gn_cg == tid) {
+            if (((p * 32 + 8 * j + 4 * hh) >> (__ffs(gn_cg) - 1)) == tid) {  // gn_cg is a power of two
               a += (double)red2[(((hh * MI + p) * 4 + j) * 2) + 0];
               qq += (double)red2[(((hh * MI + p) * 4 + j) * 2) + 1];
             }
@@ -464,6 +464,26 @@ __global__ __launch_bounds__(256) void to_h2_stats_kernel(int C, int V, int G, i
     s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
+  // the block's 8 channels as affine forms (a, b): x -> a x + b, one FMA per element in the loop below (no per-element group
+  // lookup, no integer division); channels >= C give 0
+  __shared__ float s_ab[8][2];
+  if (tid < 8) {
+    const int ch = c8 * 8 + tid;
+    float a = 0.f, bsh = 0.f;
+    if (ch < C) {
+      const int g = ch / cg - g_lo;
+      a = gamma[ch] * s_rstd[g];
+      bsh = beta[ch] - s_mean[g] * a;
+    }
+    s_ab[tid][0] = a;
+    s_ab[tid][1] = bsh;
+  }
+  __syncthreads();
+  float ca[8], cb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ca[j] = s_ab[j][0]; cb[j] = s_ab[j][1]; }
+  const float *xb = x + ((size_t)bi * C + c8 * 8) * V;
+  const int nch = min(8, C - c8 * 8);
   bool sat = false;
 #pragma unroll 2
   for (int it = 0; it < VB / 256; ++it) {
@@ -472,14 +492,8 @@ __global__ __launch_bounds__(256) void to_h2_stats_kernel(int C, int V, int G, i
     float val[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int ch = c8 * 8 + j;
-      float t = 0.f;
-      if (ch < C) {
-        t = x[((size_t)bi * C + ch) * V + v];
-        const int g = ch / cg - g_lo;
-        t = (t - s_mean[g]) * s_rstd[g] * gamma[ch] + beta[ch];
-        if (act == 1) t = swishf(t);
-      }
+      float t = xb[(size_t)min(j, nch - 1) * V + v] * ca[j] + cb[j];  // rows >= C: a = b = 0
+      if (act == 1) t = swishf(t);
       val[j] = t * act_scale;  // a power of two: exact
       sat |= !(fabsf(val[j]) <= 65504.f);
     }

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const
       for (int hh = 0; hh < 2; ++hh)
         for (int x = 0; x < MI; ++x)
           for (int j = 0; j < 4; ++j)
-            if (cg >= BM || (x * 32 + 8 * j + 4 * hh) / cg == tid) {
+            if (cg >= BM || ((x * 32 + 8 * j + 4 * hh) >> (__ffs(cg) - 1)) == tid) {  // cg is a power of two
               a += (double)red[4 * NB + ((hh * MI + x) * 4 + j) * 2 + 0];
               qq += (double)red[4 * NB + ((hh * MI + x) * 4 + j) * 2 + 1];
             }
