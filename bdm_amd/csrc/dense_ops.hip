@@ -572,11 +572,12 @@ __global__ __launch_bounds__(1024) void gn_onepass_kernel(int cg, int L, const f
   }
   const float rstd = (float)(1.0 / sqrt(block_sum((double)q, sh) / cnt + (double)eps));
   const int L4 = L / 4;
+  const float inv_L4 = 1.0f / (float)L4;  // e / L4 as a float product: exact for e < 2^20 (an integer division is ~40 instructions)
 #pragma unroll
   for (int i = 0; i < GN1_MAXV; ++i) {
     const int e = threadIdx.x + i * 1024;
     if (e < n4) {
-      const int ch = g * cg + e / L4;
+      const int ch = g * cg + (int)(((float)e + 0.5f) * inv_L4);
       const float ga = gamma[ch] * rstd, be = beta[ch] - mean * ga;
       float4 o;
       o.x = v[i].x * ga + be; o.y = v[i].y * ga + be; o.z = v[i].z * ga + be; o.w = v[i].w * ga + be;
