@@ -216,6 +216,7 @@ class PVConv(nn.Module):
     fold_gn1 = os.environ.get("BDM_FOLD_GN1", "1") == "1"  # GroupNorm-1 statistics from the sparse gather's epilogue
     fold_pf = os.environ.get("BDM_FOLD_PF", "1") == "1"  # point branch's GroupNorm folded into the devoxelisation kernel
     point_stream = os.environ.get("BDM_POINT_STREAM", "1") == "1"
+    point_stream_min = int(os.environ.get("BDM_POINT_STREAM_MIN", "8192"))  # B * N below which the branch stays on the main stream
     _streams = {}
 
     def voxel_plan_args(self):
@@ -231,7 +232,7 @@ class PVConv(nn.Module):
             if fold:
                 return self.point_features.run(features, fold_last=True)
             return self.point_features.run(features), None
-        if not (self.point_stream and features.is_cuda and features.shape[0] * features.shape[2] >= 8192):
+        if not (self.point_stream and features.is_cuda and features.shape[0] * features.shape[2] >= self.point_stream_min):
             pf, pending = run()
             return pf, None, pending
         dev = features.device
