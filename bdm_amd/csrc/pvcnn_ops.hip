@@ -80,6 +80,8 @@ __global__ void fps_kernel(int n, int m, const float *__restrict__ coords, int *
   float *sy = sx + n, *sz = sy + n;
 
   const unsigned Q = (unsigned)((n + 511) / 512);
+  const bool q_pow2 = (Q & (Q - 1u)) == 0u;
+  const unsigned q_shift = (unsigned)__ffs((int)Q) - 1u;
   float px[PPT], py[PPT], pz[PPT], dist[PPT];
   unsigned inv_rank[PPT];
 #pragma unroll
@@ -129,7 +131,8 @@ __global__ void fps_kernel(int n, int m, const float *__restrict__ coords, int *
       wr = wave_max_u32(sv.x == wd ? sv.y : 0u);
     }
     const unsigned rank = 0xFFFFFFFFu - wr;
-    cur = (int)((rank % Q) * 512u + rank / Q);
+    // rank -> point index; Q is a power of two for the usual sizes: shifts instead of two integer divisions per round
+    cur = q_pow2 ? (int)(((rank & (Q - 1u)) << 9) + (rank >> q_shift)) : (int)((rank % Q) * 512u + rank / Q);
     if (tid == 0) {
       out[j] = cur;
       if (cen) {
