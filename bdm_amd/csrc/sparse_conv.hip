@@ -292,16 +292,24 @@ bool bdm_sparse_features_lds_launch(int out_kind, int b, int c, int n, int r3, i
   const size_t smem = sizeof(float) * 8 * (size_t)n;
   *rc = BDM_OK;
   if (out_kind == 0) {
-    if (smem > 48 * 1024) {
+    static int granted0[16] = {0};  // per device: the attribute call costs microseconds of host time, once is enough
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (smem > 48 * 1024 && (dev < 0 || dev >= 16 || granted0[dev] < (int)smem)) {
       hipError_t e = hipFuncSetAttribute((const void *)sparse_vox_features_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return false;
+      if (dev >= 0 && dev < 16) granted0[dev] = (int)smem;
     }
     hipLaunchKernelGGL(sparse_vox_features_lds_kernel<0>, dim3(units * ksplit), dim3(T), smem, stream, c, n, r3, n_max, G, ksplit,
                        cells_per, features, bs_f, ld_f, cnt, start, sorted, occ_list, n_occ, out, amax);
   } else {
-    if (smem > 48 * 1024) {
+    static int granted1[16] = {0};  // per device: the attribute call costs microseconds of host time, once is enough
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (smem > 48 * 1024 && (dev < 0 || dev >= 16 || granted1[dev] < (int)smem)) {
       hipError_t e = hipFuncSetAttribute((const void *)sparse_vox_features_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) return false;
+      if (dev >= 0 && dev < 16) granted1[dev] = (int)smem;
     }
     hipLaunchKernelGGL(sparse_vox_features_lds_kernel<1>, dim3(units * ksplit), dim3(T), smem, stream, c, n, r3, n_max, G, ksplit,
                        cells_per, features, bs_f, ld_f, cnt, start, sorted, occ_list, n_occ, out, amax);
