@@ -273,7 +273,8 @@ class PVConv(nn.Module):
                 # 64-row tiles cut the padding; on the 16^3 / 32^3 levels the batched GEMM is bound by its 27x-expanded
                 # output and the extra operand split costs more than it saves (measured: tools/sparse_bench.py)
                 impl = self.sparse_gemm
-                if impl == "sparse_h2" and plan.n_max > 256:
+                wide16 = plan.n_max <= 1024 and conv1.in_channels >= 128 and conv1.out_channels >= 128  # 108 vs 121 us at 16^3
+                if impl == "sparse_h2" and plan.n_max > 256 and not wide16:
                     impl = "sparse_s3"
                 # with the fp16x3 second convolution the gather also leaves GroupNorm-1's statistics (no pass over the grid for them)
                 want_stats = (self.fold_gn1 and self.conv_impl == "fp16x3" and not getattr(self, "h2_saturated", False)
