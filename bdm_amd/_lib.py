@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("BDM_LIB_PATH") or os.path.join(_HERE, "libbdm_hip.so")  # BDM_LIB_PATH: A/B timing of two builds
 CSRC = os.path.join(_HERE, "csrc")
 _lib = None
+_keep = None  # list while tape.record() is active
 
 
 class BdmHipError(RuntimeError):
@@ -94,6 +95,8 @@ def ptr(t):
         return None
     if not t.is_cuda:
         raise BdmHipError("bdm_amd operators run on a HIP device only; got a CPU tensor (no CPU fallback)")
+    if _keep is not None:  # a launch tape is being recorded (tape.py): it owns every buffer whose address it holds
+        _keep.append(t)
     return t.data_ptr()
 
 

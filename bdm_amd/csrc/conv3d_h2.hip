@@ -334,10 +334,17 @@ static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, f
   static int r8_env = -2;
   if (r8_env == -2) { const char *e = getenv("BDM_H2_R8_SMALL"); r8_env = e ? (e[0] == '1' ? 1 : 0) : -1; }
   const bool r8_small = r == 8 && (r8_env >= 0 ? r8_env == 1 : (long long)b * 2 * cdiv(cout, 32) < 256);
+  // 16^3 / 32^3 grids of a few shapes (config C1 is ONE shape): 64-row x 512-voxel tiles give 16 / 64 workgroups, each walking
+  // the whole K loop with 12 MFMAs per step; 32-row (and at 16^3 256-voxel) tiles put 4x / 2x as many CUs on the problem with a
+  // 4x / 2x shorter chain per wave (B = 1: 114 -> 4x us at 16^3).  Same K order, same bits.  BDM_H2_SMALL=0|1 overrides.
+  static int small_env = -2;
+  if (small_env == -2) { const char *e = getenv("BDM_H2_SMALL"); small_env = e ? (e[0] == '1' ? 1 : 0) : -1; }
+  const long long big_wgs = (long long)b * (r == 32 ? 64 : 8) * cdiv(cout, 64);
+  const bool small = r != 8 && cout > 32 && (small_env >= 0 ? small_env == 1 : big_wgs < 128);
   if (r == 32) { tx = 2; ty = 8; }
-  else if (r == 16) { tx = 2; ty = 16; }
+  else if (r == 16) { tx = small ? 1 : 2; ty = 16; }
   else { tx = r8_small ? 2 : 4; ty = 8; }
-  mi = (cout > 32 && r != 8) ? 2 : 1;
+  mi = (cout > 32 && r != 8 && !small) ? 2 : 1;
   const size_t smem = 16 * ((size_t)2 * (tx + 2) * (ty + 2) * (r + 2) + (size_t)H2_PAIRS * 4 * 32 * mi);
   dim3 grid((r / tx) * (r / ty), cdiv(cout, 32 * mi), b);
   hipStream_t s = (hipStream_t)stream;
@@ -358,7 +365,8 @@ static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, f
     if (mi == 2) { if (w8) H2_LAUNCH(2, 2, 32, 2, 8, 8); else H2_LAUNCH(2, 4, 32, 2, 8, 4); }
     else { if (w8) H2_LAUNCH(1, 2, 32, 2, 8, 8); else H2_LAUNCH(1, 4, 32, 2, 8, 4); }
   } else if (r == 16) {
-    if (mi == 2) { if (w8) H2_LAUNCH(2, 2, 16, 2, 16, 8); else H2_LAUNCH(2, 4, 16, 2, 16, 4); }
+    if (small) H2_LAUNCH(1, 1, 16, 1, 16, 8);
+    else if (mi == 2) { if (w8) H2_LAUNCH(2, 2, 16, 2, 16, 8); else H2_LAUNCH(2, 4, 16, 2, 16, 4); }
     else { if (w8) H2_LAUNCH(1, 2, 16, 2, 16, 8); else H2_LAUNCH(1, 4, 16, 2, 16, 4); }
   } else {
     if (r8_small) H2_LAUNCH(1, 1, 8, 2, 8, 4);

@@ -240,6 +240,9 @@ def _timestep_list(scheduler, num_inference_steps, start_time, end_time):
 # B=1, identical GPU time at B=16: tools/time_loop.py), so the eager loop stays the default.
 GRAPH_STEPS = os.environ.get("BDM_GRAPH", "0") == "1"
 GRAPH_MIN_STEPS = 8  # shorter segments do not amortise the capture
+# BDM_TAPE: "auto" (default) replays a recorded launch tape (tape.py) for host-bound problem sizes, "1" always, "0" never.
+TAPE_STEPS = os.environ.get("BDM_TAPE", "auto")
+TAPE_MAX_POINTS = int(os.environ.get("BDM_TAPE_MAX_POINTS", "16384"))
 
 
 class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
@@ -260,9 +263,12 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
     _step_kwargs = {}  # e.g. {"eta": 0.0} for DDIM (the reference forwards eta only to schedulers that accept it)
 
     def _denoise_loop(self, x_t, camera, image_rgb, mask, scheduler, timesteps, generator=None):
-        if (GRAPH_STEPS and x_t.is_cuda and len(timesteps) >= GRAPH_MIN_STEPS and type(scheduler) is DDPMScheduler
-                and not self._step_kwargs):
+        static_ok = (x_t.is_cuda and len(timesteps) >= GRAPH_MIN_STEPS and type(scheduler) is DDPMScheduler
+                     and not self._step_kwargs and getattr(scheduler, "streams", None) is None)
+        if GRAPH_STEPS and static_ok:
             return self._denoise_loop_graph(x_t, camera, image_rgb, mask, scheduler, timesteps, generator)
+        if static_ok and (TAPE_STEPS == "1" or (TAPE_STEPS == "auto" and x_t.shape[0] * x_t.shape[1] <= TAPE_MAX_POINTS)):
+            return self._denoise_loop_tape(x_t, camera, image_rgb, mask, scheduler, timesteps, generator)
         B = x_t.shape[0]
         for t in timesteps:
             tt = torch.full((B,), t, dtype=torch.int64, device=x_t.device)
@@ -302,7 +308,7 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
         cur.wait_stream(warm)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with ops.static_step(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
             step()
         g["graph"] = graph
         self._graph_cache = g
@@ -324,6 +330,51 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
             if t > 0:
                 g["noise"].copy_(scheduler._noise(g["x"].shape, x_t.device, generator))
             g["graph"].replay()
+        return g["x"].clone()
+
+    # ---- launch-tape form of the reverse loop (tape.py) --------------------------------------------------------
+    # Same static buffers as the graph form; the step is RECORDED while it runs eagerly (second step of the loop: the
+    # first one leaves every lazy cache -- weight packs, workspaces, kernel attributes -- behind it) and later steps
+    # replay the flat list of C-ABI calls: ~3 us of host time per launch instead of ~15.  Default for small problems,
+    # which are bound by the host (B * N <= TAPE_MAX_POINTS); larger ones are bound by the GPU and stay eager (the
+    # tape keeps every intermediate buffer of a step alive).
+    def _denoise_loop_tape(self, x_t, camera, image_rgb, mask, scheduler, timesteps, generator=None):
+        from . import tape as T
+        feat, _ = self.conditioning_image(image_rgb, mask)
+        dev, B = x_t.device, x_t.shape[0]
+        key = (tuple(x_t.shape), str(dev), id(camera), id(scheduler), scheduler.num_inference_steps,
+               torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+        g = getattr(self, "_tape_cache", None)
+        if g is None or g["key"] != key or g["feat"] is not feat or g["image"] is not image_rgb:
+            g = {"key": key, "feat": feat, "image": image_rgb, "camera": camera, "tape": None, "warm": False, "off": None,
+                 "x": torch.empty_like(x_t, memory_format=torch.contiguous_format), "noise": torch.zeros_like(x_t),
+                 "t": torch.zeros(B, dtype=torch.int64, device=dev), "coef": torch.ones(5, dtype=torch.float32, device=dev)}
+            self._tape_cache = g
+
+        def step():
+            x_in = self.get_input_with_conditioning(g["x"], camera=camera, image_rgb=image_rgb, mask=mask, t=g["t"])
+            eps = self.point_cloud_model(x_in, g["t"])
+            scheduler.step_dev(eps, g["coef"], g["x"], g["noise"], out=g["x"])
+
+        table = scheduler.coefficient_table(dev)
+        g["x"].copy_(x_t)
+        for t in timesteps:
+            g["t"].fill_(t)
+            g["coef"].copy_(table[t])
+            if t > 0:
+                g["noise"].copy_(scheduler._noise(g["x"].shape, dev, generator))
+            if g["tape"] is not None:
+                g["tape"].replay()
+            elif g["warm"] and g["off"] is None:
+                with ops.static_step(), T.record() as tp:
+                    step()
+                if tp.broken:
+                    g["off"] = tp.broken  # stay eager (on the static buffers) and say why: model._tape_cache["off"]
+                else:
+                    g["tape"] = tp
+            else:
+                step()
+                g["warm"] = True
         return g["x"].clone()
 
     @torch.no_grad()

@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from . import functional as F
 from . import ops
+from . import tape
 
 __all__ = ["Swish", "SharedMLP", "SE3d", "Voxelization", "Attention", "PVConv", "BallQuery",
            "PointNetSAModule", "PointNetFPModule"]
@@ -239,11 +240,11 @@ class PVConv(nn.Module):
         side = PVConv._streams.get(dev)
         if side is None:
             side = PVConv._streams[dev] = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
+        tape.wait_stream(side, torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             pf, pending = run()
             ev = torch.cuda.Event()
-            ev.record(side)
+            tape.record_event(ev, side)
         return pf, ev, pending
 
     def forward(self, inputs):
@@ -307,16 +308,16 @@ class PVConv(nn.Module):
                         # this is only worth it where the forward is launch-bound (opt-in: BDM_SE_IN_DEVOX=1)
                         mean, coef = ops.se_means_gn(v, stats, gn2)
                         if pf_ready is not None:
-                            pf_ready.wait()
+                            tape.wait_event(pf_ready)
                         return ops.devoxelize_gn_se_add(norm_coords, v, coef, r, mean, w1, w2, add=pf), coords, temb
                     if pf_pending is not None:
                         if pf_ready is not None:
-                            pf_ready.wait()  # the branch's statistics are read by the SE kernel
+                            tape.wait_event(pf_ready)  # the branch's statistics are read by the SE kernel
                         gate, coef, pf_coef = ops.se_gate_gn(v, stats, gn2, w1, w2, pf=pf_pending, n_points=pf.shape[2])
                         return ops.devoxelize_gn_gate_add(norm_coords, v, coef, r, gate=gate, add=pf, add_coef=pf_coef), coords, temb
                     gate, coef = ops.se_gate_gn(v, stats, gn2, w1, w2)
                     if pf_ready is not None:
-                        pf_ready.wait()
+                        tape.wait_event(pf_ready)
                     return ops.devoxelize_gn_gate_add(norm_coords, v, coef, r, gate=gate, add=pf), coords, temb
                 v = ops.conv3d_h2(xh, self._packed_weight(conv2, "fp16x3"), conv2.bias, conv2.in_channels, conv2.out_channels, r)
             else:
@@ -327,7 +328,7 @@ class PVConv(nn.Module):
                 v = att(v)
             gate = se.gate(v) if se is not None else None
             if pf_ready is not None:
-                pf_ready.wait()  # the current stream waits for the point branch
+                tape.wait_event(pf_ready)  # the current stream waits for the point branch
             return ops.devoxelize_gate_add(norm_coords, v, r, gate=gate, add=pf), coords, temb
         # the first conv's input is the freshly voxelised cloud: on the 32^3 grids (<= 12.5 % occupied cells) the
         # occupancy-skipping variant wins (measured 1.3-1.4x); on 16^3 / 8^3 the dense kernel is as fast or faster
@@ -344,7 +345,7 @@ class PVConv(nn.Module):
             v = att(v)
         gate = se.gate(v) if se is not None else None
         if pf_ready is not None:
-            pf_ready.wait()
+            tape.wait_event(pf_ready)
         fused = ops.devoxelize_gate_add(norm_coords, v, r, gate=gate, add=pf)
         return fused, coords, temb
 
@@ -423,7 +424,7 @@ class PointNetSAModule(nn.Module):
         # sa_layers shared between networks, must never leave a plan behind for other coordinates)
         if planned is not None and planned[3] is coords:
             centers_coords, idx, event, _ = planned
-            event.wait()  # the current stream waits for the side stream's sampler
+            tape.wait_event(event)  # the current stream waits for the side stream's sampler
         else:
             centers_coords, idx = self.plan(coords)
         grouped, g_t = self.groupers[0](coords, centers_coords, temb, features, neighbor_indices=idx)

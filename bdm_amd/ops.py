@@ -10,6 +10,7 @@ import os
 import torch
 
 from . import _lib as L
+from . import tape
 
 
 def _bcl(t):
@@ -685,6 +686,25 @@ def sparse_conv_pack_h2(weight):
 
 SPARSE_Y_BYTES = int(float(os.environ.get("BDM_SPARSE_Y_MB", "256")) * 2 ** 20)
 _amax_rings = {}
+# != 0 while a step is being recorded for replay (hipGraph capture or launch tape: model.static_step).  A replayed step finds
+# its amax slots as the previous replay left them, so the recording must contain the zero-fill: it never takes slots of a
+# ring that was zeroed outside it (and the eager path never takes slots of a recorded ring).
+_static_epoch = 0
+_static_epochs = 0
+
+
+class static_step:
+    """`with ops.static_step():` around the capture / recording of a step that will be replayed on the same buffers."""
+
+    def __enter__(self):
+        global _static_epoch, _static_epochs
+        _static_epochs += 1
+        _static_epoch = _static_epochs
+
+    def __exit__(self, *exc):
+        global _static_epoch
+        _static_epoch = 0
+        return False
 
 
 def _amax_slot(device):
@@ -693,9 +713,9 @@ def _amax_slot(device):
     dev = torch.device(device)
     key = (str(device), torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch._C._cuda_getDevice()))
     ring = _amax_rings.get(key)
-    if ring is None or ring[1] >= ring[0].shape[0]:
+    if ring is None or ring[1] >= ring[0].shape[0] or ring[2] != _static_epoch:
         # a NEW buffer (not an in-place refill): slots handed out earlier may still be read by enqueued kernels
-        ring = [torch.zeros(256, dtype=torch.float32, device=device), 0]
+        ring = [torch.zeros(256, dtype=torch.float32, device=device), 0, _static_epoch]
         _amax_rings[key] = ring
     slot = ring[0][ring[1]:ring[1] + 1]
     ring[1] += 1
@@ -723,7 +743,7 @@ def voxel_plan(coords, r, eps=0.0):
         ready = getattr(p, "ready", None)
         if ready is not None:  # planned ahead on a side stream (pvcnn.plan_sampling_chain): the current stream waits for it
             if torch.cuda.current_stream(coords.device) != getattr(p, "stream", None):
-                ready.wait()
+                tape.wait_event(ready)
                 p.ready = None
         return p
     lib = L.lib()

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import tape
 from .modules import Attention, PointNetFPModule, PointNetSAModule, PVConv, SharedMLP
 
 SA_BLOCKS = [
@@ -134,14 +135,14 @@ def plan_sampling_chain(sa_layers, coords):
     side = _side_streams.get(coords.device)
     if side is None:
         side = _side_streams[coords.device] = torch.cuda.Stream(device=coords.device)
-    side.wait_stream(cur)
+    tape.wait_stream(side, cur)
     with torch.cuda.stream(side):
         c = coords
         for li, blocks in enumerate(sa_layers):
             sa = blocks[-1] if isinstance(blocks, nn.Sequential) else blocks
             centers, idx = sa.plan(c)
             ev = torch.cuda.Event()
-            ev.record(side)
+            tape.record_event(ev, side)
             sa._planned = (centers, idx, ev, c)
             c = centers
             # the voxel plan of the NEXT level's PVConvs (sort of the centres into cells, occupied-cell lists) is geometry
@@ -152,7 +153,7 @@ def plan_sampling_chain(sa_layers, coords):
             if args is not None:
                 plan = ops.voxel_plan(c, *args)
                 plan.ready = torch.cuda.Event()
-                plan.ready.record(side)
+                tape.record_event(plan.ready, side)
 
 
 def encode(sa_layers, global_att, inputs, t_emb):

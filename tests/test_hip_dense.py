@@ -288,6 +288,28 @@ def test_conv3d_fp16x3_has_fp32_accuracy(ops, cin, cout, r, kind):
     assert e3 < 2e-6 and e3 < 4 * e32 + 1e-7, (e3, e32)
 
 
+@pytest.mark.parametrize("cin,cout,r", [(64, 64, 32), (128, 128, 16), (64, 128, 16), (256, 256, 8)])
+def test_conv3d_fp16x3_tile_choice_does_not_change_the_bits(ops, cin, cout, r):
+    """The launcher picks smaller tiles when a few shapes cannot fill the chip (conv3d_h2.hip: 32-row / 256-voxel tiles at 16^3
+    and 32^3, 128-voxel tiles at 8^3): a shape convolved alone and inside a batch of 10 gives the same bits, and the GroupNorm
+    statistics the epilogue leaves agree to fp32 rounding of the per-wave sums (a different number of slices)."""
+    B = 10
+    g = torch.Generator().manual_seed(cin + cout + r)
+    x = torch.randn(B, cin, r ** 3, generator=g).cuda()
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    packed = ops.conv3d_h2_pack(w)
+    full, (ws, slices) = ops.conv3d_h2_gn(ops.to_h2(x, scale=16.0), packed, b, cin, cout, r)
+    one, (ws1, slices1) = ops.conv3d_h2_gn(ops.to_h2(x[3:4].contiguous(), scale=16.0), packed, b, cin, cout, r)
+    assert torch.equal(full[3:4], one)
+    assert torch.equal(ops.conv3d_h2(ops.to_h2(x[3:4].contiguous(), scale=16.0), packed, b, cin, cout, r), one)
+    st = ws.view(torch.float64)[:B * 8 * slices * 2].view(B, 8, slices, 2).sum(2)
+    st1 = ws1.view(torch.float64)[:8 * slices1 * 2].view(1, 8, slices1, 2).sum(2)
+    assert torch.allclose(st[3:4], st1, rtol=1e-7, atol=0)  # per-wave fp32 sums of 32 values, then fp64
+    ref = one.double().view(8, -1)
+    assert torch.allclose(st1[0, :, 0], ref.sum(1), rtol=1e-6, atol=1e-3) and torch.allclose(st1[0, :, 1], (ref * ref).sum(1), rtol=1e-6)
+
+
 def test_h2_producer(ops):
     """GroupNorm + Swish -> H2 reconstructs ((hi + lo) / 16) the fp32 values of the fp32 GroupNorm kernel."""
     g = torch.Generator().manual_seed(18)

@@ -97,3 +97,42 @@ def test_graph_replay_equals_eager_loop(hip, monkeypatch):
     assert torch.equal(eager, graphed)
     again = run(True)  # second use replays the cached graph
     assert torch.equal(eager, again)
+
+
+def test_launch_tape_replay_equals_eager_loop(hip, monkeypatch):
+    """The launch-tape form of the reverse loop (bdm_amd/tape.py: one step recorded as a flat list of C-ABI calls, replayed
+    per timestep) gives the bits of the eager loop, records every launch of the step, and is re-used by the next trajectory."""
+    import bdm_amd.model as M
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.utils.procedural import fill_module_
+    B, N, steps = 2, 1024, 12
+    cfg = ProjectConfig()
+    cfg.dataset.max_points = N
+    model = fill_module_(M.get_model(cfg).eval(), seed=3).cuda()
+    batch = next(iter(SyntheticShapes(range(B), B, num_points=N))).to("cuda")
+    x0 = torch.randn(B, N, 3, generator=torch.Generator().manual_seed(5)).cuda()
+    noise = [torch.randn(B, N, 3, generator=torch.Generator().manual_seed(100 + i)).cuda() for i in range(steps)]
+
+    def run(mode):
+        monkeypatch.setattr(M, "TAPE_STEPS", mode)
+        it = iter(noise)
+        model.scheduler.noise_source = lambda shape, device: next(it)
+        try:
+            return model.interaction_sample(x0.clone(), batch.camera, batch.image_rgb, None, start_time=500,
+                                            end_time=500 - steps).cpu()
+        finally:
+            model.scheduler.noise_source = None
+
+    eager = run("0")
+    assert getattr(model, "_tape_cache", None) is None
+    taped = run("1")
+    g = model._tape_cache
+    assert g["off"] is None, g["off"]
+    assert g["tape"] is not None and len(g["tape"]) > 150  # the whole step is on the tape
+    print("launch tape:", len(g["tape"]), "entries,", len(g["tape"].torch_ops), "torch operators:", sorted(set(g["tape"].torch_ops)))
+    assert torch.equal(eager, taped)
+    tape_before = g["tape"]
+    again = run("auto")  # B * N is below the host-bound threshold: the default takes the tape, and re-uses the recorded one
+    assert model._tape_cache["tape"] is tape_before
+    assert torch.equal(eager, again)

@@ -12,8 +12,10 @@ cfg = ProjectConfig(); cfg.dataset.max_points = N
 model = fill_module_(M.get_model(cfg).eval(), seed=1).cuda()
 batch = next(iter(SyntheticShapes(range(B), B, num_points=N))).to("cuda")
 x = torch.randn(B, N, 3, device="cuda")
-for graph in (False, True, False, True):
-    M.GRAPH_STEPS = graph
+M.TAPE_STEPS = "0"
+for graph in (False, True, False, "tape", "tape"):
+    M.GRAPH_STEPS = graph is True
+    M.TAPE_STEPS = "1" if graph == "tape" else "0"
     model.interaction_sample(x.clone(), batch.camera, batch.image_rgb, None, start_time=900, end_time=890)  # warm / capture
     torch.cuda.synchronize(); t0 = time.perf_counter(); c0 = time.process_time()
     model.interaction_sample(x.clone(), batch.camera, batch.image_rgb, None, start_time=800, end_time=800 - steps)
