@@ -50,8 +50,11 @@ struct PwGn {
   int amax_rows;
 };
 
+// amdgpu_waves_per_eu(2): with an occupancy target of two waves per SIMD the register allocator stops hoarding (2 x 2 tile with
+// the folded GroupNorm: 220 -> 160 VGPRs, i.e. three workgroups per CU instead of two; the 32768-column SA layer 101 -> 79 us);
+// a target of three spills the 32- and 64-deep K variants.
 template <int MI, int NI, bool ATRANS = false, int BK = 16, bool FOLD = false>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, int N, const float *__restrict__ W, int ldw,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void pw_gemm_kernel(int M, int K, int N, const float *__restrict__ W, int ldw,
                                                       long long bsw, const int *__restrict__ m_count,
                                                       const float *__restrict__ X, long long bsx, int ldx,
                                                       const float *__restrict__ bias,

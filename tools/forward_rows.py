@@ -34,7 +34,11 @@ for r in rows:
     if flt in r["function"]:
         per_fwd = r["est_total_ms"] * 1e3 / iters
         tot += per_fwd
-        print(f"{r['function']:34s} {str(tuple(r['shape'])):28s} x{r['calls'] // iters:3d}  {r['avg_us']:8.1f} us  {per_fwd:8.1f} us/forward")
+        extra = ""
+        if "pointwise" in r["function"] and len(r["shape"]) >= 4:  # (b, m, k, n): GEMM rate and the bytes of one read of x + one write of y
+            b_, m_, k_, n_ = r["shape"][:4]
+            extra = f"  {2.0 * b_ * m_ * k_ * n_ / r['avg_us'] / 1e6:6.1f} TF/s  {4.0 * b_ * n_ * (k_ + m_) / r['avg_us'] / 1e3:7.1f} GB/s"
+        print(f"{r['function']:34s} {str(tuple(r['shape'])):28s} x{r['calls'] // iters:3d}  {r['avg_us']:8.1f} us  {per_fwd:8.1f} us/forward{extra}")
 print(f"total {tot:.1f} us/forward over {sum(r['calls'] for r in rows if flt in r['function']) // iters} launches")
 if not flt:
     for c in classes:
