@@ -409,10 +409,15 @@ class PointNetSAModule(nn.Module):
         """Geometry-only part of the module (furthest point sampling + ball query): depends on the coordinates
         alone, so the denoiser's encoder runs it for all levels on a side stream while the first PVConvs compute."""
         coords = coords.contiguous()
-        centers_coords = F.furthest_point_sample(coords, self.num_centers)
+        centers_coords = self.sample(coords)
+        return centers_coords, self.query(coords, centers_coords)
+
+    def sample(self, coords):
+        return F.furthest_point_sample(coords, self.num_centers)
+
+    def query(self, coords, centers_coords):
         g = self.groupers[0]
-        idx = F.ball_query(centers_coords, coords, g.radius, g.num_neighbors)
-        return centers_coords, idx
+        return F.ball_query(centers_coords, coords, g.radius, g.num_neighbors)
 
     def forward(self, inputs):
         features, coords, temb = inputs
@@ -420,6 +425,9 @@ class PointNetSAModule(nn.Module):
         assert len(self.groupers) == 1, "multi-radius grouping is not used by the denoisers"
         planned = getattr(self, "_planned", None)
         self._planned = None
+        if planned is not None and callable(planned[0]):  # deferred rest of the sampler chain (pvcnn.plan_sampling_chain)
+            planned = planned[0]() if planned[1] is coords else None
+            self._planned = None
         # a plan is valid for the very coordinate tensor it was computed from (a forward that aborted midway, or
         # sa_layers shared between networks, must never leave a plan behind for other coordinates)
         if planned is not None and planned[3] is coords:

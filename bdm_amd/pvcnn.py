@@ -125,35 +125,54 @@ SIDE_PLAN = os.environ.get("BDM_SIDE_PLAN", "1") == "1"  # voxel plans of levels
 # per-launch host cost came down it pays even for one small shape (B=1, N=1024: 3.48 -> 3.30 ms; B=4: 3.86 -> 3.42 ms), where
 # furthest point sampling is a fifth of the forward.  (The PVConv point branch keeps its 8192-point threshold: measured slower below.)
 SIDE_STREAM_MIN_POINTS = int(os.environ.get("BDM_SIDE_STREAM_MIN", "0"))
+DEFER_CHAIN = os.environ.get("BDM_DEFER_CHAIN", "1") == "1"  # levels 1.. of the sampler chain enqueued when the first SA module is reached
 
 
 def plan_sampling_chain(sa_layers, coords):
     """Furthest point sampling + ball query of ALL set-abstraction levels depend on the input coordinates only
     (1 356 strictly sequential sampler rounds on 16 CUs).  They are enqueued on a side stream so that they overlap
-    the level-0 PVConvs; each SA module waits on its own event."""
+    the level-0 PVConvs; each SA module waits on its own event.
+
+    Host order matters when the host, not the GPU, paces the step (one small shape): only the first level's sampler -- the
+    long pole -- is enqueued up front; the other ~19 launches of the chain follow when the first SA module is reached, i.e.
+    AFTER the host has fed the main stream its first PVConvs (they could not start before that sampler finishes anyway)."""
     cur = torch.cuda.current_stream()
     side = _side_streams.get(coords.device)
     if side is None:
         side = _side_streams[coords.device] = torch.cuda.Stream(device=coords.device)
     tape.wait_stream(side, cur)
+    first = sa_layers[0][-1] if isinstance(sa_layers[0], nn.Sequential) else sa_layers[0]
     with torch.cuda.stream(side):
-        c = coords
-        for li, blocks in enumerate(sa_layers):
-            sa = blocks[-1] if isinstance(blocks, nn.Sequential) else blocks
-            centers, idx = sa.plan(c)
-            ev = torch.cuda.Event()
-            tape.record_event(ev, side)
-            sa._planned = (centers, idx, ev, c)
-            c = centers
-            # the voxel plan of the NEXT level's PVConvs (sort of the centres into cells, occupied-cell lists) is geometry
-            # too: one single-workgroup-per-shape kernel that would otherwise sit on the main stream's critical path
-            nxt = sa_layers[li + 1] if li + 1 < len(sa_layers) else None
-            pv = nxt[0] if isinstance(nxt, nn.Sequential) and hasattr(nxt[0], "voxel_plan_args") else None
-            args = pv.voxel_plan_args() if (pv is not None and SIDE_PLAN) else None
-            if args is not None:
-                plan = ops.voxel_plan(c, *args)
-                plan.ready = torch.cuda.Event()
-                tape.record_event(plan.ready, side)
+        c0 = coords.contiguous()
+        centers0 = first.sample(c0)
+
+    def rest():
+        with torch.cuda.stream(side):
+            c, centers = c0, centers0
+            for li, blocks in enumerate(sa_layers):
+                sa = blocks[-1] if isinstance(blocks, nn.Sequential) else blocks
+                if li > 0:
+                    centers = sa.sample(c)
+                idx = sa.query(c, centers)
+                ev = torch.cuda.Event()
+                tape.record_event(ev, side)
+                sa._planned = (centers, idx, ev, c if li > 0 else coords)
+                c = centers
+                # the voxel plan of the NEXT level's PVConvs (sort of the centres into cells, occupied-cell lists) is geometry
+                # too: one single-workgroup-per-shape kernel that would otherwise sit on the main stream's critical path
+                nxt = sa_layers[li + 1] if li + 1 < len(sa_layers) else None
+                pv = nxt[0] if isinstance(nxt, nn.Sequential) and hasattr(nxt[0], "voxel_plan_args") else None
+                args = pv.voxel_plan_args() if (pv is not None and SIDE_PLAN) else None
+                if args is not None:
+                    plan = ops.voxel_plan(c, *args)
+                    plan.ready = torch.cuda.Event()
+                    tape.record_event(plan.ready, side)
+        return first._planned
+
+    if DEFER_CHAIN:
+        first._planned = (rest, coords)
+    else:
+        rest()
 
 
 def encode(sa_layers, global_att, inputs, t_emb):
