@@ -20,7 +20,7 @@ from . import ops
 from .cameras import PerspectiveCameras, Pointclouds, join_cameras
 from .feature_model import FeatureModel
 from .pvcnn import PVCNN2_PC2, PVCNN_fuse
-from .schedulers import DDPMScheduler, make_schedulers_map
+from .schedulers import DDIMScheduler, DDPMScheduler, make_schedulers_map
 
 
 def compute_distance_transform(mask: Tensor):
@@ -260,14 +260,21 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
         self.point_cloud_model = PointCloudModel(model_type=point_cloud_model, embed_dim=point_cloud_model_embed_dim,
                                                  in_channels=self.in_channels, out_channels=self.out_channels)
 
+    def _weights_signature(self):
+        """Changes whenever a denoiser parameter is rewritten or replaced: a recorded step (graph or tape) holds the addresses
+        of the weight packs derived from them, so it must not outlive the weights it was recorded with."""
+        return hash(tuple((p.data_ptr(), p._version) for p in self.point_cloud_model.parameters()))
+
     _step_kwargs = {}  # e.g. {"eta": 0.0} for DDIM (the reference forwards eta only to schedulers that accept it)
 
     def _denoise_loop(self, x_t, camera, image_rgb, mask, scheduler, timesteps, generator=None):
-        static_ok = (x_t.is_cuda and len(timesteps) >= GRAPH_MIN_STEPS and type(scheduler) is DDPMScheduler
-                     and not self._step_kwargs and getattr(scheduler, "streams", None) is None)
-        if GRAPH_STEPS and static_ok:
+        long_enough = x_t.is_cuda and len(timesteps) >= GRAPH_MIN_STEPS
+        if (GRAPH_STEPS and long_enough and type(scheduler) is DDPMScheduler and not self._step_kwargs
+                and getattr(scheduler, "streams", None) is None):
             return self._denoise_loop_graph(x_t, camera, image_rgb, mask, scheduler, timesteps, generator)
-        if static_ok and (TAPE_STEPS == "1" or (TAPE_STEPS == "auto" and x_t.shape[0] * x_t.shape[1] <= TAPE_MAX_POINTS)):
+        # the tape holds the denoiser forward only; schedulers that keep earlier model outputs (PNDM) would see them overwritten
+        if (long_enough and type(scheduler) in (DDPMScheduler, DDIMScheduler)
+                and (TAPE_STEPS == "1" or (TAPE_STEPS == "auto" and x_t.shape[0] * x_t.shape[1] <= TAPE_MAX_POINTS))):
             return self._denoise_loop_tape(x_t, camera, image_rgb, mask, scheduler, timesteps, generator)
         B = x_t.shape[0]
         for t in timesteps:
@@ -285,7 +292,7 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
     # to the eager loop (same kernels, same arguments, same RNG stream: the noise is drawn eagerly, in order).
     def _step_graph(self, x_t, camera, image_rgb, mask, scheduler):
         feat, _ = self.conditioning_image(image_rgb, mask)
-        key = (tuple(x_t.shape), str(x_t.device), id(camera), id(scheduler), scheduler.num_inference_steps)
+        key = (tuple(x_t.shape), str(x_t.device), id(camera), id(scheduler), scheduler.num_inference_steps, self._weights_signature())
         g = getattr(self, "_graph_cache", None)
         if g is not None and g["key"] == key and g["feat"] is feat and g["image"] is image_rgb:
             return g
@@ -333,48 +340,47 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
         return g["x"].clone()
 
     # ---- launch-tape form of the reverse loop (tape.py) --------------------------------------------------------
-    # Same static buffers as the graph form; the step is RECORDED while it runs eagerly (second step of the loop: the
+    # The conditioning + denoiser forward on static buffers is RECORDED while it runs eagerly (second step of the loop: the
     # first one leaves every lazy cache -- weight packs, workspaces, kernel attributes -- behind it) and later steps
-    # replay the flat list of C-ABI calls: ~3 us of host time per launch instead of ~15.  Default for small problems,
-    # which are bound by the host (B * N <= TAPE_MAX_POINTS); larger ones are bound by the GPU and stay eager (the
-    # tape keeps every intermediate buffer of a step alive).
+    # replay the flat list of C-ABI calls: ~11 us of host time per launch instead of 15-20.  The scheduler step stays
+    # eager, so DDPM and DDIM, generator / noise_source draws and the per-shape Philox streams all work unchanged.
+    # Default for small problems, which are paced by the host (B * N <= TAPE_MAX_POINTS); larger ones are bound by the
+    # GPU and stay eager unless BDM_TAPE=1 (the tape keeps every intermediate buffer of a forward alive).
     def _denoise_loop_tape(self, x_t, camera, image_rgb, mask, scheduler, timesteps, generator=None):
         from . import tape as T
         feat, _ = self.conditioning_image(image_rgb, mask)
         dev, B = x_t.device, x_t.shape[0]
-        key = (tuple(x_t.shape), str(dev), id(camera), id(scheduler), scheduler.num_inference_steps,
-               torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+        key = (tuple(x_t.shape), str(dev), id(camera), torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()),
+               self._weights_signature())
         g = getattr(self, "_tape_cache", None)
         if g is None or g["key"] != key or g["feat"] is not feat or g["image"] is not image_rgb:
-            g = {"key": key, "feat": feat, "image": image_rgb, "camera": camera, "tape": None, "warm": False, "off": None,
-                 "x": torch.empty_like(x_t, memory_format=torch.contiguous_format), "noise": torch.zeros_like(x_t),
-                 "t": torch.zeros(B, dtype=torch.int64, device=dev), "coef": torch.ones(5, dtype=torch.float32, device=dev)}
+            g = {"key": key, "feat": feat, "image": image_rgb, "camera": camera, "tape": None, "warm": False, "off": None, "eps": None,
+                 "x": torch.empty_like(x_t, memory_format=torch.contiguous_format),
+                 "t": torch.zeros(B, dtype=torch.int64, device=dev)}
             self._tape_cache = g
 
-        def step():
+        def denoise():  # conditioning + denoiser on the static buffers: everything between two scheduler steps
             x_in = self.get_input_with_conditioning(g["x"], camera=camera, image_rgb=image_rgb, mask=mask, t=g["t"])
-            eps = self.point_cloud_model(x_in, g["t"])
-            scheduler.step_dev(eps, g["coef"], g["x"], g["noise"], out=g["x"])
+            return self.point_cloud_model(x_in, g["t"])
 
-        table = scheduler.coefficient_table(dev)
         g["x"].copy_(x_t)
         for t in timesteps:
             g["t"].fill_(t)
-            g["coef"].copy_(table[t])
-            if t > 0:
-                g["noise"].copy_(scheduler._noise(g["x"].shape, dev, generator))
             if g["tape"] is not None:
                 g["tape"].replay()
+                eps = g["eps"]
             elif g["warm"] and g["off"] is None:
                 with ops.static_step(), T.record() as tp:
-                    step()
+                    eps = denoise()
                 if tp.broken:
                     g["off"] = tp.broken  # stay eager (on the static buffers) and say why: model._tape_cache["off"]
                 else:
-                    g["tape"] = tp
+                    g["tape"], g["eps"] = tp, eps
             else:
-                step()
+                eps = denoise()
                 g["warm"] = True
+            # the scheduler step stays eager (one launch): its scalars, its noise draw and the per-shape Philox streams change per step
+            g["x"].copy_(scheduler.step(eps, t, g["x"], generator=generator, **self._step_kwargs).prev_sample)
         return g["x"].clone()
 
     @torch.no_grad()

@@ -136,3 +136,10 @@ def test_launch_tape_replay_equals_eager_loop(hip, monkeypatch):
     again = run("auto")  # B * N is below the host-bound threshold: the default takes the tape, and re-uses the recorded one
     assert model._tape_cache["tape"] is tape_before
     assert torch.equal(eager, again)
+    # rewriting a weight invalidates the recording (it holds the addresses of packs derived from the old values)
+    with torch.no_grad():
+        conv = next(m for m in model.point_cloud_model.modules() if isinstance(m, torch.nn.Conv3d))
+        conv.weight.mul_(1.25)
+    changed_tape, changed_eager = run("1"), run("0")
+    assert model._tape_cache["tape"] is not tape_before
+    assert torch.equal(changed_tape, changed_eager) and not torch.equal(changed_tape, eager)
