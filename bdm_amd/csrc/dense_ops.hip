@@ -323,6 +323,185 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
   }
 }
 
+// ---- skinny GEMM: n <= 32 columns per shape (the 16-point level: attention projections 1536 x 512 . 16) ---------------------
+// In pw_gemm_kernel such a problem keeps one wave of four busy and walks the whole K axis as a chain of barrier-separated chunks,
+// each exposing a global-load latency (47 us for 0.4 GFLOP).  Here the workgroup owns a 32-row x 32-column tile and its four
+// waves SPLIT K: each wave streams its quarter of W and x straight from global memory into MFMA operands (no LDS staging, no
+// barriers in the loop, loads of several 8-deep blocks in flight), then the four partial tiles are added in wave order through
+// LDS (deterministic) and the epilogue (bias, per-shape bias, activation, residual) is applied once.
+// Operand map of v_mfma_f32_32x32x2: lane (li, lh) supplies A[row li][k] and B[k][column li] for ONE k per instruction; within an
+// 8-deep block lane half lh takes k = kb + 4 lh + j at step j, so its four A values are one 16-byte load.
+template <int NB, bool FOLD>  // NB column blocks of 32 (n <= 32 NB); FOLD: the operand is Swish(GroupNorm(x)), as in pw_gemm_kernel
+__global__ __launch_bounds__(256) void pw_skinny_kernel(int M, int K, int N, const float *__restrict__ W, int ldw,
+                                                        const float *__restrict__ X, long long bsx, int ldx,
+                                                        const float *__restrict__ bias, const float *__restrict__ bbias, int ldbb,
+                                                        const float *__restrict__ R, long long bsr, int ldr,
+                                                        float *__restrict__ Y, long long bsy, int ldy, int act, float slope, PwGn gn) {
+  __shared__ float red[4][NB * 16][64];
+  __shared__ float2 coef_s[FOLD ? 1024 : 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * 32, bi = blockIdx.y;
+  if constexpr (FOLD) {  // same arithmetic as pw_gemm_kernel's prologue: the coefficients have the same bits
+    __shared__ float s_mr[16];
+    const int g = tid >> 5, l = tid & 31, cgi = K / gn.in_G;
+    double a = 0.0, q = 0.0;
+    if (g < gn.in_G) {
+      const double *pp = gn.in_partial + ((size_t)bi * gn.in_G + g) * gn.in_S * 2;
+      for (int sl = l; sl < gn.in_S; sl += 32) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
+    }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    if (l == 0 && g < gn.in_G) {
+      const double cnt = (double)cgi * N, mean = a / cnt;
+      double var = q / cnt - mean * mean;
+      if (var < 0) var = 0;
+      s_mr[2 * g] = (float)mean;
+      s_mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)gn.in_eps));
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+      const int gk = k / cgi;
+      const float ak = gn.in_gamma[k] * s_mr[2 * gk + 1];
+      coef_s[k] = make_float2(ak, gn.in_beta[k] - s_mr[2 * gk] * ak);
+    }
+    __syncthreads();
+  }
+  const float *Xb = X + (size_t)bi * bsx;
+  const float *X2b = gn.x2 ? gn.x2 + (size_t)bi * gn.bsx2 : nullptr;
+  const int k1 = X2b ? gn.k1 : K;  // rows [k1, K) of the operand live in X2b (cat([x, x2], dim=1) read in place)
+  auto xrow = [&](int k) { return k < k1 ? Xb + (unsigned)k * (unsigned)ldx : X2b + (unsigned)(k - k1) * (unsigned)gn.ldx2; };
+  const int kq = ((K + 31) / 32) * 8;                  // K range of a wave: a multiple of 8
+  const int k_lo = wave * kq, k_hi = min(K, k_lo + kq);
+  const unsigned arow = (unsigned)min(m0 + li, M - 1) * (unsigned)ldw;
+  unsigned bcol[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) bcol[c] = (unsigned)min(c * 32 + li, N - 1);
+  const bool a_vec = ((ldw & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
+  f32x16 acc[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  // groups of four 8-deep blocks, two groups of operand registers: the loads of group g + 1 are issued before the MFMAs of
+  // group g.  Blocks past the wave's range are skipped by wave-uniform branches (their A values stay zero).
+  const bool fast = a_vec && (K & 7) == 0;
+  float A0[4][4], B0[NB][4][4], A1[4][4], B1[NB][4][4];
+  auto load_group = [&](int kg, float (&A)[4][4], float (&Bv)[NB][4][4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int kb = kg + 8 * g, k0 = kb + 4 * lh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        A[g][j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) Bv[c][g][j] = 0.f;
+      }
+      if (kb < k_hi) {
+        if (fast) {
+          const float4 t = *reinterpret_cast<const float4 *>(W + arow + k0);
+          A[g][0] = t.x; A[g][1] = t.y; A[g][2] = t.z; A[g][3] = t.w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < NB; ++c) Bv[c][g][j] = xrow(k0 + j)[bcol[c]];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = min(k0 + j, K - 1);
+            const float av = W[arow + k];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) Bv[c][g][j] = xrow(k)[bcol[c]];
+            A[g][j] = k0 + j < K ? av : 0.f;  // a zero A entry removes the clamped duplicate from the sum
+          }
+        }
+      }
+    }
+  };
+  auto mfma_group = [&](int kg, float (&A)[4][4], float (&Bv)[NB][4][4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float2 cf = make_float2(1.f, 0.f);
+        if constexpr (FOLD) cf = coef_s[min(kg + 8 * g + 4 * lh + j, K - 1)];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+          float bv = Bv[c][g][j];
+          if constexpr (FOLD) bv = swishf(cf.x * bv + cf.y);
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][j], bv, acc[c], 0, 0, 0);
+        }
+      }
+  };
+  if (k_lo < k_hi) load_group(k_lo, A0, B0);
+  for (int kg = k_lo; kg < k_hi; kg += 64) {
+    if (kg + 32 < k_hi) load_group(kg + 32, A1, B1);
+    mfma_group(kg, A0, B0);
+    if (kg + 64 < k_hi) load_group(kg + 64, A0, B0);
+    if (kg + 32 < k_hi) mfma_group(kg + 32, A1, B1);
+  }
+#pragma unroll
+  for (int c = 0; c < NB; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][c * 16 + r][lane] = acc[c][r];
+  __syncthreads();
+  // NB * 1024 outputs, 256 threads: thread (wave, lane) finishes accumulator registers r = 4 wave .. 4 wave + 3 of lane `lane`,
+  // i.e. the four consecutive rows 8 wave + 4 lh .. + 3 of column li of every column block
+  float gs = 0.f, gq = 0.f, am = 0.f;
+#pragma unroll
+  for (int c = 0; c < NB; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 4 * wave + q;
+      const int m = m0 + q + 8 * wave + 4 * lh, n = c * 32 + li;
+      if (m < M && n < N) {
+        float v = ((red[0][c * 16 + r][lane] + red[1][c * 16 + r][lane]) + red[2][c * 16 + r][lane]) + red[3][c * 16 + r][lane];
+        v = (v + (bias ? bias[m] : 0.f)) + (bbias ? bbias[(size_t)bi * ldbb + m] : 0.f);
+        if (act == 2) v = v > 0.f ? v : v * slope;
+        else if (act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        if (R) v += R[(size_t)bi * bsr + (size_t)m * ldr + n];
+        Y[(size_t)bi * bsy + (size_t)m * ldy + n] = v;
+        gs += v;
+        gq += v * v;
+        am = fmaxf(am, fabsf(v));
+      }
+    }
+  if (gn.amax != nullptr) {  // (amax_rows % 32 == 0: the tile's rows share a slot)
+    const float mx = wave_max(am);
+    if (lane == 0 && mx > 0.f) atomicMax(gn.amax + m0 / gn.amax_rows, __float_as_uint(mx));
+  }
+  if (gn.out_partial != nullptr) {
+    // GroupNorm statistics of the tile (layout of pw_gemm_kernel's partials; ONE column tile, so S = row tiles per group):
+    // butterfly over the 32 columns, then the eight (wave, half) row blocks of 4 are added per group in fp64 in a fixed order
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { gs += __shfl_xor(gs, o, 64); gq += __shfl_xor(gq, o, 64); }
+    __syncthreads();  // red is dead
+    float *blk = &red[0][0][0];  // [8 row blocks][2]
+    if (li == 0) { blk[(2 * wave + lh) * 2] = gs; blk[(2 * wave + lh) * 2 + 1] = gq; }
+    __syncthreads();
+    const int cg = gn.out_cg, G = M / cg;
+    const int ngt = cg >= 32 ? 1 : 32 / cg, rt = cg >= 32 ? cg / 32 : 1;
+    if (tid < ngt && m0 + tid * cg < M) {
+      double a = 0.0, qq = 0.0;
+      for (int rb = 0; rb < 8; ++rb)
+        if (cg >= 32 || ((4 * rb) >> (__ffs(cg) - 1)) == tid) { a += (double)blk[rb * 2]; qq += (double)blk[rb * 2 + 1]; }
+      const int g = m0 / cg + tid, sl = (int)(blockIdx.x % rt);
+      double *dst = gn.out_partial + (((size_t)bi * G + g) * rt + sl) * 2;
+      dst[0] = a;
+      dst[1] = qq;
+    }
+  }
+}
+
+static int pw_skinny_enabled() {  // BDM_PW_SKINNY=0: the general kernel also for n <= 32 (experiments)
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("BDM_PW_SKINNY"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v;
+}
+// shapes of the GroupNorm-folded entry point that take the skinny kernel (the caller also needs x2 == NULL and amax == NULL; the
+// slice count of the statistics must not depend on those, so two-source / amax calls of such shapes use the general kernel's
+// layout only when this returns 0 -- see bdm_pointwise_conv_gn)
+static bool pw_skinny_shape(int k, int n) { return n <= 64 && k >= 128 && pw_skinny_enabled(); }
+
 // workgroup count below which the long-K shapes take the 64-deep K chunk (BDM_PW_DEEP_BLOCKS overrides; 0 disables)
 static int pw_deep_limit() {
   static int v = -1;
@@ -391,6 +570,15 @@ extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, in
   BDM_REQUIRE((long long)k * ld_x + n < (1ll << 31) && (long long)m * ldw + k < (1ll << 31),
               "pointwise_conv: one operand spans more than 2^31 elements");
   if (b == 0 || n == 0) return BDM_OK;
+  if (pw_skinny_shape(k, n)) {
+    if (n <= 32)
+      hipLaunchKernelGGL((pw_skinny_kernel<1, false>), dim3(cdiv(m, 32), b), dim3(256), 0, (hipStream_t)stream, m, k, n, w, ldw, x, bs_x,
+                         ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r, y, bs_y, ld_y, act, slope, PwGn{});
+    else
+      hipLaunchKernelGGL((pw_skinny_kernel<2, false>), dim3(cdiv(m, 32), b), dim3(256), 0, (hipStream_t)stream, m, k, n, w, ldw, x, bs_x,
+                         ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r, y, bs_y, ld_y, act, slope, PwGn{});
+    return launch_status("pointwise_conv");
+  }
   pw_dispatch<false>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r, y, bs_y, ld_y, act, slope,
                      PwGn{}, (hipStream_t)stream);
   return launch_status("pointwise_conv");
@@ -399,6 +587,7 @@ extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, in
 // slices per (shape, group) the GroupNorm-folded convolution below writes for an (m x n) output in `groups` groups
 extern "C" int bdm_pointwise_conv_gn_slices(int b, int m, int k, int n, int groups) {
   if (groups < 1 || m % groups) return 0;
+  if (pw_skinny_shape(k, n)) return (m / groups) >= 32 ? (m / groups) / 32 : 1;  // one column tile, 32-row tiles
   int mi, ni, bk;
   pw_tile(b, m, k, n, &mi, &ni, &bk);
   const int cg = m / groups, bm = 32 * mi;
@@ -436,6 +625,15 @@ extern "C" int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w,
     gn.out_partial = (double *)out_partial; gn.out_cg = cg;
   }
   if (b == 0) return BDM_OK;
+  if (pw_skinny_shape(k, n)) {
+#define SK_LAUNCH(NB, FOLD)                                                                                                       \
+    hipLaunchKernelGGL((pw_skinny_kernel<NB, FOLD>), dim3(cdiv(m, 32), b), dim3(256), 0, (hipStream_t)stream, m, k, n, w, ldw, x, bs_x, \
+                       ld_x, bias, (const float *)nullptr, 0, (const float *)nullptr, 0ll, 0, y, bs_y, ld_y, 0, 0.f, gn)
+    if (in_partial != nullptr) { if (n <= 32) SK_LAUNCH(1, true); else SK_LAUNCH(2, true); }
+    else { if (n <= 32) SK_LAUNCH(1, false); else SK_LAUNCH(2, false); }
+#undef SK_LAUNCH
+    return launch_status("pointwise_conv_gn");
+  }
   if (in_partial != nullptr)
     pw_dispatch<true>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, nullptr, 0, nullptr, 0ll, 0, y, bs_y, ld_y, 0, 0.f, gn, (hipStream_t)stream);
   else

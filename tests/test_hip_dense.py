@@ -44,6 +44,26 @@ def test_pointwise_conv_views_residual_leaky(ops):
     assert float(outbuf[:, :5].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,M,K,N", [(16, 1536, 512, 16), (3, 512, 512, 16), (2, 100, 136, 32), (2, 40, 131, 7), (1, 33, 1000, 1), (2, 64, 128, 20)])
+def test_pointwise_conv_skinny(ops, B, M, K, N):
+    """n <= 32 columns and k >= 128 (the 16-point level): pw_skinny_kernel, K split over the four waves and summed in wave order.
+    Aligned and unaligned weights (the 16-byte A loads need ldw % 4 == 0), K tails, row tails, strided views, every epilogue term."""
+    g = torch.Generator().manual_seed(M * K + N)
+    big = torch.randn(B, K + 3, N, generator=g).cuda()
+    x = big[:, 2:2 + K]                                    # batch stride != K * N
+    w = (torch.randn(M, K, generator=g) / K ** 0.5).cuda()
+    bias, bb = torch.randn(M, generator=g).cuda(), torch.randn(B, M, generator=g).cuda()
+    res = torch.randn(B, M, N, generator=g).cuda()
+    lin = TF.conv1d(x.cpu().double(), w.cpu().double()[:, :, None], bias.cpu().double()) + bb.cpu().double()[:, :, None]
+    got = ops.pointwise_conv(x, w, bias, batch_bias=bb)
+    assert rel(got.cpu(), lin.float()) < 2e-6
+    assert torch.equal(got, ops.pointwise_conv(x, w, bias, batch_bias=bb))   # deterministic
+    out = torch.zeros(B, M + 2, N).cuda()
+    ops.pointwise_conv(x, w, bias, batch_bias=bb, out=out[:, 2:], act=2, slope=0.1, residual=res)
+    ref = TF.leaky_relu(lin, 0.1) + res.cpu().double()
+    assert rel(out[:, 2:].cpu(), ref.float()) < 2e-6 and float(out[:, :2].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("B,C,L", [(2, 64, 32768), (3, 32, 1024 * 32), (2, 512, 16), (1, 8, 33), (2, 256, 512)])
 @pytest.mark.parametrize("swish", [False, True])
 def test_group_norm(ops, B, C, L, swish):
@@ -496,7 +516,10 @@ def test_gn2_folded_tail_equals_separate_groupnorm_pass(ops, monkeypatch, cin, c
 
 @pytest.mark.parametrize("chans,shape", [((35, 32, 64), (2, 1024, 32)), ((67, 64, 128), (3, 256, 32)), ((131, 128, 256), (2, 64, 32)),
                                          ((259, 256, 256, 512), (2, 16, 32)), ((128, 128, 64), (2, 4096)), ((96, 40, 24), (2, 300)),
-                                         ((16, 8, 8), (2, 100))])
+                                         ((16, 8, 8), (2, 100)),
+                                         # <= 64 points with k >= 128: the K-split skinny kernel (plain, folded input, statistics)
+                                         ((256, 256, 256), (2, 64)), ((832, 256, 256), (3, 64)), ((131, 128, 128), (3, 16)),
+                                         ((200, 64, 32, 32), (2, 40)), ((512, 512, 24), (2, 33))])
 def test_shared_mlp_groupnorm_folding_equals_separate_passes(ops, monkeypatch, chans, shape):
     """SharedMLP with the GroupNorms folded (statistics from the convolution's epilogue, normalise + Swish in the next
     consumer: the next convolution's operand staging or the max over neighbours) vs a GroupNorm pass per layer."""
@@ -610,6 +633,18 @@ def test_concat2_rows_fp_assemble_two_source_gemm_and_channel_first_gather(ops):
     assert torch.equal(ops.pointwise_conv_gn(x1, wt, bias, x2=x2), ref)
     big = torch.randn(B, 120, n, generator=g).cuda()
     assert torch.equal(ops.pointwise_conv_gn(x1, wt, bias, x2=big[:, 3:70]), ops.pointwise_conv(torch.cat([x1, big[:, 3:70]], 1), wt, bias))
+    # the same on a skinny shape (64 points, k = 832: pw_skinny_kernel reads the second source in place too) + statistics + amax
+    xs1, xs2 = torch.randn(B, 576, 64, generator=g).cuda(), torch.randn(B, 256, 64, generator=g).cuda()
+    ws, bs_ = (torch.randn(256, 832, generator=g) / 29).cuda(), torch.randn(256, generator=g).cuda()
+    ys, st = ops.pointwise_conv_gn(xs1, ws, bs_, x2=xs2, out_groups=8)
+    refs = ops.pointwise_conv(torch.cat([xs1, xs2], 1), ws, bs_)
+    assert torch.equal(ys, refs)
+    sums = st[0].view(B, 8, st[1], 2).sum(2)
+    rd = refs.double().view(B, 8, -1)
+    assert torch.allclose(sums[..., 0], rd.sum(-1), rtol=1e-6, atol=1e-3) and torch.allclose(sums[..., 1], (rd * rd).sum(-1), rtol=1e-6)
+    am = ops.amax_slots(xs1.device, 2)
+    ya = ops.pointwise_conv_gn(xs1, ws[:, :576].contiguous(), bs_, amax=am, amax_rows=128)
+    assert torch.equal(am, torch.stack([ya[:, :128].abs().max(), ya[:, 128:].abs().max()]))
     # conditioning gather written channel-first == the point-major gather transposed
     C, HW = 29, 50
     xt = torch.randn(B, n, 3, generator=g).cuda()
