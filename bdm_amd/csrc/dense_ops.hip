@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(int M, int K, int N, con
   __shared__ float red[4][NB * 16][64];
   __shared__ float2 coef_s[FOLD ? 1024 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * 32, bi = blockIdx.y;
+  const int m0 = blockIdx.x * 32, bi = blockIdx.y, n0 = blockIdx.z * (32 * NB);  // wider shapes: one workgroup per 32 NB columns
   if constexpr (FOLD) {  // same arithmetic as pw_gemm_kernel's prologue: the coefficients have the same bits
     __shared__ float s_mr[16];
     const int g = tid >> 5, l = tid & 31, cgi = K / gn.in_G;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(int M, int K, int N, con
   const unsigned arow = (unsigned)min(m0 + li, M - 1) * (unsigned)ldw;
   unsigned bcol[NB];
 #pragma unroll
-  for (int c = 0; c < NB; ++c) bcol[c] = (unsigned)min(c * 32 + li, N - 1);
+  for (int c = 0; c < NB; ++c) bcol[c] = (unsigned)min(n0 + c * 32 + li, N - 1);
   const bool a_vec = ((ldw & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
   f32x16 acc[NB];
 #pragma unroll
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(int M, int K, int N, con
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = 4 * wave + q;
-      const int m = m0 + q + 8 * wave + 4 * lh, n = c * 32 + li;
+      const int m = m0 + q + 8 * wave + 4 * lh, n = n0 + c * 32 + li;
       if (m < M && n < N) {
         float v = ((red[0][c * 16 + r][lane] + red[1][c * 16 + r][lane]) + red[2][c * 16 + r][lane]) + red[3][c * 16 + r][lane];
         v = (v + (bias ? bias[m] : 0.f)) + (bbias ? bbias[(size_t)bi * ldbb + m] : 0.f);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(int M, int K, int N, con
     if (lane == 0 && mx > 0.f) atomicMax(gn.amax + m0 / gn.amax_rows, __float_as_uint(mx));
   }
   if (gn.out_partial != nullptr) {
-    // GroupNorm statistics of the tile (layout of pw_gemm_kernel's partials; ONE column tile, so S = row tiles per group):
+    // GroupNorm statistics of the tile (layout of pw_gemm_kernel's partials: slices = column tiles x row tiles per group):
     // butterfly over the 32 columns, then the eight (wave, half) row blocks of 4 are added per group in fp64 in a fixed order
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) { gs += __shfl_xor(gs, o, 64); gq += __shfl_xor(gq, o, 64); }
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(int M, int K, int N, con
       double a = 0.0, qq = 0.0;
       for (int rb = 0; rb < 8; ++rb)
         if (cg >= 32 || ((4 * rb) >> (__ffs(cg) - 1)) == tid) { a += (double)blk[rb * 2]; qq += (double)blk[rb * 2 + 1]; }
-      const int g = m0 / cg + tid, sl = (int)(blockIdx.x % rt);
-      double *dst = gn.out_partial + (((size_t)bi * G + g) * rt + sl) * 2;
+      const int g = m0 / cg + tid, S = gridDim.z * rt, sl = blockIdx.z * rt + (int)(blockIdx.x % rt);
+      double *dst = gn.out_partial + (((size_t)bi * G + g) * S + sl) * 2;
       dst[0] = a;
       dst[1] = qq;
     }
@@ -500,7 +500,12 @@ static int pw_skinny_enabled() {  // BDM_PW_SKINNY=0: the general kernel also fo
 // shapes of the GroupNorm-folded entry point that take the skinny kernel (the caller also needs x2 == NULL and amax == NULL; the
 // slice count of the statistics must not depend on those, so two-source / amax calls of such shapes use the general kernel's
 // layout only when this returns 0 -- see bdm_pointwise_conv_gn)
-static bool pw_skinny_shape(int k, int n) { return n <= 64 && k >= 128 && pw_skinny_enabled(); }
+static int pw_skinny_max_n() {  // BDM_PW_SKINNY_N: widest shape (columns) that takes the skinny kernel
+  static int v = -1;
+  if (v < 0) { const char *e = getenv("BDM_PW_SKINNY_N"); v = e ? atoi(e) : 64; }
+  return v;
+}
+static bool pw_skinny_shape(int k, int n) { return n <= pw_skinny_max_n() && k >= 128 && pw_skinny_enabled(); }
 
 // workgroup count below which the long-K shapes take the 64-deep K chunk (BDM_PW_DEEP_BLOCKS overrides; 0 disables)
 static int pw_deep_limit() {
@@ -572,10 +577,10 @@ extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, in
   if (b == 0 || n == 0) return BDM_OK;
   if (pw_skinny_shape(k, n)) {
     if (n <= 32)
-      hipLaunchKernelGGL((pw_skinny_kernel<1, false>), dim3(cdiv(m, 32), b), dim3(256), 0, (hipStream_t)stream, m, k, n, w, ldw, x, bs_x,
+      hipLaunchKernelGGL((pw_skinny_kernel<1, false>), dim3(cdiv(m, 32), b, 1), dim3(256), 0, (hipStream_t)stream, m, k, n, w, ldw, x, bs_x,
                          ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r, y, bs_y, ld_y, act, slope, PwGn{});
     else
-      hipLaunchKernelGGL((pw_skinny_kernel<2, false>), dim3(cdiv(m, 32), b), dim3(256), 0, (hipStream_t)stream, m, k, n, w, ldw, x, bs_x,
+      hipLaunchKernelGGL((pw_skinny_kernel<2, false>), dim3(cdiv(m, 32), b, cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, m, k, n, w, ldw, x, bs_x,
                          ld_x, bias, batch_bias, ld_bb, residual, bs_r, ld_r, y, bs_y, ld_y, act, slope, PwGn{});
     return launch_status("pointwise_conv");
   }
@@ -587,7 +592,7 @@ extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, in
 // slices per (shape, group) the GroupNorm-folded convolution below writes for an (m x n) output in `groups` groups
 extern "C" int bdm_pointwise_conv_gn_slices(int b, int m, int k, int n, int groups) {
   if (groups < 1 || m % groups) return 0;
-  if (pw_skinny_shape(k, n)) return (m / groups) >= 32 ? (m / groups) / 32 : 1;  // one column tile, 32-row tiles
+  if (pw_skinny_shape(k, n)) return (n <= 32 ? 1 : cdiv(n, 64)) * ((m / groups) >= 32 ? (m / groups) / 32 : 1);  // 32-row tiles
   int mi, ni, bk;
   pw_tile(b, m, k, n, &mi, &ni, &bk);
   const int cg = m / groups, bm = 32 * mi;
@@ -627,7 +632,7 @@ extern "C" int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w,
   if (b == 0) return BDM_OK;
   if (pw_skinny_shape(k, n)) {
 #define SK_LAUNCH(NB, FOLD)                                                                                                       \
-    hipLaunchKernelGGL((pw_skinny_kernel<NB, FOLD>), dim3(cdiv(m, 32), b), dim3(256), 0, (hipStream_t)stream, m, k, n, w, ldw, x, bs_x, \
+    hipLaunchKernelGGL((pw_skinny_kernel<NB, FOLD>), dim3(cdiv(m, 32), b, cdiv(n, 32 * NB)), dim3(256), 0, (hipStream_t)stream, m, k, n, w, ldw, x, bs_x, \
                        ld_x, bias, (const float *)nullptr, 0, (const float *)nullptr, 0ll, 0, y, bs_y, ld_y, 0, 0.f, gn)
     if (in_partial != nullptr) { if (n <= 32) SK_LAUNCH(1, true); else SK_LAUNCH(2, true); }
     else { if (n <= 32) SK_LAUNCH(1, false); else SK_LAUNCH(2, false); }
