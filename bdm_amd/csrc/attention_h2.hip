@@ -3,7 +3,7 @@
 //
 // An fp32 operand times a power of two is stored as hi + lo (two fp16 terms, 22 signed bits); a product is
 // lo.hi + hi.lo + hi.hi accumulated in fp32 (lo.lo <= 2^-22 relative is dropped).  fp16 has a narrow exponent range, so every
-// tensor gets ONE power-of-two scale from its max |value| (amax[0..2] for q, k, v: left by the projection GEMM's epilogue,
+// tensor gets ONE power-of-two scale PER SHAPE from its max |value| (amax[3 s + 0..2] for q, k, v of shape s: left by the projection GEMM's epilogue,
 // bdm_pointwise_conv_gn, as bit patterns of non-negative floats -- an integer atomicMax, order independent): the scaled
 // operands sit in [2^14, 2^15) at the top, the scales are divided out exactly (q.k scale inside the exponential's constant,
 // v and probability scales at the final normalisation).  Probabilities (in [0, 1]) are scaled by 2^14 before their split.
@@ -44,7 +44,7 @@ __global__ void attn_split_qk_h2_kernel(int C, int L, const float *__restrict__ 
                                         int ld, const float *__restrict__ amax, uint4 *__restrict__ qs, uint4 *__restrict__ ks) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x, c8 = blockIdx.y, C8 = gridDim.y, bi = blockIdx.z >> 1, which = blockIdx.z & 1;
   if (l >= L) return;
-  const float s = h2_scale_from_max(amax[which]);
+  const float s = h2_scale_from_max(amax[bi * 3 + which]);  // per shape
   const float *src = (which ? k : q) + (size_t)bi * bs;
   uint4 *dst = (which ? ks : qs) + ((size_t)bi * C8 + c8) * 2 * (size_t)L;
   unsigned short h[8], lo[8];
@@ -62,7 +62,7 @@ __global__ void attn_split_v_h2_kernel(int C, int CP, int L, int Lp, const float
                                        const float *__restrict__ amax, unsigned short *__restrict__ vt) {
   const int l0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8, c = blockIdx.y, bi = blockIdx.z;
   if (l0 >= Lp) return;
-  const float s = h2_scale_from_max(amax[2]);
+  const float s = h2_scale_from_max(amax[bi * 3 + 2]);
   unsigned short h[8], lo[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) split2h((c < C && l0 + j < L) ? v[(size_t)bi * bs + (size_t)c * ld + l0 + j] * s : 0.f, h[j], lo[j]);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
   const int i0 = (blockIdx.x * 4 + wave) * 32;  // this wave's first query
   const uint4 *qb = qs + (size_t)bi * C8 * 2 * L, *kb = ks + (size_t)bi * C8 * 2 * L;
   const unsigned short *vb = vt + (size_t)bi * 2 * CP * Lp;
-  const float sq = h2_scale_from_max(amax[0]), sk = h2_scale_from_max(amax[1]), sv = h2_scale_from_max(amax[2]);
+  const float sq = h2_scale_from_max(amax[bi * 3]), sk = h2_scale_from_max(amax[bi * 3 + 1]), sv = h2_scale_from_max(amax[bi * 3 + 2]);
   // exp(x) = 2^(x log2 e): the q.k scale (a power of two, exact) is divided out inside the constant
   const float ec = 1.44269504088896340736f / (sq * sk);
 
@@ -236,8 +236,8 @@ extern "C" size_t bdm_attention_h2_workspace_bytes(int b, int c, int l) {
   return (size_t)b * (2 * qk + v) + 64;
 }
 
-// out (b, c, l) = softmax_keys(q^T k) applied to v, for q, k, v (b, c, l) rows of stride ld_qkv; amax[0..2] = max |q|, |k|, |v| over
-// the whole call (bit patterns of non-negative floats, e.g. from bdm_pointwise_conv_gn's amax output).  64 < l, c <= 64.
+// out (b, c, l) = softmax_keys(q^T k) applied to v, for q, k, v (b, c, l) rows of stride ld_qkv; amax[3 s + 0..2] = max |q|, |k|, |v| of
+// shape s (bit patterns of non-negative floats, e.g. from bdm_pointwise_conv_gn's amax output).  64 < l, c <= 64.
 extern "C" int bdm_attention_core_h2(int b, int c, int l, const float *q, const float *k, const float *v, long long bs_qkv,
                                      int ld_qkv, const float *amax, float *out, long long bs_o, int ld_o, void *workspace,
                                      void *stream) {

@@ -44,10 +44,11 @@ struct PwGn {
   const float *x2;
   long long bsx2;
   int ldx2, k1;
-  // max |y| per block of `amax_rows` output rows (amax_rows % 32 == 0), over the whole call: bit patterns of non-negative
-  // floats combined with an integer atomicMax (order independent).  Zero on entry.  Feeds the fp16x3 attention's scales.
+  // max |y| per (shape, block of `amax_rows` output rows) (amax_rows % 32 == 0): slot [shape * amax_slots + block], bit patterns
+  // of non-negative floats combined with an integer atomicMax (order independent).  Zero on entry.  Feeds the fp16x3 attention's
+  // scales; per SHAPE so that a shape's result does not depend on its batch-mates.
   unsigned *amax;
-  int amax_rows;
+  int amax_rows, amax_slots;
 };
 
 // amdgpu_waves_per_eu(2): with an occupancy target of two waves per SIMD the register allocator stops hoarding (2 x 2 tile with
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     __syncthreads();
     if (tid < MI && m0 + tid * 32 < M) {
       const float mx = fmaxf(fmaxf(As[tid * 4], As[tid * 4 + 1]), fmaxf(As[tid * 4 + 2], As[tid * 4 + 3]));
-      unsigned *slot = gn.amax + (m0 + tid * 32) / gn.amax_rows;
+      unsigned *slot = gn.amax + (size_t)bi * gn.amax_slots + (m0 + tid * 32) / gn.amax_rows;
       if (mx > 0.f && __float_as_uint(mx) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax(slot, __float_as_uint(mx));
     }
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(int M, int K, int N, con
     }
   if (gn.amax != nullptr) {  // (amax_rows % 32 == 0: the tile's rows share a slot)
     const float mx = wave_max(am);
-    if (lane == 0 && mx > 0.f) atomicMax(gn.amax + m0 / gn.amax_rows, __float_as_uint(mx));
+    if (lane == 0 && mx > 0.f) atomicMax(gn.amax + (size_t)bi * gn.amax_slots + m0 / gn.amax_rows, __float_as_uint(mx));
   }
   if (gn.out_partial != nullptr) {
     // GroupNorm statistics of the tile (layout of pw_gemm_kernel's partials: slices = column tiles x row tiles per group):
@@ -621,7 +622,7 @@ extern "C" int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w,
   }
   if (amax != nullptr) {
     BDM_REQUIRE(amax_rows >= 32 && amax_rows % 32 == 0, "pointwise_conv_gn: amax_rows must be a multiple of 32 (got %d)", amax_rows);
-    gn.amax = (unsigned *)amax; gn.amax_rows = amax_rows;
+    gn.amax = (unsigned *)amax; gn.amax_rows = amax_rows; gn.amax_slots = (m + amax_rows - 1) / amax_rows;
   }
   if (out_partial != nullptr) {
     const int cg = out_groups >= 1 && m % out_groups == 0 ? m / out_groups : 0;

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(1024) void sparse_vox_features_lds_kernel(int c, in
   }
   if (OUT == 1) {
     m = wave_max(m);
-    if ((tid & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));  // non-negative floats order as unsigned ints
+    if ((tid & 63) == 0 && m > 0.f) atomicMax(amax + bi, __float_as_uint(m));  // per shape; non-negative floats order as unsigned ints
   }
 }
 

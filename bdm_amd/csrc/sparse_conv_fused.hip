@@ -79,7 +79,7 @@ __device__ __forceinline__ float act_scale_from_max(float amax) {
 
 // ---------------------------------------------------------------------------------------------------
 // occupied cells' mean features as fp32 records: xr (B, G, n_max) records of 8 channels (32 bytes), rows >= n_occ zero;
-// amax[0] = max |value| over the whole call (must be zero on entry).  Same XCD-aware unit decoding and the same
+// amax[bi] = max |value| of shape bi (b slots, zero on entry).  Same XCD-aware unit decoding and the same
 // summation order as sparse_vox_features_s3_kernel (sparse_conv.hip): values equal the dense voxel grid's bit for bit.
 // ---------------------------------------------------------------------------------------------------
 __global__ void sparse_vox_features_f32_kernel(int c, int n, int r3, int n_max, int G, int units, int kblocks,
@@ -131,7 +131,7 @@ __global__ void sparse_vox_features_f32_kernel(int c, int n, int r3, int n_max, 
     o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
   }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));  // non-negative floats order as unsigned ints
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax + bi, __float_as_uint(m));  // per shape; non-negative floats order as unsigned ints
 }
 
 extern "C" int bdm_sparse_voxel_features_f32(int b, int c, int n, int r, int n_max, const float *features, long long bs_f,
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void sparse_conv_fused_kernel(int G, int Cout,
   }
   __syncthreads();
 
-  const float sx = act_scale_from_max(*amax);
+  const float sx = act_scale_from_max(amax[bi]);
   const float post = (co_ok ? inv_sw[co] : 0.f) * (1.0f / sx);  // powers of two: exact
   const int K16 = (G + 1) >> 1;
   const float4 *xb = xr + (size_t)bi * G * n_max * 2;
@@ -447,11 +447,11 @@ extern "C" int bdm_sparse_conv_pack_weights_h2(int cout, int cin, const float *w
 // fp32 records -> (hi, lo) fp16 records of x * 2^e (e from amax), layout [b][g][2][M]: done ONCE per call, so that the
 // GEMM's column tiles do not each repeat the split while staging
 __global__ void sparse_split_h2_kernel(long long rows_total, int M, const float4 *__restrict__ xr, const float *__restrict__ amax,
-                                       uint4 *__restrict__ xh) {
-  const float sx = act_scale_from_max(*amax);
+                                       uint4 *__restrict__ xh, int G) {
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < rows_total; e += (long long)gridDim.x * blockDim.x) {
     const long long bg = e / M;
     const int row = (int)(e % M);
+    const float sx = act_scale_from_max(amax[bg / G]);  // one power-of-two scale per SHAPE: results do not depend on batch-mates
     f16x8 hi, lo;
     split_record(xr[e * 2], xr[e * 2 + 1], sx, hi, lo);
     xh[(bg * 2 + 0) * M + row] = *reinterpret_cast<const uint4 *>(&hi);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N
   const int wr = wave >> 1, wc = wave & 1;  // 2 x 2 waves: rows wr * (BM/2), columns wc * 64
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, bi = blockIdx.z;
   if (m_count && m0 >= m_count[bi]) return;  // rows beyond this shape's occupied cells
-  const float sx = act_scale_from_max(*amax);
+  const float sx = act_scale_from_max(amax[bi]);
   const uint4 *Ab = A + (size_t)bi * G * 2 * M;
   f32x16 acc[MX][2];
 #pragma unroll
@@ -559,7 +559,7 @@ extern "C" int bdm_sparse_split_h2(int b, int cin, int n_max, const void *xr, co
   long long grid = (rows + 255) / 256;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(sparse_split_h2_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, rows, n_max, (const float4 *)xr,
-                     amax, (uint4 *)xh);
+                     amax, (uint4 *)xh, (cin + 7) / 8);
   return launch_status("sparse_split_h2");
 }
 

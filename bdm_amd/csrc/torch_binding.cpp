@@ -24,6 +24,10 @@ namespace {
 #define CHECK_F(x) do { CHECK_GPU(x); CHECK_CONTIGUOUS(x); CHECK_IS_FLOAT(x); } while (0)
 #define CHECK_I(x) do { CHECK_GPU(x); CHECK_CONTIGUOUS(x); CHECK_IS_INT(x); } while (0)
 
+// Every binding makes the tensor's device current for its duration: the C ABI launches on the CURRENT device, so cuda:1 tensors
+// while cuda:0 is current would otherwise be launched on the wrong GPU (the reference's shims rely on at::cuda guards likewise).
+#define ON_DEVICE_OF(x) const c10::DeviceGuard bdm_device_guard((x).device())
+
 void *stream_of(const at::Tensor &t) {
   return (void *)at::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream();
 }
@@ -39,6 +43,7 @@ at::TensorOptions iopt(const at::Tensor &like) { return at::device(like.device()
 // sampling.cpp:6-41
 at::Tensor gather_features_forward(at::Tensor features, at::Tensor indices) {
   CHECK_F(features); CHECK_I(indices);
+  ON_DEVICE_OF(features);
   const int b = features.size(0), c = features.size(1), n = features.size(2), m = indices.size(1);
   at::Tensor out = torch::empty({b, c, m}, fopt(features));
   ok(bdm_gather_features_forward(b, c, n, m, features.data_ptr<float>(), indices.data_ptr<int>(), out.data_ptr<float>(),
@@ -47,6 +52,7 @@ at::Tensor gather_features_forward(at::Tensor features, at::Tensor indices) {
 }
 at::Tensor gather_features_backward(at::Tensor grad_y, at::Tensor indices, const int n) {
   CHECK_F(grad_y); CHECK_I(indices);
+  ON_DEVICE_OF(grad_y);
   const int b = grad_y.size(0), c = grad_y.size(1), m = grad_y.size(2);
   at::Tensor gx = torch::empty({b, c, n}, fopt(grad_y));
   ok(bdm_gather_features_backward(b, c, n, m, grad_y.data_ptr<float>(), indices.data_ptr<int>(), gx.data_ptr<float>(),
@@ -56,6 +62,7 @@ at::Tensor gather_features_backward(at::Tensor grad_y, at::Tensor indices, const
 // sampling.cpp:43-58
 at::Tensor furthest_point_sampling_forward(at::Tensor coords, const int num_samples) {
   CHECK_F(coords);
+  ON_DEVICE_OF(coords);
   const int b = coords.size(0), n = coords.size(2);
   at::Tensor idx = torch::zeros({b, num_samples}, iopt(coords));
   ok(bdm_furthest_point_sampling(b, n, num_samples, coords.data_ptr<float>(), idx.data_ptr<int>(), nullptr, stream_of(coords)),
@@ -65,6 +72,7 @@ at::Tensor furthest_point_sampling_forward(at::Tensor coords, const int num_samp
 // ball_query.cpp:6-30
 at::Tensor ball_query_forward(at::Tensor centers_coords, at::Tensor points_coords, const float radius, const int num_neighbors) {
   CHECK_F(centers_coords); CHECK_F(points_coords);
+  ON_DEVICE_OF(centers_coords);
   const int b = centers_coords.size(0), m = centers_coords.size(2), n = points_coords.size(2);
   at::Tensor out = torch::empty({b, m, num_neighbors}, iopt(points_coords));
   ok(bdm_ball_query(b, n, m, radius, num_neighbors, centers_coords.data_ptr<float>(), points_coords.data_ptr<float>(),
@@ -74,6 +82,7 @@ at::Tensor ball_query_forward(at::Tensor centers_coords, at::Tensor points_coord
 // grouping.cpp:6-44
 at::Tensor grouping_forward(at::Tensor features, at::Tensor indices) {
   CHECK_F(features); CHECK_I(indices);
+  ON_DEVICE_OF(features);
   const int b = features.size(0), c = features.size(1), n = features.size(2), m = indices.size(1), u = indices.size(2);
   at::Tensor out = torch::empty({b, c, m, u}, fopt(features));
   ok(bdm_grouping_forward(b, c, n, m, u, features.data_ptr<float>(), indices.data_ptr<int>(), out.data_ptr<float>(),
@@ -82,6 +91,7 @@ at::Tensor grouping_forward(at::Tensor features, at::Tensor indices) {
 }
 at::Tensor grouping_backward(at::Tensor grad_y, at::Tensor indices, const int n) {
   CHECK_F(grad_y); CHECK_I(indices);
+  ON_DEVICE_OF(grad_y);
   const int b = grad_y.size(0), c = grad_y.size(1), m = indices.size(1), u = indices.size(2);
   at::Tensor gx = torch::empty({b, c, n}, fopt(grad_y));
   ok(bdm_grouping_backward(b, c, n, m, u, grad_y.data_ptr<float>(), indices.data_ptr<int>(), gx.data_ptr<float>(),
@@ -92,6 +102,7 @@ at::Tensor grouping_backward(at::Tensor grad_y, at::Tensor indices, const int n)
 std::vector<at::Tensor> three_nearest_neighbors_interpolate_forward(at::Tensor points_coords, at::Tensor centers_coords,
                                                                     at::Tensor centers_features) {
   CHECK_F(points_coords); CHECK_F(centers_coords); CHECK_F(centers_features);
+  ON_DEVICE_OF(points_coords);
   const int b = centers_features.size(0), c = centers_features.size(1), m = centers_features.size(2), n = points_coords.size(2);
   at::Tensor idx = torch::empty({b, 3, n}, iopt(points_coords)), w = torch::empty({b, 3, n}, fopt(points_coords));
   at::Tensor out = torch::empty({b, c, n}, fopt(points_coords));
@@ -102,6 +113,7 @@ std::vector<at::Tensor> three_nearest_neighbors_interpolate_forward(at::Tensor p
 }
 at::Tensor three_nearest_neighbors_interpolate_backward(at::Tensor grad_y, at::Tensor indices, at::Tensor weights, const int m) {
   CHECK_F(grad_y); CHECK_I(indices); CHECK_F(weights);
+  ON_DEVICE_OF(grad_y);
   const int b = grad_y.size(0), c = grad_y.size(1), n = grad_y.size(2);
   at::Tensor gx = torch::empty({b, c, m}, fopt(grad_y));
   ok(bdm_three_nn_interpolate_backward(b, c, n, m, grad_y.data_ptr<float>(), indices.data_ptr<int>(), weights.data_ptr<float>(),
@@ -112,6 +124,7 @@ at::Tensor three_nearest_neighbors_interpolate_backward(at::Tensor grad_y, at::T
 std::vector<at::Tensor> trilinear_devoxelize_forward(const int r, const bool is_training, const at::Tensor coords,
                                                      const at::Tensor features) {
   CHECK_F(features); CHECK_F(coords);
+  ON_DEVICE_OF(features);
   const int b = features.size(0), c = features.size(1), n = coords.size(2);
   at::Tensor outs = torch::empty({b, c, n}, fopt(features));
   if (is_training) {
@@ -127,6 +140,7 @@ std::vector<at::Tensor> trilinear_devoxelize_forward(const int r, const bool is_
 }
 at::Tensor trilinear_devoxelize_backward(const at::Tensor grad_y, const at::Tensor indices, const at::Tensor weights, const int r) {
   CHECK_F(grad_y); CHECK_I(indices); CHECK_F(weights);
+  ON_DEVICE_OF(grad_y);
   const int b = grad_y.size(0), c = grad_y.size(1), n = grad_y.size(2);
   at::Tensor gx = torch::empty({b, c, r * r * r}, fopt(grad_y));
   ok(bdm_trilinear_devoxelize_backward(b, c, n, r, indices.data_ptr<int>(), weights.data_ptr<float>(), grad_y.data_ptr<float>(),
@@ -136,6 +150,7 @@ at::Tensor trilinear_devoxelize_backward(const at::Tensor grad_y, const at::Tens
 // vox.cpp:17-69
 std::vector<at::Tensor> avg_voxelize_forward(const at::Tensor features, const at::Tensor coords, const int resolution) {
   CHECK_F(features); CHECK_I(coords);
+  ON_DEVICE_OF(features);
   const int b = features.size(0), c = features.size(1), n = features.size(2), r = resolution, r3 = r * r * r;
   at::Tensor ind = torch::empty({b, n}, iopt(features)), cnt = torch::empty({b, r3}, iopt(features));
   at::Tensor out = torch::empty({b, c, r3}, fopt(features));
@@ -146,6 +161,7 @@ std::vector<at::Tensor> avg_voxelize_forward(const at::Tensor features, const at
 }
 at::Tensor avg_voxelize_backward(const at::Tensor grad_y, const at::Tensor indices, const at::Tensor cnt) {
   CHECK_F(grad_y); CHECK_I(indices); CHECK_I(cnt);
+  ON_DEVICE_OF(grad_y);
   const int b = grad_y.size(0), c = grad_y.size(1), s = grad_y.size(2), n = indices.size(1);
   int r = 1;
   while (r * r * r < s) ++r;

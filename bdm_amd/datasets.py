@@ -295,10 +295,50 @@ def custom_collate(batch):
     return data
 
 
+def accelerate_batch_shard(num_samples, batch_size, rank, world):
+    """The index batches rank `rank` of `world` processes sees when accelerate shards a sequential, drop_last=False
+    DataLoader the way `accelerator.prepare(dataloader)` does by default in the reference (main_blending.py:115-124;
+    accelerate.data_loader.BatchSamplerShard, split_batches=False, even_batches=True): whole batches dealt round-robin
+    (batch i -> rank i % world); when the batch count is not a multiple of `world`, or the last batch is short, the tail is
+    completed with samples from the START of the dataset so that every rank gets the same number of full batches.
+    Restated here (accelerate is not a dependency of the sampling path); tests/test_datasets.py checks it against the
+    installed accelerate where that is importable."""
+    batches = [list(range(i, min(i + batch_size, num_samples))) for i in range(0, num_samples, batch_size)]
+    if world == 1:
+        return batches
+    mine, initial, pending, idx, batch = [], [], None, -1, []
+    for idx, batch in enumerate(batches):
+        if idx < world:
+            initial += batch
+        if idx % world == rank:
+            pending = batch
+        if idx % world == world - 1 and len(batch) == batch_size:
+            mine.append(pending)
+            pending = None
+    if initial:
+        if pending and len(pending) == batch_size:
+            mine.append(pending)
+        while len(initial) < world * batch_size:
+            initial += initial
+        if len(batch) == batch_size:
+            batch, idx = [], idx + 1
+        batch, cycle = list(batch), 0
+        while idx % world != 0 or len(batch) > 0:
+            end = cycle + batch_size - len(batch)
+            batch += initial[cycle:end]
+            if idx % world == rank:
+                mine.append(batch)
+            cycle, batch, idx = end, [], idx + 1
+    return mine
+
+
 def get_dataset(cfg, rank=0, world=1):
     """dataset/__init__.py:get_dataset for the sample_* jobs: (None, dataloader_val, dataloader_vis).  With world > 1 the
-    validation set is sharded by sample index (contiguous, balanced), as accelerator.prepare(dataloader) does in the
-    reference (main_blending.py:115-124)."""
+    validation loader is sharded as accelerator.prepare(dataloader) shards it in the reference (main_blending.py:115-124):
+    whole batches round-robin over the ranks, tail padded from the start of the dataset (`accelerate_batch_shard`), so the
+    shape -> rank assignment of a multi-GPU run is the reference's.  meta['dataset_index'] stays the GLOBAL index (the key of the
+    per-shape random streams).  As in the reference every rank builds the full dataset with numpy seeded `seed + rank`
+    (training_utils.py:373-378), so the random subsample of a ground-truth cloud depends on the rank that loads it."""
     d, dl = cfg.dataset, cfg.dataloader
     if d.type == "shapenet_r2n2":
         ds = ShapeNet_R2N2(root_dir=d.root, r2n2_dir=d.r2n2_dir, pc_dict=d.pc_dict or "pc_dict_v2.json", split_file=d.split_file,
@@ -311,8 +351,9 @@ def get_dataset(cfg, rank=0, world=1):
     else:
         raise NotImplementedError(d.type)
     if world > 1:
-        from .distributed import shard_indices
-        ds = torch.utils.data.Subset(ds, shard_indices(len(ds), rank, world))
-    val = torch.utils.data.DataLoader(ds, batch_size=dl.batch_size, shuffle=False, num_workers=0, drop_last=False,
-                                      collate_fn=custom_collate)
+        val = torch.utils.data.DataLoader(ds, batch_sampler=accelerate_batch_shard(len(ds), dl.batch_size, rank, world), num_workers=0,
+                                          collate_fn=custom_collate)
+    else:
+        val = torch.utils.data.DataLoader(ds, batch_size=dl.batch_size, shuffle=False, num_workers=0, drop_last=False,
+                                          collate_fn=custom_collate)
     return None, val, val

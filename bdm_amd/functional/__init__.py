@@ -121,8 +121,7 @@ class TrilinearDevoxelization(Function):
         return gx.view(grad_output.size(0), grad_output.size(1), ctx.r, ctx.r, ctx.r), None, None, None
 
 
-def trilinear_devoxelize(features, coords, resolution, is_training=False):
-    return TrilinearDevoxelization.apply(features, coords, resolution, is_training)
+trilinear_devoxelize = TrilinearDevoxelization.apply  # as the reference (devoxelization.py:44): is_training defaults to True
 
 
 __all__ = ["ball_query", "grouping", "gather", "furthest_point_sample", "nearest_neighbor_interpolate",

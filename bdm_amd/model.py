@@ -292,7 +292,8 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
     # to the eager loop (same kernels, same arguments, same RNG stream: the noise is drawn eagerly, in order).
     def _step_graph(self, x_t, camera, image_rgb, mask, scheduler):
         feat, _ = self.conditioning_image(image_rgb, mask)
-        key = (tuple(x_t.shape), str(x_t.device), id(camera), id(scheduler), scheduler.num_inference_steps, self._weights_signature())
+        key = (tuple(x_t.shape), str(x_t.device), id(camera), id(scheduler), scheduler.num_inference_steps, self._weights_signature(),
+               ops.saturation_epoch())
         g = getattr(self, "_graph_cache", None)
         if g is not None and g["key"] == key and g["feat"] is feat and g["image"] is image_rgb:
             return g
@@ -351,7 +352,7 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
         feat, _ = self.conditioning_image(image_rgb, mask)
         dev, B = x_t.device, x_t.shape[0]
         key = (tuple(x_t.shape), str(dev), id(camera), torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()),
-               self._weights_signature())
+               self._weights_signature(), ops.saturation_epoch())
         g = getattr(self, "_tape_cache", None)
         if g is None or g["key"] != key or g["feat"] is not feat or g["image"] is not image_rgb:
             g = {"key": key, "feat": feat, "image": image_rgb, "camera": camera, "tape": None, "warm": False, "off": None, "eps": None,

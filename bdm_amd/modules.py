@@ -147,7 +147,7 @@ class Attention(nn.Module):
         w, b = self._qkv_params()
         if flat.is_cuda and ops.attention_h2_ok(C, flat.shape[2]):
             # fp16x3 attention: the projection GEMM leaves max |q|, |k|, |v| (the operands' power-of-two scales)
-            amax = ops.amax_slots(flat.device, 3)
+            amax = ops.amax_slots(flat.device, 3 * flat.shape[0])  # per shape: max |q|, |k|, |v|
             qkv = ops.pointwise_conv_gn(flat, w, b, amax=amax, amax_rows=C)
             h = ops.attention_core(qkv, C, amax=amax)
         else:

@@ -332,7 +332,10 @@ ATTENTION_IMPL = os.environ.get("BDM_ATTENTION", "fp16x3")  # "bf16x6": six-prod
 
 
 def amax_slots(device, n):
-    """n zeroed floats (consecutive slots of the per-stream ring of _amax_slot)"""
+    """n zeroed floats (consecutive slots of the per-stream ring of _amax_slot; a buffer of their own for large n: the zero-fill
+    is then part of the step, which a recorded step replays like any other launch)"""
+    if n > 64:
+        return torch.zeros(n, dtype=torch.float32, device=device)
     while True:
         first = _amax_slot(device)
         ring = _amax_rings[(str(device), torch._C._cuda_getCurrentRawStream(first.device.index))]
@@ -348,7 +351,7 @@ def attention_h2_ok(C, l):
 
 
 def attention_core(qkv, C, impl=None, amax=None):
-    """qkv (B, 3C, L): rows [0,C) = q, [C,2C) = k, [2C,3C) = v  ->  (B, C, L).  amax (3 floats: max |q|, |k|, |v| of the call,
+    """qkv (B, 3C, L): rows [0,C) = q, [C,2C) = k, [2C,3C) = v  ->  (B, C, L).  amax (3 floats per shape: max |q|, |k|, |v|,
     from pointwise_conv_gn) selects the fp16x3 kernel."""
     B, _, l = qkv.shape
     out = torch.empty(B, C, l, dtype=torch.float32, device=qkv.device)
@@ -466,6 +469,13 @@ def h2_activation_scale(gn, sigmas=64.0):
 
 
 _sat_registry = {}  # device -> [flags tensor (int32, 256 slots), [weakref(owner) per slot]]
+_sat_epoch = 0      # bumped whenever a layer is switched to the bf16x6 route: recorded steps (launch tape, hipGraph) key on it
+
+
+def saturation_epoch():
+    """Changes when poll_h2_saturation() re-routes a layer.  A recorded reverse step has the fp16x3 kernels of that layer baked
+    in, so every cache of recorded steps carries this number in its key and re-records on the new route."""
+    return _sat_epoch
 
 
 def saturation_slot(owner, device):
@@ -498,6 +508,7 @@ def poll_h2_saturation():
     step).  Every flagged layer is switched to the bf16x6 kernels (exact split, no range limit) for all later calls and a
     warning names it: the trajectory that just finished used clamped activations in that layer."""
     import warnings
+    global _sat_epoch
     hit = []
     for key, (flags, owners) in _sat_registry.items():
         if not owners:
@@ -511,6 +522,7 @@ def poll_h2_saturation():
         if hit:
             flags.zero_()
     if hit:
+        _sat_epoch += 1
         warnings.warn(f"fp16x3 convolution input saturated (|scale * y| > 65504) in {len(hit)} layer(s): "
                       f"{[getattr(m, 'bdm_name', type(m).__name__) for m in hit]}; the trajectory that just finished used clamped "
                       "activations there.  These layers now run the bf16x6 kernels (no range limit).", stacklevel=2)
@@ -794,7 +806,7 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None):
     if isinstance(wt, tuple) and wt[0] == "h2":  # fp16x3 GEMM (sparse_conv_pack_h2) + gather: the default
         _, packed, inv_scale = wt
         xr = torch.empty(B, (C + 7) // 8, plan.n_max, 8, dtype=torch.float32, device=dev)
-        amax = _amax_slot(dev)
+        amax = amax_slots(dev, B)  # one activation scale per shape: a shape's result does not depend on its batch-mates
         L.check(lib.bdm_sparse_voxel_features_f32(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),
                                                   L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()),
                 "sparse_voxel_features_f32")
@@ -810,14 +822,14 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None):
             gn, stats = (partial, int(gn_groups)), (partial, r * r, int(gn_groups))
         for b0 in range(0, B, gb):
             nb = min(gb, B - b0)
-            L.check(lib.bdm_sparse_conv_gemm_h2(nb, plan.n_max, C, cout, L.ptr(xh[b0:]), L.ptr(amax), L.ptr(packed), L.ptr(inv_scale),
+            L.check(lib.bdm_sparse_conv_gemm_h2(nb, plan.n_max, C, cout, L.ptr(xh[b0:]), L.ptr(amax[b0:]), L.ptr(packed), L.ptr(inv_scale),
                                                 L.ptr(plan.n_occ[b0:]), L.ptr(y), L.stream()), "sparse_conv_gemm_h2")
             _gather(lib, nb, cout, r, plan, b0, y, bias, out, gn)
         return (out, stats) if gn_groups else out
     if isinstance(wt, tuple):  # fused kernel (sparse_conv_pack_fused): GEMM + scatter in one launch, no intermediate
         _, packed, inv_scale = wt
         xr = torch.empty(B, (C + 7) // 8, plan.n_max, 8, dtype=torch.float32, device=dev)
-        amax = _amax_slot(dev)
+        amax = amax_slots(dev, B)  # one activation scale per shape: a shape's result does not depend on its batch-mates
         L.check(lib.bdm_sparse_voxel_features_f32(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),
                                                   L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()),
                 "sparse_voxel_features_f32")

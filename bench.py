@@ -9,8 +9,13 @@ skipped inside the timed region.  N GPUs = N independent shards of 16 shapes (we
 collective on the data path; one barrier + MAX-over-ranks for timing).
 
     python bench.py                          # 1 GPU, 1 trajectory (about a minute)
+    python bench.py --gpus N                 # no WORLD_SIZE in the environment: starts its own N workers (one per GPU) through
+                                             # `python -m torch.distributed.run` BEFORE anything touches a GPU, relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --config c3              # the other BASELINE.json configurations at their per-GPU batch:
+                                             #   c2 Blending N=4096 B=16 (default, the metric's workload) | c3 Merging N=4096 B=16
+                                             #   c4 Blending N=8192 B=8 | c5 Blending N=16384 B=32
 
 Extra objects on the JSON line:
   roofline       -- the kernel CLASS with the largest share of kernel time (live HIP-event sampling of every 32nd launch of
@@ -143,6 +148,46 @@ def c1_full(device, n_points=1024, steps=100):
             "cpu_s": cpu_s, "speedup": cpu_s / gpu_s}
 
 
+CONFIGS = {  # BASELINE.json configs[1..4] at their per-GPU share (batch / 8 GPUs)
+    "c2": dict(kind="blending", points=4096, batch=16, label="C2: BDM-Blending, N=4096 pts, 1000 DDPM steps, batch=16 per GPU"),
+    "c3": dict(kind="merging", points=4096, batch=16, label="C3: BDM-Merging, N=4096 pts, 1000 DDPM steps, batch=16 per GPU (128 over 8)"),
+    "c4": dict(kind="blending", points=8192, batch=8, label="C4: BDM-Blending, N=8192 pts, 1000 DDPM steps, batch=8 per GPU (64 over 8)"),
+    "c5": dict(kind="blending", points=16384, batch=32, label="C5: BDM-Blending, N=16384 pts, 1000 DDPM steps, batch=32 per GPU (256 over 8)"),
+}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: start the N workers ourselves (child processes, one
+    rank per GPU over RCCL), BEFORE this process has touched a GPU, relay their output and exit with their status.  The reference
+    shards with accelerator.prepare(dataloader) under `accelerate launch` (experiments/main_blending.py:115-124)."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if have < args.gpus:
+        if env.get("BDM_SHARE_GPU") != "1":
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible (BDM_SHARE_GPU=1 runs the ranks on one GPU over gloo: "
+                  "a functional check, not a measurement)", file=sys.stderr)
+            return 2
+        env.setdefault("BDM_DIST_BACKEND", "gloo")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: worker group failed (exit {proc.returncode}, {len(lines)} result lines)", file=sys.stderr)
+        return proc.returncode or 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     if os.environ.get("BDM_WATCHDOG"):  # debugging aid: dump every thread's Python stack and exit after N seconds
         import faulthandler
@@ -151,23 +196,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1, help="timed trajectories (each = 1000 DDPM steps of a 16-shape batch)")
     ap.add_argument("--warmup", type=int, default=0, help="untimed trajectories before the timed ones")
-    ap.add_argument("--batch", type=int, default=16, help="shapes per GPU (config C2)")
-    ap.add_argument("--points", type=int, default=4096)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json configuration (default c2: the metric's)")
+    ap.add_argument("--batch", type=int, default=None, help="shapes per GPU (default: the configuration's)")
+    ap.add_argument("--points", type=int, default=None, help="points per shape (default: the configuration's)")
     ap.add_argument("--ddpm-steps", type=int, default=1000, help="ONLY for smoke runs; any value != 1000 marks the line invalid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    conf = CONFIGS[args.config]
+    custom = (args.batch is not None and args.batch != conf["batch"]) or (args.points is not None and args.points != conf["points"])
+    args.batch = conf["batch"] if args.batch is None else args.batch
+    args.points = conf["points"] if args.points is None else args.points
+    merging = conf["kind"] == "merging"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     from bdm_amd import _lib
     from bdm_amd.config import ProjectConfig
     from bdm_amd.data import SyntheticShapes
     from bdm_amd.distributed import barrier, init_from_env, max_over_ranks, shard_indices
-    from bdm_amd.model import get_model
+    from bdm_amd.model import get_fusion_model, get_model
     from bdm_amd.pvd import prepare_pvd_model
-    from bdm_amd.sampling import batch_streams, bdm_blending, count_forwards
+    from bdm_amd.sampling import batch_streams, bdm_blending, bdm_merging, count_forwards
     from bdm_amd.utils.procedural import fill_module_
 
     rank, local_rank, world = init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    rccl_ranks = torch.distributed.get_world_size() if world > 1 else 1  # the world size the process group really has
+    dist_backend = torch.distributed.get_backend() if world > 1 else None
     if os.environ.get("BDM_SHARE_GPU") == "1":  # test aid: every rank on cuda:0 (with BDM_DIST_BACKEND=gloo) on a 1-GPU box
         local_rank = 0
     device = torch.device("cuda", local_rank)
@@ -185,24 +240,36 @@ def main():
     torch.manual_seed(cfg.run.seed + rank)
     model = fill_module_(get_model(cfg).eval(), seed=cfg.run.seed).to(device)
     pvd_model = prepare_pvd_model({"model": None, "nc": 3, "embed_dim": 64, "attention": True, "dropout": 0.1}, device)
+    fusion = None
+    if merging:  # PVCNN_fuse over copies of both denoisers (main_merging.py:565-575); the "zero convolutions" get procedural weights
+        fusion = get_fusion_model(cfg, pvd_model, model)
+        fill_module_(fusion.fusion_model.model.projs, seed=cfg.run.seed + 2, prefix="projs.")
+        fill_module_(fusion.feature_model, seed=cfg.run.seed, prefix="feature_model.")
+        fusion = fusion.eval().to(device)
     total_shapes = args.batch * world
     batch = next(iter(SyntheticShapes(shard_indices(total_shapes, rank, world), args.batch, seed=cfg.run.seed,
                                       image_size=224, num_points=args.points))).to(device)
-    gen = torch.Generator().manual_seed(cfg.run.seed + rank)
     cfg.run.rng = "per_shape"  # every draw from the shapes' own Philox streams keyed by (seed, GLOBAL shape index): the
     counter = [0]              # samples do not depend on the number of ranks
 
+    def sample(c, **kw):
+        if merging:
+            return bdm_merging(None, batch, c, pvd_model, model, fusion, **kw)
+        return bdm_blending(None, batch, c, model, pvd_model, **kw)
+
     def trajectory():
         model._cond_cache = None  # the hoisted image encoder runs once per trajectory, inside the timed region
+        if fusion is not None:
+            fusion._cond_cache = None
         counter[0] += 1
-        return bdm_blending(None, batch, cfg, model, pvd_model,
-                            streams=batch_streams(cfg, batch, device, sample_idx=counter[0])).points_padded()
+        return sample(cfg, streams=batch_streams(cfg, batch, device, sample_idx=counter[0])).points_padded()
 
     # prime allocator / code objects (not a "step": a 2-forward schedule)
     prime_cfg = ProjectConfig()
     prime_cfg.dataset.max_points = args.points
-    prime_cfg.aux_run.milestones, prime_cfg.aux_run.roll_step = [1000, 998, 996], 1
-    bdm_blending(None, batch, prime_cfg, model, pvd_model, generator=gen)
+    prime_cfg.aux_run.milestones, prime_cfg.aux_run.roll_step = ([1000, 996, 993, 990], 2) if merging else ([1000, 998, 996], 1)
+    prime_cfg.run.rng = "per_shape"
+    sample(prime_cfg)
     for _ in range(args.warmup):
         trajectory()
 
@@ -221,24 +288,27 @@ def main():
     assert torch.isfinite(out).all()
 
     if rank == 0:
-        pc2_f, pvd_f, _ = count_forwards(cfg.aux_run.milestones, cfg.aux_run.roll_step)
+        pc2_f, pvd_f, fuse_f = count_forwards(cfg.aux_run.milestones, cfg.aux_run.roll_step, merging=merging)
         value = total_shapes * args.steps / elapsed
         line = {
-            "metric": "sampled shapes/sec (4096 pts, 1000 DDPM steps)", "value": value, "unit": "shapes/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "metric": f"sampled shapes/sec ({args.points} pts, 1000 DDPM steps)", "value": value, "unit": "shapes/s",
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "dist_backend": dist_backend, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rng": "per-shape Philox4x32-10 streams keyed by (seed, global shape index), noise generated inside the step kernels",
             "conv_arithmetic": CONV_IMPL + (" (fp32-grade: operands as two fp16 terms after power-of-two scaling, three partial "
                                                     "products, fp32 accumulate; first conv of each PVConv: sparse, bf16x6)"
                                                     if CONV_IMPL == "fp16x3" else " (fp32-grade: exact 3-way bf16 operand split, "
                                                     "six partial products, fp32 accumulate)"),
-            "config": {"workload": "C2: BDM-Blending, N=4096 pts, 1000 DDPM steps, batch=16 per GPU, synthetic R2N2-style "
-                                   "inputs, procedural random-init PC2 + PVD weights",
-                       "shapes_per_gpu": args.batch, "points": args.points, "pc2_forwards": pc2_f, "pvd_forwards": pvd_f,
+            "config": {"workload": conf["label"] + ", synthetic R2N2-style inputs, procedural random-init PC2 + PVD"
+                                   + (" + fusion" if merging else "") + " weights",
+                       "name": args.config, "shapes_per_gpu": args.batch, "points": args.points, "pc2_forwards": pc2_f,
+                       "pvd_forwards": pvd_f, "fusion_forwards": fuse_f,
                        "milestones": cfg.aux_run.milestones, "roll_step": cfg.aux_run.roll_step},
         }
-        if args.ddpm_steps != 1000 or args.points != 4096:
-            line["invalid"] = "smoke configuration: not the metric's workload"
+        if args.ddpm_steps != 1000 or custom:
+            line["invalid"] = "smoke / custom configuration: not one of BASELINE.json's workloads"
+        elif args.config != "c2":
+            line["note"] = "not the headline workload (the metric is quoted on C2); same trajectory definition at this configuration's size"
         # occupied fraction of the sparse convolutions' rows on the final clouds (after the timed region), per level
         from bdm_amd import functional as BF, ops as bops, profiling
         pts = out.transpose(1, 2).contiguous()
@@ -277,13 +347,13 @@ def main():
             line["roofline_rows"] = [{"kernel": f"{r['function']}{tuple(r['shape'])}", "class": r["class"], "share": round(r["share"], 4),
                                       "avg_us": round(r["avg_us"], 2), "launches": r["calls"]} for r in rows[:12]]
         # whole-path view: algorithmic FLOPs of SURVEY.md 8d per trajectory
-        tflop_per_shape = (pc2_f * 103.64 + pvd_f * 81.22) / 1e3 if args.points == 4096 else None
+        tflop_per_shape = (pc2_f * 103.64 + pvd_f * 81.22) / 1e3 if args.points == 4096 and not merging else None
         if tflop_per_shape:
             line["path_tflops"] = value * tflop_per_shape
             line["path_frac_of_fp32_mfma_peak"] = value * tflop_per_shape / (FP32_MFMA_PEAK_TFLOPS * world)
             # against the ceiling the split-precision kernels can reach: dense 16-bit MFMA peak / 3 products per fp32 product
             line["path_frac_of_fp16x3_peak"] = value * tflop_per_shape / (BF16_MFMA_PEAK_TFLOPS / 3 * world)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == "c2":
             line["cpu_baseline"] = cpu_baseline(model, pvd_model, args.points)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
             line["cpu_baseline"]["c1_full"] = c1_full(device)  # the reference's CPU-runnable config, run in full on both sides

@@ -152,8 +152,9 @@ int bdm_group_norm(int b, int c, int l, int groups, const float *x, long long bs
  *   bdm_pointwise_conv_gn: y = W x' + bias with
  *     x' = x, or (in_partial != NULL) x' = Swish(GroupNorm(x)) applied while the operand is staged, the statistics of x taken
  *          from the slice partials in_partial (b, in_groups, in_slices, 2 doubles) its producer left (in_groups <= 8, k <= 1024);
- *     amax != NULL: amax[i] (ZERO on entry) receives max |y| over rows [i * amax_rows, (i + 1) * amax_rows) of the whole call
- *          (amax_rows % 32 == 0): the scales of the fp16x3 attention, bdm_attention_core_h2;
+ *     amax != NULL: amax[s * ceil(m / amax_rows) + i] (b * ceil(m / amax_rows) slots, ZERO on entry) receives max |y| over rows
+ *          [i * amax_rows, (i + 1) * amax_rows) of shape s (amax_rows % 32 == 0): the per-shape scales of the fp16x3
+ *          attention, bdm_attention_core_h2;
  *     x2 != NULL: the operand is torch.cat([x (k1 rows), x2 (k - k1 rows)], dim=1) read in place (pointnet.py:108-110, the skip
  *          features of an FP module are never copied next to the interpolated ones);
  *     and (out_partial != NULL) the (sum, sum of squares) of y per (shape, group of m / out_groups channels) written as
@@ -227,8 +228,8 @@ size_t bdm_attention_workspace_bytes(int b, int c, int l);
 int bdm_attention_core(int b, int c, int l, const float *q, const float *k, const float *v,
                        long long bs_qkv, int ld_qkv, float *out, long long bs_o, int ld_o,
                        void *workspace, void *stream);
-/* fp16x3 form (half the matrix work of the bf16x6 kernel behind bdm_attention_core): needs amax[0..2] = max |q|, |k|, |v| of the
- * call (the projection GEMM leaves them: bdm_pointwise_conv_gn amax) and a workspace of bdm_attention_h2_workspace_bytes;
+/* fp16x3 form (half the matrix work of the bf16x6 kernel behind bdm_attention_core): needs amax[3 s + 0..2] = max |q|, |k|, |v| of
+ * shape s (the projection GEMM leaves them: bdm_pointwise_conv_gn amax with amax_rows = c) and a workspace of bdm_attention_h2_workspace_bytes;
  * 64 < l, c <= 64 */
 size_t bdm_attention_h2_workspace_bytes(int b, int c, int l);
 int bdm_attention_core_h2(int b, int c, int l, const float *q, const float *k, const float *v, long long bs_qkv, int ld_qkv,
@@ -363,7 +364,7 @@ int bdm_sparse_conv_gather_gn(int b, int cout, int r, int n_max, const float *y,
 
 /* --- the same first convolution in ONE kernel, no (n_occ x 27*cout) intermediate (sparse_conv_fused.hip; the default) ---
  *   bdm_sparse_voxel_features_f32  occupied cells' mean features as fp32 records xr (b, ceil(c/8), n_max) x 8 channels,
- *                                  rows >= n_occ zero; amax[0] (ZERO on entry) receives max |value| of the call
+ *                                  rows >= n_occ zero; amax[i] (b slots, ZERO on entry) receives max |value| of shape i
  *   bdm_sparse_conv_fused_pack_weights  (cout, cin, 3,3,3) fp32 -> [ceil(cin/8)][27][2][cout] records of 8 fp16
  *                                  (hi / lo of w * 2^e[co]); inv_scale[co] = 2^-e[co]; scale_ws (cout floats) scratch
  *   bdm_sparse_conv_fused          out (b, cout, r^3) = bias + conv: workgroup = (shape, slab of output x-planes, 32 output

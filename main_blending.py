@@ -13,7 +13,7 @@ from pathlib import Path
 import torch
 
 
-def build_models(cfg, device, need_fusion=False):
+def build_models(cfg, device, need_fusion=False, need_prior=True):
     from bdm_amd.model import get_fusion_model, get_model
     from bdm_amd.pvd import prepare_pvd_model
     from bdm_amd.utils.procedural import fill_module_
@@ -26,6 +26,8 @@ def build_models(cfg, device, need_fusion=False):
         print("checkpoint.resume not given: procedural random-init weights (benchmark mode)")
         fill_module_(model, seed=cfg.run.seed)
     model = model.to(device).eval()
+    if not need_prior:  # vanilla PC^2 sampling (main.py run.job=sample)
+        return model, None, None
     opt = {"model": cfg.aux_run.prior_ckpt, "nc": 3, "embed_dim": 64, "attention": True, "dropout": 0.1}
     pvd_model = prepare_pvd_model(opt, device)
     fusion_model = None

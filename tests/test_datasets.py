@@ -145,3 +145,20 @@ def test_cli_on_r2n2_fixture(hip, tmp_path):
     assert files == ["te0000_00.ply", "te0001_00.ply", "te0002_00.ply"]     # te0003 is not in pc_dict
     gt = load_pointcloud_ply(out / "gt" / "chair" / files[0])
     assert gt.shape == (1024, 3) and np.isfinite(load_pointcloud_ply(out / "pred" / "chair" / files[0])).all()
+
+
+def test_batch_sharding_mirrors_accelerate():
+    """get_dataset(world > 1) deals whole batches round-robin and pads the tail from the start of the dataset, as
+    accelerator.prepare(dataloader) does in the reference (main_blending.py:115-124).  Checked against the installed accelerate."""
+    from bdm_amd.datasets import accelerate_batch_shard
+    assert accelerate_batch_shard(5, 2, 0, 1) == [[0, 1], [2, 3], [4]]
+    # 5 samples, batch 2, 2 ranks: batches (0,1) (2,3) (4) -> rank 0: (0,1), (4,0); rank 1: (2,3), (1,2)
+    assert accelerate_batch_shard(5, 2, 0, 2) == [[0, 1], [4, 0]]
+    assert accelerate_batch_shard(5, 2, 1, 2) == [[2, 3], [1, 2]]
+    acc = pytest.importorskip("accelerate.data_loader")
+    import torch.utils.data as tud
+    for n, bs, world in [(5, 2, 2), (16, 4, 2), (17, 4, 8), (3, 4, 2), (100, 16, 8), (33, 8, 4), (1, 1, 3), (24, 8, 3)]:
+        for rank in range(world):
+            base = tud.BatchSampler(tud.SequentialSampler(range(n)), batch_size=bs, drop_last=False)
+            want = [list(b) for b in acc.BatchSamplerShard(base, num_processes=world, process_index=rank)]
+            assert accelerate_batch_shard(n, bs, rank, world) == want, (n, bs, world, rank)

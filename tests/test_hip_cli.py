@@ -49,6 +49,28 @@ def test_main_merging_writes_the_reference_tree(hip, tmp_path):
         main_merging.main(["run.job=training_bdm_merging"] + COMMON)
 
 
+def test_main_sample_writes_the_reference_tree(hip, tmp_path):
+    """`main.py run.job=sample` (vanilla PC^2, the recipe of example_sample.sh = BASELINE.json configs[0]; reference
+    experiments/main.py:454-601): gt / pred / images / metadata / evolutions per shape; snapshots every 10 steps + the last."""
+    import torch
+    import main as main_sample
+    out = main_sample.main(["run.job=sample", f"run.save_dir={tmp_path}", "dataset=synthetic", "dataset.max_points=1024",
+                            "dataset.num_shapes=3", "dataloader.batch_size=2", "run.num_inference_steps=25",
+                            "run.diffusion_scheduler=ddpm", "run.name=cli_test"])
+    assert out.name == "sample" and out.parent.parent.name == "cli_test"
+    clouds = _check_tree(out, 3, 1024)
+    for j in range(3):
+        meta = torch.load(out / "metadata" / "chair" / f"synthetic_{j:06d}.pth", weights_only=False)
+        assert meta["sequence_category"][meta["index"]] == "chair" and meta["camera"] is not None
+        evo = torch.load(out / "evolutions" / "chair" / f"synthetic_{j:06d}.pth", weights_only=False)
+        assert evo.shape == (4, 1024, 3)          # steps 0, 10, 20 and the last (24) of 25
+        assert np.allclose(evo[-1].numpy(), clouds[j], atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        main_sample.main(["run.job=train", "dataset=synthetic"])
+    with pytest.raises(ValueError, match="Invalid job"):
+        main_sample.main(["run.job=sample_bdm_blending", "dataset=synthetic"])
+
+
 def test_invalid_job_is_rejected(hip):
     import main_blending
     with pytest.raises(ValueError, match="Invalid job"):

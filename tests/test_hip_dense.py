@@ -129,23 +129,23 @@ def test_attention_core(ops, B, C, L):
             qs[:, :C] *= min(scale, 4.0)   # q (a large q.k would make the softmax one-hot: keep it moderate)
             qd, kd, vd = qs[:, :C].double(), qs[:, C:2 * C].double(), qs[:, 2 * C:].double()
             refs = torch.matmul(vd, torch.softmax(torch.matmul(qd.permute(0, 2, 1), kd), -1).permute(0, 2, 1)).float()
-            amax = torch.stack([qs[:, :C].abs().max(), qs[:, C:2 * C].abs().max(), qs[:, 2 * C:].abs().max()]).float().cuda()
+            amax = torch.stack([qs[:, i * C:(i + 1) * C].abs().amax(dim=(1, 2)) for i in range(3)], 1).float().contiguous().cuda()  # (B, 3)
             got = ops.attention_core(qs.cuda(), C, amax=amax).cpu()
             assert rel(got, refs) < 5e-6, ("fp16x3", scale)
 
 
 def test_projection_gemm_leaves_operand_maxima_for_the_fp16x3_attention(ops):
-    """bdm_pointwise_conv_gn amax output: max |y| per block of amax_rows rows over the whole call, and the Attention module on
-    the fp16x3 path vs the bf16x6 path."""
+    """bdm_pointwise_conv_gn amax output: max |y| per (shape, block of amax_rows rows), and the Attention module on the fp16x3
+    path vs the bf16x6 path."""
     g = torch.Generator().manual_seed(3)
     B, C, L = 3, 64, 1000
     x = torch.randn(B, C, L, generator=g).cuda()
     w, b = (torch.randn(3 * C, C, generator=g) / 8).cuda(), torch.randn(3 * C, generator=g).cuda()
-    amax = ops.amax_slots(x.device, 3)
+    amax = ops.amax_slots(x.device, 3 * B)
     y = ops.pointwise_conv_gn(x, w, b, amax=amax, amax_rows=C)
     assert torch.equal(y, ops.pointwise_conv(x, w, b))
-    want = torch.stack([y[:, i * C:(i + 1) * C].abs().max() for i in range(3)])
-    assert torch.equal(amax, want)
+    want = torch.stack([y[:, i * C:(i + 1) * C].abs().amax(dim=(1, 2)) for i in range(3)], 1)
+    assert torch.equal(amax.view(B, 3), want)
     from bdm_amd.modules import Attention
     from bdm_amd.utils.procedural import fill_module_
     att = fill_module_(Attention(64, 8, D=3).eval(), seed=2).cuda()
@@ -642,9 +642,9 @@ def test_concat2_rows_fp_assemble_two_source_gemm_and_channel_first_gather(ops):
     sums = st[0].view(B, 8, st[1], 2).sum(2)
     rd = refs.double().view(B, 8, -1)
     assert torch.allclose(sums[..., 0], rd.sum(-1), rtol=1e-6, atol=1e-3) and torch.allclose(sums[..., 1], (rd * rd).sum(-1), rtol=1e-6)
-    am = ops.amax_slots(xs1.device, 2)
+    am = ops.amax_slots(xs1.device, 2 * B)
     ya = ops.pointwise_conv_gn(xs1, ws[:, :576].contiguous(), bs_, amax=am, amax_rows=128)
-    assert torch.equal(am, torch.stack([ya[:, :128].abs().max(), ya[:, 128:].abs().max()]))
+    assert torch.equal(am.view(B, 2), torch.stack([ya[:, :128].abs().amax(dim=(1, 2)), ya[:, 128:].abs().amax(dim=(1, 2))], 1))
     # conditioning gather written channel-first == the point-major gather transposed
     C, HW = 29, 50
     xt = torch.randn(B, n, 3, generator=g).cuda()

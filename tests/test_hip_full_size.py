@@ -1,0 +1,96 @@
+"""Parity at the sizes the BASELINE.json configurations actually run per GPU.
+
+(a) ONE full-length C2 trajectory -- BDM-Blending, real milestones, 1000 PC^2 + 80 PVD forwards + 5 blends -- on the HIP
+    path at B = 16, N = 4096 in the per-shape Philox mode (`run.rng=per_shape`: exactly what bench.py times).  The CPU
+    oracle re-runs ONE sampled shape of the batch from the same streams, restated on the host by oracle/ref_rng.py, and
+    the final clouds are held to the literal north-star bound (relative L2 <= 1e-3).  HEAD_SCALE as in
+    tests/test_hip_full_trajectory.py (chaos, not kernels, decides above it: DESIGN.md section 5).
+(b) Per-GPU batches of C3 / C4 / C5: Merging on a mini schedule at B = 16, N = 4096; PC^2 forward at B = 8, N = 8192; PC^2
+    and PVD forwards at B = 32, N = 16384.  Each: finite everywhere; one sampled shape against the oracle (<= 1e-4 per
+    forward, <= 1e-3 on a final cloud); and that shape against ITSELF run alone at B = 1 on the HIP path -- batch
+    invariance catches batch-dependent dispatch (grid.z = B, tile choices, `ball_query_kernel<4,8>` above 16384 centres,
+    workspace sizing) without more oracle time.  Every operator of the path is per-shape and all
+    power-of-two activation scales are per shape, so the B = 1 run has to give the same BITS.
+"""
+import pytest
+import torch
+
+from helpers import point_cloud_inputs, rel_l2
+import trajectory_case as case
+
+pytestmark = pytest.mark.gpu
+HEAD_SCALE = 0.1
+NORTH_STAR = 1e-3
+TOL_FORWARD = 1e-4
+
+
+def test_full_c2_trajectory_batch16_sampled_shape_vs_oracle(hip, oracle_ops):
+    B, N, seed, row = 16, 4096, 42, 11
+    c = case.build(N, head_scale=HEAD_SCALE, merging=False, B=B)
+    assert len(case.program_order(c.milestones, c.roll_step)) == 1080
+    got = case.run_hip_streams(c, seed, list(range(B)))
+    assert got.shape == (B, N, 3) and bool(torch.isfinite(got).all())
+    ref = case.run_oracle(case.philox_shape_case(c, seed, row, row))
+    err = rel_l2(got[row:row + 1], ref)
+    print(f"full C2 trajectory at B=16, N=4096 (per-shape Philox streams), shape {row} vs oracle: final rel-L2 {err:.3e}")
+    assert err <= NORTH_STAR
+    # the batch-mates are different samples (different streams, images, cameras): not one cloud repeated 16 times
+    assert rel_l2(got[0:1], got[row:row + 1]) > 0.1
+
+
+def test_c3_mini_merging_batch16(hip, oracle_ops):
+    """C3's per-GPU batch (Merging, B = 16, N = 4096) on a short schedule through PVCNN_fuse."""
+    B, seed, row = 16, 7, 13
+    c = case.build(4096, head_scale=1.0, milestones=[1000, 996, 993, 990], roll_step=2, merging=True, B=B, seed=21)
+    got = case.run_hip_streams(c, seed, list(range(B)))
+    assert bool(torch.isfinite(got).all())
+    ref = case.run_oracle(case.philox_shape_case(c, seed, row, row))
+    err = rel_l2(got[row:row + 1], ref)
+    alone = case.run_hip_streams(case.subset(c, [row]), seed, [row])
+    inv = rel_l2(alone, got[row:row + 1])
+    print(f"mini BDM-Merging at B=16, N=4096: shape {row} vs oracle {err:.3e}; vs itself at B=1 {inv:.3e}")
+    assert err <= NORTH_STAR
+    assert torch.equal(alone, got[row:row + 1]), f"batch-dependent result: rel-L2 {inv:.3e}"
+
+
+def _forward_case(cls, B, N, extra, seed, row):
+    from bdm_amd.utils.procedural import fill_module_
+    from oracle import ref_net
+    net = fill_module_(cls(3, 64, extra_feature_channels=extra).eval(), seed=seed)
+    x = point_cloud_inputs(B, 3 + extra, N, seed=7000 + N + B)
+    t = (torch.arange(B) * 31 + 5) % 1000
+    ref = ref_net.pvcnn_forward(net.state_dict(), x[row:row + 1].contiguous(), t[row:row + 1])
+    net = net.cuda()
+    got = net(x.cuda(), t.cuda()).cpu()
+    alone = net(x[row:row + 1].contiguous().cuda(), t[row:row + 1].cuda()).cpu()
+    return got, ref, alone
+
+
+@pytest.mark.parametrize("name,B,N,extra,row", [("c4_pc2", 8, 8192, 387, 5), ("c5_pc2", 32, 16384, 387, 29),
+                                                ("c5_pvd", 32, 16384, 0, 17)])
+def test_per_gpu_batch_forward(hip, oracle_ops, name, B, N, extra, row):
+    from bdm_amd.pvcnn import PVCNN2_PC2, PVCNN2_PVD
+    got, ref, alone = _forward_case(PVCNN2_PC2 if extra else PVCNN2_PVD, B, N, extra, 31 + B, row)
+    assert got.shape == (B, 3, N) and bool(torch.isfinite(got).all())
+    err, inv = rel_l2(got[row:row + 1], ref), rel_l2(alone, got[row:row + 1])
+    print(f"{name}: B={B}, N={N}: shape {row} vs oracle {err:.3e}; vs itself at B=1 {inv:.3e}")
+    assert err < TOL_FORWARD
+    assert torch.equal(alone, got[row:row + 1]), f"batch-dependent result: rel-L2 {inv:.3e}"
+
+
+def test_a_shape_does_not_see_its_batch_mates(hip):
+    """the fp16x3 activation scales (sparse first convolution, attention q / k / v) are per SHAPE, so a shape batched with
+    a mate whose features are 1000x larger gives the same BITS as the shape run alone (C1-sized level: the 8^3 sparse GEMMs, the
+    voxel attention and every other operator of both denoisers are on this path)."""
+    from bdm_amd.pvcnn import PVCNN2_PC2, PVCNN2_PVD
+    from bdm_amd.utils.procedural import fill_module_
+    for cls, extra in ((PVCNN2_PC2, 387), (PVCNN2_PVD, 0)):
+        net = fill_module_(cls(3, 64, extra_feature_channels=extra).eval(), seed=3).cuda()
+        x = point_cloud_inputs(3, 3 + extra, 1024, seed=91)
+        x[1] *= 1000.0
+        x[2, :3] *= 0.01
+        t = torch.tensor([10, 500, 990])
+        got = net(x.cuda(), t.cuda()).cpu()
+        for s in range(3):
+            alone = net(x[s:s + 1].contiguous().cuda(), t[s:s + 1].cuda()).cpu()
+            assert torch.equal(alone, got[s:s + 1]), (cls.__name__, s, rel_l2(alone, got[s:s + 1]))

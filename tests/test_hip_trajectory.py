@@ -1,12 +1,13 @@
-"""Config C1 of BASELINE.json as a parity case: vanilla PC^2 sampling of ONE shape, N = 1024 points, 100 DDPM
-steps (leading spacing: t = 990, 980, ..., 0), projection conditioning at every step, identical injected noise on
-both sides.  HIP path vs CPU oracle.
+"""Config C1 of BASELINE.json -- vanilla PC^2 sampling of ONE shape, N = 1024 points, 100 DDPM steps (leading spacing:
+t = 990, 980, ..., 0), projection conditioning at every step, identical injected noise on both sides -- as a CHAOS MONITOR, plus
+the bit-equality tests of the recorded forms of the reverse loop (hipGraph, launch tape).
 
-Criterion: the sampler contains discrete decisions (which pixel a point owns, ball-query membership,
-FPS arg-max, voxel rounding) that flip on 1-ulp input changes, and with random-init weights the denoiser amplifies a flip.
-The oracle's OWN sensitivity is therefore measured in the same test (same trajectory started from x0 perturbed by one
-float32 ulp) and the HIP path must satisfy  final rel-L2 <= max(1e-3, 4 x oracle self-sensitivity);  before the first
-flip (first 10 steps) it must stay below 1e-5."""
+The C1 test is NOT the parity claim: with head scale 1 the random-init sampler amplifies 1-ulp changes through
+its discrete decisions (pixel ownership, ball-query membership, FPS arg-max, voxel rounding), so a free-running comparison at this
+head scale measures chaos.  Parity is held by tests/test_hip_teacher_forced.py (every timestep, head scale 1, <= 1e-5 per step)
+and tests/test_hip_full_trajectory.py / test_hip_full_size.py (literal 1e-3 on full-length trajectories).  What this test still
+pins: the HIP path tracks the oracle to 1e-5 until the first flip (first 10 steps), and afterwards diverges no faster than the
+oracle diverges from ITSELF when started one float32 ulp away (final rel-L2 <= max(1e-3, 4 x oracle self-sensitivity))."""
 import pytest
 import torch
 
@@ -15,7 +16,7 @@ from helpers import rel_l2, seeded
 pytestmark = pytest.mark.gpu
 
 
-def test_c1_vanilla_pc2_100_steps(hip, oracle_ops):
+def test_c1_chaos_monitor_divergence_no_faster_than_the_oracles_own(hip, oracle_ops):
     from bdm_amd.cameras import join_cameras
     from bdm_amd.config import ProjectConfig
     from bdm_amd.data import SyntheticShapes
@@ -143,3 +144,52 @@ def test_launch_tape_replay_equals_eager_loop(hip, monkeypatch):
     changed_tape, changed_eager = run("1"), run("0")
     assert model._tape_cache["tape"] is not tape_before
     assert torch.equal(changed_tape, changed_eager) and not torch.equal(changed_tape, eager)
+
+
+def test_saturation_reroute_reaches_a_recorded_step(hip, monkeypatch):
+    """a recorded reverse step has a layer's fp16x3 kernels baked in.  When poll_h2_saturation() switches
+    that layer to bf16x6, the recording must not be replayed: the cache key carries ops.saturation_epoch(), the next loop
+    re-records, and the new tape launches the bf16x6 convolution for the flagged layer."""
+    import warnings
+    import bdm_amd.model as M
+    from bdm_amd import ops
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.modules import PVConv
+    from bdm_amd.utils.procedural import fill_module_
+    B, N, steps = 1, 1024, 10
+    cfg = ProjectConfig()
+    cfg.dataset.max_points = N
+    model = fill_module_(M.get_model(cfg).eval(), seed=3).cuda()
+    batch = next(iter(SyntheticShapes(range(B), B, num_points=N))).to("cuda")
+    x0 = torch.randn(B, N, 3, generator=torch.Generator().manual_seed(5)).cuda()
+    monkeypatch.setattr(M, "TAPE_STEPS", "1")
+
+    def run():
+        it = iter(torch.randn(B, N, 3, generator=torch.Generator().manual_seed(100 + i)).cuda() for i in range(steps))
+        model.scheduler.noise_source = lambda shape, device: next(it)
+        try:
+            return model.interaction_sample(x0.clone(), batch.camera, batch.image_rgb, None, start_time=500, end_time=500 - steps).cpu()
+        finally:
+            model.scheduler.noise_source = None
+
+    def names(tp):
+        return [getattr(fn, "__name__", "") for fn, _ in tp.calls]
+
+    before = run()
+    tape0 = model._tape_cache["tape"]
+    assert tape0 is not None and model._tape_cache["off"] is None
+    n_s3_before = sum(n == "bdm_conv3d_3x3x3_s3" for n in names(tape0))
+    # a degenerate cloud would do this: raise the sticky word of ONE fp16x3 layer
+    pv = next(m for m in model.point_cloud_model.modules() if isinstance(m, PVConv) and getattr(m, "conv_impl", "") == "fp16x3")
+    ops.saturation_slot(pv, x0.device).fill_(1)
+    epoch = ops.saturation_epoch()
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        assert ops.poll_h2_saturation() == [pv]
+    assert ops.saturation_epoch() == epoch + 1 and pv.h2_saturated
+    after = run()
+    tape1 = model._tape_cache["tape"]
+    assert tape1 is not tape0, "the recorded step with the clamped fp16x3 kernels was replayed"
+    assert sum(n == "bdm_conv3d_3x3x3_s3" for n in names(tape1)) == n_s3_before + 1   # the flagged layer's second convolution
+    assert float((after - before).norm() / before.norm()) < 1e-3                       # same sampler, bf16x6 in one layer

@@ -180,3 +180,95 @@ def run_hip(c, device="cuda"):
     for it, name in ((pc2, "PC^2"), (prior, "PVD"), (fuse, "fusion")):
         assert next(it, None) is None, f"{name} draws left over: program order differs from the sampler's"
     return out.points_padded().cpu()
+
+
+# ---- one shape of a batch, and the per-shape Philox mode of the samplers ------------------------------------------------
+class _Rows:
+    """View of a KeyedNoise restricted to some shapes of the batch (same draws, rows `idx`)."""
+
+    def __init__(self, full, idx):
+        self.full, self.idx = full, list(idx)
+
+    def __getitem__(self, t):
+        return self.full[t][self.idx].contiguous()
+
+    def get(self, t, default=None):
+        return self[t]
+
+
+def subset(c, idx):
+    """The same case restricted to shapes `idx` of its batch: identical weights, inputs and draws for those shapes (every
+    operator of the path is per-shape), so that the oracle -- or the HIP path at a smaller batch -- can re-run
+    a sampled shape of a large batch."""
+    import dataclasses
+    idx = list(idx)
+    b = c.batch
+    batch = dataclasses.replace(b, image_rgb=b.image_rgb[idx].contiguous(), camera=[b.camera[i] for i in idx],
+                                sequence_point_cloud=b.sequence_point_cloud[idx].contiguous(),
+                                sequence_name=[b.sequence_name[i] for i in idx],
+                                sequence_category=[b.sequence_category[i] for i in idx],
+                                frame_number=[b.frame_number[i] for i in idx])
+    s = SimpleNamespace(**vars(c))
+    s.batch, s.B, s.init = batch, len(idx), c.init[idx].contiguous()
+    for name in ("recon_noise", "branch_noise", "prior_noise", "fuse_noise"):
+        setattr(s, name, _Rows(getattr(c, name), idx))
+    s.masks = [m[idx].contiguous() for m in c.masks]
+    return s
+
+
+class PhiloxDraws:
+    """dict-like {t: (1, ...) float32}: ONE shape's draws of the per-shape Philox mode (bdm_amd/rng.py), restated on the host by
+    oracle/ref_rng.py.  `draw_of_t` maps a timestep to the draw index the sampler's stream counter has when it gets there."""
+
+    def __init__(self, key, shape, purpose, draw_of_t):
+        self.key, self.shape, self.purpose, self.draw_of_t = key, tuple(shape), purpose, dict(draw_of_t)
+
+    def __getitem__(self, t):
+        import numpy as np
+        from oracle import ref_rng
+        per = 1
+        for s in self.shape:
+            per *= s
+        z = ref_rng.normal(self.key, per, self.draw_of_t[int(t)], self.purpose).astype(np.float32)
+        return torch.from_numpy(z).reshape((1,) + self.shape)
+
+    def get(self, t, default=None):
+        return self[t]
+
+
+def philox_shape_case(c, seed, shape_index, row):
+    """The oracle-side description of shape `row` of case `c` (global index `shape_index`) when the HIP samplers draw from
+    rng.ShapeStreams(seed, ...): initial cloud = INIT draw 0; DDPM noise = PC2 draws numbered in program order over the
+    recon / branch steps with t > 0; PVD noise = PVD draws numbered over the prior steps (t == 0 included); masks = MASK
+    draws; fused steps = FUSE draws."""
+    import numpy as np
+    from bdm_amd import rng as prod_rng
+    from oracle import ref_rng
+    key = ref_rng.shape_key(seed, shape_index)
+    order = program_order(c.milestones, c.roll_step, c.merging)
+    pc2_t = [t for k, t in order if k in ("recon", "branch") and t > 0]
+    pvd_t = [t for k, t in order if k == "prior"]
+    fuse_t = [t for k, t in order if k == "fuse" and t > 0]
+    assert len(set(pc2_t)) == len(pc2_t) and len(set(pvd_t)) == len(pvd_t)
+    s = subset(c, [row])
+    N = c.N
+    s.init = torch.from_numpy(ref_rng.normal(key, 3 * N, 0, prod_rng.INIT).astype(np.float32)).reshape(1, N, 3)
+    pc2 = PhiloxDraws(key, (N, 3), prod_rng.PC2, {t: i for i, t in enumerate(pc2_t)})
+    s.recon_noise = s.branch_noise = pc2
+    s.prior_noise = PhiloxDraws(key, (3, N), prod_rng.PVD, {t: i for i, t in enumerate(pvd_t)})
+    s.fuse_noise = PhiloxDraws(key, (N, 3), prod_rng.FUSE, {t: i for i, t in enumerate(fuse_t)})
+    s.masks = [torch.from_numpy(ref_rng.bits(key, N, k, prod_rng.MASK)).reshape(1, N) for k in range(len(c.masks))]
+    return s
+
+
+def run_hip_streams(c, seed, shape_indices, device="cuda"):
+    """Final (B, N, 3) cloud of the HIP samplers in the per-shape Philox mode (what bench.py runs): no injected draws."""
+    from bdm_amd import rng as prod_rng
+    from bdm_amd.sampling import bdm_blending, bdm_merging
+    model, pvd = c.model.to(device), c.pvd.to(device)
+    streams = prod_rng.ShapeStreams(seed, shape_indices, device)
+    if c.merging:
+        out = bdm_merging(None, c.batch.to(device), c.cfg, pvd, model, c.fusion.to(device), streams=streams)
+    else:
+        out = bdm_blending(None, c.batch.to(device), c.cfg, model, pvd, streams=streams)
+    return out.points_padded().cpu()
