@@ -60,7 +60,7 @@ def abi_signatures(header: str = HEADER):
     sigs = {}
     for ret, name, args in re.findall(r"([A-Za-z_][\w \*]*?)\b(bdm_\w+)\s*\(([^)]*)\)\s*;", text):
         ret = " ".join(ret.replace("const", " ").split())
-        restype = ctypes.c_char_p if ret == "char *" else (ctypes.c_void_p if ret.endswith("*") else _CTYPES[ret])
+        restype = ctypes.c_char_p if ret == "char *" else (ctypes.c_void_p if ret.endswith("*") else (None if ret == "void" else _CTYPES[ret]))
         argtypes = []
         for a in [a.strip() for a in args.split(",")]:
             if a in ("void", ""):

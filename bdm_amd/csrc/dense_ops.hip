@@ -38,7 +38,7 @@ struct PwGn {
   int in_S, in_G;
   const float *in_gamma, *in_beta;
   float in_eps;
-  double *out_partial;       // (b, M / out_cg, S_out, 2) or NULL;  S_out = gridDim.x * max(1, out_cg / BM)
+  double *out_partial;       // (b, M / out_cg, S_out, 2) or NULL;  S_out = ceil(N / 128) * max(1, out_cg / 32): canonical, tile-independent
   int out_cg;
   // second source of the K axis: rows k >= k1 of the operand come from x2 (torch.cat([x, x2], dim=1) without the copy)
   const float *x2;
@@ -212,8 +212,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
   }
   // ---- epilogue: C/D map  row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31.  The per-row terms (bias, per-shape bias)
   // and the residual are fetched in batches under workgroup-uniform branches (clamped addresses), then applied.
-  float bs[MI][4], bq[MI][4];  // GroupNorm partials of this lane's 4-row blocks j: rows x*32 + 8j + 4lh .. +3
+  float bs[MI][4], bq[MI][4];  // GroupNorm partials of this lane's 4-row blocks j: rows x*32 + 8j + 4lh .. +3, ONE 32 x 32 sub-tile at a time
   float am[MI];                // max |y| of this lane's part of row block x
+  // GroupNorm statistics are defined on a CANONICAL decomposition -- one slice per (32-row block, 128-column block), summed in the
+  // order of the 1 x 1 tile: lane (4 rows), half-wave butterfly (32 columns), the block's four 32-column sub-tiles left to right,
+  // then the 4-row blocks of a group in fp64 -- so the partials, and with them every normalised value downstream, do not depend
+  // on the tile this launch happened to pick (the tile follows the batch size: a shape must not see its batch-mates).
+  constexpr int NBW = MI * NI * 2 * 4 * 2;  // per wave: [x][y][lh][j][stat]
+  float *red = Bs;                          // [4 waves][NBW], then [NI column blocks][MI][lh][j][stat]
+  if (gn.out_partial != nullptr) __syncthreads();  // slower waves may still read operand fragments from Bs
 #pragma unroll
   for (int x = 0; x < MI; ++x) {
     am[x] = 0.f;
@@ -257,6 +264,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
           am[x] = fmaxf(am[x], fabsf(v));
         }
       }
+      if (gn.out_partial != nullptr) {  // this 32 x 32 sub-tile's sums: butterfly over its 32 columns, parked in LDS
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) {
+            bs[x][j] += __shfl_xor(bs[x][j], o, 64);
+            bq[x][j] += __shfl_xor(bq[x][j], o, 64);
+          }
+          if (li == 0) {
+            red[wave * NBW + (((x * NI + y) * 2 + lh) * 4 + j) * 2 + 0] = bs[x][j];
+            red[wave * NBW + (((x * NI + y) * 2 + lh) * 4 + j) * 2 + 1] = bq[x][j];
+          }
+          bs[x][j] = 0.f;
+          bq[x][j] = 0.f;
+        }
+      }
     }
   }
   if (gn.amax != nullptr) {
@@ -278,48 +301,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     __syncthreads();
   }
   if (gn.out_partial != nullptr) {
-    // (sum, sum of squares) of the tile per GroupNorm group: fixed order inside the lane, half-wave butterflies, the four
-    // waves added in wave order, then the 4-row blocks of a group in fp64 by one thread per group
+    __syncthreads();
+    // the four sub-tiles of each canonical 128-column block, left to right: sub-tile g of the workgroup lives in wave g / NI, slot g % NI
+    constexpr int NC = NI * MI * 2 * 4 * 2;  // [cb][x][lh][j][stat]
+    if (tid < NC) {
+      const int stat = tid & 1, j = (tid >> 1) & 3, lhh = (tid >> 3) & 1, x = (tid >> 4) % MI, cb = tid / (16 * MI);
+      float sum = 0.f;
 #pragma unroll
-    for (int x = 0; x < MI; ++x)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
-          bs[x][j] += __shfl_xor(bs[x][j], o, 64);
-          bq[x][j] += __shfl_xor(bq[x][j], o, 64);
-        }
-    __syncthreads();  // the operand tiles are dead: reuse Bs
-    constexpr int NB = 2 * MI * 4 * 2;  // [lh][x][j][stat]
-    float *red = Bs;                    // [4 waves][NB], then [NB]
-    if (li == 0) {
-#pragma unroll
-      for (int x = 0; x < MI; ++x)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          red[wave * NB + ((lh * MI + x) * 4 + j) * 2 + 0] = bs[x][j];
-          red[wave * NB + ((lh * MI + x) * 4 + j) * 2 + 1] = bq[x][j];
-        }
+      for (int st = 0; st < 4; ++st) {
+        const int g = cb * 4 + st;
+        const float v = red[(g / NI) * NBW + (((x * NI + (g % NI)) * 2 + lhh) * 4 + j) * 2 + stat];
+        sum = st == 0 ? v : sum + v;
+      }
+      red[4 * NBW + tid] = sum;
     }
     __syncthreads();
-    if (tid < NB) red[4 * NB + tid] = ((red[tid] + red[NB + tid]) + red[2 * NB + tid]) + red[3 * NB + tid];
-    __syncthreads();
     const int cg = gn.out_cg, G = M / cg;
-    const int ngt = cg >= BM ? 1 : BM / cg;      // groups inside this row tile
-    const int rt = cg >= BM ? cg / BM : 1;       // row tiles per group
-    if (tid < ngt && m0 + tid * cg < M) {
-      double a = 0.0, qq = 0.0;
-      for (int hh = 0; hh < 2; ++hh)
-        for (int x = 0; x < MI; ++x)
+    const int ngt = cg >= 32 ? 1 : 32 / cg;   // groups inside a 32-row block
+    const int rt = cg >= 32 ? cg / 32 : 1;    // 32-row blocks per group
+    if (tid < NI * MI * ngt) {
+      const int gi = tid % ngt, x = (tid / ngt) % MI, cb = tid / (ngt * MI);
+      const int row0 = m0 + x * 32, colblock = blockIdx.x * NI + cb, ncb = (N + 127) / 128;
+      if (row0 + gi * cg < M && colblock < ncb) {
+        double a = 0.0, qq = 0.0;
+        for (int hh = 0; hh < 2; ++hh)
           for (int j = 0; j < 4; ++j)
-            if (cg >= BM || ((x * 32 + 8 * j + 4 * hh) >> (__ffs(cg) - 1)) == tid) {  // cg is a power of two
-              a += (double)red[4 * NB + ((hh * MI + x) * 4 + j) * 2 + 0];
-              qq += (double)red[4 * NB + ((hh * MI + x) * 4 + j) * 2 + 1];
+            if (cg >= 32 || ((8 * j + 4 * hh) >> (__ffs(cg) - 1)) == gi) {  // cg is a power of two
+              a += (double)red[4 * NBW + (((cb * MI + x) * 2 + hh) * 4 + j) * 2 + 0];
+              qq += (double)red[4 * NBW + (((cb * MI + x) * 2 + hh) * 4 + j) * 2 + 1];
             }
-      const int g = m0 / cg + tid, S = gridDim.x * rt, sl = blockIdx.x * rt + (int)(blockIdx.y % rt);
-      double *dst = gn.out_partial + (((size_t)bi * G + g) * S + sl) * 2;
-      dst[0] = a;
-      dst[1] = qq;
+        const int g = row0 / cg + gi, S = ncb * rt, sl = colblock * rt + (row0 / 32) % rt;
+        double *dst = gn.out_partial + (((size_t)bi * G + g) * S + sl) * 2;
+        dst[0] = a;
+        dst[1] = qq;
+      }
     }
   }
 }
@@ -594,10 +609,8 @@ extern "C" int bdm_pointwise_conv(int b, int m, int k, int n, const float *w, in
 extern "C" int bdm_pointwise_conv_gn_slices(int b, int m, int k, int n, int groups) {
   if (groups < 1 || m % groups) return 0;
   if (pw_skinny_shape(k, n)) return (n <= 32 ? 1 : cdiv(n, 64)) * ((m / groups) >= 32 ? (m / groups) / 32 : 1);  // 32-row tiles
-  int mi, ni, bk;
-  pw_tile(b, m, k, n, &mi, &ni, &bk);
-  const int cg = m / groups, bm = 32 * mi;
-  return cdiv(n, 128 * ni) * (cg >= bm ? cg / bm : 1);
+  const int cg = m / groups;  // canonical decomposition (independent of the tile and of b): 128-column blocks x 32-row blocks
+  return cdiv(n, 128) * (cg >= 32 ? cg / 32 : 1);
 }
 
 extern "C" int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x,

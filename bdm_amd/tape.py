@@ -14,10 +14,18 @@ while it executes eagerly:
     TorchDispatchMode and recorded as in-place operations on their (kept) outputs;
   * stream / event edges of the side streams go through `wait_stream` / `record_event` / `wait_event` below.
 
-Replay = `for fn, args in calls: fn(*args)`: ~3 us of host time per launch.  Same kernels, same arguments, same
+Replay: the recorded list is handed to the C-side step executor of the library (include/bdm_hip.h section 5, csrc/tape.hip):
+`LaunchTape.finalize()` appends every C-ABI call (name + 8-byte argument slots), every zero-fill / device copy (memset /
+memcpy) and every stream / event edge to a `bdm_tape`, and `replay()` is then ONE ctypes call per run of native entries --
+Python touches the step once, not once per launch.  Anything the executor has no native form for (a torch operator other than
+a fill or a plain copy) stays a Python entry between two native runs.  `BDM_TAPE_NATIVE=0` keeps the pure-Python replay
+(`for fn, args in calls: fn(*args)`, ~3 us of interpreter time per launch) for A/B timing.  Same kernels, same arguments, same
 order, same streams as the eager step: the results are bit-identical (tests/test_hip_trajectory.py).
 An operator the recorder does not understand marks the tape broken and the caller stays on the eager path.
 """
+import ctypes
+import os
+import struct
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
@@ -102,10 +110,19 @@ class _TorchOps(TorchDispatchMode):
         cur = torch.cuda.current_stream()
         stream = None if cur == tape.main_stream else cur
         tape.keep.extend(touched)
+        raw = cur.cuda_stream
         if func._schema.is_mutable:  # in-place / out= operator: the same call lands in the same (kept) tensors
             tape.calls.append((_py, (stream, func, args, kwargs)))
+            dst = args[0] if args and isinstance(args[0], torch.Tensor) else None
+            if name == "aten::zero_" or (name == "aten::fill_" and len(args) > 1 and not isinstance(args[1], torch.Tensor) and args[1] == 0):
+                tape.native[len(tape.calls) - 1] = ("memset", dst, raw)
+            elif (name == "aten::copy_" and len(args) > 1 and isinstance(args[1], torch.Tensor) and args[1].is_cuda
+                  and args[1].dtype == dst.dtype and args[1].shape == dst.shape):
+                tape.native[len(tape.calls) - 1] = ("memcpy", dst, args[1], raw)
         elif name in _FILLS and isinstance(out, torch.Tensor):
             tape.calls.append((_py, (stream, out.fill_, (_FILLS[name],), {})))
+            if _FILLS[name] == 0:
+                tape.native[len(tape.calls) - 1] = ("memset", out, raw)
         elif name in ("aten::full", "aten::full_like", "aten::new_full") and isinstance(out, torch.Tensor):
             value = kwargs["fill_value"] if "fill_value" in kwargs else args[2 if name == "aten::new_full" else 1]
             tape.calls.append((_py, (stream, out.fill_, (value,), {})))
@@ -117,20 +134,126 @@ class _TorchOps(TorchDispatchMode):
         return out
 
 
+NATIVE = os.environ.get("BDM_TAPE_NATIVE", "1") == "1"
+_U64 = (1 << 64) - 1
+
+
+def _slots(name, args):
+    """8-byte argument slots of a recorded C-ABI call (include/bdm_hip.h section 5): integers and pointers as they are (two's
+    complement), float arguments as the bit pattern of a double."""
+    argtypes = L.abi_signatures()[name][1] if name not in _slots.cache else _slots.cache[name]
+    _slots.cache[name] = argtypes
+    if len(argtypes) != len(args):
+        raise L.BdmHipError(f"launch tape: {name} recorded with {len(args)} arguments, the header declares {len(argtypes)}")
+    out = []
+    for ty, v in zip(argtypes, args):
+        if ty in (ctypes.c_float, ctypes.c_double):
+            out.append(struct.unpack("<Q", struct.pack("<d", float(v)))[0])
+        elif v is None:
+            out.append(0)
+        else:
+            out.append(int(v) & _U64)
+    return out
+
+
+_slots.cache = {}
+
+
 class LaunchTape:
     def __init__(self):
         self.calls, self.keep, self.torch_ops, self.broken = [], [], [], None
+        self.native = {}     # index into calls -> native form of a non-C-ABI entry: ("memset", tensor, raw stream) | ...
         self.main_stream = None
+        self.handle, self.program, self.python_entries = None, None, None
 
     def __len__(self):
         return len(self.calls)
 
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h and L._lib is not None:
+            L._lib.bdm_tape_destroy(h)
+
+    @staticmethod
+    def _contiguous_bytes(t):
+        return t.numel() * t.element_size() if t.is_contiguous() else None
+
+    def finalize(self):
+        """Hand the recording to the C-side executor: program = [(first, count) native runs | (fn, args) Python entries]."""
+        if not NATIVE or self.handle is not None or self.broken:
+            return self
+        lib = L.lib()
+        h = lib.bdm_tape_create()
+        program, run_first, py = [], None, 0
+
+        def close_run():
+            nonlocal run_first
+            n = lib.bdm_tape_length(h)
+            if run_first is not None and n > run_first:
+                program.append((run_first, n - run_first))
+            run_first = None
+
+        for i, (fn, args) in enumerate(self.calls):
+            ok = False
+            nat = self.native.get(i)
+            if isinstance(fn, ctypes._CFuncPtr):
+                name = fn.__name__
+                sl = _slots(name, args)
+                arr = (ctypes.c_ulonglong * max(len(sl), 1))(*sl)
+                L.check(lib.bdm_tape_append_call(h, name.encode(), ctypes.addressof(arr), len(sl)), f"tape_append_call({name})")
+                ok = True
+            elif nat is not None and nat[0] == "memset":
+                nb = self._contiguous_bytes(nat[1])
+                if nb is not None:
+                    L.check(lib.bdm_tape_append_memset(h, nat[1].data_ptr(), 0, nb, nat[2]), "tape_append_memset")
+                    ok = True
+            elif nat is not None and nat[0] == "memcpy":
+                nb, nb2 = self._contiguous_bytes(nat[1]), self._contiguous_bytes(nat[2])
+                if nb is not None and nb == nb2:
+                    L.check(lib.bdm_tape_append_memcpy(h, nat[1].data_ptr(), nat[2].data_ptr(), nb, nat[3]), "tape_append_memcpy")
+                    ok = True
+            elif nat is not None and nat[0] == "wait_stream":
+                L.check(lib.bdm_tape_append_wait_stream(h, nat[1].cuda_stream, nat[2].cuda_stream), "tape_append_wait_stream")
+                ok = True
+            elif nat is not None and nat[0] == "event_record":
+                L.check(lib.bdm_tape_append_event_record(h, nat[1].cuda_event, nat[2].cuda_stream), "tape_append_event_record")
+                ok = True
+            elif nat is not None and nat[0] == "event_wait":
+                L.check(lib.bdm_tape_append_event_wait(h, nat[1].cuda_stream, nat[2].cuda_event), "tape_append_event_wait")
+                ok = True
+            if ok:
+                if run_first is None:
+                    run_first = lib.bdm_tape_length(h) - 1
+            else:
+                close_run()
+                program.append((fn, args))
+                py += 1
+        close_run()
+        self.handle, self.program, self.python_entries = h, program, py
+        return self
+
+    def _fail(self, what, rc):
+        msg = L.lib().bdm_last_error()
+        raise L.BdmHipError(f"launch tape: {what} failed (code {rc}): {msg.decode() if msg else ''}")
+
     def replay(self):
+        if self.program is not None:
+            replay_c = L.lib().bdm_tape_replay
+            h = self.handle
+            for a, b in self.program:
+                if type(a) is int:
+                    rc = replay_c(h, a, b)
+                    if rc:
+                        self._fail(f"native entry {L.lib().bdm_tape_failed_entry(h)}", rc)
+                else:
+                    rc = a(*b)
+                    if rc:
+                        self._fail(getattr(a, "__name__", a), rc)
+            return
         for fn, args in self.calls:
             rc = fn(*args)
             if rc:
-                msg = L.lib().bdm_last_error()
-                raise L.BdmHipError(f"launch tape: {getattr(fn, '__name__', fn)} failed (code {rc}): {msg.decode() if msg else ''}")
+                self._fail(getattr(fn, "__name__", fn), rc)
 
 
 class record:
@@ -158,6 +281,8 @@ class record:
         L._lib = self._saved
         if et is not None:
             self.tape.broken = f"exception while recording: {ev!r}"
+        else:
+            self.tape.finalize()
         return False
 
 
@@ -166,12 +291,16 @@ def wait_stream(waiter, other):
     waiter.wait_stream(other)
     if _active is not None:
         _active.calls.append((_py, (None, waiter.wait_stream, (other,), {})))
+        _active.native[len(_active.calls) - 1] = ("wait_stream", waiter, other)
+        _active.keep.extend((waiter, other))
 
 
 def record_event(event, stream):
     event.record(stream)
     if _active is not None:
         _active.calls.append((_py, (None, event.record, (stream,), {})))
+        _active.native[len(_active.calls) - 1] = ("event_record", event, stream)
+        _active.keep.extend((event, stream))
 
 
 def wait_event(event):
@@ -180,3 +309,5 @@ def wait_event(event):
     s.wait_event(event)
     if _active is not None:
         _active.calls.append((_py, (None, s.wait_event, (event,), {})))
+        _active.native[len(_active.calls) - 1] = ("event_wait", s, event)
+        _active.keep.extend((s, event))

@@ -502,6 +502,34 @@ int bdm_layer_norm_channels(int b, int d, int t, const float *x, const float *ga
 int bdm_vit_conditioning_image(int b, int d, int grid, int h, int w, float colors_mean, float colors_std,
                                const float *tokens, const float *img, float *out, void *stream);
 
+
+/* ------------------------------------------------------------------------------------
+ * 5. Step executor: one recorded reverse step replayed by ONE call
+ *    Replaces the per-step Python of the reference's reverse loop (experiments/model/model.py:275-287: conditioning ->
+ *    denoiser -> scheduler.step, ~230 dependent launches) once its arguments are static: the host framework records the
+ *    step's C-ABI calls (function name + arguments, 8 bytes per argument: integers and pointers as they are, float / double
+ *    arguments as the bit pattern of a double), its memsets / device copies and its stream / event edges, and replays the
+ *    list from C.  No allocation, no synchronisation, nothing Python per launch.  The tape does NOT own the buffers whose
+ *    addresses it holds: the recorder keeps them alive (bdm_amd/tape.py).
+ * ---------------------------------------------------------------------------------- */
+void *bdm_tape_create(void);
+void bdm_tape_destroy(void *tape);
+int bdm_tape_length(const void *tape);
+/* append `function` (an `int bdm_*(...)` entry point of this header, by name) with n_args 8-byte argument slots */
+int bdm_tape_append_call(void *tape, const char *function, const unsigned long long *args, int n_args);
+int bdm_tape_append_memset(void *tape, void *dst, int byte_value, size_t bytes, void *stream);
+int bdm_tape_append_memcpy(void *tape, void *dst, const void *src, size_t bytes, void *stream);
+/* `waiter` waits for everything enqueued on `other` up to this point of the replay (torch's Stream.wait_stream) */
+int bdm_tape_append_wait_stream(void *tape, void *waiter, void *other);
+int bdm_tape_append_event_record(void *tape, void *event, void *stream);
+int bdm_tape_append_event_wait(void *tape, void *stream, void *event);
+/* replay entries [first, first + count) (count < 0: to the end); returns 0 or the status of the first failing entry, whose
+ * index bdm_tape_failed_entry reports (-1: none) */
+int bdm_tape_replay(void *tape, int first, int count);
+int bdm_tape_failed_entry(const void *tape);
+/* test hook of the argument marshalling (no GPU work): writes its arguments, converted to double, to out16 (host memory) */
+int bdm_tape_echo(int a, long long b, float c, const void *d, unsigned int e, float f, int g, void *out16);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,10 +118,15 @@ def build(num_points, head_scale=1.0, milestones=None, roll_step=16, merging=Fal
     return c
 
 
+def _cpu_sd(module):
+    """state dict on the host (run_hip moves the modules to the GPU in place; the oracle may run after it)"""
+    return {k: v.detach().cpu() for k, v in module.state_dict().items()}
+
+
 def oracle_inputs(c):
     from bdm_amd.cameras import join_cameras
     from oracle import ref_vit
-    local = ref_vit.local_conditioning(c.model.state_dict(), c.batch.image_rgb)
+    local = ref_vit.local_conditioning(_cpu_sd(c.model), c.batch.image_rgb)
     cams = join_cameras(c.batch.camera).packed()
     return local, cams
 
@@ -145,10 +150,10 @@ def run_oracle(c, progress=False):
     try:
         if c.merging:
             from oracle import ref_vit
-            local_f = ref_vit.local_conditioning(c.fusion.state_dict(), c.batch.image_rgb)
-            return R.bdm_merging(c.model.state_dict(), c.pvd.state_dict(), c.fusion.state_dict(), c.init, cams, local, local_f,
+            local_f = ref_vit.local_conditioning(_cpu_sd(c.fusion), c.batch.image_rgb)
+            return R.bdm_merging(_cpu_sd(c.model), _cpu_sd(c.pvd), _cpu_sd(c.fusion), c.init, cams, local, local_f,
                                  c.milestones, c.roll_step, c.recon_noise, c.branch_noise, c.prior_noise, c.fuse_noise)
-        return R.bdm_blending(c.model.state_dict(), c.pvd.state_dict(), c.init, cams, local, c.milestones, c.roll_step,
+        return R.bdm_blending(_cpu_sd(c.model), _cpu_sd(c.pvd), c.init, cams, local, c.milestones, c.roll_step,
                               c.recon_noise, c.branch_noise, c.prior_noise, c.masks)
     finally:
         R.TRACE = None

@@ -1,0 +1,148 @@
+// two_proc_repro.hip -- torch-free reproduction of the two-process difference.
+//
+//   hipcc --offload-arch=gfx950 -O2 -I include tools/two_proc_repro.hip -o /tmp/two_proc_repro -L bdm_amd -l:libbdm_hip.so \
+//         -Wl,-rpath,$PWD/bdm_amd
+//   /tmp/two_proc_repro 300            # alone: every line must report 0 differing repetitions
+//   /tmp/two_proc_repro 300 & /tmp/two_proc_repro 300   # two PROCESSES on one GPU at the same time
+//
+// Every case launches ONE kernel (or one C-ABI call) REPS times on fixed inputs with a device-wide synchronisation after every
+// launch, copies the output back and compares it bit by bit with the first repetition.  Cases:
+//   library kernels through the C ABI (no torch, no second stream, plain hipMalloc memory):
+//     pointwise_conv_gn (GroupNorm-folded 1x1 GEMM), pointwise_conv, devoxelize_gn_gate_add, conv3d fp16x3
+//   trivial kernels defined in this file (nothing of the library):
+//     copy        y = x, one float4 per thread, no LDS
+//     swish       y = x * rcp(1 + exp2(-x log2 e)) per element (v_exp_f32 / v_rcp_f32)
+//     lds_copy    float4 through LDS with a barrier
+//     long_copy   grid-stride copy, few workgroups, long-running waves
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+#include <vector>
+
+#include "bdm_hip.h"
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+#define ABI_OK(x) do { int rc_ = (x); if (rc_ != 0) { fprintf(stderr, "%s: code %d: %s\n", #x, rc_, bdm_last_error()); exit(2); } } while (0)
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static float rnd() {  // xorshift64*, uniform in [-1, 1)
+  rng_state ^= rng_state >> 12; rng_state ^= rng_state << 25; rng_state ^= rng_state >> 27;
+  return (float)((double)((rng_state * 0x2545F4914F6CDD1Dull) >> 11) / 9007199254740992.0 * 2.0 - 1.0);
+}
+static float *dev_random(size_t n, float scale = 1.f, float shift = 0.f) {
+  std::vector<float> h(n);
+  for (auto &v : h) v = rnd() * scale + shift;
+  float *d;
+  HIP_OK(hipMalloc(&d, n * sizeof(float)));
+  HIP_OK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  return d;
+}
+template <typename T> static T *dev_alloc(size_t n) {
+  T *d;
+  HIP_OK(hipMalloc(&d, n * sizeof(T)));
+  HIP_OK(hipMemset(d, 0, n * sizeof(T)));
+  return d;
+}
+
+__global__ void copy_kernel(const float4 *x, float4 *y, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) y[i] = x[i];
+}
+__global__ void swish_kernel(const float4 *x, float4 *y, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = x[i];
+  auto sw = [](float t) { return t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-t * 1.44269504088896340736f)); };
+  y[i] = make_float4(sw(v.x), sw(v.y), sw(v.z), sw(v.w));
+}
+__global__ void lds_copy_kernel(const float4 *x, float4 *y, size_t n4) {
+  __shared__ float4 tile[256];
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  tile[threadIdx.x] = i < n4 ? x[i] : make_float4(0, 0, 0, 0);
+  __syncthreads();
+  if (i < n4) y[i] = tile[threadIdx.x ^ 1];
+}
+__global__ void long_copy_kernel(const float4 *x, float4 *y, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i];
+}
+
+struct Case {
+  const char *name;
+  std::function<void()> launch;
+  const void *out;
+  size_t bytes;
+};
+
+int main(int argc, char **argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 200;
+  const char *only = argc > 2 ? argv[2] : nullptr;
+  std::vector<Case> cases;
+
+  // ---- library: SharedMLP pair at the SA0 shape of the denoiser (B=2, 32 -> 64 -> 64 channels, 1024 x 32 columns)
+  const int B = 2, K0 = 32, M = 64, N = 1024 * 32, G = 8;
+  float *x0 = dev_random((size_t)B * K0 * N), *w1 = dev_random((size_t)M * K0, 0.2f), *b1 = dev_random(M, 0.1f);
+  float *w2 = dev_random((size_t)M * M, 0.15f), *b2 = dev_random(M, 0.1f), *gamma = dev_random(M, 0.2f, 1.f), *beta = dev_random(M, 0.1f);
+  float *y1 = dev_alloc<float>((size_t)B * M * N), *y2 = dev_alloc<float>((size_t)B * M * N), *y3 = dev_alloc<float>((size_t)B * M * N);
+  const int s1 = bdm_pointwise_conv_gn_slices(B, M, K0, N, G), s2 = bdm_pointwise_conv_gn_slices(B, M, M, N, G);
+  double *p1 = dev_alloc<double>((size_t)B * G * s1 * 2), *p2 = dev_alloc<double>((size_t)B * G * s2 * 2);
+  ABI_OK(bdm_pointwise_conv_gn(B, M, K0, N, w1, K0, x0, (long long)K0 * N, N, nullptr, 0, 0, 0, b1, y1, (long long)M * N, N, nullptr, 0, 0,
+                               nullptr, nullptr, 0.f, G, p1, nullptr, 0, nullptr));
+  HIP_OK(hipDeviceSynchronize());
+  cases.push_back({"lib pointwise_conv_gn: statistics epilogue only (32 -> 64, 32768 columns)", [&] {
+    ABI_OK(bdm_pointwise_conv_gn(B, M, K0, N, w1, K0, x0, (long long)K0 * N, N, nullptr, 0, 0, 0, b1, y3, (long long)M * N, N, nullptr, 0, 0,
+                                 nullptr, nullptr, 0.f, G, p2, nullptr, 0, nullptr)); }, y3, (size_t)B * M * N * 4});
+  cases.push_back({"lib pointwise_conv_gn: folded GroupNorm input + statistics (64 -> 64, 32768 columns)", [&] {
+    ABI_OK(bdm_pointwise_conv_gn(B, M, M, N, w2, M, y1, (long long)M * N, N, nullptr, 0, 0, 0, b2, y2, (long long)M * N, N, p1, s1, G, gamma,
+                                 beta, 1e-5f, G, p2, nullptr, 0, nullptr)); }, y2, (size_t)B * M * N * 4});
+  cases.push_back({"lib pointwise_conv (64 -> 64, 32768 columns)", [&] {
+    ABI_OK(bdm_pointwise_conv(B, M, M, N, w2, M, y1, (long long)M * N, N, b2, nullptr, 0, nullptr, 0, 0, y3, (long long)M * N, N, 0, 0.f,
+                              nullptr)); }, y3, (size_t)B * M * N * 4});
+  // ---- library: devoxelisation with folded GroupNorm (B=2, 128 channels, 1024 points, 16^3)
+  const int C = 128, NP = 1024, R = 16;
+  float *coords = dev_random((size_t)B * 3 * NP, 7.4f, 7.5f);  // voxel-grid coordinates in [0.1, 14.9]
+  float *grid = dev_random((size_t)B * C * R * R * R), *coef = dev_random((size_t)B * C * 2, 0.3f, 0.8f), *gate = dev_random((size_t)B * C, 0.4f, 0.5f);
+  float *add = dev_random((size_t)B * C * NP), *dout = dev_alloc<float>((size_t)B * C * NP);
+  cases.push_back({"lib devoxelize_gn_gate_add (128 channels, 1024 points, 16^3)", [&] {
+    ABI_OK(bdm_devoxelize_gn_gate_add(B, C, NP, R, coords, grid, coef, gate, add, (long long)C * NP, NP, dout, (long long)C * NP, NP, nullptr)); },
+    dout, (size_t)B * C * NP * 4});
+  // ---- trivial kernels of this file
+  const size_t n4 = (size_t)B * M * N / 4;
+  cases.push_back({"trivial copy (float4 per thread)", [&] { hipLaunchKernelGGL(copy_kernel, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4 *)y1, (float4 *)y3, n4); }, y3, n4 * 16});
+  cases.push_back({"trivial swish (v_exp_f32 / v_rcp_f32)", [&] { hipLaunchKernelGGL(swish_kernel, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4 *)y1, (float4 *)y3, n4); }, y3, n4 * 16});
+  cases.push_back({"trivial copy through LDS", [&] { hipLaunchKernelGGL(lds_copy_kernel, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4 *)y1, (float4 *)y3, n4); }, y3, n4 * 16});
+  cases.push_back({"trivial grid-stride copy (256 long-running workgroups)", [&] { hipLaunchKernelGGL(long_copy_kernel, dim3(256), dim3(256), 0, 0, (const float4 *)y1, (float4 *)y3, n4); }, y3, n4 * 16});
+
+  int total_bad = 0;
+  for (Case &c : cases) {
+    if (only && !strstr(c.name, only)) continue;
+    std::vector<uint32_t> ref(c.bytes / 4), cur(c.bytes / 4);
+    int bad = 0;
+    bool shown = false;
+    for (int r = 0; r <= reps; ++r) {
+      HIP_OK(hipMemset(const_cast<void *>(c.out), 0xFF, c.bytes));  // a launch that writes nothing is a difference, not a repeat
+      c.launch();
+      HIP_OK(hipDeviceSynchronize());
+      HIP_OK(hipMemcpy(r == 0 ? ref.data() : cur.data(), c.out, c.bytes, hipMemcpyDeviceToHost));
+      if (r == 0 || memcmp(ref.data(), cur.data(), c.bytes) == 0) continue;
+      ++bad;
+      if (!shown) {
+        shown = true;
+        size_t first = 0, count = 0, last = 0;
+        for (size_t i = 0; i < ref.size(); ++i)
+          if (ref[i] != cur[i]) { if (!count) first = i; last = i; ++count; }
+        float a, b;
+        memcpy(&a, &ref[first], 4); memcpy(&b, &cur[first], 4);
+        printf("    first differing repetition %d: %zu words differ, word range [%zu, %zu], byte offset %% 128 of the first = %zu; first: %g vs %g\n",
+               r, count, first, last, first * 4 % 128, a, b);
+      }
+    }
+    printf("%-92s %4d / %d repetitions differ from the first\n", c.name, bad, reps);
+    fflush(stdout);
+    total_bad += bad;
+  }
+  return total_bad ? 1 : 0;
+}
