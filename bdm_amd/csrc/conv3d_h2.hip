@@ -238,74 +238,79 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     }
   }
   // Epilogue: scale + bias + store.  When gn_partial is given, the workgroup also leaves the (sum, sum of squares) of the
-  // values it wrote, per GroupNorm group of its channel tile, as slice blockIdx.x of the group's partials -- the GroupNorm
-  // that follows the convolution (pvconv.py:84) then needs no statistics pass of its own.  Deterministic: fixed order inside
-  // the lane, half-wave butterflies, then a fixed-order sum over waves by one thread per group.
-  float bs[MI][4], bq[MI][4];  // per 4-row block j of this lane: rows p*32 + 8j + 4lh .. +3 (never straddle a group)
+  // values it wrote, per GroupNorm group of its channel tile, as slice partials -- the GroupNorm that follows the convolution
+  // (pvconv.py:84) then needs no statistics pass of its own.  The slices are defined on a CANONICAL decomposition that does not
+  // depend on the tile this launch picked (the tile follows the batch size; a shape must not see its batch-mates): one slice per
+  // smallest spatial tile of the resolution (16^3: one x-plane = the 1 x 16 tile; 8^3: two x-planes = the 2 x 8 tile; 32^3: the
+  // 2 x 8 tile), summed as: lane (4 rows of ONE 32-voxel block), half-wave butterfly, the unit's blocks in ascending block
+  // order, then the 4-row blocks of a group in fp64.  Deterministic and identical for every tile choice.
+  constexpr int UN = (R == 16 && TX == 2) ? 2 : ((R == 8 && TX == 4) ? 2 : 1);  // canonical units inside this workgroup's tile
+  constexpr int NBLK = NI * NW, BPU = NBLK / UN;                                  // 32-voxel blocks, blocks per unit
+  constexpr int NB = 2 * MI * 4 * 2;                                              // [lh][p][j][stat]
+  float *red = reinterpret_cast<float *>(smem4);                                  // [NBLK][NB], then [UN][NB]
+  if (gn_partial != nullptr) __syncthreads();  // the operand tiles are dead (slower waves may still be reading fragments)
 #pragma unroll
   for (int p = 0; p < MI; ++p)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { bs[p][j] = 0.f; bq[p][j] = 0.f; }
+    for (int q = 0; q < NI; ++q) {
+      float bs[4], bq[4];  // per 4-row block j of this lane: rows p*32 + 8j + 4lh .. +3 (never straddle a group)
 #pragma unroll
-  for (int p = 0; p < MI; ++p)
-#pragma unroll
-    for (int q = 0; q < NI; ++q)
+      for (int j = 0; j < 4; ++j) { bs[j] = 0.f; bq[j] = 0.f; }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int m = m0 + p * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
         if (m < Cout) {
           const float v = acc[p][q][i] * (inv_scale[m] * x_inv_scale) + (bias ? bias[m] : 0.f);
           yb[(size_t)m * R3 + gvox[q]] = v;
-          bs[p][i >> 2] += v;
-          bq[p][i >> 2] += v * v;
+          bs[i >> 2] += v;
+          bq[i >> 2] += v * v;
         }
       }
-  if (gn_partial != nullptr) {
-#pragma unroll
-    for (int p = 0; p < MI; ++p)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
-          bs[p][j] += __shfl_xor(bs[p][j], o, 64);
-          bq[p][j] += __shfl_xor(bq[p][j], o, 64);
-        }
-    __syncthreads();  // the operand tiles are dead: reuse the LDS
-    float *red = reinterpret_cast<float *>(smem4);  // [NW][2][MI][4][2]
-    if (li == 0) {
-#pragma unroll
-      for (int p = 0; p < MI; ++p)
+      if (gn_partial != nullptr) {
+        const int nb = q * NW + wave;  // this block's index inside the tile (plane-major, see gvox)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          red[((((wave * 2 + lh) * MI + p) * 4 + j) * 2) + 0] = bs[p][j];
-          red[((((wave * 2 + lh) * MI + p) * 4 + j) * 2) + 1] = bq[p][j];
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) {
+            bs[j] += __shfl_xor(bs[j], o, 64);
+            bq[j] += __shfl_xor(bq[j], o, 64);
+          }
+          if (li == 0) {
+            red[nb * NB + (((lh * MI + p) * 4 + j) * 2) + 0] = bs[j];
+            red[nb * NB + (((lh * MI + p) * 4 + j) * 2) + 1] = bq[j];
+          }
         }
+      }
     }
+  if (gn_partial != nullptr) {
     __syncthreads();
-    // stage 1: one thread per (half, p, j, statistic) adds the NW waves' values in wave order (NW reads deep, not NW*32)
-    constexpr int NB = 2 * MI * 4 * 2;
-    float *red2 = red + NW * NB;
-    if (tid < NB) {
+    // stage 1: one thread per (unit, half, p, j, statistic) adds the unit's blocks in ascending block order
+    float *red2 = red + NBLK * NB;
+    if (tid < UN * NB) {
+      const int un = tid / NB, e = tid % NB;
       float a = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) a += red[w * NB + tid];
+      for (int k = 0; k < BPU; ++k) a += red[(un * BPU + k) * NB + e];
       red2[tid] = a;
     }
     __syncthreads();
     const int ngt = BM / gn_cg;  // groups inside this channel tile
-    if (tid < ngt && m0 + tid * gn_cg < Cout) {
-      double a = 0.0, qq = 0.0;
-      for (int hh = 0; hh < 2; ++hh)
-        for (int p = 0; p < MI; ++p)
-          for (int j = 0; j < 4; ++j)
-            if (((p * 32 + 8 * j + 4 * hh) >> (__ffs(gn_cg) - 1)) == tid) {  // gn_cg is a power of two
-              a += (double)red2[(((hh * MI + p) * 4 + j) * 2) + 0];
-              qq += (double)red2[(((hh * MI + p) * 4 + j) * 2) + 1];
-            }
-      const int G = Cout / gn_cg, g = m0 / gn_cg + tid, S = gridDim.x;
-      double *dst = gn_partial + (((size_t)bi * G + g) * S + blockIdx.x) * 2;
-      dst[0] = a;
-      dst[1] = qq;
+    if (tid < UN * ngt) {
+      const int un = tid / ngt, gi = tid % ngt;
+      if (m0 + gi * gn_cg < Cout) {
+        double a = 0.0, qq = 0.0;
+        for (int hh = 0; hh < 2; ++hh)
+          for (int p = 0; p < MI; ++p)
+            for (int j = 0; j < 4; ++j)
+              if (((p * 32 + 8 * j + 4 * hh) >> (__ffs(gn_cg) - 1)) == gi) {  // gn_cg is a power of two
+                a += (double)red2[un * NB + (((hh * MI + p) * 4 + j) * 2) + 0];
+                qq += (double)red2[un * NB + (((hh * MI + p) * 4 + j) * 2) + 1];
+              }
+        const int G = Cout / gn_cg, g = m0 / gn_cg + gi, S = gridDim.x * UN;
+        double *dst = gn_partial + (((size_t)bi * G + g) * S + blockIdx.x * UN + un) * 2;
+        dst[0] = a;
+        dst[1] = qq;
+      }
     }
   }
 }
@@ -349,9 +354,10 @@ static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, f
   dim3 grid((r / tx) * (r / ty), cdiv(cout, 32 * mi), b);
   hipStream_t s = (hipStream_t)stream;
   if (gn_partial != nullptr) {
-    BDM_REQUIRE(gn_cg >= 4 && gn_cg % 4 == 0 && (32 * mi) % gn_cg == 0 && cout % gn_cg == 0 && (int)grid.x <= 64,
-                "conv3d_h2: GroupNorm statistics need 4 | channels-per-group | %d and <= 64 spatial tiles (got cg=%d)", 32 * mi, gn_cg);
-    if (slices_out) *slices_out = (int)grid.x;
+    BDM_REQUIRE(gn_cg >= 4 && (gn_cg & (gn_cg - 1)) == 0 && (32 * mi) % gn_cg == 0 && cout % gn_cg == 0 && (int)grid.x <= 64,
+                "conv3d_h2: GroupNorm statistics need a power-of-two channels-per-group dividing %d and <= 64 spatial tiles (got cg=%d)", 32 * mi, gn_cg);
+    // canonical slices (independent of the tile): 16^3 one per x-plane, 8^3 one per two x-planes, 32^3 one per 2 x 8 tile
+    if (slices_out) *slices_out = r == 16 ? 16 : (r == 8 ? 4 : (int)grid.x);
   }
 #define H2_LAUNCH(MI, NI, R, TX, TY, NW)                                                                        \
   do {                                                                                                          \

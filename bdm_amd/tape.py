@@ -151,6 +151,10 @@ def _slots(name, args):
             out.append(struct.unpack("<Q", struct.pack("<d", float(v)))[0])
         elif v is None:
             out.append(0)
+        elif hasattr(v, "_obj"):  # ctypes.byref(x): a host out-parameter (e.g. slices_out); x stays alive with the recorded args
+            out.append(ctypes.addressof(v._obj))
+        elif isinstance(v, ctypes._SimpleCData):
+            out.append(int(v.value or 0) & _U64)
         else:
             out.append(int(v) & _U64)
     return out

@@ -4,6 +4,7 @@
 //         -Wl,-rpath,$PWD/bdm_amd
 //   /tmp/two_proc_repro 300            # alone: every line must report 0 differing repetitions
 //   /tmp/two_proc_repro 300 & /tmp/two_proc_repro 300   # two PROCESSES on one GPU at the same time
+//   /tmp/two_proc_repro 300 - 1 & /tmp/two_proc_repro 300 - 2   # ... holding DIFFERENT data (seed argument)
 //
 // Every case launches ONE kernel (or one C-ABI call) REPS times on fixed inputs with a device-wide synchronisation after every
 // launch, copies the output back and compares it bit by bit with the first repetition.  Cases:
@@ -79,7 +80,10 @@ struct Case {
 
 int main(int argc, char **argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 200;
-  const char *only = argc > 2 ? argv[2] : nullptr;
+  const char *only = argc > 2 && strcmp(argv[2], "-") ? argv[2] : nullptr;
+  // a different seed per process makes data of the OTHER process recognisable: with equal seeds both processes hold the same
+  // bytes at the same virtual addresses, and a read that was served with the neighbour's data would go unnoticed
+  if (argc > 3) rng_state ^= 0xD1B54A32D192ED03ull * (uint64_t)atoll(argv[3]);
   std::vector<Case> cases;
 
   // ---- library: SharedMLP pair at the SA0 shape of the denoiser (B=2, 32 -> 64 -> 64 channels, 1024 x 32 columns)
@@ -109,6 +113,15 @@ int main(int argc, char **argv) {
   cases.push_back({"lib devoxelize_gn_gate_add (128 channels, 1024 points, 16^3)", [&] {
     ABI_OK(bdm_devoxelize_gn_gate_add(B, C, NP, R, coords, grid, coef, gate, add, (long long)C * NP, NP, dout, (long long)C * NP, NP, nullptr)); },
     dout, (size_t)B * C * NP * 4});
+  // ---- library: the three calls back to back, 40 rounds without any synchronisation in between (the shape of a real forward)
+  cases.push_back({"lib chain: 40 x [gemm+stats -> folded gemm+stats -> devoxelize] without synchronisation", [&] {
+    for (int it = 0; it < 40; ++it) {
+      ABI_OK(bdm_pointwise_conv_gn(B, M, K0, N, w1, K0, x0, (long long)K0 * N, N, nullptr, 0, 0, 0, b1, y1, (long long)M * N, N, nullptr, 0, 0,
+                                   nullptr, nullptr, 0.f, G, p1, nullptr, 0, nullptr));
+      ABI_OK(bdm_pointwise_conv_gn(B, M, M, N, w2, M, y1, (long long)M * N, N, nullptr, 0, 0, 0, b2, y2, (long long)M * N, N, p1, s1, G, gamma,
+                                   beta, 1e-5f, G, p2, nullptr, 0, nullptr));
+      ABI_OK(bdm_devoxelize_gn_gate_add(B, C, NP, R, coords, grid, coef, gate, add, (long long)C * NP, NP, dout, (long long)C * NP, NP, nullptr));
+    } }, y2, (size_t)B * M * N * 4});
   // ---- trivial kernels of this file
   const size_t n4 = (size_t)B * M * N / 4;
   cases.push_back({"trivial copy (float4 per thread)", [&] { hipLaunchKernelGGL(copy_kernel, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4 *)y1, (float4 *)y3, n4); }, y3, n4 * 16});
