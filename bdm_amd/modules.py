@@ -237,10 +237,11 @@ class PVConv(nn.Module):
             pf, pending = run()
             return pf, None, pending
         dev = features.device
-        side = PVConv._streams.get(dev)
+        cur = torch.cuda.current_stream(dev)
+        side = PVConv._streams.get((dev, cur.cuda_stream))  # one branch stream per main stream (concurrent lanes stay independent)
         if side is None:
-            side = PVConv._streams[dev] = torch.cuda.Stream(device=dev)
-        tape.wait_stream(side, torch.cuda.current_stream(dev))
+            side = PVConv._streams[(dev, cur.cuda_stream)] = torch.cuda.Stream(device=dev)
+        tape.wait_stream(side, cur)
         with torch.cuda.stream(side):
             pf, pending = run()
             ev = torch.cuda.Event()

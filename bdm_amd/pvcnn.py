@@ -137,9 +137,10 @@ def plan_sampling_chain(sa_layers, coords):
     long pole -- is enqueued up front; the other ~19 launches of the chain follow when the first SA module is reached, i.e.
     AFTER the host has fed the main stream its first PVConvs (they could not start before that sampler finishes anyway)."""
     cur = torch.cuda.current_stream()
-    side = _side_streams.get(coords.device)
+    key = (coords.device, cur.cuda_stream)  # one sampler stream per main stream: concurrent lanes do not queue behind each other
+    side = _side_streams.get(key)
     if side is None:
-        side = _side_streams[coords.device] = torch.cuda.Stream(device=coords.device)
+        side = _side_streams[key] = torch.cuda.Stream(device=coords.device)
     tape.wait_stream(side, cur)
     first = sa_layers[0][-1] if isinstance(sa_layers[0], nn.Sequential) else sa_layers[0]
     with torch.cuda.stream(side):

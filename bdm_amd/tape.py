@@ -77,7 +77,7 @@ _FILLS = {"aten::zeros": 0, "aten::zeros_like": 0, "aten::new_zeros": 0, "aten::
 
 def _py(stream, fn, args, kwargs):
     """A torch operator on the tape: re-issued on the stream it was recorded on; returns 0 like the C functions."""
-    if stream is None:
+    if stream is None or torch.cuda.current_stream() == stream:
         fn(*args, **kwargs)
     else:
         with torch.cuda.stream(stream):
@@ -108,7 +108,7 @@ class _TorchOps(TorchDispatchMode):
             tape.broken = f"{name}: host <-> device traffic inside the step"
             return out
         cur = torch.cuda.current_stream()
-        stream = None if cur == tape.main_stream else cur
+        stream = cur  # replayed on the stream it was recorded on, whatever stream is current then
         tape.keep.extend(touched)
         raw = cur.cuda_stream
         if func._schema.is_mutable:  # in-place / out= operator: the same call lands in the same (kept) tensors
@@ -128,6 +128,10 @@ class _TorchOps(TorchDispatchMode):
             tape.calls.append((_py, (stream, out.fill_, (value,), {})))
         elif isinstance(out, torch.Tensor):  # functional operator: recompute, then land in the recorded output
             tape.calls.append((_into, (stream, out, func, args, kwargs)))
+            src = args[0] if args and isinstance(args[0], torch.Tensor) else None
+            if (name in ("aten::clone", "aten::_to_copy", "aten::contiguous") and src is not None and src.is_cuda and src.dtype == out.dtype
+                    and src.shape == out.shape and src.is_contiguous() and out.is_contiguous()):
+                tape.native[len(tape.calls) - 1] = ("memcpy", out, src, raw)
         else:
             tape.broken = f"{name}: operator with a non-tensor result"
         tape.torch_ops.append(name)
@@ -175,7 +179,7 @@ class LaunchTape:
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
-        if h and L._lib is not None:
+        if h and L is not None and getattr(L, "_lib", None) is not None:  # (module globals are gone at interpreter shutdown)
             L._lib.bdm_tape_destroy(h)
 
     @staticmethod
