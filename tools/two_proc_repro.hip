@@ -78,7 +78,42 @@ struct Case {
   size_t bytes;
 };
 
+// trivial aggressor: streams data through a big dynamic-LDS allocation (the library's convolutions hold up to 135 KB per workgroup)
+__global__ void big_lds_kernel(const float4 *x, float4 *y, size_t n4, int lds_items) {
+  extern __shared__ float4 big[];
+  for (int i = threadIdx.x; i < lds_items; i += blockDim.x) big[i] = x[((size_t)blockIdx.x * lds_items + i) % n4];
+  __syncthreads();
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (int i = threadIdx.x; i < lds_items; i += blockDim.x) { const float4 v = big[(i * 33) % lds_items]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+  y[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+static int aggress(const char *kind, double seconds) {  // usage: two_proc_repro --aggress lds128k|lds32k|copy <seconds>
+  const size_t n4 = (size_t)1 << 22;
+  float *x = dev_random(n4 * 4), *y = dev_alloc<float>(n4 * 4);
+  const int bytes = !strcmp(kind, "lds128k") ? 128 * 1024 : (!strcmp(kind, "lds32k") ? 32 * 1024 : 0);
+  if (bytes > 48 * 1024) HIP_OK(hipFuncSetAttribute((const void *)big_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  HIP_OK(hipEventRecord(e0, 0));
+  long iters = 0;
+  for (;;) {
+    for (int i = 0; i < 50; ++i) {
+      if (bytes) hipLaunchKernelGGL(big_lds_kernel, dim3(2048), dim3(512), bytes, 0, (const float4 *)x, (float4 *)y, n4, bytes / 16);
+      else hipLaunchKernelGGL(copy_kernel, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4 *)x, (float4 *)y, n4);
+    }
+    iters += 50;
+    HIP_OK(hipEventRecord(e1, 0)); HIP_OK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms > seconds * 1e3) break;
+  }
+  printf("aggressor %s: %ld launches\n", kind, iters);
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 3 && !strcmp(argv[1], "--aggress")) return aggress(argv[2], atof(argv[3]));
   const int reps = argc > 1 ? atoi(argv[1]) : 200;
   const char *only = argc > 2 && strcmp(argv[2], "-") ? argv[2] : nullptr;
   // a different seed per process makes data of the OTHER process recognisable: with equal seeds both processes hold the same
