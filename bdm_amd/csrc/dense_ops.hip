@@ -33,23 +33,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // needs no statistics pass -- and (b) take its INPUT as the raw output of such a convolution plus that convolution's partials,
 // applying normalise + Swish while the operand goes to LDS -- the normalised tensor is never written.  Deterministic: fixed
 // summation orders everywhere (no float atomics).
-struct PwGn {
-  const double *in_partial;  // (b, in_G, in_S, 2) or NULL
-  int in_S, in_G;
-  const float *in_gamma, *in_beta;
-  float in_eps;
-  double *out_partial;       // (b, M / out_cg, S_out, 2) or NULL;  S_out = ceil(N / 128) * max(1, out_cg / 32): canonical, tile-independent
-  int out_cg;
-  // second source of the K axis: rows k >= k1 of the operand come from x2 (torch.cat([x, x2], dim=1) without the copy)
-  const float *x2;
-  long long bsx2;
-  int ldx2, k1;
-  // max |y| per (shape, block of `amax_rows` output rows) (amax_rows % 32 == 0): slot [shape * amax_slots + block], bit patterns
-  // of non-negative floats combined with an integer atomicMax (order independent).  Zero on entry.  Feeds the fp16x3 attention's
-  // scales; per SHAPE so that a shape's result does not depend on its batch-mates.
-  unsigned *amax;
-  int amax_rows, amax_slots;
-};
+#include "pointwise_common.h"
 
 // amdgpu_waves_per_eu(2): with an occupancy target of two waves per SIMD the register allocator stops hoarding (2 x 2 tile with
 // the folded GroupNorm: 220 -> 160 VGPRs, i.e. three workgroups per CU instead of two; the 32768-column SA layer 101 -> 79 us);
@@ -558,6 +542,8 @@ static void pw_tile(int b, int m, int k, int n, int *mi, int *ni, int *bk) {
     *mi = 1; *ni = 1; if (k >= 128 && blocks(1, 1) < deep_limit) *bk = 64;
   }
 }
+
+void bdm_pw_tile(int b, int m, int k, int n, int *mi, int *ni, int *bk) { pw_tile(b, m, k, n, mi, ni, bk); }  // for pointwise_s3.hip
 
 // tile choice + launch, shared by the plain and the GroupNorm-folded entry points.  *bm_out = rows of the chosen tile,
 // *gx_out = column tiles (the GroupNorm slice count derives from both)

@@ -56,6 +56,33 @@ def workspace(nbytes, device, tag="ws"):
     return buf
 
 
+# 1x1 convolutions: "bf16x6" (default) = exact 3-way bf16 operand split, six partial products on the 16-bit matrix pipe, fp32
+# accumulate (pointwise_s3.hip: fp32-grade, no scale, no range limit, 2.7x the matrix rate); "fp32" = fp32-input MFMA
+# (dense_ops.hip).  The skinny shapes (<= 64 columns, K >= 128) keep their K-split fp32 kernel either way.
+PW_IMPL = os.environ.get("BDM_PW", "bf16x6")
+PW_S3_MIN_COLUMNS = 65   # shapes with fewer columns per shape stay on the fp32 kernels (latency-bound: nothing to gain)
+_pw_s3_packs = {}
+
+
+def _pw_s3_weights(w, weight):
+    """bf16x6 records of a (M, K) weight matrix, packed once per (tensor, version).  Only for views of a long-lived tensor (a
+    module parameter or a cached concatenation): a temporary copy would be re-packed on every call -> None (fp32 kernel)."""
+    if PW_IMPL != "bf16x6" or not w.is_cuda or w.data_ptr() != weight.data_ptr():
+        return None
+    M, K = w.shape
+    key = (w.data_ptr(), M, K)
+    hit = _pw_s3_packs.get(key)
+    if hit is None or hit[0] != weight._version or hit[2] is not weight:
+        if len(_pw_s3_packs) > 1024:  # (a model has ~50 such matrices; tests create many throw-away ones)
+            _pw_s3_packs.clear()
+        lib = L.lib()
+        packed = torch.empty(lib.bdm_pointwise_s3_weight_elems(M, K), dtype=torch.bfloat16, device=w.device)
+        L.check(lib.bdm_pointwise_s3_pack_weights(M, K, L.ptr(w), K, L.ptr(packed), L.stream()), "pointwise_s3_pack_weights")
+        hit = (weight._version, packed, weight)  # holds the weight tensor: its address cannot be recycled while the pack lives
+        _pw_s3_packs[key] = hit
+    return hit[1]
+
+
 def pointwise_conv(x, weight, bias=None, out=None, batch_bias=None, act=0, slope=0.0, residual=None):
     """y = W x + b  over the channel axis; weight (M,K[,1[,1]]) as in nn.Conv1d/Conv2d(k=1)/nn.Linear."""
     x, B, K, n, bs_x, ld_x = _bcl(x)
@@ -72,6 +99,12 @@ def pointwise_conv(x, weight, bias=None, out=None, batch_bias=None, act=0, slope
         assert rr.data_ptr() == residual.data_ptr() and residual.shape[1] == M
     else:
         bs_r, ld_r = 0, 0
+    packed = _pw_s3_weights(w, weight) if (n >= PW_S3_MIN_COLUMNS and int(act) in (0, 2, 3)) else None
+    if packed is not None:
+        L.check(L.lib().bdm_pointwise_conv_s3(B, M, K, n, L.ptr(packed), L.ptr(x), L.c_ll(bs_x), ld_x, L.ptr(bias),
+                                              L.ptr(batch_bias), M, L.ptr(residual), L.c_ll(bs_r), ld_r, L.ptr(out),
+                                              L.c_ll(bs_y), ld_y, int(act), L.c_float(slope), L.stream()), "pointwise_conv_s3")
+        return out
     L.check(L.lib().bdm_pointwise_conv(B, M, K, n, L.ptr(w), K, L.ptr(x), L.c_ll(bs_x), ld_x, L.ptr(bias),
                                        L.ptr(batch_bias), M, L.ptr(residual), L.c_ll(bs_r), ld_r, L.ptr(out),
                                        L.c_ll(bs_y), ld_y, int(act), L.c_float(slope), L.stream()), "pointwise_conv")
@@ -115,6 +148,12 @@ def pointwise_conv_gn(x, weight, bias=None, out=None, fold_in=None, out_groups=N
         assert slices > 0
         out_p = torch.empty(B * og * slices * 2, dtype=torch.float64, device=x.device)
         stats = (out_p, slices, og)
+    packed = _pw_s3_weights(w, weight) if n >= PW_S3_MIN_COLUMNS else None
+    if packed is not None:
+        L.check(lib.bdm_pointwise_conv_gn_s3(B, M, K, n, L.ptr(packed), L.ptr(x), L.c_ll(bs_x), ld_x, L.ptr(x2p), L.c_ll(bs_x2), ld_x2, k1,
+                                             L.ptr(bias), L.ptr(out), L.c_ll(bs_y), ld_y, L.ptr(in_p), in_s, in_g, L.ptr(in_gamma), L.ptr(in_beta),
+                                             L.c_float(in_eps), og, L.ptr(out_p), L.ptr(amax), int(amax_rows), L.stream()), "pointwise_conv_gn_s3")
+        return (out, stats) if out_groups else out
     L.check(lib.bdm_pointwise_conv_gn(B, M, K, n, L.ptr(w), K, L.ptr(x), L.c_ll(bs_x), ld_x, L.ptr(x2p), L.c_ll(bs_x2), ld_x2, k1,
                                       L.ptr(bias), L.ptr(out), L.c_ll(bs_y), ld_y, L.ptr(in_p), in_s, in_g, L.ptr(in_gamma), L.ptr(in_beta), L.c_float(in_eps), og,
                                       L.ptr(out_p), L.ptr(amax), int(amax_rows), L.stream()), "pointwise_conv_gn")

@@ -169,6 +169,21 @@ int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w, int ldw, c
                           int ld_y, const void *in_partial, int in_slices, int in_groups, const float *in_gamma,
                           const float *in_beta, float in_eps, int out_groups, void *out_partial, float *amax, int amax_rows,
                           void *stream);
+/* bf16x6 form of the two entry points above (pointwise_s3.hip): the weights are split ONCE into exact bf16 triples
+ * (bdm_pointwise_s3_pack_weights: packed = bdm_pointwise_s3_weight_elems(m, k) 16-bit elements), the activations while they are
+ * staged; six partial products per fp32 product on v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-grade (no scale, no range limit)
+ * at 2.7x the matrix rate of the fp32-MFMA kernel.  Same arguments and semantics otherwise; statistics slices are always
+ * ceil(n / 128) * max(1, (m / groups) / 32) (the canonical layout).  Not for the skinny shapes (n <= 64, k >= 128: K-split kernel). */
+size_t bdm_pointwise_s3_weight_elems(int m, int k);
+int bdm_pointwise_s3_pack_weights(int m, int k, const float *w, int ldw, void *packed, void *stream);
+int bdm_pointwise_conv_s3(int b, int m, int k, int n, const void *packed_w, const float *x, long long bs_x, int ld_x,
+                          const float *bias, const float *batch_bias, int ld_bb, const float *residual, long long bs_r,
+                          int ld_r, float *y, long long bs_y, int ld_y, int act, float slope, void *stream);
+int bdm_pointwise_conv_gn_s3(int b, int m, int k, int n, const void *packed_w, const float *x, long long bs_x, int ld_x,
+                             const float *x2, long long bs_x2, int ld_x2, int k1, const float *bias, float *y, long long bs_y,
+                             int ld_y, const void *in_partial, int in_slices, int in_groups, const float *in_gamma,
+                             const float *in_beta, float in_eps, int out_groups, void *out_partial, float *amax,
+                             int amax_rows, void *stream);
 int bdm_max_over_neighbors_gn(int b, int c, int m, int u, const float *x, const void *in_partial, int in_slices, int groups,
                               const float *gamma, const float *beta, float eps, float *y, long long bs_y, int ld_y,
                               void *stream);

@@ -29,6 +29,36 @@ def test_pointwise_conv(ops, B, M, K, N):
     assert rel(got, ref) < 2e-6  # fp32 MFMA, k-ordered accumulation vs fp64 reference
 
 
+@pytest.mark.parametrize("B,M,K,N", [(2, 64, 35, 1024 * 32), (2, 32, 390, 4096), (1, 3, 128, 1100), (1, 192, 64, 4096), (2, 8, 8, 133),
+                                     (2, 100, 579, 1000), (3, 512, 256, 512), (2, 256, 323, 65)])
+def test_pointwise_conv_bf16x6_and_fp32_kernels(ops, monkeypatch, B, M, K, N):
+    """The two kernel families of the 1x1 convolutions (pointwise_s3.hip: exact bf16 triples, six products, the default;
+    dense_ops.hip: fp32-input MFMA) against fp64, with every epilogue term, a strided operand and K / M / N tails; and the
+    GroupNorm statistics the bf16x6 kernel leaves against the values it wrote."""
+    g = torch.Generator().manual_seed(M * K + N)
+    big = torch.randn(B, K + 3, N, generator=g).cuda()
+    x = big[:, 1:1 + K]
+    w = (torch.randn(M, K, generator=g) / K ** 0.5).cuda()
+    bias, bb, res = torch.randn(M, generator=g).cuda(), torch.randn(B, M, generator=g).cuda(), torch.randn(B, M, N, generator=g).cuda()
+    lin = TF.conv1d(x.cpu().double(), w.cpu().double()[:, :, None], bias.cpu().double()) + bb.cpu().double()[:, :, None]
+    ref = TF.leaky_relu(lin, 0.1) + res.cpu().double()
+    outs = {}
+    for impl in ("bf16x6", "fp32"):
+        monkeypatch.setattr(ops, "PW_IMPL", impl)
+        got = ops.pointwise_conv(x, w, bias, batch_bias=bb, act=2, slope=0.1, residual=res)
+        assert rel(got.cpu(), ref.float()) < 2e-6, impl
+        assert torch.equal(got, ops.pointwise_conv(x, w, bias, batch_bias=bb, act=2, slope=0.1, residual=res)), impl  # deterministic
+        outs[impl] = got
+    assert not torch.equal(outs["bf16x6"], outs["fp32"])  # really two different kernels
+    if M % 8 == 0 and ops.gn_foldable(M, 8):
+        monkeypatch.setattr(ops, "PW_IMPL", "bf16x6")
+        y, (partial, slices, groups) = ops.pointwise_conv_gn(x, w, bias, out_groups=8)
+        assert rel(y.cpu(), (lin - bb.cpu().double()[:, :, None]).float()) < 2e-6
+        sums = partial.view(B, 8, slices, 2).sum(2)
+        yd = y.double().view(B, 8, -1)
+        assert torch.allclose(sums[..., 0], yd.sum(-1), rtol=1e-6, atol=1e-3) and torch.allclose(sums[..., 1], (yd * yd).sum(-1), rtol=1e-6)
+
+
 def test_pointwise_conv_views_residual_leaky(ops):
     g = torch.Generator().manual_seed(5)
     B, K, M, N = 2, 67, 40, 300
