@@ -38,7 +38,7 @@ def lib():
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C bdm_amd/csrc`). There is no CPU fallback for the HIP path.")
         handle = ctypes.CDLL(SO_PATH)
-        for name, (restype, argtypes) in abi_signatures().items():
+        for name, (restype, argtypes) in abi_signatures(experimental=hasattr(handle, "bdm_conv3d_3x3x3")).items():
             fn = getattr(handle, name)  # AttributeError here = header and library disagree: fail loudly
             fn.restype, fn.argtypes = restype, argtypes
         _lib = handle
@@ -50,12 +50,28 @@ _CTYPES = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.
            "unsigned long long": ctypes.c_ulonglong, "unsigned int": ctypes.c_uint, "double": ctypes.c_double, "int64_t": ctypes.c_int64}
 
 
-def abi_signatures(header: str = HEADER):
+def has_experimental() -> bool:
+    """Was the library built with `make EXPERIMENTAL=1` (fp32-MFMA convolution / flash attention, one-kernel sparse convolution)?"""
+    return hasattr(lib(), "bdm_conv3d_3x3x3")
+
+
+def experimental(name: str):
+    """Entry point of the experimental build, or a clear error (never a silent fallback)."""
+    fn = getattr(lib(), name, None)
+    if fn is None:
+        raise BdmHipError(f"{name} belongs to the experimental kernel families; rebuild with `make -C bdm_amd/csrc EXPERIMENTAL=1`")
+    return fn
+
+
+def abi_signatures(header: str = HEADER, experimental: bool = False):
     """{function: (restype, [argtypes])} parsed from include/bdm_hip.h, the single source of truth for the C ABI:
     every exported function gets its ctypes prototype from its declaration (a size_t result or a long long stride
     is never squeezed through ctypes' default 32-bit int)."""
     import re
-    text = re.sub(r"/\*.*?\*/", " ", open(header).read(), flags=re.S)
+    text = open(header).read()
+    if not experimental:
+        text = re.sub(r"#ifdef BDM_EXPERIMENTAL.*?#endif /\* BDM_EXPERIMENTAL \*/", " ", text, flags=re.S)
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)
     sigs = {}
     for ret, name, args in re.findall(r"([A-Za-z_][\w \*]*?)\b(bdm_\w+)\s*\(([^)]*)\)\s*;", text):

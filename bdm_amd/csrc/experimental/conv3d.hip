@@ -1,4 +1,5 @@
-// conv3d.hip -- 3x3x3, stride 1, zero-padded convolution on the dense r^3 voxel grids of PVConv
+// experimental/conv3d.hip (built with `make EXPERIMENTAL=1` only: the fp32-MFMA convolution family, superseded by the fp16x3 /
+// bf16x6 kernels of conv3d_h2.hip / conv3d_s3.hip; kept as the arithmetic yardstick of the accuracy tests) -- 3x3x3, stride 1, zero-padded convolution on the dense r^3 voxel grids of PVConv
 // (reference: nn.Conv3d in experiments/model/pvcnn/modules/pvconv.py:75-85; ~95 % of the
 // denoiser's FLOPs).
 //
@@ -12,8 +13,8 @@
 //   conflict-free read of 32 consecutive output channels;
 // * one 256-thread workgroup = 4 waves side by side along the voxel axis, each holding
 //   MI x NI accumulator tiles of 32 x 32.
-#include "../../include/bdm_hip.h"
-#include "common.h"
+#include "../../../include/bdm_hip.h"
+#include "../common.h"
 
 using namespace bdm;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -279,20 +280,6 @@ static size_t conv3d_smem(const C3Cfg &c, int r) {
   return sizeof(float) * ((size_t)C3_BKC * (c.tx + 2) * (c.ty + 2) * (r + 8) + (size_t)27 * C3_BKC * 32 * c.mi);
 }
 
-__global__ void row_occupancy_kernel(int r, const int *__restrict__ cnt, unsigned char *__restrict__ rowocc) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.y;
-  if (row >= r * r) return;
-  const int *c = cnt + ((size_t)bi * r * r + row) * r;
-  int any = 0;
-  for (int z = 0; z < r; ++z) any |= c[z];
-  rowocc[(size_t)bi * r * r + row] = any ? 1 : 0;
-}
-extern "C" int bdm_voxel_row_occupancy(int b, int r, const int *cnt, unsigned char *rowocc, void *stream) {
-  BDM_REQUIRE(b >= 0 && r >= 1, "voxel_row_occupancy: bad sizes");
-  if (b == 0) return BDM_OK;
-  hipLaunchKernelGGL(row_occupancy_kernel, dim3(cdiv(r * r, 256), b), dim3(256), 0, (hipStream_t)stream, r, cnt, rowocc);
-  return launch_status("voxel_row_occupancy");
-}
 
 extern "C" int bdm_conv3d_3x3x3_sparse(int b, int cin, int cout, int r, const float *x, const float *packed_w,
                                        const float *bias, const unsigned char *rowocc, float *y, void *stream);

@@ -62,6 +62,22 @@ extern "C" int bdm_voxel_compact(int b, int r, int n_max, const int *cnt, int *o
   return launch_status("voxel_compact");
 }
 
+// rowocc (b, r*r) uint8: does grid row (x, y) hold an occupied cell?  (the gather skips empty rows of the neighbourhood)
+__global__ void row_occupancy_kernel(int r, const int *__restrict__ cnt, unsigned char *__restrict__ rowocc) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.y;
+  if (row >= r * r) return;
+  const int *c = cnt + ((size_t)bi * r * r + row) * r;
+  int any = 0;
+  for (int z = 0; z < r; ++z) any |= c[z];
+  rowocc[(size_t)bi * r * r + row] = any ? 1 : 0;
+}
+extern "C" int bdm_voxel_row_occupancy(int b, int r, const int *cnt, unsigned char *rowocc, void *stream) {
+  BDM_REQUIRE(b >= 0 && r >= 1, "voxel_row_occupancy: bad sizes");
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(row_occupancy_kernel, dim3(cdiv(r * r, 256), b), dim3(256), 0, (hipStream_t)stream, r, cnt, rowocc);
+  return launch_status("voxel_row_occupancy");
+}
+
 // ---------------------------------------------------------------------------------------------------
 // 1b. mean features of the occupied cells: Xc (B, C, n_max) channel-first; columns >= n_occ are zero
 // ---------------------------------------------------------------------------------------------------

@@ -412,7 +412,7 @@ def conv3d_pack(weight):
     cout, cin = weight.shape[:2]
     w = weight.contiguous()
     packed = torch.empty(27, cin, cout, dtype=torch.float32, device=w.device)
-    L.check(L.lib().bdm_conv3d_pack_weights(cout, cin, L.ptr(w), L.ptr(packed), L.stream()), "conv3d_pack_weights")
+    L.check(L.experimental("bdm_conv3d_pack_weights")(cout, cin, L.ptr(w), L.ptr(packed), L.stream()), "conv3d_pack_weights")
     return packed
 
 
@@ -422,7 +422,7 @@ def conv3d(x, packed_w, bias, r, rowocc=None):
     B, cin = x.shape[:2]
     cout = packed_w.shape[2]
     y = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=x.device)
-    L.check(L.lib().bdm_conv3d_3x3x3_sparse(B, cin, cout, int(r), L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(rowocc),
+    L.check(L.experimental("bdm_conv3d_3x3x3_sparse")(B, cin, cout, int(r), L.ptr(x), L.ptr(packed_w), L.ptr(bias), L.ptr(rowocc),
                                             L.ptr(y), L.stream()), "conv3d")
     return y
 
@@ -715,10 +715,10 @@ def sparse_conv_pack_fused(weight):
     """(Cout, Cin, 3,3,3) fp32 -> (fp16 records [ceil(Cin/8)][27][2][Cout][8], inv_scale (Cout,)) for bdm_sparse_conv_fused."""
     cout, cin = weight.shape[:2]
     lib = L.lib()
-    packed = torch.empty(lib.bdm_sparse_conv_fused_weight_elems(cout, cin), dtype=torch.float16, device=weight.device)
+    packed = torch.empty(L.experimental("bdm_sparse_conv_fused_weight_elems")(cout, cin), dtype=torch.float16, device=weight.device)
     scale = torch.empty(cout, dtype=torch.float32, device=weight.device)
     inv_scale = torch.empty(cout, dtype=torch.float32, device=weight.device)
-    L.check(lib.bdm_sparse_conv_fused_pack_weights(cout, cin, L.ptr(weight.contiguous()), L.ptr(packed), L.ptr(scale),
+    L.check(L.experimental("bdm_sparse_conv_fused_pack_weights")(cout, cin, L.ptr(weight.contiguous()), L.ptr(packed), L.ptr(scale),
                                                    L.ptr(inv_scale), L.stream()), "sparse_conv_fused_pack_weights")
     return "fused", packed, inv_scale
 
@@ -873,7 +873,7 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None):
                                                   L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()),
                 "sparse_voxel_features_f32")
         out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
-        L.check(lib.bdm_sparse_conv_fused(B, C, cout, r, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(packed), L.ptr(inv_scale),
+        L.check(L.experimental("bdm_sparse_conv_fused")(B, C, cout, r, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(packed), L.ptr(inv_scale),
                                           L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(bias), L.ptr(out), L.stream()),
                 "sparse_conv_fused")
         return (out, None) if gn_groups else out

@@ -237,7 +237,7 @@ int bdm_devoxelize_gate_add(int b, int c, int n, int r, const float *coords, con
 /* Attention core (pvconv.py:46-55): out[c][i] = sum_j v[c][j] softmax_j(sum_c' q[c'][i] k[c'][j]),
  * no 1/sqrt(c) scale.  q, k, v share strides.  l <= 64: one workgroup per shape (global attention);
  * otherwise a flash-style MFMA kernel (c <= 64; the 16^3-token voxel attention).
- * workspace: NULL -> fp32-input MFMA kernel; else >= bdm_attention_workspace_bytes(b, c, l) bytes -> the bf16x6
+ * workspace: NULL -> fp32-input MFMA kernel (only in `make EXPERIMENTAL=1` builds; BDM_ERR_UNSUPPORTED otherwise); else >= bdm_attention_workspace_bytes(b, c, l) bytes -> the bf16x6
  * kernel (q, k, v pre-split into exact bf16 triples, six partial products per fp32 product; fp32-grade accuracy). */
 size_t bdm_attention_workspace_bytes(int b, int c, int l);
 int bdm_attention_core(int b, int c, int l, const float *q, const float *k, const float *v,
@@ -250,6 +250,7 @@ size_t bdm_attention_h2_workspace_bytes(int b, int c, int l);
 int bdm_attention_core_h2(int b, int c, int l, const float *q, const float *k, const float *v, long long bs_qkv, int ld_qkv,
                           const float *amax, float *out, long long bs_o, int ld_o, void *workspace, void *stream);
 
+#ifdef BDM_EXPERIMENTAL  /* fp32-input MFMA convolution family (csrc/experimental/conv3d.hip): `make EXPERIMENTAL=1` */
 /* nn.Conv3d(cin, cout, 3, padding=1) on (b, cin, r, r, r), r in {8, 16, 32} (pvconv.py:75-85).
  * packed_w = bdm_conv3d_pack_weights(w) : [27][cin][cout] from the module's (cout, cin, 3, 3, 3). */
 int bdm_conv3d_pack_weights(int cout, int cin, const float *w, float *packed, void *stream);
@@ -258,9 +259,11 @@ int bdm_conv3d_3x3x3(int b, int cin, int cout, int r, const float *x, const floa
 /* Same convolution for an input that is a freshly voxelised point cloud (first Conv3d of a PVConv): rowocc
  * (b, r*r) uint8 flags the (x, y) grid rows holding at least one point (bdm_voxel_row_occupancy from the
  * voxeliser's cnt); work on all-zero operand rows is skipped.  Results are bit-identical to the dense call. */
-int bdm_voxel_row_occupancy(int b, int r, const int *cnt, unsigned char *rowocc, void *stream);
 int bdm_conv3d_3x3x3_sparse(int b, int cin, int cout, int r, const float *x, const float *packed_w,
                             const float *bias, const unsigned char *rowocc, float *y, void *stream);
+#endif /* BDM_EXPERIMENTAL */
+/* rowocc (b, r*r) uint8: grid row (x, y) holds an occupied cell (from the voxeliser's cnt) */
+int bdm_voxel_row_occupancy(int b, int r, const int *cnt, unsigned char *rowocc, void *stream);
 
 /* --- the same convolution at fp32 accuracy on the BF16 matrix cores ("bf16x6", conv3d_s3.hip) ---
  * Every fp32 operand is split exactly into three bf16 terms and the six leading partial products are accumulated in
@@ -377,7 +380,8 @@ int bdm_sparse_conv_gather_gn(int b, int cout, int r, int n_max, const float *y,
                               const unsigned char *rowocc, const float *bias, float *out, int groups, void *gn_partial,
                               void *stream);
 
-/* --- the same first convolution in ONE kernel, no (n_occ x 27*cout) intermediate (sparse_conv_fused.hip; the default) ---
+/* --- fp32 feature records of the occupied cells (sparse_conv_h2.hip), and the same first convolution in ONE kernel, no
+ *     (n_occ x 27*cout) intermediate (experimental: correct and deterministic but slower than GEMM + gather) ---
  *   bdm_sparse_voxel_features_f32  occupied cells' mean features as fp32 records xr (b, ceil(c/8), n_max) x 8 channels,
  *                                  rows >= n_occ zero; amax[i] (b slots, ZERO on entry) receives max |value| of shape i
  *   bdm_sparse_conv_fused_pack_weights  (cout, cin, 3,3,3) fp32 -> [ceil(cin/8)][27][2][cout] records of 8 fp16
@@ -390,12 +394,14 @@ int bdm_sparse_conv_gather_gn(int b, int cout, int r, int n_max, const float *y,
 int bdm_sparse_voxel_features_f32(int b, int c, int n, int r, int n_max, const float *features, long long bs_f,
                                   int ld_f, const int *cnt, const void *plan_workspace, const int *occ_list,
                                   const int *n_occ, void *xr, float *amax, void *stream);
+#ifdef BDM_EXPERIMENTAL  /* one-kernel form (csrc/experimental/sparse_conv_fused.hip): `make EXPERIMENTAL=1` */
 size_t bdm_sparse_conv_fused_weight_elems(int cout, int cin);
 int bdm_sparse_conv_fused_pack_weights(int cout, int cin, const float *w, void *packed, float *scale_ws,
                                        float *inv_scale, void *stream);
 int bdm_sparse_conv_fused(int b, int cin, int cout, int r, int n_max, const void *xr, const float *amax,
                           const void *packed_w, const float *inv_scale, const int *occ_list, const int *n_occ,
                           const float *bias, float *out, void *stream);
+#endif /* BDM_EXPERIMENTAL */
 
 /* fp16x3 form of bdm_sparse_conv_gemm_s3 (the default GEMM of the first convolution): half the matrix work.  xr / amax from
  * bdm_sparse_voxel_features_f32, split once into (hi, lo) fp16 records xh (b, ceil(cin/8), 2, n_max) by bdm_sparse_split_h2;

@@ -1,5 +1,13 @@
 import numpy as np
+import pytest
 import torch
+
+# The superseded kernel families (fp32-MFMA convolution / flash attention, one-kernel sparse convolution) live in
+# bdm_amd/csrc/experimental and are built by `make EXPERIMENTAL=1` only; tests of them run against such a build:
+#   make -C bdm_amd/csrc EXPERIMENTAL=1 OUT=../libbdm_hip_experimental.so EXT=/tmp/_pvcnn_backend_exp.so
+#   BDM_LIB_PATH=bdm_amd/libbdm_hip_experimental.so python -m pytest tests -m gpu
+experimental = pytest.mark.skipif("not __import__('bdm_amd._lib', fromlist=['x']).has_experimental()",
+                                  reason="kernel family of the EXPERIMENTAL=1 build")
 
 
 def seeded(shape, seed, scale=1.0):

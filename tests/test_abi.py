@@ -6,8 +6,12 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
+def declared_symbols(experimental=False):
+    """Functions the header declares; the `#ifdef BDM_EXPERIMENTAL` blocks (superseded kernel families, `make EXPERIMENTAL=1`) only
+    on request."""
     text = open(os.path.join(ROOT, "include", "bdm_hip.h")).read()
+    if not experimental:
+        text = re.sub(r"#ifdef BDM_EXPERIMENTAL.*?#endif /\* BDM_EXPERIMENTAL \*/", "", text, flags=re.S)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(bdm_[a-z0-9_]+)\s*\(", text)))
 
@@ -17,10 +21,14 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(_lib.SO_PATH):
         _lib.build()
     lib = ctypes.CDLL(_lib.SO_PATH)
-    names = declared_symbols()
+    is_experimental = hasattr(lib, "bdm_conv3d_3x3x3")
+    names = declared_symbols(is_experimental)
     assert len(names) >= 10
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in bdm_hip.h but not exported: {missing}"
+    if not is_experimental:  # the default library holds ONE kernel family per operator (+ the bf16x6 fallback): nothing experimental
+        extra = [n for n in declared_symbols(True) if n not in names and hasattr(lib, n)]
+        assert not extra, f"experimental entry points in the default build: {extra}"
     lib.bdm_abi_version.restype = ctypes.c_int
     assert lib.bdm_abi_version() >= 1
 
@@ -31,8 +39,8 @@ def test_every_declared_symbol_has_a_ctypes_prototype():
     from bdm_amd import _lib
     if not os.path.exists(_lib.SO_PATH):
         _lib.build()
-    sigs = _lib.abi_signatures()
-    assert sorted(sigs) == declared_symbols()
+    sigs = _lib.abi_signatures(experimental=_lib.has_experimental())
+    assert sorted(sigs) == declared_symbols(_lib.has_experimental())
     lib = _lib.lib()
     for name, (restype, argtypes) in sigs.items():
         fn = getattr(lib, name)

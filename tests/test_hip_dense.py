@@ -17,6 +17,14 @@ def ops(hip):
     return o
 
 
+def _has_experimental():
+    from bdm_amd import _lib
+    return _lib.has_experimental()
+
+
+from helpers import experimental  # noqa: E402  (tests of the EXPERIMENTAL=1 kernel families)
+
+
 @pytest.mark.parametrize("B,M,K,N", [(2, 64, 35, 1024 * 32), (2, 32, 390, 4096), (1, 3, 128, 1100), (3, 512, 323, 16),
                                      (2, 256, 832, 64), (1, 192, 64, 4096), (2, 8, 8, 33)])
 def test_pointwise_conv(ops, B, M, K, N):
@@ -117,6 +125,7 @@ def test_group_norm_residual(ops):
     assert rel(got, ref) < 3e-6
 
 
+@experimental
 @pytest.mark.parametrize("cin,cout,r", [(35, 32, 32), (32, 32, 32), (64, 64, 32), (128, 64, 16), (128, 128, 16),
                                         (192, 128, 8), (256, 256, 8), (7, 8, 8), (16, 40, 16)])
 def test_conv3d(ops, cin, cout, r):
@@ -131,6 +140,7 @@ def test_conv3d(ops, cin, cout, r):
     assert rel(got, ref) < 2e-6
 
 
+@experimental
 def test_conv3d_boundary_exact(ops):
     """all-ones input and weights: interior = 27*cin, faces/edges/corners smaller (zero padding)."""
     cin, cout, r = 8, 32, 8
@@ -149,7 +159,7 @@ def test_attention_core(ops, B, C, L):
     q, k, v = qkv[:, :C].double(), qkv[:, C:2 * C].double(), qkv[:, 2 * C:].double()
     w = torch.softmax(torch.matmul(q.permute(0, 2, 1), k), -1)
     ref = torch.matmul(v, w.permute(0, 2, 1)).float()
-    for impl in ("bf16x6", "fp32"):
+    for impl in ("bf16x6", "fp32") if (_has_experimental() or L <= 64) else ("bf16x6",):
         got = ops.attention_core(qkv.cuda(), C, impl=impl).cpu()
         assert rel(got, ref) < 5e-6, impl
     if L > 64 and C <= 64:  # fp16x3 kernel: scales from max |q|, |k|, |v| (here computed on the host; the projection GEMM leaves them)
@@ -268,6 +278,7 @@ def test_pvconv_tail_and_sa_group(ops, oracle_ops):
     assert torch.equal(ops.sa_group(pts.cuda(), ctr.cuda(), big.cuda()[:, 20:279], nb.cuda()).cpu(), ref)
 
 
+@experimental
 @pytest.mark.parametrize("cin,cout,r,npts", [(35, 32, 32, 4096), (64, 64, 32, 4096), (128, 64, 16, 1024), (256, 256, 8, 64),
                                              (192, 128, 8, 256), (16, 8, 32, 50)])
 def test_conv3d_sparse_input_bit_identical(ops, cin, cout, r, npts):
@@ -304,9 +315,11 @@ def test_conv3d_bf16x6_has_fp32_accuracy(ops, cin, cout, r):
     ref = TF.conv3d(x.double().view(B, cin, r, r, r), w.double(), b.double(), padding=1).float().reshape(B, cout, -1)
     xs = ops.to_s3(x.cuda())
     got = ops.conv3d_s3(xs, ops.conv3d_s3_pack(w.cuda()), b.cuda(), cin, cout, r).cpu()
-    fp32 = ops.conv3d(x.cuda(), ops.conv3d_pack(w.cuda()), b.cuda(), r).cpu()
-    e6, e32 = rel(got, ref), rel(fp32, ref)
-    assert e6 < 2e-6 and e6 < 4 * e32 + 1e-7, (e6, e32)
+    e6 = rel(got, ref)
+    assert e6 < 2e-6, e6
+    if _has_experimental():  # ... and at the level of the fp32-MFMA kernel's own error
+        e32 = rel(ops.conv3d(x.cuda(), ops.conv3d_pack(w.cuda()), b.cuda(), r).cpu(), ref)
+        assert e6 < 4 * e32 + 1e-7, (e6, e32)
 
 
 @pytest.mark.parametrize("cin,cout,r,kind", [(35, 32, 32, "normal"), (64, 64, 32, "normal"), (128, 64, 16, "wide"), (128, 128, 16, "normal"),
@@ -331,11 +344,13 @@ def test_conv3d_fp16x3_has_fp32_accuracy(ops, cin, cout, r, kind):
         assert bool(torch.isfinite(got).all())
         return
     got = ops.conv3d_h2(ops.to_h2(x.cuda()), ops.conv3d_h2_pack(w.cuda()), b.cuda(), cin, cout, r).cpu()
-    fp32 = ops.conv3d(x.cuda(), ops.conv3d_pack(w.cuda()), b.cuda(), r).cpu()
     # per output channel (the weight scales differ by decades): every channel must be fp32-grade
     e3 = ((got - ref).norm(dim=(0, 2)) / ref.norm(dim=(0, 2))).max().item()
-    e32 = ((fp32 - ref).norm(dim=(0, 2)) / ref.norm(dim=(0, 2))).max().item()
-    assert e3 < 2e-6 and e3 < 4 * e32 + 1e-7, (e3, e32)
+    assert e3 < 2e-6, e3
+    if _has_experimental():  # ... and at the level of the fp32-MFMA kernel's own error
+        fp32 = ops.conv3d(x.cuda(), ops.conv3d_pack(w.cuda()), b.cuda(), r).cpu()
+        e32 = ((fp32 - ref).norm(dim=(0, 2)) / ref.norm(dim=(0, 2))).max().item()
+        assert e3 < 4 * e32 + 1e-7, (e3, e32)
 
 
 @pytest.mark.parametrize("cin,cout,r", [(64, 64, 32), (128, 128, 16), (64, 128, 16), (256, 256, 8)])
@@ -432,6 +447,7 @@ def test_sparse_first_conv_equals_dense(ops, oracle_ops, cin, cout, r, npts):
     assert torch.equal(gotf, gotf2)
 
 
+@experimental
 def test_sparse_fused_conv_wide_dynamic_range_and_empty_shape(ops, oracle_ops):
     """channels of very different magnitude (the activation scale is ONE power of two from max |x|), a shape whose points
     all fall into a single voxel, batch 16 with 4096 points (the bench's grid)."""

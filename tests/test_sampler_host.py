@@ -123,9 +123,13 @@ assert torch.equal(full, ref), "gathered result differs from the single-rank res
 assert max_over_ranks(float(rank), torch.device("cpu")) == world - 1
 print("OK", rank)
 """)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    import socket
+    with socket.socket() as sk:  # a free port (a fixed one collides with the TIME_WAIT of a run just before)
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.count("OK") == 2

@@ -88,11 +88,62 @@ __global__ void big_lds_kernel(const float4 *x, float4 *y, size_t n4, int lds_it
   y[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
-static int aggress(const char *kind, double seconds) {  // usage: two_proc_repro --aggress lds128k|lds32k|copy <seconds>
+// trivial aggressors with fp64 / fp32 division in every lane (v_rcp_f64 / v_div_* sequences; the library's sparse feature kernel
+// computes 1.0 / (double)count per cell)
+__global__ void f64div_kernel(const float *x, float *y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double v = (double)x[i] + 2.5;
+    float acc = 0.f;
+    for (int k = 0; k < 16; ++k) { acc += (float)(1.0 / v); v += 1.0; }
+    y[i] = acc;
+  }
+}
+__global__ void f32div_kernel(const float *x, float *y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = x[i] + 2.5f, acc = 0.f;
+    for (int k = 0; k < 16; ++k) { acc += 1.0f / v; v += 1.0f; }
+    y[i] = acc;
+  }
+}
+
+// The library's sparse first convolution, kernel by kernel (torch-free set-up of a voxel plan for B = 2 clouds of 1024 points, 16^3)
+struct SparseSetup {
+  int B = 2, n = 1024, r = 16, C = 64, cout = 64, n_max = 1024;
+  float *feat, *y, *out;
+  int *cnt, *occ_index, *occ_list, *n_occ;
+  unsigned char *rowocc;
+  void *ws, *xs, *wpk;
+  SparseSetup() {
+    const int r3 = r * r * r;
+    float *coords = dev_random((size_t)B * 3 * n, 0.3f), *norm = dev_alloc<float>((size_t)B * 3 * n);
+    int *vox = dev_alloc<int>((size_t)B * 3 * n), *ind = dev_alloc<int>((size_t)B * n);
+    cnt = dev_alloc<int>((size_t)B * r3); occ_index = dev_alloc<int>((size_t)B * r3); occ_list = dev_alloc<int>((size_t)B * n_max);
+    n_occ = dev_alloc<int>(B); rowocc = dev_alloc<unsigned char>((size_t)B * r * r);
+    ws = dev_alloc<unsigned char>(bdm_voxelize_workspace_bytes(B, n, r));
+    ABI_OK(bdm_voxel_coords(B, n, r, 0.f, coords, norm, vox, nullptr));
+    ABI_OK(bdm_voxelize_plan_full(B, n, r, n_max, vox, ind, cnt, ws, occ_index, occ_list, n_occ, rowocc, nullptr));
+    feat = dev_random((size_t)B * C * n);
+    xs = dev_alloc<unsigned char>((size_t)B * (C / 8) * 3 * n_max * 16);
+    float *w = dev_random((size_t)cout * C * 27, 0.05f);
+    wpk = dev_alloc<unsigned short>(bdm_sparse_conv_s3_weight_elems(cout, C));
+    ABI_OK(bdm_sparse_conv_pack_weights_s3(cout, C, w, wpk, nullptr));
+    y = dev_alloc<float>((size_t)B * n_max * 27 * cout);
+    out = dev_alloc<float>((size_t)B * cout * r3);
+    features(); gemm(); gather();
+    HIP_OK(hipDeviceSynchronize());
+  }
+  void features() { ABI_OK(bdm_sparse_voxel_features_s3(B, C, n, r, n_max, feat, (long long)C * n, n, cnt, ws, occ_list, n_occ, xs, nullptr)); }
+  void gemm() { ABI_OK(bdm_sparse_conv_gemm_s3(B, n_max, C, 27 * cout, xs, wpk, n_occ, y, nullptr)); }
+  void gather() { ABI_OK(bdm_sparse_conv_gather(B, cout, r, n_max, y, occ_index, rowocc, nullptr, out, nullptr)); }
+};
+
+// usage: two_proc_repro --aggress <kind> <seconds>   kind: lds128k | lds32k | copy | f64div | f32div | features | gemm_s3 | gather
+static int aggress(const char *kind, double seconds) {
   const size_t n4 = (size_t)1 << 22;
   float *x = dev_random(n4 * 4), *y = dev_alloc<float>(n4 * 4);
   const int bytes = !strcmp(kind, "lds128k") ? 128 * 1024 : (!strcmp(kind, "lds32k") ? 32 * 1024 : 0);
   if (bytes > 48 * 1024) HIP_OK(hipFuncSetAttribute((const void *)big_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  SparseSetup *sp = (!strcmp(kind, "features") || !strcmp(kind, "gemm_s3") || !strcmp(kind, "gather")) ? new SparseSetup() : nullptr;
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
   HIP_OK(hipEventRecord(e0, 0));
@@ -100,6 +151,11 @@ static int aggress(const char *kind, double seconds) {  // usage: two_proc_repro
   for (;;) {
     for (int i = 0; i < 50; ++i) {
       if (bytes) hipLaunchKernelGGL(big_lds_kernel, dim3(2048), dim3(512), bytes, 0, (const float4 *)x, (float4 *)y, n4, bytes / 16);
+      else if (!strcmp(kind, "f64div")) hipLaunchKernelGGL(f64div_kernel, dim3(4096), dim3(256), 0, 0, x, y, n4 * 4);
+      else if (!strcmp(kind, "f32div")) hipLaunchKernelGGL(f32div_kernel, dim3(4096), dim3(256), 0, 0, x, y, n4 * 4);
+      else if (!strcmp(kind, "features")) sp->features();
+      else if (!strcmp(kind, "gemm_s3")) sp->gemm();
+      else if (!strcmp(kind, "gather")) sp->gather();
       else hipLaunchKernelGGL(copy_kernel, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4 *)x, (float4 *)y, n4);
     }
     iters += 50;
