@@ -110,7 +110,8 @@ class VisionTransformer(nn.Module):
                                                 L.ptr(out), L.stream()), "layer_norm_channels")
             return out
 
-        nbytes = lib.bdm_attention_workspace_bytes(B, hd, T1) if ops.ATTENTION_IMPL == "bf16x6" else 0
+        # bf16x6 flash kernel (fp32-grade) for the heads; "fp32" = the fp32-input MFMA kernel of the EXPERIMENTAL=1 build
+        nbytes = lib.bdm_attention_workspace_bytes(B, hd, T1) if ops.ATTENTION_IMPL != "fp32" else 0
         att_ws = ops.workspace(nbytes, dev, "attention") if nbytes else None
         for blk in self.blocks:
             h = layer_norm(x, blk.norm1)

@@ -22,6 +22,8 @@
 #include <string.h>
 
 #include <functional>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "bdm_hip.h"
@@ -106,7 +108,34 @@ __global__ void f32div_kernel(const float *x, float *y, size_t n) {
   }
 }
 
+// Trivial stand-ins for what distinguishes the library's sparse_gemm_s3_kernel (the kernel tools/two_proc_aggressors2.sh named):
+// 48 KB of static LDS, 256 threads, bf16 MFMA, and WHOLE WORKGROUPS THAT RETURN AT ONCE (rows beyond a shape's occupied count).
+//   mode bit 0: most workgroups exit before touching anything      bit 1: use the matrix cores      bit 2: only 8 KB of LDS
+typedef __attribute__((ext_vector_type(16))) float t_f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 t_bf16x8;
+template <int LDS_ITEMS>
+__global__ __launch_bounds__(256) void lds_exit_kernel(int mode, const int *__restrict__ live, const uint4 *__restrict__ x, float *__restrict__ y) {
+  __shared__ uint4 A[LDS_ITEMS], Bm[LDS_ITEMS];
+  if ((mode & 1) && (int)blockIdx.y * 128 >= live[blockIdx.z]) return;  // as `if (m_count && m0 >= m_count[bi]) return;`
+  const int tid = threadIdx.x;
+  t_f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int it = 0; it < 8; ++it) {
+    __syncthreads();
+    for (int e = tid; e < LDS_ITEMS; e += 256) { A[e] = x[(blockIdx.x * 64 + it * 7 + e) & 0xFFFF]; Bm[e] = x[(blockIdx.y * 32 + it * 5 + e) & 0xFFFF]; }
+    __syncthreads();
+    const uint4 a = A[(tid * 5 + it) % LDS_ITEMS], b = Bm[(tid * 3 + it) % LDS_ITEMS];
+    if (mode & 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const t_bf16x8 *>(&a), *reinterpret_cast<const t_bf16x8 *>(&b), acc, 0, 0, 0);
+    else acc[0] += __uint_as_float((a.x ^ b.y) & 0x3F800000u);
+  }
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += acc[r];
+  y[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x * 256 + blockIdx.x * 256 + tid] = s;
+}
+
 // The library's sparse first convolution, kernel by kernel (torch-free set-up of a voxel plan for B = 2 clouds of 1024 points, 16^3)
+static hipStream_t g_agg_stream = 0;  // stream of the aggressor's launches (null stream unless --inproc)
+
 struct SparseSetup {
   int B = 2, n = 1024, r = 16, C = 64, cout = 64, n_max = 1024;
   float *feat, *y, *out;
@@ -132,34 +161,41 @@ struct SparseSetup {
     features(); gemm(); gather();
     HIP_OK(hipDeviceSynchronize());
   }
-  void features() { ABI_OK(bdm_sparse_voxel_features_s3(B, C, n, r, n_max, feat, (long long)C * n, n, cnt, ws, occ_list, n_occ, xs, nullptr)); }
-  void gemm() { ABI_OK(bdm_sparse_conv_gemm_s3(B, n_max, C, 27 * cout, xs, wpk, n_occ, y, nullptr)); }
-  void gather() { ABI_OK(bdm_sparse_conv_gather(B, cout, r, n_max, y, occ_index, rowocc, nullptr, out, nullptr)); }
+  void features() { ABI_OK(bdm_sparse_voxel_features_s3(B, C, n, r, n_max, feat, (long long)C * n, n, cnt, ws, occ_list, n_occ, xs, (void *)g_agg_stream)); }
+  void gemm() { ABI_OK(bdm_sparse_conv_gemm_s3(B, n_max, C, 27 * cout, xs, wpk, n_occ, y, (void *)g_agg_stream)); }
+  void gather() { ABI_OK(bdm_sparse_conv_gather(B, cout, r, n_max, y, occ_index, rowocc, nullptr, out, (void *)g_agg_stream)); }
 };
 
-// usage: two_proc_repro --aggress <kind> <seconds>   kind: lds128k | lds32k | copy | f64div | f32div | features | gemm_s3 | gather
+// usage: two_proc_repro --aggress <kind> <seconds>   kind: lds128k | lds32k | copy | f64div | f32div | features | gemm_s3 | gather |
+//        exit48k (48 KB LDS, most workgroups return at once) | noexit48k | exit48k_mfma | noexit48k_mfma | exit8k
 static int aggress(const char *kind, double seconds) {
   const size_t n4 = (size_t)1 << 22;
   float *x = dev_random(n4 * 4), *y = dev_alloc<float>(n4 * 4);
   const int bytes = !strcmp(kind, "lds128k") ? 128 * 1024 : (!strcmp(kind, "lds32k") ? 32 * 1024 : 0);
   if (bytes > 48 * 1024) HIP_OK(hipFuncSetAttribute((const void *)big_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  int *live = dev_alloc<int>(2);
+  { const int h[2] = {150, 90}; HIP_OK(hipMemcpy(live, h, sizeof(h), hipMemcpyHostToDevice)); }
+  const int exit_mode = !strcmp(kind, "exit48k") ? 1 : !strcmp(kind, "noexit48k") ? 0 : !strcmp(kind, "exit48k_mfma") ? 3 :
+                        !strcmp(kind, "noexit48k_mfma") ? 2 : !strcmp(kind, "exit8k") ? 5 : -1;
   SparseSetup *sp = (!strcmp(kind, "features") || !strcmp(kind, "gemm_s3") || !strcmp(kind, "gather")) ? new SparseSetup() : nullptr;
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
-  HIP_OK(hipEventRecord(e0, 0));
+  HIP_OK(hipEventRecord(e0, g_agg_stream));
   long iters = 0;
   for (;;) {
     for (int i = 0; i < 50; ++i) {
       if (bytes) hipLaunchKernelGGL(big_lds_kernel, dim3(2048), dim3(512), bytes, 0, (const float4 *)x, (float4 *)y, n4, bytes / 16);
-      else if (!strcmp(kind, "f64div")) hipLaunchKernelGGL(f64div_kernel, dim3(4096), dim3(256), 0, 0, x, y, n4 * 4);
-      else if (!strcmp(kind, "f32div")) hipLaunchKernelGGL(f32div_kernel, dim3(4096), dim3(256), 0, 0, x, y, n4 * 4);
+      else if (exit_mode >= 0 && (exit_mode & 4)) hipLaunchKernelGGL(lds_exit_kernel<256>, dim3(14, 8, 2), dim3(256), 0, g_agg_stream, exit_mode, live, (const uint4 *)x, y);
+      else if (exit_mode >= 0) hipLaunchKernelGGL(lds_exit_kernel<1536>, dim3(14, 8, 2), dim3(256), 0, g_agg_stream, exit_mode, live, (const uint4 *)x, y);
+      else if (!strcmp(kind, "f64div")) hipLaunchKernelGGL(f64div_kernel, dim3(4096), dim3(256), 0, g_agg_stream, x, y, n4 * 4);
+      else if (!strcmp(kind, "f32div")) hipLaunchKernelGGL(f32div_kernel, dim3(4096), dim3(256), 0, g_agg_stream, x, y, n4 * 4);
       else if (!strcmp(kind, "features")) sp->features();
       else if (!strcmp(kind, "gemm_s3")) sp->gemm();
       else if (!strcmp(kind, "gather")) sp->gather();
-      else hipLaunchKernelGGL(copy_kernel, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4 *)x, (float4 *)y, n4);
+      else hipLaunchKernelGGL(copy_kernel, dim3((n4 + 255) / 256), dim3(256), 0, g_agg_stream, (const float4 *)x, (float4 *)y, n4);
     }
     iters += 50;
-    HIP_OK(hipEventRecord(e1, 0)); HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipEventRecord(e1, g_agg_stream)); HIP_OK(hipEventSynchronize(e1));
     float ms = 0;
     HIP_OK(hipEventElapsedTime(&ms, e0, e1));
     if (ms > seconds * 1e3) break;
@@ -168,8 +204,22 @@ static int aggress(const char *kind, double seconds) {
   return 0;
 }
 
+static int aggress_on_stream(const char *kind, double seconds) {
+  HIP_OK(hipStreamCreateWithFlags(&g_agg_stream, hipStreamNonBlocking));
+  return aggress(kind, seconds);
+}
+
 int main(int argc, char **argv) {
   if (argc > 3 && !strcmp(argv[1], "--aggress")) return aggress(argv[2], atof(argv[3]));
+  // --inproc <kind> <seconds> [victim args]: the aggressor runs in THIS process (host thread; the null stream does not serialise with
+  // it: the victim cases then use a non-blocking stream) -- does the disturbance need a second PROCESS at all?
+  std::thread *bg = nullptr;
+  if (argc > 3 && !strcmp(argv[1], "--inproc")) {
+    static std::string kind = argv[2];
+    static double secs = atof(argv[3]);
+    bg = new std::thread([] { HIP_OK(hipSetDevice(0)); aggress_on_stream(kind.c_str(), secs); });
+    argc -= 3; argv += 3;
+  }
   const int reps = argc > 1 ? atoi(argv[1]) : 200;
   const char *only = argc > 2 && strcmp(argv[2], "-") ? argv[2] : nullptr;
   // a different seed per process makes data of the OTHER process recognisable: with equal seeds both processes hold the same
@@ -248,5 +298,6 @@ int main(int argc, char **argv) {
     fflush(stdout);
     total_bad += bad;
   }
+  if (bg) { bg->join(); }
   return total_bad ? 1 : 0;
 }
