@@ -52,6 +52,11 @@ def _pw(a):
     return ("mfma", 2.0 * b * m * k * n, MFMA32_PEAK_TFLOPS)
 
 
+def _pw_s3(a):
+    b, m, k, n = a[0], a[1], a[2], a[3]
+    return ("mfma", 2.0 * b * m * k * n, MFMA16_PEAK_TFLOPS / 6)
+
+
 def _attn(a):
     b, c, l = a[0], a[1], a[2]
     return _f(4.0 * b * c * l * l, 6) if l > 64 else ("hbm", 4.0 * 4 * b * c * l)
@@ -85,6 +90,8 @@ SPEC = {
     # 1x1 convolutions / linear layers
     "bdm_pointwise_conv": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:4], _pw),
     "bdm_pointwise_conv_gn": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:4], _pw),  # + GroupNorm statistics / folded input GroupNorm
+    "bdm_pointwise_conv_s3": ("1x1 conv GEMM (bf16x6)", lambda a: a[:4], _pw_s3),
+    "bdm_pointwise_conv_gn_s3": ("1x1 conv GEMM (bf16x6)", lambda a: a[:4], _pw_s3),
     # normalisation and operand repacks: 1 read + 1 write of the tensor
     "bdm_group_norm": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", 8.0 * a[0] * a[1] * a[2])),
     "bdm_group_norm_to_h2": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", (4.0 + 4.0 + 4.0) * a[0] * a[1] * a[2])),

@@ -73,6 +73,56 @@ __global__ void long_copy_kernel(const float4 *x, float4 *y, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i];
 }
 
+
+// ---- probes: WHAT does a disturbed kernel lose?  Each probe checks one hardware resource of its own workgroup and counts
+// violations into bad[0..2] (they need no reference run: any non-zero count is a fault).
+__device__ __forceinline__ double slow_chain(double v, int n) {
+  for (int k = 0; k < n; ++k) v = sqrt(v + 1.0);  // a long dependent fp64 chain (like the mean / rstd of a folded GroupNorm)
+  return v;
+}
+// (0) barrier: ONE slow lane writes an LDS word, everybody reads it after __syncthreads(); an early release shows the old value
+__global__ __launch_bounds__(256) void probe_barrier_kernel(int *bad, int iters) {
+  __shared__ int flag;
+  if (threadIdx.x == 0) flag = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int it = 1; it <= iters; ++it) {
+    if (threadIdx.x == 255) flag = it + (slow_chain((double)it, 48) < 0.0 ? 1 : 0);
+    __syncthreads();
+    if (flag != it) ++mine;
+    __syncthreads();
+  }
+  if (mine) atomicAdd(bad + 0, mine);
+}
+// (1) LDS contents: every thread fills its own words, waits, and checks its OWN words again (no barrier involved)
+__global__ __launch_bounds__(256) void probe_lds_kernel(int *bad, int iters) {
+  __shared__ unsigned buf[6144];  // 24 KB
+  int mine = 0;
+  for (int it = 1; it <= iters; ++it) {
+    for (int i = threadIdx.x; i < 6144; i += 256) buf[i] = (unsigned)(i * 2654435761u) ^ (unsigned)(it * 40503u + blockIdx.x);
+    const double d = slow_chain((double)(it + threadIdx.x), 24);
+    for (int i = threadIdx.x; i < 6144; i += 256)
+      if (buf[i] != ((unsigned)(i * 2654435761u) ^ (unsigned)(it * 40503u + blockIdx.x))) ++mine;
+    if (d < 0.0) buf[0] = 1u;
+  }
+  if (mine) atomicAdd(bad + 1, mine);
+}
+// (2) registers: 48 live values per lane across a long wait
+__global__ __launch_bounds__(256) void probe_regs_kernel(int *bad, int iters, const float *x) {
+  int mine = 0;
+  for (int it = 1; it <= iters; ++it) {
+    float r[48];
+#pragma unroll
+    for (int j = 0; j < 48; ++j) r[j] = x[(threadIdx.x * 48 + j + it) & 0xFFFF];
+    const double d = slow_chain((double)(it + threadIdx.x), 24);
+#pragma unroll
+    for (int j = 0; j < 48; ++j)
+      if (__float_as_uint(r[j]) != __float_as_uint(x[(threadIdx.x * 48 + j + it) & 0xFFFF])) ++mine;
+    if (d < 0.0) ++mine;
+  }
+  if (mine) atomicAdd(bad + 2, mine);
+}
+
 struct Case {
   const char *name;
   std::function<void()> launch;
@@ -271,6 +321,21 @@ int main(int argc, char **argv) {
   cases.push_back({"trivial grid-stride copy (256 long-running workgroups)", [&] { hipLaunchKernelGGL(long_copy_kernel, dim3(256), dim3(256), 0, 0, (const float4 *)y1, (float4 *)y3, n4); }, y3, n4 * 16});
 
   int total_bad = 0;
+  if (!only || strstr("probe", only)) {  // hardware-resource probes (absolute: no reference repetition needed)
+    int *bad = dev_alloc<int>(4);
+    float *px = dev_random(1 << 16);
+    for (int r = 0; r < reps; ++r) {
+      hipLaunchKernelGGL(probe_barrier_kernel, dim3(1024), dim3(256), 0, 0, bad, 8);
+      hipLaunchKernelGGL(probe_lds_kernel, dim3(1024), dim3(256), 0, 0, bad, 4);
+      hipLaunchKernelGGL(probe_regs_kernel, dim3(1024), dim3(256), 0, 0, bad, 4, px);
+      HIP_OK(hipDeviceSynchronize());
+    }
+    int h[4];
+    HIP_OK(hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost));
+    printf("probe: barrier released early %d times; LDS words changed under their owner %d times; live registers changed %d times (%d launches each)\n",
+           h[0], h[1], h[2], reps);
+    total_bad += h[0] + h[1] + h[2];
+  }
   for (Case &c : cases) {
     if (only && !strstr(c.name, only)) continue;
     std::vector<uint32_t> ref(c.bytes / 4), cur(c.bytes / 4);
