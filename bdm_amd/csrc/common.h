@@ -106,4 +106,17 @@ __device__ __forceinline__ float swishf(float x) {
 }
 #endif
 
+// LDS-return settle point.  Measured on MI355X / ROCm 7.2 (tools/two_proc_repro.hip): when a workgroup with
+// heavy 16-byte LDS traffic (sparse_gemm_s3_kernel) is co-resident on the CU -- another stream or another process -- a VALU
+// instruction issued right behind the compiler's partial wait `s_waitcnt lgkmcnt(N > 0)` can read a VGPR whose ds_read has NOT
+// landed yet (ds_write x 3, ds_read_b64 x 2, s_waitcnt lgkmcnt(1), v_pk_fma: one operand stale in ~50 % of the launches; never
+// when the kernel runs alone).  Waiting for ALL outstanding LDS operations before the first use removes it (0 / 240 launches).
+// The kernels that consume LDS-resident parameters inside their staging code call this right after the read.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void lds_settle(float &a, float &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lds_settle8(float (&v)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+#endif
+
 }  // namespace bdm

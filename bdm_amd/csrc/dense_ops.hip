@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
       const bool ok = k0 + k < K;
       float4 v = br[i];
       if constexpr (FOLD) {
-        const float2 cf = coef_s[min(k0 + k, K - 1)];
+        float2 cf = coef_s[min(k0 + k, K - 1)];
+        lds_settle(cf.x, cf.y);  // (common.h: the compiler's partial lgkmcnt wait is not enough next to an LDS-heavy neighbour)
         v = make_float4(swishf(cf.x * v.x + cf.y), swishf(cf.x * v.y + cf.y), swishf(cf.x * v.z + cf.y), swishf(cf.x * v.w + cf.y));
       }
       *reinterpret_cast<float4 *>(&Bs[k * BN + c4]) = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(int M, int K, int N, con
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float2 cf = make_float2(1.f, 0.f);
-        if constexpr (FOLD) cf = coef_s[min(kg + 8 * g + 4 * lh + j, K - 1)];
+        if constexpr (FOLD) { cf = coef_s[min(kg + 8 * g + 4 * lh + j, K - 1)]; lds_settle(cf.x, cf.y); }  // (common.h)
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
           float bv = Bv[c][g][j];
@@ -1625,14 +1626,16 @@ __global__ __launch_bounds__(1024) void devox_gn_lds_kernel(int c, int n, int r,
         const int ci = c0 + cl;
         const float *v = vals + (size_t)cl * r3;
         // corners with weight 0 (frac == 0 on an axis) alias an in-grid cell: their value is finite and multiplies 0
-        float acc = w000 * v[i000];
-        acc += w001 * v[i001];
-        acc += w010 * v[i010];
-        acc += w011 * v[i011];
-        acc += w100 * v[i100];
-        acc += w101 * v[i101];
-        acc += w110 * v[i110];
-        acc += w111 * v[i111];
+        float cv[8] = {v[i000], v[i001], v[i010], v[i011], v[i100], v[i101], v[i110], v[i111]};
+        lds_settle8(cv);  // all eight LDS reads have landed before the first use (common.h)
+        float acc = w000 * cv[0];
+        acc += w001 * cv[1];
+        acc += w010 * cv[2];
+        acc += w011 * cv[3];
+        acc += w100 * cv[4];
+        acc += w101 * cv[5];
+        acc += w110 * cv[6];
+        acc += w111 * cv[7];
         if (add) {
           float av = add[(size_t)bi * bs_a + (size_t)ci * ld_a + i];
           if (add_coef) {

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         const int k = g * 8 + j;
         float t = xr[i][j];
         if constexpr (FOLD) {
-          const float2 cf = coef_s[min(k, K - 1)];
+          float2 cf = coef_s[min(k, K - 1)];
+          lds_settle(cf.x, cf.y);  // (common.h)
           t = swishf(cf.x * t + cf.y);
         }
         v[j] = k < K ? t : 0.f;

@@ -38,7 +38,7 @@ def gpu_turn(device=None):
     64-byte sector (16 consecutive floats of one row; all inputs bit-identical, the same launch alone or in a single
     process is always right -- tools/determinism_trace.py).  One process per GPU, the production layout, never shares a
     device, so this only matters for the shared-GPU test mode.  No-op otherwise."""
-    if os.environ.get("BDM_SHARE_GPU") != "1":
+    if os.environ.get("BDM_SHARE_GPU") != "1" or os.environ.get("BDM_GPU_TURN", "1") == "0":
         yield
         return
     import fcntl

@@ -123,6 +123,33 @@ __global__ __launch_bounds__(256) void probe_regs_kernel(int *bad, int iters, co
   if (mine) atomicAdd(bad + 2, mine);
 }
 
+// (3) LDS to the brim: workgroups whose dynamic LDS adds up to (nearly) the CU's whole 160 KB; each fills ALL of its allocation,
+// waits, and verifies it.  No second kernel, no second process: does the top of the LDS hold?  log: up to 32 records of
+// {HW_REG_LDS_ALLOC of the workgroup, first bad word, bad words, value found}.
+__global__ __launch_bounds__(256) void probe_brim_kernel(int words, int iters, int *bad, unsigned *log) {
+  extern __shared__ unsigned brim[];
+  const unsigned alloc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 6);  // HW_REG_LDS_ALLOC: base / size of this workgroup
+  for (int it = 1; it <= iters; ++it) {
+    for (int i = threadIdx.x; i < words; i += 256) brim[i] = (unsigned)(i * 2654435761u) ^ (unsigned)(it * 40503u + blockIdx.x * 7u);
+    __syncthreads();
+    const double d = slow_chain((double)(it + threadIdx.x), 64);
+    __syncthreads();
+    int mine = 0, first = -1;
+    unsigned seen = 0;
+    for (int i = threadIdx.x; i < words; i += 256) {
+      const unsigned v = brim[i];
+      if (v != ((unsigned)(i * 2654435761u) ^ (unsigned)(it * 40503u + blockIdx.x * 7u))) { if (!mine) { first = i; seen = v; } ++mine; }
+    }
+    if (d < 0.0) brim[0] = 1u;
+    if (mine) {
+      const int slot = atomicAdd(bad + 3, 1);
+      atomicAdd(bad + 4, mine);
+      if (slot < 32) { log[slot * 4] = alloc; log[slot * 4 + 1] = (unsigned)first; log[slot * 4 + 2] = (unsigned)mine; log[slot * 4 + 3] = seen; }
+    }
+    __syncthreads();
+  }
+}
+
 struct Case {
   const char *name;
   std::function<void()> launch;
@@ -329,6 +356,27 @@ int main(int argc, char **argv) {
       hipLaunchKernelGGL(probe_lds_kernel, dim3(1024), dim3(256), 0, 0, bad, 4);
       hipLaunchKernelGGL(probe_regs_kernel, dim3(1024), dim3(256), 0, 0, bad, 4, px);
       HIP_OK(hipDeviceSynchronize());
+    }
+    {
+      int *bad2 = dev_alloc<int>(8);
+      unsigned *log = dev_alloc<unsigned>(128);
+      HIP_OK(hipFuncSetAttribute((const void *)probe_brim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      const int sizes_kb[] = {16, 20, 32, 40, 53, 64, 80, 160};
+      for (int kb : sizes_kb) {
+        HIP_OK(hipMemset(bad2, 0, 8 * sizeof(int)));
+        const int bytes = kb * 1024, per_cu = (160 * 1024) / bytes;
+        for (int r = 0; r < (reps < 40 ? reps : 40); ++r) {
+          hipLaunchKernelGGL(probe_brim_kernel, dim3(256 * per_cu * 2), dim3(256), bytes, 0, bytes / 4, 4, bad2, log);
+          HIP_OK(hipDeviceSynchronize());
+        }
+        int hb[8]; unsigned hl[128];
+        HIP_OK(hipMemcpy(hb, bad2, sizeof(hb), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(hl, log, sizeof(hl), hipMemcpyDeviceToHost));
+        printf("probe brim: %3d KB per workgroup (%d fit a CU): %d workgroup-iterations with changed LDS words, %d words", kb, per_cu, hb[3], hb[4]);
+        for (int q = 0; q < hb[3] && q < 4; ++q) printf("  [LDS_ALLOC 0x%08x first word %u count %u saw 0x%08x]", hl[q * 4], hl[q * 4 + 1], hl[q * 4 + 2], hl[q * 4 + 3]);
+        printf("\n");
+        total_bad += hb[3];
+      }
     }
     int h[4];
     HIP_OK(hipMemcpy(h, bad, sizeof(h), hipMemcpyDeviceToHost));
