@@ -1,4 +1,8 @@
-// pointwise_s3.hip -- the 1x1 convolutions (SharedMLP / FP-module MLPs / attention projections / classifier:
+// experimental/pointwise_s3.hip (built with `make EXPERIMENTAL=1` only; opt-in at run time with BDM_PW=bf16x6).  MEASURED (round 3, B = 16,
+// tools/forward_rows.py): no gain over the fp32-MFMA kernel -- 1272 vs 1271 us per forward over the 38 GEMMs; +7 % on the long-K layer
+// (128 x 579 x 4096: 120 -> 112 us), slower on the narrow ones (32 x 390 x 4096: 49 -> 73 us).  The 1x1 GEMMs are bound by operand
+// staging (global -> LDS) and not by the matrix pipe, so 2.7x the matrix rate buys nothing.  Kept as a negative result.
+// -- the 1x1 convolutions (SharedMLP / FP-module MLPs / attention projections / classifier:
 // modules/shared_mlp.py:25-30, pvconv.py:21-31, pvcnn.py:62-69) as a bf16x6 GEMM on the 16-bit matrix pipe.
 //
 //   Y[b] (M x N) = W (M x K) . X'[b] (K x N) + bias ...       X' = X or Swish(GroupNorm(X)) (folded, as in dense_ops.hip)
@@ -19,10 +23,10 @@
 //   -- bias, per-shape bias, activation, residual, canonical GroupNorm partials, per-shape amax -- as pw_gemm_kernel).
 #include <stdlib.h>
 
-#include "../../include/bdm_hip.h"
-#include "common.h"
-#include "pointwise_common.h"
-#include "s3_split.h"
+#include "../../../include/bdm_hip.h"
+#include "../common.h"
+#include "../pointwise_common.h"
+#include "../s3_split.h"
 
 using namespace bdm;
 

@@ -56,10 +56,11 @@ def workspace(nbytes, device, tag="ws"):
     return buf
 
 
-# 1x1 convolutions: "bf16x6" (default) = exact 3-way bf16 operand split, six partial products on the 16-bit matrix pipe, fp32
-# accumulate (pointwise_s3.hip: fp32-grade, no scale, no range limit, 2.7x the matrix rate); "fp32" = fp32-input MFMA
-# (dense_ops.hip).  The skinny shapes (<= 64 columns, K >= 128) keep their K-split fp32 kernel either way.
-PW_IMPL = os.environ.get("BDM_PW", "bf16x6")
+# 1x1 convolutions: "fp32" (default) = fp32-input MFMA (dense_ops.hip); "bf16x6" = exact 3-way bf16 operand split, six partial
+# products on the 16-bit matrix pipe (csrc/experimental/pointwise_s3.hip, EXPERIMENTAL=1 builds only).  Measured at B = 16: no
+# faster (the GEMMs are bound by operand staging, not by the matrix pipe), so it stays opt-in.  The skinny shapes (<= 64 columns,
+# K >= 128) keep their K-split fp32 kernel either way.
+PW_IMPL = os.environ.get("BDM_PW", "fp32")
 PW_S3_MIN_COLUMNS = 65   # shapes with fewer columns per shape stay on the fp32 kernels (latency-bound: nothing to gain)
 _pw_s3_packs = {}
 
@@ -69,6 +70,7 @@ def _pw_s3_weights(w, weight):
     module parameter or a cached concatenation): a temporary copy would be re-packed on every call -> None (fp32 kernel)."""
     if PW_IMPL != "bf16x6" or not w.is_cuda or w.data_ptr() != weight.data_ptr():
         return None
+    L.experimental("bdm_pointwise_s3_pack_weights")  # a clear error in a default build (never a silent fallback)
     M, K = w.shape
     key = (w.data_ptr(), M, K)
     hit = _pw_s3_packs.get(key)

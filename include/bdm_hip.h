@@ -169,7 +169,8 @@ int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w, int ldw, c
                           int ld_y, const void *in_partial, int in_slices, int in_groups, const float *in_gamma,
                           const float *in_beta, float in_eps, int out_groups, void *out_partial, float *amax, int amax_rows,
                           void *stream);
-/* bf16x6 form of the two entry points above (pointwise_s3.hip): the weights are split ONCE into exact bf16 triples
+#ifdef BDM_EXPERIMENTAL
+/* bf16x6 form of the two entry points above (csrc/experimental/pointwise_s3.hip; measured: no faster, the GEMMs are staging-bound): the weights are split ONCE into exact bf16 triples
  * (bdm_pointwise_s3_pack_weights: packed = bdm_pointwise_s3_weight_elems(m, k) 16-bit elements), the activations while they are
  * staged; six partial products per fp32 product on v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-grade (no scale, no range limit)
  * at 2.7x the matrix rate of the fp32-MFMA kernel.  Same arguments and semantics otherwise; statistics slices are always
@@ -184,6 +185,7 @@ int bdm_pointwise_conv_gn_s3(int b, int m, int k, int n, const void *packed_w, c
                              int ld_y, const void *in_partial, int in_slices, int in_groups, const float *in_gamma,
                              const float *in_beta, float in_eps, int out_groups, void *out_partial, float *amax,
                              int amax_rows, void *stream);
+#endif /* BDM_EXPERIMENTAL */
 int bdm_max_over_neighbors_gn(int b, int c, int m, int u, const float *x, const void *in_partial, int in_slices, int groups,
                               const float *gamma, const float *beta, float eps, float *y, long long bs_y, int ld_y,
                               void *stream);

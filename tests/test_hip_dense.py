@@ -37,10 +37,11 @@ def test_pointwise_conv(ops, B, M, K, N):
     assert rel(got, ref) < 2e-6  # fp32 MFMA, k-ordered accumulation vs fp64 reference
 
 
+@experimental
 @pytest.mark.parametrize("B,M,K,N", [(2, 64, 35, 1024 * 32), (2, 32, 390, 4096), (1, 3, 128, 1100), (1, 192, 64, 4096), (2, 8, 8, 133),
                                      (2, 100, 579, 1000), (3, 512, 256, 512), (2, 256, 323, 65)])
 def test_pointwise_conv_bf16x6_and_fp32_kernels(ops, monkeypatch, B, M, K, N):
-    """The two kernel families of the 1x1 convolutions (pointwise_s3.hip: exact bf16 triples, six products, the default;
+    """The two kernel families of the 1x1 convolutions (experimental/pointwise_s3.hip: exact bf16 triples, six products, opt-in;
     dense_ops.hip: fp32-input MFMA) against fp64, with every epilogue term, a strided operand and K / M / N tails; and the
     GroupNorm statistics the bf16x6 kernel leaves against the values it wrote."""
     g = torch.Generator().manual_seed(M * K + N)
