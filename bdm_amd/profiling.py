@@ -24,6 +24,7 @@ from . import _lib as L
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 MFMA16_PEAK_TFLOPS = 2500.0      # dense fp16 / bf16 MFMA
 MFMA32_PEAK_TFLOPS = 157.3       # fp32-input MFMA
+VALU_TESTS_PEAK = 1024 * 64 * 2.4e9 / 4 / 6.7 / 1e9   # ball-query distance tests per ns the VALUs can issue (= 5868 G tests/s)
 OCCUPANCY = {}                   # n_max -> mean occupied fraction of the sparse convolution's rows (set by bench.py)
 
 
@@ -102,14 +103,16 @@ SPEC = {
     # point operators (SURVEY.md 8d byte formulas)
     "bdm_furthest_point_sampling": ("furthest point sampling", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * (3 * a[1] + 4 * a[2]))),
     "bdm_gather_features_forward": ("furthest point sampling", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (2 * a[1] * a[3] + a[3]))),
-    "bdm_ball_query": ("ball query + grouping", lambda a: (a[0], a[1], a[2], a[4]),
-                       lambda a: ("hbm", 4.0 * a[0] * (3 * a[1] + 3 * a[2] + a[2] * a[4]))),
-    "bdm_sa_group": ("ball query + grouping", lambda a: a[:5],
+    # the query is bound by VALU issue, not by its 3 MB of traffic: b * m * n distance tests at 6.7 VALU instructions per test per
+    # lane (ISA count of ball_query_kernel<4,8>: DESIGN.md); the chip issues 1024 SIMDs x 64 lanes x 2.4 GHz / 4 cycles
+    "bdm_ball_query": ("ball query (distance tests)", lambda a: (a[0], a[1], a[2], a[4]),
+                       lambda a: ("valu", 1.0 * a[0] * a[1] * a[2], VALU_TESTS_PEAK, "G tests/s")),
+    "bdm_sa_group": ("grouping gather + max over neighbours", lambda a: a[:5],
                      lambda a: ("hbm", 4.0 * a[0] * ((3 + a[1]) * a[2] + a[3] * a[4] + (a[1] + 3) * a[3] * a[4]))),
-    "bdm_grouping_forward": ("ball query + grouping", lambda a: a[:5],
+    "bdm_grouping_forward": ("grouping gather + max over neighbours", lambda a: a[:5],
                              lambda a: ("hbm", 4.0 * a[0] * (a[1] * a[2] + a[3] * a[4] + a[1] * a[3] * a[4]))),
-    "bdm_max_over_neighbors": ("ball query + grouping", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] * (a[3] + 1))),
-    "bdm_max_over_neighbors_gn": ("ball query + grouping", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] * (a[3] + 1))),
+    "bdm_max_over_neighbors": ("grouping gather + max over neighbours", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] * (a[3] + 1))),
+    "bdm_max_over_neighbors_gn": ("grouping gather + max over neighbours", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] * (a[3] + 1))),
     "bdm_three_nn_search": ("3-NN interpolation", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 3 * a[1] + 6 * a[2]))),
     "bdm_three_nn_apply": ("3-NN interpolation", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (a[1] * a[2] + a[1] * a[3] + 6 * a[3]))),
     "bdm_fp_assemble": ("3-NN interpolation", lambda a: (a[0], a[1], a[2], a[5], a[9], a[13]),
@@ -223,11 +226,16 @@ class KernelClassProfiler:
         classes = {}
         for r in rows:
             c = classes.setdefault(r["class"], {"class": r["class"], "est_total_ms": 0.0, "calls": 0, "flops": 0.0, "bytes": 0.0,
-                                                "mfma_ms": 0.0, "hbm_ms": 0.0, "peak_tflops": None})
+                                                "mfma_ms": 0.0, "hbm_ms": 0.0, "peak_tflops": None, "valu": 0.0, "valu_ms": 0.0,
+                                                "valu_peak": None, "valu_unit": None})
             c["est_total_ms"] += r["est_total_ms"]
             c["calls"] += r["calls"]
             if r["cost"] is not None:
-                if r["cost"][0] == "mfma_aux":  # matrix work inside a class whose algorithmic measure is bytes
+                if r["cost"][0] == "valu":  # VALU-issue-bound kernels: work items and the chip's issue-rate peak for them
+                    c["valu"] += r["cost"][1] * r["calls"]
+                    c["valu_ms"] += r["est_total_ms"]
+                    c["valu_peak"], c["valu_unit"] = r["cost"][2], r["cost"][3]
+                elif r["cost"][0] == "mfma_aux":  # matrix work inside a class whose algorithmic measure is bytes
                     c["flops"] += r["cost"][1] * r["calls"]
                     c["hbm_ms"] += r["est_total_ms"]
                 elif r["cost"][0] == "mfma":
@@ -240,7 +248,10 @@ class KernelClassProfiler:
         out = []
         for c in classes.values():
             d = {"class": c["class"], "share": c["est_total_ms"] / total, "kernel_ms": c["est_total_ms"], "launches": c["calls"]}
-            if c["flops"] > 0 and c["mfma_ms"] > 0 and c["mfma_ms"] >= c["hbm_ms"]:
+            if c["valu"] > 0 and c["valu_ms"] >= max(c["mfma_ms"], c["hbm_ms"]):
+                ach = c["valu"] / (c["valu_ms"] * 1e-3) / 1e9
+                d.update(bound="valu", achieved=ach, peak=c["valu_peak"], unit=c["valu_unit"], frac=ach / c["valu_peak"])
+            elif c["flops"] > 0 and c["mfma_ms"] > 0 and c["mfma_ms"] >= c["hbm_ms"]:
                 ach = c["flops"] / (c["mfma_ms"] * 1e-3) / 1e12
                 d.update(bound="mfma", achieved=ach, peak=c["peak_tflops"], unit="TFLOP/s", frac=ach / c["peak_tflops"])
             elif c["bytes"] > 0 and c["hbm_ms"] > 0:

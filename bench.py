@@ -23,8 +23,8 @@ Extra objects on the JSON line:
                     bytes) of its launches / their summed duration, against the peak that bounds it (dense 16-bit MFMA peak
                     / 3 partial products for the fp16x3 convolution); `kernel` names the heaviest (function, shape) row of
                     the class, whose avg_launch_us is the number to compare with the rocprofv3 summary under profiles/.
-                    `traffic` comes from the committed PMC pass profiles/r02_pmc_traffic.json (same kernel; the JSON records
-                    the commit it was measured at).
+                    `traffic` comes from the committed PMC pass profiles/r03_pmc_traffic.json (separate rocprofv3 --pmc runs of one
+                    forward, same kernel; `traffic_commit` = the commit it was measured at -- not measured inside this run).
   roofline_table -- every kernel class: share of kernel time, launches, achieved vs peak.
   cpu_baseline   -- the CPU oracle ("port": oracle/ref_net.py + oracle/pvcnn_ops_ref.c, the reference has no CPU
                     path) timed on this box's host cores on a bounded sample and extrapolated to a trajectory.
@@ -325,13 +325,14 @@ def main():
             head = top_rows[0]
             traffic, traffic_commit = None, None
             try:  # HBM bytes per launch of that kernel from the committed PMC pass (separate rocprofv3 --pmc runs)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+                pm_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(p))
+                pm = json.load(open(pm_path))
                 key = f"{head['function']}{tuple(head['shape'])}"
                 ent = (pm["kernels"].get(key) or pm["kernels"].get(key.replace("_h2_gn(", "_h2("))  # same kernels + GN epilogue
                        or pm["kernels"].get(key.replace("_gather_gn(", "_gather(")))
                 if ent:
                     traffic, traffic_commit = ent["bytes_per_launch"], pm.get("commit")
-            except (OSError, KeyError, ValueError):
+            except (OSError, KeyError, ValueError, StopIteration):
                 pass
             line["roofline"] = {"bound": top["bound"], "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
                                 "frac": top["frac"], "traffic": traffic, "traffic_commit": traffic_commit,

@@ -24,9 +24,20 @@ STATE = {"B": B, "row": ROW}
 LOG = []
 
 
+class Stats:
+    """GroupNorm slice partials (partial, slices, groups): only the first B * groups * slices * 2 doubles are meaningful"""
+
+    def __init__(self, partial, slices, groups):
+        self.partial, self.slices, self.groups = partial, int(slices), int(groups)
+
+
 def leaves(o):
     if torch.is_tensor(o):
         return [o] if (o.is_cuda and o.numel() > 0) else []
+    if isinstance(o, tuple) and len(o) == 3 and torch.is_tensor(o[0]) and isinstance(o[1], int) and isinstance(o[2], int):
+        return [Stats(*o)]
+    if isinstance(o, tuple) and len(o) == 2 and torch.is_tensor(o[0]) and o[0].dtype == torch.uint8 and isinstance(o[1], int):
+        return [Stats(o[0].view(torch.float64), o[1], 8)]   # conv3d_h2_gn's (workspace, slices); GroupNorm(8)
     if isinstance(o, (list, tuple)):
         return [t for x in o for t in leaves(x)]
     if isinstance(o, dict):
@@ -37,6 +48,13 @@ def leaves(o):
 
 
 def rowsum(t):
+    if isinstance(t, Stats):
+        per = t.groups * t.slices * 2
+        flat = t.partial.reshape(-1).view(torch.float64) if t.partial.dtype != torch.float64 else t.partial.reshape(-1)
+        t = flat[STATE["row"] * per:(STATE["row"] + 1) * per]
+        return (("stats", per), t.contiguous().view(torch.int64).sum())
+    if t.dim() == 1 and t.numel() == STATE["B"] and STATE["B"] > 1:
+        t = t[STATE["row"]:STATE["row"] + 1]
     if t.dim() >= 2 and t.shape[0] == STATE["B"]:
         t = t[STATE["row"]]
     elif t.dim() == 1 and STATE["B"] > 1 and t.numel() % STATE["B"] == 0 and t.numel() >= 8 * STATE["B"]:
