@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
           const float v = acc[p][q][i] * (inv_scale[m] * x_inv_scale) + (bias ? bias[m] : 0.f);
           yb[(size_t)m * R3 + gvox[q]] = v;
           bs[i >> 2] += v;
-          bq[i >> 2] += v * v;
+          bq[i >> 2] = __builtin_fmaf(v, v, bq[i >> 2]);  // explicitly fused: the same rounding in every tile variant
         }
       }
       if (gn_partial != nullptr) {

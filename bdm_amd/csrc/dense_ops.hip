@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
         if (m < M && n < N) {
           Yb[(size_t)m * ldy + n] = v;
           bs[x][r >> 2] += v;
-          bq[x][r >> 2] += v * v;
+          bq[x][r >> 2] = __builtin_fmaf(v, v, bq[x][r >> 2]);  // explicitly fused: the same rounding in every tile variant
           am[x] = fmaxf(am[x], fabsf(v));
         }
       }
