@@ -315,11 +315,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   }
 }
 
-static int h2_waves() {  // experiment switch: BDM_H2_WAVES=4 selects the 4-wave tiling
-  static int w = 0;
-  if (!w) { const char *e = getenv("BDM_H2_WAVES"); w = (e && e[0] == '4') ? 4 : 8; }
-  return w;
-}
+static int h2_waves() { return 8; }  // the 4-wave / NI = 4 tiling measured 2-15 % slower (DESIGN.md negative results); its instantiations stay compilable
 
 static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale, const void *packed_w,
                             const float *inv_scale, const float *bias, float *y, int gn_cg, double *gn_partial,
@@ -335,17 +331,13 @@ static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, f
   // matrix pipe fed while the other wave of the SIMD waits on LDS (measured vs 4 waves with NI = 4)
   int tx, ty, mi;
   // 8^3 grids: 128-voxel tiles with 4 waves double the workgroup count; they win when the 256-voxel tiling cannot fill the chip
-  // (128 -> 128 at B = 16: 40.6 -> 30.4 us) and lose when it can (256 -> 256: 96 -> 114 us).  BDM_H2_R8_SMALL=0|1 overrides.
-  static int r8_env = -2;
-  if (r8_env == -2) { const char *e = getenv("BDM_H2_R8_SMALL"); r8_env = e ? (e[0] == '1' ? 1 : 0) : -1; }
-  const bool r8_small = r == 8 && (r8_env >= 0 ? r8_env == 1 : (long long)b * 2 * cdiv(cout, 32) < 256);
+  // (128 -> 128 at B = 16: 40.6 -> 30.4 us) and lose when it can (256 -> 256: 96 -> 114 us).
+  const bool r8_small = r == 8 && (long long)b * 2 * cdiv(cout, 32) < 256;
   // 16^3 / 32^3 grids of a few shapes (config C1 is ONE shape): 64-row x 512-voxel tiles give 16 / 64 workgroups, each walking
   // the whole K loop with 12 MFMAs per step; 32-row (and at 16^3 256-voxel) tiles put 4x / 2x as many CUs on the problem with a
-  // 4x / 2x shorter chain per wave (B = 1: 114 -> 4x us at 16^3).  Same K order, same bits.  BDM_H2_SMALL=0|1 overrides.
-  static int small_env = -2;
-  if (small_env == -2) { const char *e = getenv("BDM_H2_SMALL"); small_env = e ? (e[0] == '1' ? 1 : 0) : -1; }
+  // 4x / 2x shorter chain per wave (B = 1: 114 -> 4x us at 16^3).  Same K order, same bits.
   const long long big_wgs = (long long)b * (r == 32 ? 64 : 8) * cdiv(cout, 64);
-  const bool small = r != 8 && cout > 32 && (small_env >= 0 ? small_env == 1 : big_wgs < 128);
+  const bool small = r != 8 && cout > 32 && big_wgs < 128;
   if (r == 32) { tx = 2; ty = 8; }
   else if (r == 16) { tx = small ? 1 : 2; ty = 16; }
   else { tx = r8_small ? 2 : 4; ty = 8; }

@@ -493,40 +493,20 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(int M, int K, int N, con
   }
 }
 
-static int pw_skinny_enabled() {  // BDM_PW_SKINNY=0: the general kernel also for n <= 32 (experiments)
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("BDM_PW_SKINNY"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v;
-}
 // shapes of the GroupNorm-folded entry point that take the skinny kernel (the caller also needs x2 == NULL and amax == NULL; the
 // slice count of the statistics must not depend on those, so two-source / amax calls of such shapes use the general kernel's
 // layout only when this returns 0 -- see bdm_pointwise_conv_gn)
-static int pw_skinny_max_n() {  // BDM_PW_SKINNY_N: widest shape (columns) that takes the skinny kernel
-  static int v = -1;
-  if (v < 0) { const char *e = getenv("BDM_PW_SKINNY_N"); v = e ? atoi(e) : 64; }
-  return v;
-}
-static bool pw_skinny_shape(int k, int n) { return n <= pw_skinny_max_n() && k >= 128 && pw_skinny_enabled(); }
+static int pw_skinny_max_n() { return 64; }  // widest shape (columns) that takes the skinny kernel (wider measured slower)
+static bool pw_skinny_shape(int k, int n) { return n <= pw_skinny_max_n() && k >= 128; }
 
-// workgroup count below which the long-K shapes take the 64-deep K chunk (BDM_PW_DEEP_BLOCKS overrides; 0 disables)
-static int pw_deep_limit() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("BDM_PW_DEEP_BLOCKS");
-    v = e ? atoi(e) : 1024;
-  }
-  return v;
-}
+// workgroup count below which the long-K shapes take the 64-deep K chunk
+static int pw_deep_limit() { return 1024; }
 
 // biggest tile that still gives the 256 CUs two workgroups each; small problems (the 16..256-point levels) are latency-bound
 // and prefer many small tiles over operand reuse, and take the 64-deep K chunk when K is long
-// K chunk of the 256-column tiles (BDM_PW_WIDE_BK=16|32).  32 halves the barrier pairs of the short-K layers but measured
-// neutral to slightly slower on the forward (7.42 vs 7.46 ms): 16 stays the default
-static int pw_wide_bk() {
-  static int v = 0;
-  if (!v) { const char *e = getenv("BDM_PW_WIDE_BK"); v = (e && atoi(e) == 32) ? 32 : 16; }
-  return v;
-}
+// K chunk of the 256-column tiles: 32 halves the barrier pairs of the short-K layers but measured neutral to slightly slower on
+// the forward (7.42 vs 7.46 ms), so 16 it is
+static int pw_wide_bk() { return 16; }
 
 static void pw_tile(int b, int m, int k, int n, int *mi, int *ni, int *bk) {
   auto blocks = [&](int a, int c) { return (long long)cdiv(n, 128 * c) * cdiv(m, 32 * a) * b; };

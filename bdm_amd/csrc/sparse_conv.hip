@@ -298,11 +298,8 @@ bool bdm_sparse_features_lds_launch(int out_kind, int b, int c, int n, int r3, i
   if ((sel && sel[0] == '0') || n > 4096 || n_max > 4096) return false;
   const int G = (c + 7) / 8, units = b * G;
   // workgroups per unit: every extra one refills the rows, which costs more than the parallelism gains (measured: 32-channel
-  // layer at 32^3, 8 slices: 132 -> 207 us); BDM_FEATURES_KSPLIT overrides for experiments
-  static int ks_env = -1;
-  if (ks_env < 0) { const char *e = getenv("BDM_FEATURES_KSPLIT"); ks_env = e ? atoi(e) : 0; }
-  int ksplit = ks_env > 0 ? ks_env : 1;
-  ksplit = ksplit < 1 ? 1 : (ksplit > 8 ? 8 : ksplit);
+  // layer at 32^3, 8 slices: 132 -> 207 us)
+  const int ksplit = 1;
   const int cells_per = ((n_max + ksplit - 1) / ksplit + 63) & ~63;
   const int T = cells_per > 1024 ? 1024 : 256;  // 4 cells per thread cover the slice
   const size_t smem = sizeof(float) * 8 * (size_t)n;
@@ -666,8 +663,7 @@ static int sparse_gather_launch(int b, int cout, int r, int n_max, const float *
   if (b == 0) return BDM_OK;
   const size_t smem = sizeof(float) * (size_t)r * (cout + 1) + sizeof(int) * 9 * (size_t)(r + 2);
   if ((cout & 3) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0) {
-    static int gu = 0;  // BDM_GATHER_INFLIGHT=4|8 (experiment switch)
-    if (!gu) { const char *e = getenv("BDM_GATHER_INFLIGHT"); gu = (e && e[0] == '4') ? 4 : 8; }
+    const int gu = 8;  // row reads in flight per lane (4 measured 1.5 % slower)
     const size_t sm4 = smem + sizeof(unsigned) * r + sizeof(float) * 512;
     if (gu == 8)
       hipLaunchKernelGGL(sparse_gather_v4_kernel<8>, dim3(r * r, b), dim3(256), sm4, (hipStream_t)stream, cout, r, n_max, y,

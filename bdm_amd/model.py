@@ -226,7 +226,7 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
         return out
 
 
-CHANNEL_FIRST_CONDITIONING = os.environ.get("BDM_CONDITION_CF", "1") == "1"
+CHANNEL_FIRST_CONDITIONING = True  # the conditioning gather writes the denoiser's channel-first input directly (tests flip the attribute)
 
 
 def _timestep_list(scheduler, num_inference_steps, start_time, end_time):
@@ -242,7 +242,7 @@ GRAPH_STEPS = os.environ.get("BDM_GRAPH", "0") == "1"
 GRAPH_MIN_STEPS = 8  # shorter segments do not amortise the capture
 # BDM_TAPE: "auto" (default) replays a recorded launch tape (tape.py) for host-bound problem sizes, "1" always, "0" never.
 TAPE_STEPS = os.environ.get("BDM_TAPE", "auto")
-TAPE_MAX_POINTS = int(os.environ.get("BDM_TAPE_MAX_POINTS", "16384"))
+TAPE_MAX_POINTS = 16384  # B * N up to which "auto" takes the tape (host-bound sizes)
 
 
 class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):

@@ -47,10 +47,10 @@ class SharedMLP(nn.Module):
             in_channels = oc
         self.layers = nn.Sequential(*layers)
 
-    # GroupNorm folding (BDM_FOLD_GN_MLP=0 disables): a layer's convolution leaves the GroupNorm statistics of its output
+    # GroupNorm folding (class attribute; the equality tests flip it): a layer's convolution leaves the GroupNorm statistics of its output
     # and the NEXT consumer (the next layer's convolution, or the caller's max over neighbours with fold_last) normalises +
     # Swishes on the fly -- no GroupNorm pass, the normalised tensor is never written
-    fold_gn = os.environ.get("BDM_FOLD_GN_MLP", "1") == "1"
+    fold_gn = True
 
     def run(self, x, out_last=None, fold_last=False, x2=None):
         """-> activations; with fold_last -> (raw output of the last convolution, (stats, gn) | None): the caller applies the
@@ -189,9 +189,9 @@ class PVConv(nn.Module):
     #   "bf16x6": exact 3-way bf16 split of both operands, six partial products on the bf16 matrix cores;
     #   "fp32"  : v_mfma_f32_32x32x2_f32 kernels of conv3d.hip (BDM_CONV=fp32).
     conv_impl = os.environ.get("BDM_CONV", "fp16x3")
-    fold_gn2 = os.environ.get("BDM_FOLD_GN2", "1") == "1"  # second GroupNorm folded into its consumers (fp16x3 path)
-    sparse_first_conv = os.environ.get("BDM_SPARSE_CONV1", "1") == "1"
-    sparse_resolutions = {int(v) for v in os.environ.get("BDM_SPARSE_R", "8,16,32").split(",") if v}
+    fold_gn2 = True  # second GroupNorm folded into its consumers (fp16x3 path)
+    sparse_first_conv = True
+    sparse_resolutions = {8, 16, 32}
     # first convolution on the occupied voxels: "fp16x3" (default: batched GEMM on two-term fp16 operands, activation scale
     # from a device-side max, + gather) | "bf16x6" (same structure, exact 3-way bf16 split, twice the matrix work) | "fp32"
     # (fp32 MFMA) | "fused" (sparse_conv_fused.hip: one kernel, accumulators in LDS; correct and deterministic but measured
@@ -213,11 +213,11 @@ class PVConv(nn.Module):
     # The point branch (1x1 conv + GroupNorm + Swish on the N points) does not depend on the voxel branch: it is enqueued on
     # a second stream and joined before the devoxelisation adds it, so its small, latency-bound kernels run beside the
     # voxel convolutions instead of after them (BDM_POINT_STREAM=0: serial).
-    se_in_devox = os.environ.get("BDM_SE_IN_DEVOX", "0") == "1"
-    fold_gn1 = os.environ.get("BDM_FOLD_GN1", "1") == "1"  # GroupNorm-1 statistics from the sparse gather's epilogue
-    fold_pf = os.environ.get("BDM_FOLD_PF", "1") == "1"  # point branch's GroupNorm folded into the devoxelisation kernel
+    se_in_devox = False  # SE block's FC layers inside the devoxelisation kernel: measured slower (DESIGN.md negative results)
+    fold_gn1 = True  # GroupNorm-1 statistics from the sparse gather's epilogue
+    fold_pf = True  # point branch's GroupNorm folded into the devoxelisation kernel
     point_stream = os.environ.get("BDM_POINT_STREAM", "1") == "1"
-    point_stream_min = int(os.environ.get("BDM_POINT_STREAM_MIN", "8192"))  # B * N below which the branch stays on the main stream
+    point_stream_min = 8192  # B * N below which the branch stays on the main stream
     _streams = {}
 
     def voxel_plan_args(self):
@@ -306,7 +306,7 @@ class PVConv(nn.Module):
                     if self.se_in_devox and w1.shape[0] <= 64:
                         # SE block's FC layers inside the devoxelisation kernel: one launch less, but every workgroup re-reads
                         # w1 / w2 (measured at B=16: devoxelisation 325 -> 650 us per forward for 100 us of se_fc saved), so
-                        # this is only worth it where the forward is launch-bound (opt-in: BDM_SE_IN_DEVOX=1)
+                        # this is only worth it where the forward is launch-bound (PVConv.se_in_devox, off)
                         mean, coef = ops.se_means_gn(v, stats, gn2)
                         if pf_ready is not None:
                             tape.wait_event(pf_ready)
@@ -448,7 +448,7 @@ class PointNetSAModule(nn.Module):
 
 class PointNetFPModule(nn.Module):
     """pointnet.py:96-113."""
-    two_source = os.environ.get("BDM_FP_TWO_SOURCE", "1") == "1"  # skip features read in place by the MLP's first convolution
+    two_source = True  # skip features read in place by the MLP's first convolution
 
     def __init__(self, in_channels, out_channels):
         super().__init__()

@@ -737,7 +737,7 @@ def sparse_conv_pack_h2(weight):
     return "h2", packed, inv_scale
 
 
-SPARSE_Y_BYTES = int(float(os.environ.get("BDM_SPARSE_Y_MB", "256")) * 2 ** 20)
+SPARSE_Y_BYTES = 256 * 2 ** 20
 _amax_rings = {}
 # != 0 while a step is being recorded for replay (hipGraph capture or launch tape: model.static_step).  A replayed step finds
 # its amax slots as the previous replay left them, so the recording must contain the zero-fill: it never takes slots of a
@@ -881,7 +881,7 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None):
         return (out, None) if gn_groups else out
     out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
     # The 27x-expanded intermediate Y (n_occ x 27*cout fp32 per shape) is written by the GEMM and read once by the gather.
-    # Shapes are processed in groups whose Y stays within BDM_SPARSE_Y_MB (default 256 MiB, about the memory-side cache),
+    # Shapes are processed in groups whose Y stays within SPARSE_Y_BYTES (256 MiB, about the memory-side cache),
     # reusing ONE Y buffer.  Measured (tools/sparse_bench.py): two groups of 8 at the 64 -> 64 / 32^3 layer: 287 -> 261 us;
     # smaller groups lose more to the extra launches than they gain.
     per_shape = plan.n_max * 27 * cout * 4

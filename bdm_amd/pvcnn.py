@@ -124,8 +124,8 @@ SIDE_PLAN = os.environ.get("BDM_SIDE_PLAN", "1") == "1"  # voxel plans of levels
 # B * N below which the sampler chain stays on the main stream.  0: always on its own stream -- since the launch count and the
 # per-launch host cost came down it pays even for one small shape (B=1, N=1024: 3.48 -> 3.30 ms; B=4: 3.86 -> 3.42 ms), where
 # furthest point sampling is a fifth of the forward.  (The PVConv point branch keeps its 8192-point threshold: measured slower below.)
-SIDE_STREAM_MIN_POINTS = int(os.environ.get("BDM_SIDE_STREAM_MIN", "0"))
-DEFER_CHAIN = os.environ.get("BDM_DEFER_CHAIN", "1") == "1"  # levels 1.. of the sampler chain enqueued when the first SA module is reached
+SIDE_STREAM_MIN_POINTS = 0
+DEFER_CHAIN = True  # levels 1.. of the sampler chain enqueued when the first SA module is reached
 
 
 def plan_sampling_chain(sa_layers, coords):

@@ -189,9 +189,6 @@ def self_launch(args):
 
 
 def main():
-    if os.environ.get("BDM_WATCHDOG"):  # debugging aid: dump every thread's Python stack and exit after N seconds
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["BDM_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1, help="timed trajectories (each = 1000 DDPM steps of a 16-shape batch)")
