@@ -3,7 +3,7 @@
 # forward, per-kernel HBM traffic (two --pmc passes).  Outputs under gpurun_out/ (copy the summaries into profiles/).
 R=${GRAFT_REPO_ROOT:-$PWD}; TAG=${1:-r02}; COMMIT=${2:-unknown}
 mkdir -p $R/gpurun_out; cd $R
-BDM_WATCHDOG=800 timeout 900 python bench.py --steps 2 --warmup 0 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
+timeout 900 python bench.py --steps 2 --warmup 0 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> /dev/null; echo "rocprof rc=$?"
 cp $(find /tmp/prof -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_bench_kernel_stats.csv
