@@ -475,6 +475,75 @@ extern "C" int bdm_sparse_conv_gemm_s3(int b, int n_max, int cin, int n27, const
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 2''. Steps 1b + 2 for an input whose feature channels are a GATHER of a per-image map (the projection conditioning of PC^2:
+//      x_in[i] = [xyz_i, F[pix_i]] with F the hoisted conditioning image, projection_model.py:179-231).  The GEMM commutes with the
+//      gather and with the voxel mean:  Y[k] = mean_{i in cell k} (W . [xyz_i, F[pix_i]]) = mean_i (Wx . xyz_i + Hmap[pix_i])  with
+//      Hmap = F . Wf^T (HW x 27*Cout) computed ONCE per trajectory (the image is step-invariant, like the image encoder itself).
+//      Per step the 390-channel feature gather (step 1b) and the K = 390 GEMM (step 2) become ONE pass that reads a 27*Cout-float
+//      row per point: 226 MB instead of the features' 102 MB + a 56 GFLOP bf16x6 GEMM at B = 16.  Same sums up to the
+//      reassociation of each dot product (<= 1e-6 relative, tests/test_hip_dense.py); deterministic (ascending point index).
+//      One workgroup = 8 cells of one shape; a lane owns 4 consecutive columns.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sparse_rows_from_map_kernel(int n, int r3, int n_max, int n27, int hw,
+                                                                   const float *__restrict__ hmap, const int *__restrict__ pix,
+                                                                   const float *__restrict__ xyz, const float *__restrict__ wx,
+                                                                   const int *__restrict__ cnt, const int *__restrict__ start,
+                                                                   const int *__restrict__ sorted, const int *__restrict__ occ_list,
+                                                                   const int *__restrict__ n_occ, float *__restrict__ y) {
+  const int bi = blockIdx.y, k0 = blockIdx.x * 8, nocc = min(n_occ[bi], n_max);
+  if (k0 >= nocc) return;
+  const int c4 = threadIdx.x;  // float4 column
+  if (c4 * 4 >= n27) return;
+  const float4 w0 = make_float4(wx[(c4 * 4 + 0) * 3 + 0], wx[(c4 * 4 + 1) * 3 + 0], wx[(c4 * 4 + 2) * 3 + 0], wx[(c4 * 4 + 3) * 3 + 0]);
+  const float4 w1 = make_float4(wx[(c4 * 4 + 0) * 3 + 1], wx[(c4 * 4 + 1) * 3 + 1], wx[(c4 * 4 + 2) * 3 + 1], wx[(c4 * 4 + 3) * 3 + 1]);
+  const float4 w2 = make_float4(wx[(c4 * 4 + 0) * 3 + 2], wx[(c4 * 4 + 1) * 3 + 2], wx[(c4 * 4 + 2) * 3 + 2], wx[(c4 * 4 + 3) * 3 + 2]);
+  const float *px = xyz + (size_t)bi * 3 * n;
+  const int *pp = pix + (size_t)bi * n;
+  const float4 *hb = reinterpret_cast<const float4 *>(hmap + (size_t)bi * hw * n27);
+  const int n27q = n27 >> 2;
+  for (int k = k0; k < min(k0 + 8, nocc); ++k) {
+    const int v = occ_list[(size_t)bi * n_max + k];
+    const int cv = cnt[(size_t)bi * r3 + v];
+    const int *so = sorted + (size_t)bi * n + start[(size_t)bi * r3 + v];
+    const float inv = cv > 0 ? (float)(1.0 / (double)(float)cv) : 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q0 = 0; q0 < cv; q0 += 2) {  // two points per round: their row reads are in flight together
+      const int i0 = so[q0], i1 = so[min(q0 + 1, cv - 1)];
+      const int p0 = pp[i0], p1 = pp[i1];
+      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 h0 = p0 >= 0 ? hb[(size_t)p0 * n27q + c4] : zero;
+      const float4 h1 = (p1 >= 0 && q0 + 1 < cv) ? hb[(size_t)p1 * n27q + c4] : zero;
+      const float x0 = px[i0], y0 = px[n + i0], z0 = px[2 * n + i0];
+      const float x1 = px[i1], y1 = px[n + i1], z1 = px[2 * n + i1];
+      float4 t;
+      t.x = h0.x + (w0.x * x0 + w1.x * y0 + w2.x * z0); t.y = h0.y + (w0.y * x0 + w1.y * y0 + w2.y * z0);
+      t.z = h0.z + (w0.z * x0 + w1.z * y0 + w2.z * z0); t.w = h0.w + (w0.w * x0 + w1.w * y0 + w2.w * z0);
+      acc.x += t.x * inv; acc.y += t.y * inv; acc.z += t.z * inv; acc.w += t.w * inv;
+      if (q0 + 1 < cv) {
+        t.x = h1.x + (w0.x * x1 + w1.x * y1 + w2.x * z1); t.y = h1.y + (w0.y * x1 + w1.y * y1 + w2.y * z1);
+        t.z = h1.z + (w0.z * x1 + w1.z * y1 + w2.z * z1); t.w = h1.w + (w0.w * x1 + w1.w * y1 + w2.w * z1);
+        acc.x += t.x * inv; acc.y += t.y * inv; acc.z += t.z * inv; acc.w += t.w * inv;
+      }
+    }
+    reinterpret_cast<float4 *>(y + ((size_t)bi * n_max + k) * n27)[c4] = acc;
+  }
+}
+
+extern "C" int bdm_sparse_conv_rows_from_map(int b, int n, int r, int n_max, int n27, int hw, const float *hmap, const int *pix,
+                                             const float *xyz, const float *wx, const int *cnt, const void *plan_workspace,
+                                             const int *occ_list, const int *n_occ, float *y, void *stream) {
+  BDM_REQUIRE(b >= 0 && n >= 1 && r >= 1 && n_max >= 1 && n27 >= 4 && (n27 & 3) == 0 && n27 <= 1024 && hw >= 1,
+              "sparse_conv_rows_from_map: bad sizes (n27 = %d must be a multiple of 4, <= 1024)", n27);
+  BDM_REQUIRE((reinterpret_cast<size_t>(hmap) & 15) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0, "sparse_conv_rows_from_map: map and output must be 16-byte aligned");
+  if (b == 0) return BDM_OK;
+  const int r3 = r * r * r;
+  VoxWs w = vox_ws(const_cast<void *>(plan_workspace), b, n, r3);
+  hipLaunchKernelGGL(sparse_rows_from_map_kernel, dim3(cdiv(n_max, 8), b), dim3(256), 0, (hipStream_t)stream, n, r3, n_max, n27, hw,
+                     hmap, pix, xyz, wx, cnt, w.start, w.sorted, occ_list, n_occ, y);
+  return launch_status("sparse_conv_rows_from_map");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 3. output-stationary gather.  One workgroup = one grid row (x, y): r cells x Cout channels.
 //    A wave sums one cell at a time over 64 channels (coalesced 256-B reads of a Y row segment); the tile is
 //    transposed through LDS so that the channel-first output is written as contiguous z-runs.

@@ -73,7 +73,11 @@ class PointCloudModel(_DeviceMixin, nn.Module):
     @torch.no_grad()
     def forward(self, inputs: Tensor, t: Tensor) -> Tensor:
         """(B, N, in_channels) -> (B, N, out_channels)."""
-        return ops.transpose12(self.model(ops.transpose12(inputs), t))
+        x = ops.transpose12(inputs)
+        cond = getattr(inputs, "_bdm_cond", None)  # projection conditioning in factored form (ops.Conditioning)
+        if cond is not None and cond.x_cf.data_ptr() == x.data_ptr():
+            x._bdm_cond = cond
+        return ops.transpose12(self.model(x, t))
 
 
 class PC2_PVDFusionModel(_DeviceMixin, nn.Module):
@@ -166,7 +170,7 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
             extra = self._mask_channels(image_rgb, mask)
             if extra:  # once per image batch (hoisted): the mask / distance-transform channels join the pixel-major image
                 img = torch.cat([img] + [e.reshape(e.shape[0], H * W, 1) for e in extra], dim=2).contiguous()
-            hit = (image_rgb, image_rgb._version, img, (H, W), mask)
+            hit = (image_rgb, image_rgb._version, img, (H, W), mask, {})  # {}: hoisted maps of this image batch (ops.Conditioning)
             self._cond_cache = hit
         return hit[2], hit[3]
 
@@ -219,7 +223,10 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
             out = torch.empty(B, 3 + C, N, dtype=torch.float32, device=x_t.device)
             L.check(L.lib().bdm_condition_gather_cf(B, N, C, hw[0] * hw[1], L.ptr(x_t), L.ptr(feat), L.ptr(pix), L.ptr(out),
                                                     L.stream()), "condition_gather_cf")
-            return out.transpose(1, 2)
+            res = out.transpose(1, 2)
+            if ops.HOIST_CONDITIONING and x_t.shape[2] == 3:
+                res._bdm_cond = ops.Conditioning(feat, hw, pix, x_t, out, self._cond_cache[5])
+            return res
         out = torch.empty(B, N, 3 + C, dtype=torch.float32, device=x_t.device)
         L.check(L.lib().bdm_condition_gather(B, N, C, hw[0] * hw[1], L.ptr(x_t), L.ptr(feat), L.ptr(pix), L.ptr(out),
                                              L.stream()), "condition_gather")

@@ -52,10 +52,11 @@ class SharedMLP(nn.Module):
     # Swishes on the fly -- no GroupNorm pass, the normalised tensor is never written
     fold_gn = True
 
-    def run(self, x, out_last=None, fold_last=False, x2=None):
+    def run(self, x, out_last=None, fold_last=False, x2=None, first_weight=None):
         """-> activations; with fold_last -> (raw output of the last convolution, (stats, gn) | None): the caller applies the
         last GroupNorm + Swish inside its own consumer kernel (None: already applied).  x2: the input is cat([x, x2], dim=1),
-        read in place by the first convolution."""
+        read in place by the first convolution.  first_weight: matrix used instead of the first convolution's weight (the hoisted
+        projection conditioning feeds the layer [other inputs, W_f . F[pix]] with [W_other | I]: ops.Conditioning)."""
         n = len(self.layers) // 3
         pending = None
         for i in range(n):
@@ -64,8 +65,9 @@ class SharedMLP(nn.Module):
             dst = out_last if last else None
             defer = (self.fold_gn and x.is_cuda and (not last or fold_last) and ops.gn_foldable(conv.out_channels, gn.num_groups))
             second = x2 if i == 0 else None
+            weight = first_weight if (i == 0 and first_weight is not None) else conv.weight
             if defer or pending is not None or second is not None:
-                r = ops.pointwise_conv_gn(x, conv.weight, conv.bias, out=dst, fold_in=pending,
+                r = ops.pointwise_conv_gn(x, weight, conv.bias, out=dst, fold_in=pending,
                                           out_groups=gn.num_groups if defer else None, x2=second)
                 if defer:
                     x, stats = r
@@ -74,7 +76,7 @@ class SharedMLP(nn.Module):
                     x, pending = r, None
                     ops.group_norm_(x, gn.weight, gn.bias, gn.num_groups, gn.eps, swish=True)
             else:
-                x = ops.pointwise_conv(x, conv.weight, conv.bias, out=dst)
+                x = ops.pointwise_conv(x, weight, conv.bias, out=dst)
                 ops.group_norm_(x, gn.weight, gn.bias, gn.num_groups, gn.eps, swish=True)
         return (x, pending) if fold_last else x
 
@@ -82,6 +84,20 @@ class SharedMLP(nn.Module):
         if isinstance(inputs, (list, tuple)):
             return (self.run(inputs[0]), *inputs[1:])
         return self.run(inputs)
+
+
+def hoisted_first_weight(owner, conv, keep_cols):
+    """[W[:, :keep_cols] | I] for a 1x1 convolution whose remaining input columns were hoisted into a per-image map (ops.Conditioning):
+    the gathered map rows enter through an identity block.  Cached on `owner` per weight version."""
+    w = conv.weight
+    hit = getattr(owner, "_hoist_w", None)
+    if hit is None or hit[0] != (w._version, w.data_ptr(), keep_cols):
+        M = w.shape[0]
+        w2 = w.detach().reshape(M, -1)
+        mat = torch.cat([w2[:, :keep_cols], torch.eye(M, dtype=w2.dtype, device=w2.device)], dim=1).contiguous()
+        hit = ((w._version, w.data_ptr(), keep_cols), mat)
+        owner._hoist_w = hit
+    return hit[1]
 
 
 class SE3d(nn.Module):
@@ -226,13 +242,31 @@ class PVConv(nn.Module):
             return self.resolution, self.voxelization.eps
         return None
 
+    _cond = None  # ops.Conditioning of this forward when the input is the raw conditioned cloud (set by PVCNN2Base.forward)
+
+    def _hoisted(self, features):
+        """The handle, if `features` IS the conditioned input it describes (first PVConv of the PC^2 denoiser)."""
+        cond = self._cond
+        if cond is None or features.data_ptr() != cond.x_cf.data_ptr() or features.shape[1] != 3 + cond.C:
+            return None
+        return cond
+
     def _point_branch(self, features, fold=False):
         """-> (activations, event | None, pending): with fold the LAST GroupNorm + Swish of the branch is left to the caller
         (pending = (stats, gn), activations = raw convolution output; None when the layer cannot be folded)."""
+        cond = self._hoisted(features)
+        first_weight = None
+        if cond is not None and len(self.point_features.layers) == 3:
+            # W . [xyz, F[pix]] = Wx . xyz + (F . Wf^T)[pix]: gather 32 map channels instead of convolving 390 (ops.Conditioning)
+            conv = self.point_features.layers[0]
+            fmap = cond.map("point_branch", conv.weight, lambda: conv.weight.detach().reshape(conv.out_channels, -1)[:, 3:3 + cond.C])
+            features = cond.gather(fmap)
+            first_weight = hoisted_first_weight(self.point_features, conv, 3)
+
         def run():
             if fold:
-                return self.point_features.run(features, fold_last=True)
-            return self.point_features.run(features), None
+                return self.point_features.run(features, fold_last=True, first_weight=first_weight)
+            return self.point_features.run(features, first_weight=first_weight), None
         if not (self.point_stream and features.is_cuda and features.shape[0] * features.shape[2] >= self.point_stream_min):
             pf, pending = run()
             return pf, None, pending
@@ -281,8 +315,12 @@ class PVConv(nn.Module):
                 # with the fp16x3 second convolution the gather also leaves GroupNorm-1's statistics (no pass over the grid for them)
                 want_stats = (self.fold_gn1 and self.conv_impl == "fp16x3" and not getattr(self, "h2_saturated", False)
                               and impl != "sparse_fused")
-                v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, impl), conv1.bias, conv1.out_channels,
-                                                  gn_groups=gn1.num_groups if want_stats else None)
+                cond = self._hoisted(features)
+                if cond is not None and 27 * conv1.out_channels <= 1024:  # hoisted map instead of feature gather + K = 390 GEMM
+                    v = ops.sparse_first_conv_from_map(cond, plan, conv1, conv1.out_channels, gn_groups=gn1.num_groups if want_stats else None)
+                else:
+                    v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, impl), conv1.bias, conv1.out_channels,
+                                                      gn_groups=gn1.num_groups if want_stats else None)
                 if want_stats:
                     v, gn1_stats = v
             else:
@@ -449,6 +487,7 @@ class PointNetSAModule(nn.Module):
 class PointNetFPModule(nn.Module):
     """pointnet.py:96-113."""
     two_source = True  # skip features read in place by the MLP's first convolution
+    _cond = None       # ops.Conditioning of this forward when the skip features are the raw conditioning channels
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
@@ -492,5 +531,12 @@ class PointNetFPModule(nn.Module):
                                         L.c_ll(bs_s), ld_s, c_t, L.ptr(ft), L.c_ll(bs_t), ld_t, L.ptr(buf), L.c_ll(bs_0), ld_0,
                                         L.ptr(interpolated_temb), L.c_ll(bs_1), ld_1, L.stream()), "fp_assemble")
         if two_source:
+            cond = self._cond
+            if (cond is not None and skip_src.shape[1] == cond.C and skip_src.data_ptr() == cond.x_cf[:, 3:].data_ptr()):
+                # the skip channels are F[pix]: their share of the first layer, (F . W_skip^T)[pix], is gathered from the hoisted map
+                conv = self.mlp.layers[0]
+                fmap = cond.map("fp_skip", conv.weight, lambda: conv.weight.detach().reshape(conv.out_channels, -1)[:, c_int:c_int + cond.C])
+                g = cond.gather(fmap)
+                return self.mlp.run(buf, x2=g[:, 3:], first_weight=hoisted_first_weight(self.mlp, conv, c_int)), points_coords, interpolated_temb
             return self.mlp.run(buf, x2=skip_src), points_coords, interpolated_temb
         return self.mlp.run(buf), points_coords, interpolated_temb

@@ -822,6 +822,81 @@ def voxel_plan(coords, r, eps=0.0):
     return p
 
 
+# ---- projection conditioning in factored form ---------------------------------------------------------------------------------
+# x_in[i] = [xyz_i, F[pix_i]] (projection_model.py:179-231): F, the pixel-major conditioning image, is fixed for a trajectory; only
+# xyz and the owning pixel change per step.  Every LINEAR first-layer map of x_in therefore commutes with the gather:
+#     W . x_in[i] = Wx . xyz_i + (F . Wf^T)[pix_i]
+# and F . Wf^T is computed once per (image batch, weight) -- hoisted out of the reverse loop like the image encoder itself.  Per step
+# the consumers gather rows of 32 / 128 / 864 channels instead of convolving 390: SA0's point branch, the first sparse
+# convolution and the last FP module's first MLP layer (pvcnn.py:90-127).  Same sums up to the reassociation of each dot product.
+HOIST_CONDITIONING = os.environ.get("BDM_HOIST", "1") == "1"
+
+
+class Conditioning:
+    """Handle that travels with the denoiser input of ONE reverse step (attribute `_bdm_cond` of the x_in tensor)."""
+
+    def __init__(self, feat, hw, pix, x_t, x_cf, maps):
+        # feat (B, HW, C) pixel-major image; pix (B, N) int32 owning pixel or -1; x_t (B, N, 3) point-major and x_cf (B, 3 + C, N)
+        # channel-first (rows 0..2 = xyz) forms of the step's cloud; maps: the per-image cache of hoisted maps
+        self.feat, self.hw, self.pix, self.x_t, self.x_cf, self.maps = feat, hw, pix, x_t, x_cf, maps
+        self.C = feat.shape[2]
+
+    def map(self, kind, weight, build):
+        """(B, HW, M) = F . Wf^T for the (M, C) matrix `build()` returns; cached per (kind, weight tensor, version) for the image batch."""
+        key = (kind, weight.data_ptr())
+        hit = self.maps.get(key)
+        if hit is None or hit[0] != weight._version or hit[2] is not weight:
+            wf = build().contiguous()                                  # (M, C)
+            M = wf.shape[0]
+            B, HW, C = self.feat.shape
+            out = torch.empty(B, HW, M, dtype=torch.float32, device=self.feat.device)
+            xt = wf.t().contiguous()[None]                             # (1, C, M): the "activation" operand of the GEMM below
+            for b in range(B):                                          # y (HW x M) = F[b] (HW x C) . Wf^T: pixels on the GEMM's row axis
+                pointwise_conv(xt, self.feat[b], out=out[b:b + 1])
+            hit = (weight._version, out, weight)
+            self.maps[key] = hit
+        return hit[1]
+
+    def gather(self, fmap):
+        """(B, 3 + M, N) = [xyz, fmap[pix]] channel-first (zeros where a point owns no pixel)."""
+        B, HW, M = fmap.shape
+        N = self.pix.shape[1]
+        out = torch.empty(B, 3 + M, N, dtype=torch.float32, device=fmap.device)
+        L.check(L.lib().bdm_condition_gather_cf(B, N, M, HW, L.ptr(self.x_t), L.ptr(fmap), L.ptr(self.pix), L.ptr(out), L.stream()),
+                "condition_gather_cf")
+        return out
+
+
+def sparse_first_conv_from_map(cond, plan, conv, cout, gn_groups=None):
+    """Conv3d(k3, p1)(avg_voxelize(x_in)) for x_in = [xyz, F[pix]] via the hoisted map (bdm_sparse_conv_rows_from_map) + the usual
+    gather: (B, cout, r^3) fp32 (+ GroupNorm statistics as sparse_first_conv_planned)."""
+    w = conv.weight
+    n27 = 27 * cout
+    C = cond.C
+    hmap = cond.map("conv1", w, lambda: w.detach()[:, 3:3 + C].reshape(cout, C, 27).permute(2, 0, 1).reshape(n27, C))  # row tap*cout+co
+    key = ("conv1_wx", w.data_ptr())
+    hit = cond.maps.get(key)
+    if hit is None or hit[0] != w._version:
+        hit = (w._version, w.detach()[:, :3].reshape(cout, 3, 27).permute(2, 0, 1).reshape(n27, 3).contiguous())
+        cond.maps[key] = hit
+    wx = hit[1]
+    B, _, n = cond.x_cf.shape
+    dev, lib, r = cond.x_cf.device, L.lib(), plan.r
+    xyz = cond.x_cf[:, :3]
+    xyz = xyz if xyz.is_contiguous() else xyz.contiguous()
+    y = torch.empty(B, plan.n_max, n27, dtype=torch.float32, device=dev)
+    L.check(lib.bdm_sparse_conv_rows_from_map(B, n, r, plan.n_max, n27, hmap.shape[1], L.ptr(hmap), L.ptr(cond.pix), L.ptr(xyz), L.ptr(wx),
+                                              L.ptr(plan.cnt), L.ptr(plan.ws), L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(y), L.stream()),
+            "sparse_conv_rows_from_map")
+    out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
+    gn, stats = None, None
+    if gn_groups and gather_gn_ok(cout, gn_groups):
+        partial = torch.empty(B, gn_groups, r * r, 2, dtype=torch.float64, device=dev)
+        gn, stats = (partial, int(gn_groups)), (partial, r * r, int(gn_groups))
+    _gather(lib, B, cout, r, plan, 0, y, conv.bias, out, gn)
+    return (out, stats) if gn_groups else out
+
+
 def gather_gn_ok(cout, groups):
     cg = cout // groups if groups and cout % groups == 0 else 0
     return cg >= 4 and cg % 4 == 0 and cout % 4 == 0 and 256 % (cout // 4) == 0

@@ -245,11 +245,28 @@ class PVCNN2Base(nn.Module):
     @torch.no_grad()
     def forward(self, inputs, t):
         """inputs (B, 3+S, N) channel-first fp32 on the GPU; t (B,).  Returns (B, num_classes, N)."""
+        cond = getattr(inputs, "_bdm_cond", None)
         inputs = inputs.contiguous()
         t_emb = embed_time(self.embedf, t, self.embed_dim, inputs.shape[-1])
-        features, coords, t_emb, coords_list, in_features_list = encode(self.sa_layers, self.global_att, inputs, t_emb)
-        in_features_list[0] = inputs[:, 3:, :]
-        return decode(self.fp_layers, self.classifier, features, coords, t_emb, coords_list, in_features_list)
+        hoisted = self._hoist_targets(cond, inputs)
+        try:
+            for m in hoisted:
+                m._cond = cond
+            features, coords, t_emb, coords_list, in_features_list = encode(self.sa_layers, self.global_att, inputs, t_emb)
+            in_features_list[0] = inputs[:, 3:, :]
+            return decode(self.fp_layers, self.classifier, features, coords, t_emb, coords_list, in_features_list)
+        finally:
+            for m in hoisted:
+                m._cond = None
+
+    def _hoist_targets(self, cond, inputs):
+        """Modules whose first linear map reads the raw conditioned input (ops.Conditioning): the first PVConv of the first
+        set-abstraction level and the last feature-propagation module.  Empty unless this forward's input carries a handle."""
+        if cond is None or not ops.HOIST_CONDITIONING or inputs.shape[1] != 3 + cond.C or cond.x_cf.data_ptr() != inputs.data_ptr():
+            return []
+        first = self.sa_layers[0][0] if isinstance(self.sa_layers[0], nn.Sequential) else None
+        last = self.fp_layers[-1][0] if isinstance(self.fp_layers[-1], nn.Sequential) else self.fp_layers[-1]
+        return [m for m in (first, last) if m is not None and hasattr(m, "_cond")]
 
 
 class PVCNN2_PC2(PVCNN2Base):

@@ -358,6 +358,15 @@ int bdm_sparse_conv_pack_weights_s3(int cout, int cin, const float *w, void *ws,
 int bdm_sparse_conv_gemm_s3(int b, int n_max, int cin, int n27, const void *xs, const void *ws, const int *n_occ,
                             float *y, void *stream);
 
+/* Hoisted form of bdm_sparse_voxel_features* + bdm_sparse_conv_gemm* for an input whose feature channels are a gather of a per-image
+ * map (the projection conditioning x_in[i] = [xyz_i, F[pix_i]], projection_model.py:179-231): with hmap (b, hw, n27) = F . Wf^T
+ * computed once per trajectory (n27 = 27 * cout columns ordered tap * cout + co) and wx (n27, 3) the coordinate columns of the
+ * weights,  y (b, n_max, n27)[k] = mean over the points i of occupied cell k (ascending i) of (hmap[pix_i] (0 where pix_i < 0) +
+ * wx . xyz_i): the rows bdm_sparse_conv_gather consumes.  xyz (b, 3, n), pix (b, n) from bdm_rasterize_points. */
+int bdm_sparse_conv_rows_from_map(int b, int n, int r, int n_max, int n27, int hw, const float *hmap, const int *pix,
+                                  const float *xyz, const float *wx, const int *cnt, const void *plan_workspace,
+                                  const int *occ_list, const int *n_occ, float *y, void *stream);
+
 /* --- first convolution of a PVConv on the occupied voxels only (sparse_conv.hip) ---
  * out = Conv3d(avg_voxelize(features)) without materialising the dense grid:
  *   bdm_voxel_compact          cnt (b, r^3) -> occ_index (b, r^3) [-1 = empty], occ_list (b, n_max), n_occ (b)

@@ -132,3 +132,52 @@ def test_forward_is_run_to_run_deterministic(hip):
     a = net(x, t).clone()
     for _ in range(3):
         assert torch.equal(net(x, t), a)
+
+
+def test_hoisted_projection_conditioning_equals_the_generic_path(hip, monkeypatch):
+    """ops.Conditioning: x_in = [xyz, F[pix]] lets the first linear maps of the PC^2 denoiser (SA0 point branch, first sparse
+    convolution, last FP module's first layer) be applied to the conditioning IMAGE once and gathered per step.  Same forward as the
+    generic path up to the reassociation of those dot products; points without a pixel, a weight update and a new image are covered."""
+    from bdm_amd import _lib as L, ops
+    from bdm_amd.pvcnn import PVCNN2_PC2
+    from bdm_amd.utils.procedural import fill_module_
+    B, N, H, C = 2, 1024, 48, 387
+    g = torch.Generator().manual_seed(4)
+    net = fill_module_(PVCNN2_PC2(3, 64, extra_feature_channels=C).eval(), seed=6).cuda()
+    t = torch.tensor([700, 20]).cuda()
+
+    def inputs(seed):
+        gg = torch.Generator().manual_seed(seed)
+        feat = torch.randn(B, H * H, C, generator=gg).cuda()
+        x_t = (torch.randn(B, N, 3, generator=gg) * 0.5).cuda()
+        pix = torch.randint(-1, H * H, (B, N), generator=gg, dtype=torch.int32).cuda()
+        pix[0, :100] = -1                                                    # points that own no pixel
+        x_cf = torch.empty(B, 3 + C, N, device="cuda")
+        L.check(L.lib().bdm_condition_gather_cf(B, N, C, H * H, L.ptr(x_t), L.ptr(feat), L.ptr(pix), L.ptr(x_cf), L.stream()), "gather")
+        return feat, x_t, pix, x_cf
+
+    maps = {}
+    feat, x_t, pix, x_cf = inputs(1)
+    ref = net(x_cf, t).clone()                                               # no handle: generic path
+    x_cf._bdm_cond = ops.Conditioning(feat, (H, H), pix, x_t, x_cf, maps)
+    got = net(x_cf, t)
+    assert len(maps) >= 3 and rel_l2(got.cpu(), ref.cpu()) < 5e-6, rel_l2(got.cpu(), ref.cpu())
+    assert not torch.equal(got, ref)                                         # really another route
+    monkeypatch.setattr(ops, "HOIST_CONDITIONING", False)
+    assert torch.equal(net(x_cf, t), ref)                                    # switch off: the generic path, bit for bit
+    monkeypatch.setattr(ops, "HOIST_CONDITIONING", True)
+    # a second step on the same image re-uses the maps; other points, other pixels
+    n_maps = {k: v[1].data_ptr() for k, v in maps.items() if torch.is_tensor(v[1])}
+    _, x_t2, pix2, x_cf2 = inputs(2)
+    L.check(L.lib().bdm_condition_gather_cf(B, N, C, H * H, L.ptr(x_t2), L.ptr(feat), L.ptr(pix2), L.ptr(x_cf2), L.stream()), "gather")
+    ref2 = net(x_cf2, t).clone()
+    x_cf2._bdm_cond = ops.Conditioning(feat, (H, H), pix2, x_t2, x_cf2, maps)
+    assert rel_l2(net(x_cf2, t).cpu(), ref2.cpu()) < 5e-6
+    assert {k: v[1].data_ptr() for k, v in maps.items() if torch.is_tensor(v[1])} == n_maps
+    # rewriting a weight invalidates its map
+    with torch.no_grad():
+        net.sa_layers[0][0].point_features.layers[0].weight.mul_(1.5)
+    x_cf2._bdm_cond = None
+    ref3 = net(x_cf2, t).clone()
+    x_cf2._bdm_cond = ops.Conditioning(feat, (H, H), pix2, x_t2, x_cf2, maps)
+    assert rel_l2(net(x_cf2, t).cpu(), ref3.cpu()) < 5e-6 and rel_l2(ref3.cpu(), ref2.cpu()) > 1e-4
