@@ -580,11 +580,12 @@ extern "C" int bdm_pointwise_conv_gn_slices(int b, int m, int k, int n, int grou
   return cdiv(n, 128) * (cg >= 32 ? cg / 32 : 1);
 }
 
-extern "C" int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x,
-                                     int ld_x, const float *x2, long long bs_x2, int ld_x2, int k1, const float *bias, float *y,
-                                     long long bs_y, int ld_y, const void *in_partial, int in_slices, int in_groups,
-                                     const float *in_gamma, const float *in_beta, float in_eps, int out_groups,
-                                     void *out_partial, float *amax, int amax_rows, void *stream) {
+static int pointwise_conv_gn_impl(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x,
+                                 int ld_x, const float *x2, long long bs_x2, int ld_x2, int k1, const float *bias, float *y,
+                                 long long bs_y, int ld_y, const void *in_partial, int in_slices, int in_groups,
+                                 const float *in_gamma, const float *in_beta, float in_eps, int out_groups,
+                                 void *out_partial, float *amax, int amax_rows, const float *add, long long bs_add, int ld_add,
+                                 void *stream) {
   BDM_REQUIRE(b >= 0 && m >= 1 && k >= 1 && n >= 1, "pointwise_conv_gn: bad sizes m=%d k=%d n=%d", m, k, n);
   BDM_REQUIRE((long long)k * ld_x + n < (1ll << 31) && (long long)m * ldw + k < (1ll << 31),
               "pointwise_conv_gn: one operand spans more than 2^31 elements");
@@ -611,6 +612,7 @@ extern "C" int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w,
     gn.out_partial = (double *)out_partial; gn.out_cg = cg;
   }
   if (b == 0) return BDM_OK;
+  BDM_REQUIRE(add == nullptr || !pw_skinny_shape(k, n), "pointwise_conv_gn_add: not for the skinny shapes (n <= 64, k >= 128)");
   if (pw_skinny_shape(k, n)) {
 #define SK_LAUNCH(NB, FOLD)                                                                                                       \
     hipLaunchKernelGGL((pw_skinny_kernel<NB, FOLD>), dim3(cdiv(m, 32), b, cdiv(n, 32 * NB)), dim3(256), 0, (hipStream_t)stream, m, k, n, w, ldw, x, bs_x, \
@@ -621,14 +623,36 @@ extern "C" int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w,
     return launch_status("pointwise_conv_gn");
   }
   if (in_partial != nullptr)
-    pw_dispatch<true>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, nullptr, 0, nullptr, 0ll, 0, y, bs_y, ld_y, 0, 0.f, gn, (hipStream_t)stream);
+    pw_dispatch<true>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, nullptr, 0, add, bs_add, ld_add, y, bs_y, ld_y, 0, 0.f, gn, (hipStream_t)stream);
   else
-    pw_dispatch<false>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, nullptr, 0, nullptr, 0ll, 0, y, bs_y, ld_y, 0, 0.f, gn, (hipStream_t)stream);
+    pw_dispatch<false>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, nullptr, 0, add, bs_add, ld_add, y, bs_y, ld_y, 0, 0.f, gn, (hipStream_t)stream);
   return launch_status("pointwise_conv_gn");
 }
 
 // Sparse first-convolution GEMM (sparse_conv.hip): Y[b] (n_max x n27) = Xc[b]^T (n_max x cin) . Wt (cin x n27), rows
 // >= n_occ[b] skipped.  Xc is channel-first (b, cin, n_max): the A operand arrives transposed.
+extern "C" int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x,
+                                     int ld_x, const float *x2, long long bs_x2, int ld_x2, int k1, const float *bias, float *y,
+                                     long long bs_y, int ld_y, const void *in_partial, int in_slices, int in_groups,
+                                     const float *in_gamma, const float *in_beta, float in_eps, int out_groups,
+                                     void *out_partial, float *amax, int amax_rows, void *stream) {
+  return pointwise_conv_gn_impl(b, m, k, n, w, ldw, x, bs_x, ld_x, x2, bs_x2, ld_x2, k1, bias, y, bs_y, ld_y, in_partial, in_slices,
+                                in_groups, in_gamma, in_beta, in_eps, out_groups, out_partial, amax, amax_rows, nullptr, 0ll, 0, stream);
+}
+
+// The same with a per-element addend: y = W x' + bias + add, statistics / amax over y INCLUDING the addend (the hoisted share of a
+// layer whose remaining input columns were applied to the conditioning image once per trajectory: sparse_conv.hip 2'').
+extern "C" int bdm_pointwise_conv_gn_add(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x,
+                                         int ld_x, const float *x2, long long bs_x2, int ld_x2, int k1, const float *bias, float *y,
+                                         long long bs_y, int ld_y, const void *in_partial, int in_slices, int in_groups,
+                                         const float *in_gamma, const float *in_beta, float in_eps, int out_groups,
+                                         void *out_partial, float *amax, int amax_rows, const float *add, long long bs_add,
+                                         int ld_add, void *stream) {
+  BDM_REQUIRE(add != nullptr, "pointwise_conv_gn_add: add is NULL");
+  return pointwise_conv_gn_impl(b, m, k, n, w, ldw, x, bs_x, ld_x, x2, bs_x2, ld_x2, k1, bias, y, bs_y, ld_y, in_partial, in_slices,
+                                in_groups, in_gamma, in_beta, in_eps, out_groups, out_partial, amax, amax_rows, add, bs_add, ld_add, stream);
+}
+
 extern "C" int bdm_sparse_conv_gemm(int b, int n_max, int cin, int n27, const float *xc, const float *wt,
                                     const int *n_occ, float *y, void *stream) {
   BDM_REQUIRE(b >= 0 && n_max >= 1 && cin >= 1 && n27 >= 1, "sparse_conv_gemm: bad sizes");

@@ -52,11 +52,12 @@ class SharedMLP(nn.Module):
     # Swishes on the fly -- no GroupNorm pass, the normalised tensor is never written
     fold_gn = True
 
-    def run(self, x, out_last=None, fold_last=False, x2=None, first_weight=None):
+    def run(self, x, out_last=None, fold_last=False, x2=None, first_weight=None, first_add=None):
         """-> activations; with fold_last -> (raw output of the last convolution, (stats, gn) | None): the caller applies the
         last GroupNorm + Swish inside its own consumer kernel (None: already applied).  x2: the input is cat([x, x2], dim=1),
-        read in place by the first convolution.  first_weight: matrix used instead of the first convolution's weight (the hoisted
-        projection conditioning feeds the layer [other inputs, W_f . F[pix]] with [W_other | I]: ops.Conditioning)."""
+        read in place by the first convolution.  first_weight / first_add: the first convolution's weight restricted to the columns
+        of `x` and the per-element addend that stands for its other columns (the hoisted projection conditioning:
+        W . [x, F[pix]] = W_x . x + (F . W_f^T)[pix], ops.Conditioning)."""
         n = len(self.layers) // 3
         pending = None
         for i in range(n):
@@ -66,9 +67,10 @@ class SharedMLP(nn.Module):
             defer = (self.fold_gn and x.is_cuda and (not last or fold_last) and ops.gn_foldable(conv.out_channels, gn.num_groups))
             second = x2 if i == 0 else None
             weight = first_weight if (i == 0 and first_weight is not None) else conv.weight
-            if defer or pending is not None or second is not None:
+            addend = first_add if i == 0 else None
+            if defer or pending is not None or second is not None or addend is not None:
                 r = ops.pointwise_conv_gn(x, weight, conv.bias, out=dst, fold_in=pending,
-                                          out_groups=gn.num_groups if defer else None, x2=second)
+                                          out_groups=gn.num_groups if defer else None, x2=second, add=addend)
                 if defer:
                     x, stats = r
                     pending = (stats, gn)
@@ -87,15 +89,12 @@ class SharedMLP(nn.Module):
 
 
 def hoisted_first_weight(owner, conv, keep_cols):
-    """[W[:, :keep_cols] | I] for a 1x1 convolution whose remaining input columns were hoisted into a per-image map (ops.Conditioning):
-    the gathered map rows enter through an identity block.  Cached on `owner` per weight version."""
+    """W[:, :keep_cols] (contiguous copy) of a 1x1 convolution whose remaining input columns were hoisted into a per-image map
+    (ops.Conditioning); the gathered map rows enter the layer as its addend.  Cached on `owner` per weight version."""
     w = conv.weight
     hit = getattr(owner, "_hoist_w", None)
     if hit is None or hit[0] != (w._version, w.data_ptr(), keep_cols):
-        M = w.shape[0]
-        w2 = w.detach().reshape(M, -1)
-        mat = torch.cat([w2[:, :keep_cols], torch.eye(M, dtype=w2.dtype, device=w2.device)], dim=1).contiguous()
-        hit = ((w._version, w.data_ptr(), keep_cols), mat)
+        hit = ((w._version, w.data_ptr(), keep_cols), w.detach().reshape(w.shape[0], -1)[:, :keep_cols].contiguous())
         owner._hoist_w = hit
     return hit[1]
 
@@ -260,13 +259,16 @@ class PVConv(nn.Module):
             # W . [xyz, F[pix]] = Wx . xyz + (F . Wf^T)[pix]: gather 32 map channels instead of convolving 390 (ops.Conditioning)
             conv = self.point_features.layers[0]
             fmap = cond.map("point_branch", conv.weight, lambda: conv.weight.detach().reshape(conv.out_channels, -1)[:, 3:3 + cond.C])
-            features = cond.gather(fmap)
+            gathered = cond.gather(fmap)                         # (B, 3 + M, N): rows 0..2 = xyz, the rest = map rows
+            features, first_add = gathered[:, :3], gathered[:, 3:]
             first_weight = hoisted_first_weight(self.point_features, conv, 3)
+        else:
+            first_add = None
 
         def run():
             if fold:
-                return self.point_features.run(features, fold_last=True, first_weight=first_weight)
-            return self.point_features.run(features, first_weight=first_weight), None
+                return self.point_features.run(features, fold_last=True, first_weight=first_weight, first_add=first_add)
+            return self.point_features.run(features, first_weight=first_weight, first_add=first_add), None
         if not (self.point_stream and features.is_cuda and features.shape[0] * features.shape[2] >= self.point_stream_min):
             pf, pending = run()
             return pf, None, pending
@@ -537,6 +539,6 @@ class PointNetFPModule(nn.Module):
                 conv = self.mlp.layers[0]
                 fmap = cond.map("fp_skip", conv.weight, lambda: conv.weight.detach().reshape(conv.out_channels, -1)[:, c_int:c_int + cond.C])
                 g = cond.gather(fmap)
-                return self.mlp.run(buf, x2=g[:, 3:], first_weight=hoisted_first_weight(self.mlp, conv, c_int)), points_coords, interpolated_temb
+                return self.mlp.run(buf, first_weight=hoisted_first_weight(self.mlp, conv, c_int), first_add=g[:, 3:]), points_coords, interpolated_temb
             return self.mlp.run(buf, x2=skip_src), points_coords, interpolated_temb
         return self.mlp.run(buf), points_coords, interpolated_temb

@@ -169,6 +169,14 @@ int bdm_pointwise_conv_gn(int b, int m, int k, int n, const float *w, int ldw, c
                           int ld_y, const void *in_partial, int in_slices, int in_groups, const float *in_gamma,
                           const float *in_beta, float in_eps, int out_groups, void *out_partial, float *amax, int amax_rows,
                           void *stream);
+/* bdm_pointwise_conv_gn with a per-element addend: y = W x' + bias + add (add (b, m, n) strided as y), statistics and amax taken
+ * over y including the addend -- the hoisted share of a layer whose other input columns were applied to the conditioning image once
+ * per trajectory (bdm_sparse_conv_rows_from_map, ops.Conditioning).  Not for the skinny shapes. */
+int bdm_pointwise_conv_gn_add(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x, int ld_x,
+                              const float *x2, long long bs_x2, int ld_x2, int k1, const float *bias, float *y, long long bs_y,
+                              int ld_y, const void *in_partial, int in_slices, int in_groups, const float *in_gamma,
+                              const float *in_beta, float in_eps, int out_groups, void *out_partial, float *amax, int amax_rows,
+                              const float *add, long long bs_add, int ld_add, void *stream);
 #ifdef BDM_EXPERIMENTAL
 /* bf16x6 form of the two entry points above (csrc/experimental/pointwise_s3.hip; measured: no faster, the GEMMs are staging-bound): the weights are split ONCE into exact bf16 triples
  * (bdm_pointwise_s3_pack_weights: packed = bdm_pointwise_s3_weight_elems(m, k) 16-bit elements), the activations while they are
