@@ -109,7 +109,8 @@ class _TorchOps(TorchDispatchMode):
             return out
         cur = torch.cuda.current_stream()
         stream = cur  # replayed on the stream it was recorded on, whatever stream is current then
-        tape.keep.extend(touched)
+        if tape.pool is None:
+            tape.keep.extend(touched)
         raw = cur.cuda_stream
         if func._schema.is_mutable:  # in-place / out= operator: the same call lands in the same (kept) tensors
             tape.calls.append((_py, (stream, func, args, kwargs)))
@@ -139,6 +140,10 @@ class _TorchOps(TorchDispatchMode):
 
 
 NATIVE = os.environ.get("BDM_TAPE_NATIVE", "1") == "1"
+# Recording inside a private memory pool (torch.cuda.MemPool, what graph capture uses): the step's intermediates are freed and
+# re-used WITHIN the step exactly as in the eager loop (cache-hot blocks), and nobody outside the tape can be handed an address of the
+# pool between replays.  Without it the tape keeps every intermediate alive (distinct buffers: measured 1 % slower per B=16 step).
+POOL = hasattr(torch.cuda, "MemPool") and hasattr(torch.cuda, "use_mem_pool")
 _U64 = (1 << 64) - 1
 
 
@@ -173,6 +178,7 @@ class LaunchTape:
         self.native = {}     # index into calls -> native form of a non-C-ABI entry: ("memset", tensor, raw stream) | ...
         self.main_stream = None
         self.handle, self.program, self.python_entries = None, None, None
+        self.pool = None     # the private memory pool the step was recorded in (owns every address the tape holds)
 
     def __len__(self):
         return len(self.calls)
@@ -275,7 +281,14 @@ class record:
         self.tape.main_stream = torch.cuda.current_stream()
         self._saved = L.lib()
         L._lib = _RecordingLib(self._saved, self.tape)
-        L._keep = self.tape.keep
+        self._pool_ctx = None
+        if POOL and torch.cuda.is_available():
+            self.tape.pool = torch.cuda.MemPool()
+            self._pool_ctx = torch.cuda.use_mem_pool(self.tape.pool)
+            self._pool_ctx.__enter__()
+            L._keep = None            # the pool owns the addresses; intermediates may be recycled inside the step, as in the eager loop
+        else:
+            L._keep = self.tape.keep  # no pool: the tape owns every buffer whose address it holds
         self._mode = _TorchOps(self.tape)
         self._mode.__enter__()
         _active = self.tape
@@ -285,6 +298,8 @@ class record:
         global _active
         _active = None
         self._mode.__exit__(et, ev, tb)
+        if self._pool_ctx is not None:
+            self._pool_ctx.__exit__(et, ev, tb)
         L._keep = None
         L._lib = self._saved
         if et is not None:
