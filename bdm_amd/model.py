@@ -249,7 +249,8 @@ GRAPH_STEPS = os.environ.get("BDM_GRAPH", "0") == "1"
 GRAPH_MIN_STEPS = 8  # shorter segments do not amortise the capture
 # BDM_TAPE: "auto" (default) replays a recorded launch tape (tape.py) for host-bound problem sizes, "1" always, "0" never.
 TAPE_STEPS = os.environ.get("BDM_TAPE", "auto")
-TAPE_MAX_POINTS = 16384  # B * N up to which "auto" takes the tape (host-bound sizes)
+TAPE_MAX_POINTS = 1 << 20  # B * N up to which "auto" takes the tape: every BASELINE.json configuration (C5: 32 x 16384).  Recorded
+# inside a private memory pool the replayed step costs the GPU what the eager step costs, and the host 1 ms instead of 5
 
 
 class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
@@ -352,8 +353,8 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
     # first one leaves every lazy cache -- weight packs, workspaces, kernel attributes -- behind it) and later steps
     # replay the flat list of C-ABI calls: ~11 us of host time per launch instead of 15-20.  The scheduler step stays
     # eager, so DDPM and DDIM, generator / noise_source draws and the per-shape Philox streams all work unchanged.
-    # Default for small problems, which are paced by the host (B * N <= TAPE_MAX_POINTS); larger ones are bound by the
-    # GPU and stay eager unless BDM_TAPE=1 (the tape keeps every intermediate buffer of a forward alive).
+    # Default for every configuration up to B * N = TAPE_MAX_POINTS: recorded inside a private memory pool (tape.py) the replay
+    # costs the GPU what the eager step costs, and the host one library call per step.
     def _denoise_loop_tape(self, x_t, camera, image_rgb, mask, scheduler, timesteps, generator=None):
         from . import tape as T
         feat, _ = self.conditioning_image(image_rgb, mask)
