@@ -254,21 +254,23 @@ class PVConv(nn.Module):
         """-> (activations, event | None, pending): with fold the LAST GroupNorm + Swish of the branch is left to the caller
         (pending = (stats, gn), activations = raw convolution output; None when the layer cannot be folded)."""
         cond = self._hoisted(features)
-        first_weight = None
-        if cond is not None and len(self.point_features.layers) == 3:
-            # W . [xyz, F[pix]] = Wx . xyz + (F . Wf^T)[pix]: gather 32 map channels instead of convolving 390 (ops.Conditioning)
-            conv = self.point_features.layers[0]
-            fmap = cond.map("point_branch", conv.weight, lambda: conv.weight.detach().reshape(conv.out_channels, -1)[:, 3:3 + cond.C])
-            gathered = cond.gather(fmap)                         # (B, 3 + M, N): rows 0..2 = xyz, the rest = map rows
-            features, first_add = gathered[:, :3], gathered[:, 3:]
-            first_weight = hoisted_first_weight(self.point_features, conv, 3)
-        else:
-            first_add = None
+        if cond is not None and len(self.point_features.layers) != 3:
+            cond = None
 
         def run():
+            x, first_weight, first_add = features, None, None
+            if cond is not None:
+                # W . [xyz, F[pix]] = Wx . xyz + (F . Wf^T)[pix]: gather 32 map channels instead of convolving 390 (ops.Conditioning).
+                # The gather runs HERE, on the branch's stream: its output is allocated on the stream that consumes it (a block of
+                # the main stream freed at return could be handed out again while the branch still reads it)
+                conv = self.point_features.layers[0]
+                fmap = cond.map("point_branch", conv.weight, lambda: conv.weight.detach().reshape(conv.out_channels, -1)[:, 3:3 + cond.C])
+                gathered = cond.gather(fmap)                         # (B, 3 + M, N): rows 0..2 = xyz, the rest = map rows
+                x, first_add = gathered[:, :3], gathered[:, 3:]
+                first_weight = hoisted_first_weight(self.point_features, conv, 3)
             if fold:
-                return self.point_features.run(features, fold_last=True, first_weight=first_weight, first_add=first_add)
-            return self.point_features.run(features, first_weight=first_weight, first_add=first_add), None
+                return self.point_features.run(x, fold_last=True, first_weight=first_weight, first_add=first_add)
+            return self.point_features.run(x, first_weight=first_weight, first_add=first_add), None
         if not (self.point_stream and features.is_cuda and features.shape[0] * features.shape[2] >= self.point_stream_min):
             pf, pending = run()
             return pf, None, pending

@@ -148,6 +148,9 @@ SPEC = {
 }
 
 
+PROBE_WEIGHT = [1]  # launches one profiled launch stands for (the tape loop profiles every k-th step only: model._denoise_loop_tape)
+
+
 def _plain(v):
     return v.value if hasattr(v, "value") else v
 
@@ -159,7 +162,7 @@ class _Proxy:
     def __getattr__(self, name):
         fn = getattr(self._h, name)
         host_only = (not name.startswith("bdm_") or name.endswith("_bytes") or name.endswith("_elems") or name.endswith("_slices")
-                     or name in ("bdm_last_error", "bdm_abi_version"))
+                     or name in ("bdm_last_error", "bdm_abi_version") or name.startswith("bdm_tape_"))
         if host_only:
             return fn
         spec = SPEC.get(name, ("other", lambda a: (), None))
@@ -173,8 +176,9 @@ class _Proxy:
             except (TypeError, ValueError):
                 sig = ()
             row = prof.rows[(name, sig)]
-            row[0] += 1
-            if row[0] % prof.every:
+            row[0] += PROBE_WEIGHT[0]
+            row[2] += 1
+            if row[2] % prof.every:
                 return fn(*args)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -195,7 +199,7 @@ class _Proxy:
 class KernelClassProfiler:
     def __init__(self, every=8):
         self.every, self.enabled = int(every), False
-        self.rows = collections.defaultdict(lambda: [0, []])  # (name, sig) -> [calls, [(e0, e1, cost)]]
+        self.rows = collections.defaultdict(lambda: [0, [], 0])  # (name, sig) -> [launches stood for, [(e0, e1, cost)], calls seen]
         self._saved = None
 
     def install(self):
@@ -214,7 +218,7 @@ class KernelClassProfiler:
     def table(self):
         """(rows, classes): rows = per (function, shape) dicts, classes = per kernel class dicts sorted by time share."""
         rows = []
-        for (name, sig), (calls, samples) in self.rows.items():
+        for (name, sig), (calls, samples, _) in self.rows.items():
             if not samples:
                 continue
             ms = [e0.elapsed_time(e1) for e0, e1, _ in samples]

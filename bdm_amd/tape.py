@@ -143,7 +143,8 @@ NATIVE = os.environ.get("BDM_TAPE_NATIVE", "1") == "1"
 # Recording inside a private memory pool (torch.cuda.MemPool, what graph capture uses): the step's intermediates are freed and
 # re-used WITHIN the step exactly as in the eager loop (cache-hot blocks), and nobody outside the tape can be handed an address of the
 # pool between replays.  Without it the tape keeps every intermediate alive (distinct buffers: measured 1 % slower per B=16 step).
-POOL = hasattr(torch.cuda, "MemPool") and hasattr(torch.cuda, "use_mem_pool")
+POOL = (hasattr(torch.cuda, "MemPool") and hasattr(torch.cuda, "use_mem_pool")
+        and os.environ.get("BDM_TAPE_POOL", "1") == "1")
 _U64 = (1 << 64) - 1
 
 
@@ -280,7 +281,10 @@ class record:
         self.tape = LaunchTape()
         self.tape.main_stream = torch.cuda.current_stream()
         self._saved = L.lib()
-        L._lib = _RecordingLib(self._saved, self.tape)
+        base = self._saved
+        while "_h" in getattr(base, "__dict__", {}):  # a profiling proxy (profiling.KernelClassProfiler): the tape holds the library's
+            base = base.__dict__["_h"]                # own entry points; profiled steps are the caller's eager ones
+        L._lib = _RecordingLib(base, self.tape)
         self._pool_ctx = None
         if POOL and torch.cuda.is_available():
             self.tape.pool = torch.cuda.MemPool()

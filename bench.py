@@ -270,9 +270,10 @@ def main():
     for _ in range(args.warmup):
         trajectory()
 
-    model.eager_probe_every = 50  # only with BDM_GRAPH=1: every 50th step runs eagerly so that single launches can be timed
+    model.eager_probe_every = 50  # replayed loops (launch tape, BDM_GRAPH=1): every 50th step runs eagerly so that single launches
+                                  # can be timed; the profiler counts each of its launches 50 times (profiling.PROBE_WEIGHT)
     from bdm_amd.profiling import KernelClassProfiler
-    prof = KernelClassProfiler(every=32).install()
+    prof = KernelClassProfiler(every=4).install()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
