@@ -66,11 +66,25 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   return ab > cd ? ab : cd;
 }
 
-template <int PPT>
-__global__ void fps_kernel(int n, int m, const float *__restrict__ coords, int *__restrict__ indices,
-                           float *__restrict__ centers_out, int use_lds) {
+// Round of the register-resident sampler, T threads x PPT points (T * PPT >= n):
+//   * ownership is laid out so that a thread's points come in INCREASING rank: the per-thread best is "max distance bits,
+//     first such i" (max3 + one compare/select per point) instead of a lexicographic (distance, rank) compare per point;
+//   * distances two points at a time (float2 arithmetic -> v_pk_add_f32 / v_pk_mul_f32, no contraction: bit-equal to the scalar
+//     (dx*dx + dy*dy) + dz*dz of the oracle);
+//   * 64-lane max of the distance bits, then the rank of the winner by BALLOT: one lane holds the maximum in all but
+//     degenerate rounds (equal distances), so a readlane replaces the second 64-lane reduction; ties take the reduction;
+//   * <= 4 waves: every thread reads all wave slots and folds them in a pairwise tree of 64-bit keys (no second DPP reduction);
+//   * the centre of round j-1 is written by thread 0 at the top of round j, from the coordinates every thread has just read.
+template <int T, int PPT, bool use_lds>
+__global__ __launch_bounds__(T) void fps_kernel(int n, int m, const float *__restrict__ coords, int *__restrict__ indices,
+                                                float *__restrict__ centers_out) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+  constexpr int NW = T / 64;
+  constexpr int H = T >= 512 ? 1 : 512 / T;   // T < 512: a thread owns (k mod 512) = tid + T*h, h < H
+  constexpr int J = PPT / H;                  // ... and k div 512 = j (T >= 512: k = tid + T*i)
+  static_assert(PPT % H == 0 && PPT % 2 == 0, "points per thread: a multiple of 2 and of 512 / T");
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float *cx = coords + (size_t)blockIdx.x * 3 * n, *cy = cx + n, *cz = cy + n;
   int *out = indices + (size_t)blockIdx.x * m;
   float *cen = centers_out ? centers_out + (size_t)blockIdx.x * 3 * m : nullptr;
@@ -82,67 +96,96 @@ __global__ void fps_kernel(int n, int m, const float *__restrict__ coords, int *
   const unsigned Q = (unsigned)((n + 511) / 512);
   const bool q_pow2 = (Q & (Q - 1u)) == 0u;
   const unsigned q_shift = (unsigned)__ffs((int)Q) - 1u;
-  float px[PPT], py[PPT], pz[PPT], dist[PPT];
-  unsigned inv_rank[PPT];
+  auto point_of = [&](int i) -> int { return T >= 512 ? tid + T * i : tid + T * (i / J) + 512 * (i % J); };
+  f2 px[PPT / 2], py[PPT / 2], pz[PPT / 2];
+  unsigned dist[PPT];  // running minimum as BITS: squared distances are >= +0, so their bits order like unsigned integers
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
-    const int k = tid + i * T;
+    const int k = point_of(i);
+    float x = 0.f, y = 0.f, z = 0.f;
+    dist[i] = 0u;  // a slot beyond n: distance 0 for ever, and point 0 (rank 0) wins every all-zero round
     if (k < n) {
-      px[i] = cx[k]; py[i] = cy[k]; pz[i] = cz[k];
-      if (use_lds) { sx[k] = px[i]; sy[k] = py[i]; sz[k] = pz[i]; }
-      inv_rank[i] = 0xFFFFFFFFu - ((unsigned)(k & 511) * Q + (unsigned)(k >> 9));
-    } else {
-      px[i] = py[i] = pz[i] = 0.f;
-      inv_rank[i] = 0u;  // never wins
+      x = cx[k]; y = cy[k]; z = cz[k];
+      if (use_lds) { sx[k] = x; sy[k] = y; sz[k] = z; }
+      dist[i] = __float_as_uint(1e38f);  // sampling.cpp:53-54
     }
-    dist[i] = 1e38f;  // sampling.cpp:53-54
+    px[i >> 1][i & 1] = x; py[i >> 1][i & 1] = y; pz[i >> 1][i & 1] = z;
   }
-  if (tid == 0) {
-    out[0] = 0;
-    if (cen) { cen[0] = cx[0]; cen[m] = cy[0]; cen[2 * m] = cz[0]; }
-  }
+  if (tid == 0) out[0] = 0;
   __syncthreads();
 
   int cur = 0;
-  for (int j = 1; j < m; ++j) {
+  for (int j = 1; j <= m; ++j) {
     float x1, y1, z1;
     if (use_lds) { x1 = sx[cur]; y1 = sy[cur]; z1 = sz[cur]; }
     else { x1 = cx[cur]; y1 = cy[cur]; z1 = cz[cur]; }
-    // per-thread best under the order (distance, ~rank); distances are >= 0 so their bits order like unsigned ints
-    unsigned bd = 0u, br = 0u;
+    if (tid == 0 && cen) { cen[j - 1] = x1; cen[m + j - 1] = y1; cen[2 * m + j - 1] = z1; }
+    if (j == m) break;
+    const f2 qx = {x1, x1}, qy = {y1, y1}, qz = {z1, z1};
+    unsigned bd = 0u;
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const float d = sqdist3(px[i], py[i], pz[i], x1, y1, z1);
-      const float d2 = fminf(d, dist[i]);
-      dist[i] = d2;
-      const unsigned db = inv_rank[i] ? __float_as_uint(d2) : 0u;
-      const bool better = db > bd || (db == bd && inv_rank[i] > br);
-      bd = better ? db : bd;
-      br = better ? inv_rank[i] : br;
+    for (int i = 0; i < PPT / 2; ++i) {
+      const f2 dx = px[i] - qx, dy = py[i] - qy, dz = pz[i] - qz;
+      const f2 d = (dx * dx + dy * dy) + dz * dz;
+      const unsigned a = min(__float_as_uint(d[0]), dist[2 * i]), b = min(__float_as_uint(d[1]), dist[2 * i + 1]);
+      dist[2 * i] = a;
+      dist[2 * i + 1] = b;
+      const unsigned ab = a > b ? a : b;
+      bd = bd > ab ? bd : ab;
     }
-    unsigned wd = wave_max_u32(bd);
-    unsigned wr = wave_max_u32(bd == wd ? br : 0u);
-    if (nwaves > 1) {
+    int bi = PPT - 1;
+#pragma unroll
+    for (int i = PPT - 2; i >= 0; --i) bi = dist[i] == bd ? i : bi;  // first (= best-ranked) point at the maximum
+    const unsigned k = (unsigned)point_of(bi);
+    const unsigned br = 0xFFFFFFFFu - ((k & 511u) * Q + (k >> 9));
+    unsigned wd = wave_max_u32(bd), wr;
+    {
+      const unsigned long long hit = __ballot(bd == wd);
+      if ((hit & (hit - 1ull)) == 0ull) wr = (unsigned)__builtin_amdgcn_readlane((int)br, (int)__builtin_ctzll(hit));
+      else wr = wave_max_u32(bd == wd ? br : 0u);
+    }
+    if (NW > 1) {
       uint2 *slot = slots + (j & 1) * 16;
       if (lane == 0) slot[wave] = make_uint2(wd, wr);
       __syncthreads();
-      const uint2 sv = lane < nwaves ? slot[lane] : make_uint2(0u, 0u);
-      wd = wave_max_u32(sv.x);
-      wr = wave_max_u32(sv.x == wd ? sv.y : 0u);
+      if (NW <= 4) {
+        // every thread folds all wave slots: (distance bits, ~rank) as one 64-bit key, pairwise tree (independent compares)
+        unsigned long long key[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w += 2) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(slot + w);
+          key[w] = ((unsigned long long)v.x << 32) | v.y;
+          key[w + 1] = ((unsigned long long)v.z << 32) | v.w;
+        }
+#pragma unroll
+        for (int span = 1; span < NW; span *= 2)
+#pragma unroll
+          for (int w = 0; w + span < NW; w += 2 * span) key[w] = key[w] > key[w + span] ? key[w] : key[w + span];
+        wd = (unsigned)(key[0] >> 32);
+        wr = (unsigned)key[0];
+      } else {
+        const uint2 sv = lane < NW ? slot[lane] : make_uint2(0u, 0u);
+        wd = wave_max_u32(sv.x);
+        const unsigned long long hit = __ballot(sv.x == wd && lane < NW);
+        if ((hit & (hit - 1ull)) == 0ull) wr = (unsigned)__builtin_amdgcn_readlane((int)sv.y, (int)__builtin_ctzll(hit));
+        else wr = wave_max_u32((sv.x == wd && lane < NW) ? sv.y : 0u);
+      }
     }
     const unsigned rank = 0xFFFFFFFFu - wr;
     // rank -> point index; Q is a power of two for the usual sizes: shifts instead of two integer divisions per round
     cur = q_pow2 ? (int)(((rank & (Q - 1u)) << 9) + (rank >> q_shift)) : (int)((rank % Q) * 512u + rank / Q);
-    if (tid == 0) {
-      out[j] = cur;
-      if (cen) {
-        float ox, oy, oz;
-        if (use_lds) { ox = sx[cur]; oy = sy[cur]; oz = sz[cur]; }
-        else { ox = cx[cur]; oy = cy[cur]; oz = cz[cur]; }
-        cen[j] = ox; cen[m + j] = oy; cen[2 * m + j] = oz;
-      }
-    }
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    if (tid == 0) out[j] = cur;
   }
+}
+
+// Threads per shape, measured at B = 16 on MI355X (us per call, round 3): n=4096,m=1024: 128 thr 981 | 256: 711 | 512: 705 | 1024: 780
+// (round 2's 1024 x 4 kernel: 1130); n=1024,m=256: 64: 143 | 128: 128 | 256: 124 | 512: 158 (round 2: 197); n=8192: 512: 973 | 1024: 988.
+static int fps_threads(int n) {
+  if (n <= 128) return 64;
+  if (n <= 2048) return 256;
+  if (n <= 8192) return 512;
+  return 1024;
 }
 
 extern "C" int bdm_furthest_point_sampling(int b, int n, int m, const float *coords, int *indices,
@@ -151,27 +194,28 @@ extern "C" int bdm_furthest_point_sampling(int b, int n, int m, const float *coo
   BDM_REQUIRE(n <= 16384, "fps: n=%d exceeds the 16384-point limit of the register-resident sampler", n);
   if (b == 0 || m == 0) return BDM_OK;
   hipStream_t s = (hipStream_t)stream;
-  int ppt = 1;
-  if (n >= 256) ppt = 4;
-  while ((n + ppt - 1) / ppt > 1024) ppt *= 2;
-  int T = ((n + ppt - 1) / ppt + 63) / 64 * 64;
-  const int use_lds = n <= 12288;
+  int T = fps_threads(n);
+  int ppt = T >= 512 ? 2 : 2 * (512 / T);  // smallest legal count: even, a multiple of 512 / T
+  while ((long long)T * ppt < n) ppt *= 2;
+  const bool use_lds = n <= 12288;
   const size_t smem = 2 * 16 * sizeof(uint2) + (use_lds ? (size_t)3 * n * sizeof(float) : 0);
-#define FPS_LAUNCH(P)                                                                                   \
-  do {                                                                                                  \
-    BDM_ALLOW_LDS(fps_kernel<P>, smem);                                                                 \
-    hipLaunchKernelGGL(fps_kernel<P>, dim3(b), dim3(T), smem, s, n, m, coords, indices, centers_out,    \
-                       use_lds);                                                                        \
-  } while (0)
-  switch (ppt) {
-    case 1: FPS_LAUNCH(1); break;
-    case 4: FPS_LAUNCH(4); break;
-    case 8: FPS_LAUNCH(8); break;
-    case 16: FPS_LAUNCH(16); break;
-    default: set_error("fps: unsupported points-per-thread %d", ppt); return BDM_ERR_UNSUPPORTED;
+#define FPS_LAUNCH_(TT, P, LDS)                                                                          \
+  if (T == TT && ppt == P && use_lds == LDS) {                                                          \
+    BDM_ALLOW_LDS((fps_kernel<TT, P, LDS>), smem);                                                      \
+    hipLaunchKernelGGL((fps_kernel<TT, P, LDS>), dim3(b), dim3(TT), smem, s, n, m, coords, indices,     \
+                       centers_out);                                                                    \
+    return launch_status("fps");                                                                        \
   }
+#define FPS_LAUNCH(TT, P) FPS_LAUNCH_(TT, P, true)
+  FPS_LAUNCH(64, 16) FPS_LAUNCH(64, 32)
+  FPS_LAUNCH(128, 8) FPS_LAUNCH(128, 16) FPS_LAUNCH(128, 32)
+  FPS_LAUNCH(256, 4) FPS_LAUNCH(256, 8) FPS_LAUNCH(256, 16) FPS_LAUNCH(256, 32)
+  FPS_LAUNCH(512, 2) FPS_LAUNCH(512, 4) FPS_LAUNCH(512, 8) FPS_LAUNCH(512, 16) FPS_LAUNCH(512, 32)
+  FPS_LAUNCH(1024, 2) FPS_LAUNCH(1024, 4) FPS_LAUNCH(1024, 8) FPS_LAUNCH(1024, 16) FPS_LAUNCH_(1024, 16, false)
 #undef FPS_LAUNCH
-  return launch_status("fps");
+#undef FPS_LAUNCH_
+  set_error("fps: no kernel for %d threads x %d points per thread (n=%d)", T, ppt, n);
+  return BDM_ERR_UNSUPPORTED;
 }
 
 // =====================================================================================

@@ -375,8 +375,9 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
         g["x"].copy_(x_t)
         probe = int(getattr(self, "eager_probe_every", 0))  # bench.py: every k-th step runs eagerly, through the kernel-class
         from . import profiling                               # profiler (HIP events around single launches inside the timed loop)
-        for i, t in enumerate(timesteps):
+        for t in timesteps:
             g["t"].fill_(t)
+            g["steps"] = i = g.get("steps", -1) + 1  # counted across calls: the samplers run the loop in segments of 32 ... 744 steps
             if g["tape"] is not None and probe and i % probe == probe - 1:
                 profiling.PROBE_WEIGHT[0] = probe
                 try:

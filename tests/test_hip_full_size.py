@@ -103,3 +103,36 @@ def test_a_shape_does_not_see_its_batch_mates(hip):
         for s in range(3):
             alone = net(wild[s:s + 1].contiguous().cuda(), t[s:s + 1].cuda()).cpu()
             assert rel_l2(alone, got[s:s + 1]) <= TOL_BATCH, (cls.__name__, s, rel_l2(alone, got[s:s + 1]))
+
+
+def test_recorded_step_equals_eager_loop_at_the_bench_batch(hip, monkeypatch):
+    """The launch tape (default for every BASELINE configuration: model.TAPE_MAX_POINTS) replays the step out of a PRIVATE memory
+    pool, i.e. with the block re-use of the eager loop but a host that runs ahead: a buffer allocated on one stream and read on
+    another after its last Python reference is gone shows up here as a difference (the hoisted point-branch gather did, at
+    B = 16 only).  Blending at B = 16, N = 4096 over two real segments (64 PC^2 steps, 16 PVD steps, one blend): bit-equal."""
+    from bdm_amd import model as M
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.model import get_model
+    from bdm_amd.pvd import prepare_pvd_model
+    from bdm_amd.sampling import batch_streams, bdm_blending
+    from bdm_amd.utils.procedural import fill_module_
+    dev = torch.device("cuda", 0)
+    cfg = ProjectConfig()
+    cfg.dataset.max_points, cfg.aux_run.roll_step, cfg.aux_run.milestones, cfg.run.rng = 4096, 16, [1000, 968, 936], "per_shape"
+    model = fill_module_(get_model(cfg).eval(), seed=cfg.run.seed).to(dev)
+    with pytest.warns(UserWarning, match="PROCEDURAL"):
+        pvd = prepare_pvd_model({"model": None, "nc": 3, "embed_dim": 64, "attention": True, "dropout": 0.1}, dev)
+    batch = next(iter(SyntheticShapes(list(range(16)), 16, seed=cfg.run.seed, image_size=224, num_points=4096))).to(dev)
+
+    def run(mode):
+        monkeypatch.setattr(M, "TAPE_STEPS", mode)
+        model._cond_cache = None
+        return bdm_blending(None, batch, cfg, model, pvd, streams=batch_streams(cfg, batch, dev, sample_idx=1)).points_padded().clone()
+
+    eager = run("0")
+    for _ in range(2):
+        taped = run("auto")
+        g = model._tape_cache
+        assert g["tape"] is not None and g["off"] is None and g["tape"].python_entries <= 4
+        assert torch.isfinite(taped).all() and torch.equal(taped, eager)

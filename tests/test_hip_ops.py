@@ -29,6 +29,18 @@ def test_fps_bit_exact(hip, oracle_ops, n, m):
     assert torch.equal(ref, got)
 
 
+@pytest.mark.parametrize("n,m", [(4096, 300), (1024, 256), (700, 200), (130, 130), (2049, 64), (5000, 40), (12289, 24)])
+def test_fps_lattice_ties_bit_exact(hip, oracle_ops, n, m):
+    """Points on a coarse integer lattice: most rounds have MANY points at exactly the same distance (and duplicates: m exceeds
+    the number of distinct points in the small cases, so the all-zero rounds are covered).  The winner must follow the
+    reference's (k mod 512, k) preference whatever thread / wave / register slot of the sampler owns the point."""
+    g = torch.Generator().manual_seed(n * 31 + m)
+    pts = torch.randint(-2, 3, (2, 3, n), generator=g).float() * 0.25
+    ref = oracle_ops.furthest_point_sampling(pts, m)
+    got = hip.furthest_point_sampling(pts.cuda(), m).cpu()
+    assert torch.equal(ref, got)
+
+
 def test_fps_tie_rule_known_answer(hip):
     n = 1024
     c = torch.zeros(1, 3, n)

@@ -9,7 +9,7 @@ def t(fn, n=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for n, m in [(4096, 1024), (1024, 256), (256, 64), (8192, 1024), (16384, 1024)]:
+for n, m in [(4096, 1024), (1024, 256), (256, 64), (64, 16), (8192, 1024), (16384, 1024)]:
     pts = torch.randn(16, 3, n).cuda()
     us = t(lambda: F.furthest_point_sample(pts, m))
-    print(f"N={n} M={m}: {us:8.1f} us  ({us / (m - 1) * 1e3:6.0f} ns / round)")
+    print(f"N={n} M={m}: {us:8.1f} us ({us / (m - 1) * 1e3:5.0f} ns/round)")
