@@ -1,5 +1,6 @@
 // Shared helpers for the gfx950 kernels of libbdm_hip.so.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -38,6 +39,14 @@ inline int launch_status(const char *what) {
 // Raise a kernel's dynamic-LDS ceiling (up to the CU's 160 KiB); not a stream operation.  The attribute is sticky per
 // (kernel, device), and hipFuncSetAttribute is a slow driver call (measured ~0.2 ms: at one call per launch it made every
 // big-LDS kernel host-bound), so each expansion site remembers the size it has already granted on each device.
+// BDM_STAGING (read per call: the equality tests flip it): "0" keeps the global-memory / one-workgroup forms of the three kernels
+// that have an LDS-staged form (devoxelisation gather, sparse feature gather, 32^3 voxel plan in slabs), "1" forces the staged
+// form wherever it fits; unset = the measured per-shape choice.  -> -1 (unset), 0, 1
+inline int bdm_staging_choice() {
+  const char *e = getenv("BDM_STAGING");
+  return (e == nullptr || e[0] == 0) ? -1 : (e[0] == '0' ? 0 : 1);
+}
+
 #define BDM_ALLOW_LDS(kernel, bytes)                                                                      \
   do {                                                                                                    \
     if ((bytes) > 48 * 1024) {                                                                            \

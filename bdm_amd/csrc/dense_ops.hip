@@ -1661,14 +1661,13 @@ static int devox_gn_launch(int b, int c, int n, int r, const float *coords, cons
   BDM_REQUIRE(b >= 0 && c >= 1 && n >= 1 && r >= 1 && coef != nullptr, "devoxelize_gn_gate_add: bad arguments");
   BDM_REQUIRE(se_mean == nullptr || (hidden >= 1 && hidden <= 64 && w1 != nullptr && w2 != nullptr), "devoxelize_gn_se_add: bad SE arguments");
   if (b == 0) return BDM_OK;
-  const char *lsel = getenv("BDM_DEVOX_LDS");  // BDM_DEVOX_LDS=0 keeps the global-memory gather (read per call: tests flip it)
+  const int lsel = bdm_staging_choice();  // BDM_STAGING=0 keeps the global-memory gather, =1 forces the LDS form (common.h)
   const int r3 = r * r * r;
   // measured per shape at B = 16 (tools/forward_rows.py): the LDS form wins at 16^3 (29.5 -> 21.9 us) and at 32^3 with >= 64
   // channels (70.5 -> 64.8 us); at 8^3 and for the 32-channel 32^3 layers it has too few workgroups and loses.
-  // BDM_DEVOX_LDS=1 forces it for every shape that fits (tests), =0 disables it.
   const bool lds_fits = se_mean == nullptr && (r3 & 3) == 0 && r3 <= 32768 && ((reinterpret_cast<size_t>(grid) & 15) == 0);
   const bool lds_pays = r == 16 || (r == 32 && (long long)b * c >= 1024);
-  if (lds_fits && !(lsel && lsel[0] == '0') && (lds_pays || (lsel && lsel[0] == '1'))) {
+  if (lds_fits && lsel != 0 && (lds_pays || lsel == 1)) {
     int cpw = 8192 / r3;  // channels per workgroup: 32 KB of LDS for the small grids, one channel (128 KB) at 32^3
     cpw = cpw < 1 ? 1 : (cpw > c ? c : cpw);
     const size_t smem = sizeof(float) * (size_t)cpw * r3;

@@ -1,4 +1,4 @@
-// experimental/pointwise_s3.hip (built with `make EXPERIMENTAL=1` only; opt-in at run time with BDM_PW=bf16x6).  MEASURED (round 3, B = 16,
+// experimental/pointwise_s3.hip (built with `make EXPERIMENTAL=1` only; opt-in at run time with ops.PW_IMPL = "bf16x6").  MEASURED (round 3, B = 16,
 // tools/forward_rows.py): no gain over the fp32-MFMA kernel -- 1272 vs 1271 us per forward over the 38 GEMMs; +7 % on the long-K layer
 // (128 x 579 x 4096: 120 -> 112 us), slower on the narrow ones (32 x 390 x 4096: 49 -> 73 us).  The 1x1 GEMMs are bound by operand
 // staging (global -> LDS) and not by the matrix pipe, so 2.7x the matrix rate buys nothing.  Kept as a negative result.

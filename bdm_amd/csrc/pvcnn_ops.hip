@@ -835,11 +835,8 @@ __global__ void vox_reduce_kernel(int c, int n, int r3, const float *__restrict_
   }
 }
 
-// BDM_VOX_PLAN_SLABS=0 keeps the one-workgroup-per-shape plan kernel at 32^3 (read per call: tests flip it)
-static bool vox_plan_slabs() {
-  const char *e = getenv("BDM_VOX_PLAN_SLABS");
-  return !(e && e[0] == '0');
-}
+// BDM_STAGING=0 keeps the one-workgroup-per-shape plan kernel at 32^3 (common.h)
+static bool vox_plan_slabs() { return bdm_staging_choice() != 0; }
 
 extern "C" int bdm_voxelize_plan(int b, int n, int r, const int *coords, int *ind, int *cnt, void *workspace,
                                  void *stream) {

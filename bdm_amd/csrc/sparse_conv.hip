@@ -294,8 +294,7 @@ __global__ __launch_bounds__(1024) void sparse_vox_features_lds_kernel(int c, in
 bool bdm_sparse_features_lds_launch(int out_kind, int b, int c, int n, int r3, int n_max, const float *features, long long bs_f,
                                     int ld_f, const int *cnt, const int *start, const int *sorted, const int *occ_list,
                                     const int *n_occ, void *out, unsigned *amax, hipStream_t stream, int *rc) {
-  const char *sel = getenv("BDM_FEATURES_LDS");  // BDM_FEATURES_LDS=0 keeps the global-memory gather (read per call: tests flip it)
-  if ((sel && sel[0] == '0') || n > 4096 || n_max > 4096) return false;
+  if (bdm_staging_choice() == 0 || n > 4096 || n_max > 4096) return false;  // BDM_STAGING=0 keeps the global-memory gather (common.h)
   const int G = (c + 7) / 8, units = b * G;
   // workgroups per unit: every extra one refills the rows, which costs more than the parallelism gains (measured: 32-channel
   // layer at 32^3, 8 slices: 132 -> 207 us)

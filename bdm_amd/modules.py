@@ -227,11 +227,11 @@ class PVConv(nn.Module):
 
     # The point branch (1x1 conv + GroupNorm + Swish on the N points) does not depend on the voxel branch: it is enqueued on
     # a second stream and joined before the devoxelisation adds it, so its small, latency-bound kernels run beside the
-    # voxel convolutions instead of after them (BDM_POINT_STREAM=0: serial).
+    # voxel convolutions instead of after them (point_stream = False: serial).
     se_in_devox = False  # SE block's FC layers inside the devoxelisation kernel: measured slower (DESIGN.md negative results)
     fold_gn1 = True  # GroupNorm-1 statistics from the sparse gather's epilogue
     fold_pf = True  # point branch's GroupNorm folded into the devoxelisation kernel
-    point_stream = os.environ.get("BDM_POINT_STREAM", "1") == "1"
+    point_stream = True  # the point branch of a PVConv on its own stream (False: inline; tests and tools/two_proc_race.py flip it)
     point_stream_min = 8192  # B * N below which the branch stays on the main stream
     _streams = {}
 

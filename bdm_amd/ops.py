@@ -60,7 +60,7 @@ def workspace(nbytes, device, tag="ws"):
 # products on the 16-bit matrix pipe (csrc/experimental/pointwise_s3.hip, EXPERIMENTAL=1 builds only).  Measured at B = 16: no
 # faster (the GEMMs are bound by operand staging, not by the matrix pipe), so it stays opt-in.  The skinny shapes (<= 64 columns,
 # K >= 128) keep their K-split fp32 kernel either way.
-PW_IMPL = os.environ.get("BDM_PW", "fp32")
+PW_IMPL = "fp32"  # "bf16x6": experimental build only (tests / tools/pw_bench.py set it)
 PW_S3_MIN_COLUMNS = 65   # shapes with fewer columns per shape stay on the fp32 kernels (latency-bound: nothing to gain)
 _pw_s3_packs = {}
 

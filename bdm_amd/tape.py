@@ -143,8 +143,7 @@ NATIVE = os.environ.get("BDM_TAPE_NATIVE", "1") == "1"
 # Recording inside a private memory pool (torch.cuda.MemPool, what graph capture uses): the step's intermediates are freed and
 # re-used WITHIN the step exactly as in the eager loop (cache-hot blocks), and nobody outside the tape can be handed an address of the
 # pool between replays.  Without it the tape keeps every intermediate alive (distinct buffers: measured 1 % slower per B=16 step).
-POOL = (hasattr(torch.cuda, "MemPool") and hasattr(torch.cuda, "use_mem_pool")
-        and os.environ.get("BDM_TAPE_POOL", "1") == "1")
+POOL = hasattr(torch.cuda, "MemPool") and hasattr(torch.cuda, "use_mem_pool")  # (tools/tape_check.py --no-pool flips it)
 _U64 = (1 << 64) - 1
 
 

@@ -604,9 +604,9 @@ def test_sparse_feature_gather_from_lds_equals_global_gather(ops, monkeypatch, c
     plan = ops.voxel_plan(c, r)
     for pack in (ops.sparse_conv_pack_s3, ops.sparse_conv_pack_h2):
         wt = pack(w)
-        monkeypatch.setenv("BDM_FEATURES_LDS", "0")
+        monkeypatch.setenv("BDM_STAGING", "0")
         ref = ops.sparse_first_conv_planned(f, plan, wt, b, cout).clone()
-        monkeypatch.delenv("BDM_FEATURES_LDS")
+        monkeypatch.delenv("BDM_STAGING")
         got = ops.sparse_first_conv_planned(f, plan, wt, b, cout)
         assert torch.equal(got, ref)
 
@@ -621,9 +621,9 @@ def test_devoxelisation_from_lds_equals_global_gather(ops, monkeypatch, cin, cou
     g = torch.Generator().manual_seed(n)
     f, c = torch.randn(3, cin, n, generator=g).cuda(), (torch.randn(3, 3, n, generator=g) * 0.3).cuda()
     t = torch.zeros(3, 8, n, device="cuda")
-    monkeypatch.setenv("BDM_DEVOX_LDS", "0")
+    monkeypatch.setenv("BDM_STAGING", "0")
     ref = pv((f, c, t))[0].clone()
-    monkeypatch.setenv("BDM_DEVOX_LDS", "1")     # forced for every shape (the default picks it where it is faster)
+    monkeypatch.setenv("BDM_STAGING", "1")     # forced for every shape (the default picks it where it is faster)
     assert torch.equal(pv((f, c, t))[0], ref)
 
 

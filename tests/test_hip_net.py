@@ -106,7 +106,7 @@ def test_pc2_vs_oracle_fresh_inputs(hip, oracle_ops, N, B):
     ("fp16x3", "sparse_s3", "bf16x6", True), ("bf16x6", "sparse_s3", "bf16x6", False), ("bf16x6", "sparse", "bf16x6", True),
     pytest.param("fp32", "sparse", "fp32", True, marks=experimental), pytest.param("bf16x6", "sparse", "fp32", False, marks=experimental)])
 def test_arithmetic_and_stream_modes_all_match_the_golden(hip, monkeypatch, conv, sparse_gemm, attention, point_stream):
-    """every selectable kernel family (BDM_CONV / BDM_SPARSE_GEMM / BDM_ATTENTION / BDM_POINT_STREAM) reproduces the reference."""
+    """every selectable kernel family (BDM_CONV / BDM_SPARSE_GEMM / BDM_ATTENTION / PVConv.point_stream) reproduces the reference."""
     from bdm_amd import ops
     from bdm_amd.modules import PVConv
     from bdm_amd.pvcnn import PVCNN2_PVD

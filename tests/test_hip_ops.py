@@ -214,7 +214,7 @@ def test_voxel_plan_eight_slab_kernel_equals_one_workgroup_kernel(monkeypatch, n
     fields = ("vox_coords", "ind", "cnt", "occ_index", "n_occ", "rowocc")
     plans = []
     for flag in ("0", "1"):
-        monkeypatch.setenv("BDM_VOX_PLAN_SLABS", flag)
+        monkeypatch.setenv("BDM_STAGING", flag)
         ops.clear_plan_cache()
         p = ops.voxel_plan(coords, 32)
         torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 """Does the launch tape reproduce the eager loop on a (short) C2 blending trajectory?  Prints max |tape - eager| for a few
-setups.  Usage: python tools/tape_check.py [--batch 16] [--points 4096] [--profiler]   (env: BDM_TAPE_POOL, BDM_TAPE_NATIVE, BDM_HOIST)"""
+setups.  Usage: python tools/tape_check.py [--batch 16] [--points 4096] [--profiler] [--no-pool]   (env: BDM_TAPE_NATIVE, BDM_HOIST)"""
 import argparse
 import os
 import sys
@@ -13,9 +13,12 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--profiler", action="store_true")
+    ap.add_argument("--no-pool", action="store_true")
     ap.add_argument("--milestones", type=str, default="1000,968,936")
     args = ap.parse_args()
-    from bdm_amd import model as M, ops
+    from bdm_amd import model as M, ops, tape
+    if args.no_pool:
+        tape.POOL = False
     from bdm_amd.config import ProjectConfig
     from bdm_amd.data import SyntheticShapes
     from bdm_amd.model import get_model

@@ -17,8 +17,8 @@ run_single() {
 run_single "baseline" X=1
 run_pair "baseline" X=1
 run_pair "sampler chain inline (BDM_SIDE_STREAM=0)" BDM_SIDE_STREAM=0
-run_pair "all inline (BDM_SIDE_STREAM=0 BDM_POINT_STREAM=0 BDM_SIDE_PLAN=0)" BDM_SIDE_STREAM=0 BDM_POINT_STREAM=0 BDM_SIDE_PLAN=0
-run_pair "voxel plans on main only (BDM_SIDE_PLAN=0)" BDM_SIDE_PLAN=0
+run_pair "all inline (BDM_SIDE_STREAM=0 RACE_POINT_STREAM=0 RACE_SIDE_PLAN=0)" BDM_SIDE_STREAM=0 RACE_POINT_STREAM=0 RACE_SIDE_PLAN=0
+run_pair "voxel plans on main only (RACE_SIDE_PLAN=0)" RACE_SIDE_PLAN=0
 run_pair "device sync after every operator (RACE_SYNC=1)" RACE_SYNC=1
 run_pair "no caching allocator (PYTORCH_NO_CUDA_MEMORY_CACHING=1)" PYTORCH_NO_CUDA_MEMORY_CACHING=1
 run_pair "PC2 denoiser" RACE_MODEL=pc2

@@ -6,8 +6,8 @@ output differs it prints: the operator, which elements differ (shape, index rang
 and where else in the first repetition's outputs the bad bytes occur (a stale or foreign buffer shows up there).
 
 Run two copies at the same time on one GPU (tools/two_proc_matrix.sh) under different switches:
-   BDM_SIDE_STREAM=0   sampler chain inline (no second stream)      BDM_POINT_STREAM=0   PVConv point branch inline
-   BDM_SIDE_PLAN=0     voxel plans on the main stream               RACE_SYNC=1          device-wide sync after every operator
+   BDM_SIDE_STREAM=0   sampler chain inline (no second stream)      RACE_POINT_STREAM=0  PVConv point branch inline
+   RACE_SIDE_PLAN=0    voxel plans on the main stream               RACE_SYNC=1          device-wide sync after every operator
    RACE_MODEL=pc2|pvd  which denoiser                               RACE_B / RACE_N      batch and points
 """
 import collections
@@ -24,6 +24,12 @@ from bdm_amd import ops  # noqa: E402
 from bdm_amd.functional.backend import _backend, _Backend  # noqa: E402
 
 SYNC = os.environ.get("RACE_SYNC") == "1"
+if os.environ.get("RACE_POINT_STREAM") == "0":
+    from bdm_amd.modules import PVConv as _PV
+    _PV.point_stream = False
+if os.environ.get("RACE_SIDE_PLAN") == "0":
+    from bdm_amd import pvcnn as _pvcnn
+    _pvcnn.SIDE_PLAN = False
 HOSTSYNC = os.environ.get("RACE_HOSTSYNC") == "1"  # read every checksum back right away (drains the main stream after every operator)
 
 
