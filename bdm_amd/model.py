@@ -170,7 +170,15 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
             extra = self._mask_channels(image_rgb, mask)
             if extra:  # once per image batch (hoisted): the mask / distance-transform channels join the pixel-major image
                 img = torch.cat([img] + [e.reshape(e.shape[0], H * W, 1) for e in extra], dim=2).contiguous()
-            hit = (image_rgb, image_rgb._version, img, (H, W), mask, {})  # {}: hoisted maps of this image batch (ops.Conditioning)
+            # A same-shaped image batch rewrites the conditioning image and its hoisted maps IN PLACE: a recorded step (launch
+            # tape) that holds their addresses stays valid for the new images -- no re-recording per trajectory / per batch
+            maps, prev = {}, getattr(self, "_cond_static", None)
+            if prev is not None and prev[0].shape == img.shape and prev[0].device == img.device and prev[0].dtype == img.dtype:
+                prev[0].copy_(img)
+                img, maps = prev
+                ops.refresh_conditioning_maps(img, maps)
+            self._cond_static = (img, maps)
+            hit = (image_rgb, image_rgb._version, img, (H, W), mask, maps)  # maps: hoisted maps of this image batch (ops.Conditioning)
             self._cond_cache = hit
         return hit[2], hit[3]
 
@@ -362,7 +370,7 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
         key = (tuple(x_t.shape), str(dev), id(camera), torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()),
                self._weights_signature(), ops.saturation_epoch())
         g = getattr(self, "_tape_cache", None)
-        if g is None or g["key"] != key or g["feat"] is not feat or g["image"] is not image_rgb:
+        if g is None or g["key"] != key or g["feat"] is not feat:  # (feat is a static buffer: conditioning_image)
             g = {"key": key, "feat": feat, "image": image_rgb, "camera": camera, "tape": None, "warm": False, "off": None, "eps": None,
                  "x": torch.empty_like(x_t, memory_format=torch.contiguous_format),
                  "t": torch.zeros(B, dtype=torch.int64, device=dev)}

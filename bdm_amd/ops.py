@@ -841,6 +841,24 @@ def voxel_plan(coords, r, eps=0.0):
 HOIST_CONDITIONING = os.environ.get("BDM_HOIST", "1") == "1"
 
 
+def _fill_conditioning_map(feat, wf, out):
+    xt = wf.t().contiguous()[None]                                     # (1, C, M): the "activation" operand of the GEMM below
+    for b in range(feat.shape[0]):                                      # y (HW x M) = F[b] (HW x C) . Wf^T: pixels on the GEMM's row axis
+        pointwise_conv(xt, feat[b], out=out[b:b + 1])
+
+
+def refresh_conditioning_maps(feat, maps):
+    """New image features in the same buffer (model.conditioning_image): every hoisted map is recomputed into ITS buffer, so the
+    addresses a recorded step holds stay valid.  Maps of rewritten weights are dropped (rebuilt on first use)."""
+    for key, ent in list(maps.items()):
+        if len(ent) != 4:
+            continue                                                    # weight-only entries (conv1_wx): image-independent
+        if ent[0] != ent[2]._version:
+            del maps[key]
+        else:
+            _fill_conditioning_map(feat, ent[3]().contiguous(), ent[1])
+
+
 class Conditioning:
     """Handle that travels with the denoiser input of ONE reverse step (attribute `_bdm_cond` of the x_in tensor)."""
 
@@ -856,13 +874,11 @@ class Conditioning:
         hit = self.maps.get(key)
         if hit is None or hit[0] != weight._version or hit[2] is not weight:
             wf = build().contiguous()                                  # (M, C)
-            M = wf.shape[0]
-            B, HW, C = self.feat.shape
-            out = torch.empty(B, HW, M, dtype=torch.float32, device=self.feat.device)
-            xt = wf.t().contiguous()[None]                             # (1, C, M): the "activation" operand of the GEMM below
-            for b in range(B):                                          # y (HW x M) = F[b] (HW x C) . Wf^T: pixels on the GEMM's row axis
-                pointwise_conv(xt, self.feat[b], out=out[b:b + 1])
-            hit = (weight._version, out, weight)
+            B, HW, _ = self.feat.shape
+            out = hit[1] if hit is not None and tuple(hit[1].shape) == (B, HW, wf.shape[0]) else \
+                torch.empty(B, HW, wf.shape[0], dtype=torch.float32, device=self.feat.device)
+            _fill_conditioning_map(self.feat, wf, out)
+            hit = (weight._version, out, weight, build)
             self.maps[key] = hit
         return hit[1]
 

@@ -127,7 +127,7 @@ def test_recorded_step_equals_eager_loop_at_the_bench_batch(hip, monkeypatch):
 
     def run(mode):
         monkeypatch.setattr(M, "TAPE_STEPS", mode)
-        model._cond_cache = None
+        model._cond_cache = None  # (bench.py does this per trajectory: the image encoder runs inside the timed region)
         return bdm_blending(None, batch, cfg, model, pvd, streams=batch_streams(cfg, batch, dev, sample_idx=1)).points_padded().clone()
 
     eager = run("0")
@@ -136,3 +136,11 @@ def test_recorded_step_equals_eager_loop_at_the_bench_batch(hip, monkeypatch):
         g = model._tape_cache
         assert g["tape"] is not None and g["off"] is None and g["tape"].python_entries <= 4
         assert torch.isfinite(taped).all() and torch.equal(taped, eager)
+    # New images in the same batch object: the conditioning image and the hoisted maps are rewritten in place
+    # (model.conditioning_image), so the SAME recorded step serves them -- and must give what the eager loop gives for them
+    first_tape = model._tape_cache["tape"]
+    batch.image_rgb.copy_(torch.rand(batch.image_rgb.shape, generator=torch.Generator().manual_seed(5)).to(dev))
+    taped = run("auto")
+    assert model._tape_cache["tape"] is first_tape, "a new image batch of the same shape re-recorded the step"
+    other = run("0")
+    assert torch.equal(taped, other) and not torch.equal(other, eager)
