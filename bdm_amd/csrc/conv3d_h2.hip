@@ -3,7 +3,7 @@
 // Half the matrix work of the bf16x6 form (conv3d_s3.hip) at the same accuracy class.  An fp32 operand is stored as
 // TWO fp16 terms  x * 2^s = hi + lo  (hi = RN_11(x 2^s), lo = RN_11(x 2^s - hi); 11 + 11 signed bits capture x to
 // <= 2^-24 |x|), and a product is the three partial products  lo.hi + hi.lo + hi.hi , each exact in fp32 (11 x 11
-// bits) and accumulated in fp32 by v_mfma_f32_32x32x16_f16; the dropped lo.lo term is <= 2^-24 |a b|.
+// bits) and accumulated in fp32 by v_mfma_f32_16x16x32_f16; the dropped lo.lo term is <= 2^-24 |a b|.
 // fp16 has a 5-bit exponent, so both operands are pre-scaled by exact powers of two that keep hi AND lo in the normal
 // range, and the scales are divided out of the fp32 accumulator in the epilogue:
 //   weights      per output channel: max |w[co]| -> [2^9, 2^10)  (pack time; inv_scale[co] for the epilogue)
@@ -104,64 +104,77 @@ extern "C" int bdm_conv3d_h2_pack_weights(int cout, int cin, const float *w, voi
 }
 
 // ---------------------------------------------------------------------------------------------------
-// the convolution
+// the convolution, on v_mfma_f32_16x16x32_f16 (K = 8 channels x FOUR taps per instruction)
 // ---------------------------------------------------------------------------------------------------
-template <int MI, int NI, int R, int TX, int TY, int NW>  // NW waves per workgroup; NI * NW column blocks of 32 voxels
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void conv3d_h2_kernel(int C8, int Cout, const float4 *__restrict__ x,
-                                                        const float4 *__restrict__ wq, const float *__restrict__ inv_scale,
-                                                        float x_inv_scale, const float *__restrict__ bias,
-                                                        float *__restrict__ y, int gn_cg, double *__restrict__ gn_partial) {
+// Implicit GEMM: a workgroup owns BM output channels x a TX x TY x R brick of voxels; per 8-channel chunk it stages the brick's
+// halo (both fp16 planes) and the chunk's 27 x BM weights in LDS, then walks the 7 tap quads.  Round 3 moved it from
+// v_mfma_f32_32x32x16_f16 (tap PAIRS) to the 16x16x32 shape: the chip holds a higher clock on it at the same flops
+// (MI355X_MICROARCH.md, DVFS item 7), measured on random data at B = 16: 256->256 at 8^3 94.0 -> 85.0 us, 512->256 190.5 -> 172.6,
+// 32->32 at 32^3 124.1 -> 118.4, 128->128 at 16^3 166.0 -> 158.4, 64->64 at 32^3 389.7 -> 380.6 (tools/conv_h2_check.py); and a
+// 16 x 16 output tile lets a tiny batch spread a layer over twice the workgroups with half the dependent chain per wave.
+//   wave tile   MT x NT tiles of 16 output channels x 16 voxels; a workgroup = NW waves on the same 16 MT channels
+//   K step      tap quad Q (7 of them; tap 27 is a zero-weight pad): lane group kg = lane / 16 holds tap 4Q + kg, 8 channels
+//   A operand   weights  Ws[pair 2Q + kg/2][split][half kg&1][channel]   (the pair-major image of the packer, read as quads)
+//   B operand   voxels   Xs[split][halo record of the lane's voxel + offset of tap 4Q + kg]
+// GroupNorm slice partials on a canonical decomposition (independent of the tile): a unit = 16^3: one x-plane, 8^3: one x-plane,
+// 32^3: the 2 x 8 tile; summed as: lane (4 rows of ONE 16-voxel block), butterfly over the 16 lanes of the block, the unit's
+// blocks in ascending order (fp32), then the 4-row blocks of a group in ascending row order (fp64).
+typedef __attribute__((ext_vector_type(4))) float f32x4a;
+template <int MT, int NT, int R, int TX, int TY, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void conv3d_h2q_kernel(
+    int C8, int Cout, const float4 *__restrict__ x, const float4 *__restrict__ wq, const float *__restrict__ inv_scale, float x_inv_scale,
+    const float *__restrict__ bias, float *__restrict__ y, int gn_cg, double *__restrict__ gn_partial) {
   extern __shared__ __align__(16) float4 smem4[];
-  constexpr int BM = 32 * MI;
+  constexpr int BM = 16 * MT;
   constexpr int RSV = R + 2;                 // voxel records per halo row (one zero pad at each end)
   constexpr int ROWS = (TX + 2) * (TY + 2);
   constexpr int HALO = ROWS * RSV;           // records per split
   constexpr int R2 = R * R, R3 = R2 * R;
-  constexpr int NT = NW * 64;
-  constexpr int XV = 2 * ROWS * R, XI = (XV + NT - 1) / NT;          // 16-byte pieces of the input tile
-  constexpr int WV = H2_PAIRS * 2 * 2 * BM, WI = (WV + NT - 1) / NT;  // 16-byte pieces of the weight tile
+  constexpr int NT_ = NW * 64;
+  constexpr int XV = 2 * ROWS * R, XI = (XV + NT_ - 1) / NT_;          // 16-byte pieces of the input tile
+  constexpr int WV = H2_PAIRS * 2 * 2 * BM, WI = (WV + NT_ - 1) / NT_;  // 16-byte pieces of the weight tile
+  constexpr int NQ = H2_PAIRS / 2;                                      // tap quads
+  static_assert(TX * TY * R == NT * NW * 16, "tile = NT * NW blocks of 16 voxels");
   float4 *Xs = smem4;              // [2][HALO]
   float4 *Ws = smem4 + 2 * HALO;   // [14][2][2][BM]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kg = lane >> 4;
   constexpr int tiles_y = R / TY;
   const int X0 = (blockIdx.x / tiles_y) * TX, Y0 = (blockIdx.x % tiles_y) * TY;
   const int m0 = blockIdx.y * BM, bi = blockIdx.z;
   const float4 *xb = x + (size_t)bi * C8 * 2 * R3;
   float *yb = y + (size_t)bi * Cout * R3;
 
-  constexpr int rpb = 32 / R;
-  const int dyl = li / R, zl = li % R;
-  constexpr int blocks_per_plane = TY / rpb;
-  int lbase[NI], gvox[NI];
+  int lbase[NT], gvox[NT];
 #pragma unroll
-  for (int q = 0; q < NI; ++q) {
-    const int nb = q * NW + wave;
-    const int tx = nb / blocks_per_plane, ty = (nb % blocks_per_plane) * rpb + dyl;
-    lbase[q] = ((tx + 1) * (TY + 2) + (ty + 1)) * RSV + 1 + zl;
-    gvox[q] = ((X0 + tx) * R + (Y0 + ty)) * R + zl;
+  for (int q = 0; q < NT; ++q) {
+    const int v = (q * NW + wave) * 16 + l16;  // voxel of this lane inside the tile, (x-plane, y, z) order
+    const int tz = v % R, trow = v / R, tx = trow / TY, ty = trow % TY;
+    lbase[q] = ((tx + 1) * (TY + 2) + (ty + 1)) * RSV + 1 + tz;
+    gvox[q] = ((X0 + tx) * R + (Y0 + ty)) * R + tz;
   }
-  // this lane half's tap of pair p is 2p + lh; record offset of that tap (pad tap 27 reuses tap 26's address)
-  f32x16 acc[MI][NI];
+  // record offset of this lane group's tap in every quad (pad tap 27 reuses tap 26's address: its weights are zero)
+  int toff[NQ], woff[NQ];
 #pragma unroll
-  for (int a = 0; a < MI; ++a)
+  for (int Q = 0; Q < NQ; ++Q) {
+    const int t = min(4 * Q + kg, 26);
+    toff[Q] = ((t / 9 - 1) * (TY + 2) + ((t / 3) % 3 - 1)) * RSV + (t % 3 - 1);
+    woff[Q] = ((2 * Q + (kg >> 1)) * 4 + (kg & 1)) * BM + l16;  // + s * 2 * BM + mt * 16
+  }
+  f32x4a acc[MT][NT];
 #pragma unroll
-    for (int q = 0; q < NI; ++q)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][q][i] = 0.f;
+    for (int q = 0; q < NT; ++q) acc[a][q] = f32x4a{0.f, 0.f, 0.f, 0.f};
 
-  for (int e = tid; e < 2 * HALO; e += NT) Xs[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = tid; e < 2 * HALO; e += NT_) Xs[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // (staging registers are native vectors: an array of HIP float4 structs loaded unconditionally ends up in scratch memory)
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   f32x4v xr[XI], wr[WI];
-  // Branch-free, select-free loads: out-of-range pieces read a clamped (valid) address and are simply never stored
-  // (halo cells outside the grid keep the zeros written above; weight rows >= Cout only feed output rows that are never
-  // written).  A branch or a select on a freshly loaded value makes the wave wait for memory inside the load phase.
   auto load_chunk = [&](int c8) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const int e = tid + i * NT;
+      const int e = tid + i * NT_;
       const int z = e % R, row = (e / R) % ROWS, s = e / (R * ROWS);
       const int gx = X0 + row / (TY + 2) - 1, gy = Y0 + row % (TY + 2) - 1;
       const bool ok = e < XV && gx >= 0 && gx < R && gy >= 0 && gy < R;
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      const int e = tid + i * NT;
+      const int e = tid + i * NT_;
       const int m = e % BM, psh = e / BM;  // psh = (p*2 + s)*2 + h
       const bool ok = e < WV && m0 + m < Cout;
       wr[i] = *reinterpret_cast<const f32x4v *>(&wq[ok ? (unsigned)((c8 * (H2_PAIRS * 4) + psh) * Cout + m0 + m) : 0u]);
@@ -178,14 +191,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const int e = tid + i * NT;
+      const int e = tid + i * NT_;
       const int z = e % R, row = (e / R) % ROWS, s = e / (R * ROWS);
       const int gx = X0 + row / (TY + 2) - 1, gy = Y0 + row % (TY + 2) - 1;
       if (e < XV && gx >= 0 && gx < R && gy >= 0 && gy < R) *reinterpret_cast<f32x4v *>(&Xs[s * HALO + row * RSV + 1 + z]) = xr[i];
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      const int e = tid + i * NT;
+      const int e = tid + i * NT_;
       if (e < WV) *reinterpret_cast<f32x4v *>(&Ws[e]) = wr[i];
     }
   };
@@ -196,102 +209,90 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     store_chunk();
     __syncthreads();
     if (c8 + 1 < C8) load_chunk(c8 + 1);
-    // Operand fragments of tap pair p + 1 are read from LDS BEFORE the matrix work of pair p is issued (two register
-    // buffers, scheduling barriers keep the order): the MFMAs never wait for an LDS read issued just ahead of them.
-    f16x8 fa[2][MI][2], fb[2][NI][2];
-    auto read_pair = [&](int p, int buf) {
-      // tap of this lane half: 2p + lh  (compile-time pair, run-time half -> select between two constants)
-      const int t0 = 2 * p, t1 = (2 * p + 1 < 27) ? 2 * p + 1 : 26;
-      const int off0 = ((t0 / 9 - 1) * (TY + 2) + ((t0 / 3) % 3 - 1)) * RSV + (t0 % 3 - 1);
-      const int off1 = ((t1 / 9 - 1) * (TY + 2) + ((t1 / 3) % 3 - 1)) * RSV + (t1 % 3 - 1);
-      const int toff = lh ? off1 : off0;
+    // Fragments of quad Q + 1 are read from LDS before the matrix work of quad Q is issued (two register buffers).  The 64 x 64 wave
+    // tile (MT = NT = 4) has no registers for two buffers at two waves per SIMD (64 accumulator + 128 fragment + 48 staging
+    // registers): its fragments are single-buffered and re-read right after the quad's 48 MFMAs are issued -- the other wave of
+    // the SIMD covers that latency.
+    constexpr bool DB = MT * NT < 16;
+    f16x8 fa[DB ? 2 : 1][MT][2], fb[DB ? 2 : 1][NT][2];
+    auto read_quad = [&](int Q, int buf) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const float4 t = Ws[((p * 2 + s) * 2 + lh) * BM + mi * 32 + li];
-          fa[buf][mi][s] = *reinterpret_cast<const f16x8 *>(&t);
+        for (int mt = 0; mt < MT; ++mt) {
+          const float4 t = Ws[woff[Q] + s * 2 * BM + mt * 16];
+          fa[buf][mt][s] = *reinterpret_cast<const f16x8 *>(&t);
         }
 #pragma unroll
-        for (int q = 0; q < NI; ++q) {
-          const float4 t = Xs[s * HALO + lbase[q] + toff];
+        for (int q = 0; q < NT; ++q) {
+          const float4 t = Xs[s * HALO + lbase[q] + toff[Q]];
           fb[buf][q][s] = *reinterpret_cast<const f16x8 *>(&t);
         }
       }
     };
-    read_pair(0, 0);
+    read_quad(0, 0);
 #pragma unroll
-    for (int p = 0; p < H2_PAIRS; ++p) {
-      if (p + 1 < H2_PAIRS) read_pair(p + 1, (p + 1) & 1);
+    for (int Q = 0; Q < NQ; ++Q) {
+      if (DB && Q + 1 < NQ) read_quad(Q + 1, (Q + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-      // smallest terms first: lo.hi, hi.lo, hi.hi (lo.lo <= 2^-24 |a b| is dropped).  Term-major order: the MI*NI
-      // accumulators are independent, so no MFMA waits on the one issued just before it.
+      // smallest terms first: lo.hi, hi.lo, hi.hi; term-major: the MT * NT accumulators are independent
 #pragma unroll
       for (int term = 0; term < 3; ++term)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int q = 0; q < NI; ++q)
-            acc[mi][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[p & 1][mi][term == 0 ? 1 : 0], fb[p & 1][q][term == 1 ? 1 : 0],
-                                                               acc[mi][q], 0, 0, 0);
+          for (int q = 0; q < NT; ++q)
+            acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[DB ? (Q & 1) : 0][mt][term == 0 ? 1 : 0], fb[DB ? (Q & 1) : 0][q][term == 1 ? 1 : 0],
+                                                               acc[mt][q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (!DB && Q + 1 < NQ) read_quad(Q + 1, 0);
     }
   }
-  // Epilogue: scale + bias + store.  When gn_partial is given, the workgroup also leaves the (sum, sum of squares) of the
-  // values it wrote, per GroupNorm group of its channel tile, as slice partials -- the GroupNorm that follows the convolution
-  // (pvconv.py:84) then needs no statistics pass of its own.  The slices are defined on a CANONICAL decomposition that does not
-  // depend on the tile this launch picked (the tile follows the batch size; a shape must not see its batch-mates): one slice per
-  // smallest spatial tile of the resolution (16^3: one x-plane = the 1 x 16 tile; 8^3: two x-planes = the 2 x 8 tile; 32^3: the
-  // 2 x 8 tile), summed as: lane (4 rows of ONE 32-voxel block), half-wave butterfly, the unit's blocks in ascending block
-  // order, then the 4-row blocks of a group in fp64.  Deterministic and identical for every tile choice.
-  constexpr int UN = (R == 16 && TX == 2) ? 2 : ((R == 8 && TX == 4) ? 2 : 1);  // canonical units inside this workgroup's tile
-  constexpr int NBLK = NI * NW, BPU = NBLK / UN;                                  // 32-voxel blocks, blocks per unit
-  constexpr int NB = 2 * MI * 4 * 2;                                              // [lh][p][j][stat]
-  float *red = reinterpret_cast<float *>(smem4);                                  // [NBLK][NB], then [UN][NB]
+  // Epilogue: scale + bias + store (+ GroupNorm slice partials, see the head comment).  A lane holds rows 4 kg .. 4 kg + 3 of
+  // channel tile mt for ONE voxel: a 4-row block never straddles a group (gn_cg >= 4).
+  constexpr int UB = (R == 32 ? TX * TY * R : R * R) / 16;   // 16-voxel blocks per canonical unit
+  constexpr int NBLK = NT * NW, UN = NBLK / UB;             // blocks of this tile, units of this tile
+  constexpr int NB = MT * 4 * 2;                            // [mt][kg][stat]
+  static_assert(NBLK % UB == 0 && UN >= 1, "a tile holds whole canonical units");
+  float *red = reinterpret_cast<float *>(smem4);            // [NBLK][NB], then [UN][NB]
   if (gn_partial != nullptr) __syncthreads();  // the operand tiles are dead (slower waves may still be reading fragments)
 #pragma unroll
-  for (int p = 0; p < MI; ++p)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int q = 0; q < NI; ++q) {
-      float bs[4], bq[4];  // per 4-row block j of this lane: rows p*32 + 8j + 4lh .. +3 (never straddle a group)
+    for (int q = 0; q < NT; ++q) {
+      float bs = 0.f, bq = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { bs[j] = 0.f; bq[j] = 0.f; }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int m = m0 + p * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + mt * 16 + 4 * kg + i;
         if (m < Cout) {
-          const float v = acc[p][q][i] * (inv_scale[m] * x_inv_scale) + (bias ? bias[m] : 0.f);
+          const float v = acc[mt][q][i] * (inv_scale[m] * x_inv_scale) + (bias ? bias[m] : 0.f);
           yb[(size_t)m * R3 + gvox[q]] = v;
-          bs[i >> 2] += v;
-          bq[i >> 2] = __builtin_fmaf(v, v, bq[i >> 2]);  // explicitly fused: the same rounding in every tile variant
+          bs += v;
+          bq = __builtin_fmaf(v, v, bq);  // explicitly fused: the same rounding in every tile variant
         }
       }
       if (gn_partial != nullptr) {
-        const int nb = q * NW + wave;  // this block's index inside the tile (plane-major, see gvox)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-          for (int o = 1; o < 32; o <<= 1) {
-            bs[j] += __shfl_xor(bs[j], o, 64);
-            bq[j] += __shfl_xor(bq[j], o, 64);
-          }
-          if (li == 0) {
-            red[nb * NB + (((lh * MI + p) * 4 + j) * 2) + 0] = bs[j];
-            red[nb * NB + (((lh * MI + p) * 4 + j) * 2) + 1] = bq[j];
-          }
+        for (int o = 1; o < 16; o <<= 1) {
+          bs += __shfl_xor(bs, o, 64);
+          bq += __shfl_xor(bq, o, 64);
+        }
+        if (l16 == 0) {
+          const int nb = q * NW + wave;
+          red[nb * NB + (mt * 4 + kg) * 2 + 0] = bs;
+          red[nb * NB + (mt * 4 + kg) * 2 + 1] = bq;
         }
       }
     }
   if (gn_partial != nullptr) {
     __syncthreads();
-    // stage 1: one thread per (unit, half, p, j, statistic) adds the unit's blocks in ascending block order
     float *red2 = red + NBLK * NB;
-    if (tid < UN * NB) {
-      const int un = tid / NB, e = tid % NB;
+    for (int e = tid; e < UN * NB; e += NT_) {
+      const int un = e / NB, k = e % NB;
       float a = 0.f;
 #pragma unroll
-      for (int k = 0; k < BPU; ++k) a += red[(un * BPU + k) * NB + e];
-      red2[tid] = a;
+      for (int j = 0; j < UB; ++j) a += red[(un * UB + j) * NB + k];  // the unit's blocks in ascending order
+      red2[e] = a;
     }
     __syncthreads();
     const int ngt = BM / gn_cg;  // groups inside this channel tile
@@ -299,13 +300,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       const int un = tid / ngt, gi = tid % ngt;
       if (m0 + gi * gn_cg < Cout) {
         double a = 0.0, qq = 0.0;
-        for (int hh = 0; hh < 2; ++hh)
-          for (int p = 0; p < MI; ++p)
-            for (int j = 0; j < 4; ++j)
-              if (((p * 32 + 8 * j + 4 * hh) >> (__ffs(gn_cg) - 1)) == gi) {  // gn_cg is a power of two
-                a += (double)red2[un * NB + (((hh * MI + p) * 4 + j) * 2) + 0];
-                qq += (double)red2[un * NB + (((hh * MI + p) * 4 + j) * 2) + 1];
-              }
+        const int nb4 = gn_cg / 4;  // 4-row blocks per group, ascending rows
+        for (int j = 0; j < nb4; ++j) {
+          a += (double)red2[un * NB + (gi * nb4 + j) * 2 + 0];
+          qq += (double)red2[un * NB + (gi * nb4 + j) * 2 + 1];
+        }
         const int G = Cout / gn_cg, g = m0 / gn_cg + gi, S = gridDim.x * UN;
         double *dst = gn_partial + (((size_t)bi * G + g) * S + blockIdx.x * UN + un) * 2;
         dst[0] = a;
@@ -314,8 +313,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
     }
   }
 }
-
-static int h2_waves() { return 8; }  // the 4-wave / NI = 4 tiling measured 2-15 % slower (DESIGN.md negative results); its instantiations stay compilable
 
 static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale, const void *packed_w,
                             const float *inv_scale, const float *bias, float *y, int gn_cg, double *gn_partial,
@@ -327,20 +324,22 @@ static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, f
   }
   if (b == 0) return BDM_OK;
   const int c8 = (cin + 7) / 8;
-  // tile = TX x TY grid rows x R cells = NI * NW column blocks of 32 voxels; 8 waves (two per SIMD) with NI = 2 keep the
-  // matrix pipe fed while the other wave of the SIMD waits on LDS (measured vs 4 waves with NI = 4)
+  // tile = TX x TY grid rows x R cells = NT * NW blocks of 16 voxels x 32 * mi output channels; 8 waves (two per SIMD) keep the
+  // matrix pipe fed while the other wave of the SIMD waits on LDS (round 2 measured 4 waves with twice the tile per wave: 2-15 % slower)
   int tx, ty, mi;
   // 8^3 grids: 128-voxel tiles with 4 waves double the workgroup count; they win when the 256-voxel tiling cannot fill the chip
   // (128 -> 128 at B = 16: 40.6 -> 30.4 us) and lose when it can (256 -> 256: 96 -> 114 us).
   const bool r8_small = r == 8 && (long long)b * 2 * cdiv(cout, 32) < 256;
+  // one or two shapes (config C1): 64-voxel tiles, one 16 x 16 block per wave -- twice the workgroups, half the chain per wave
+  const bool r8_tiny = r == 8 && (long long)b * 4 * cdiv(cout, 32) <= 64;
   // 16^3 / 32^3 grids of a few shapes (config C1 is ONE shape): 64-row x 512-voxel tiles give 16 / 64 workgroups, each walking
-  // the whole K loop with 12 MFMAs per step; 32-row (and at 16^3 256-voxel) tiles put 4x / 2x as many CUs on the problem with a
+  // the whole K loop with 48 MFMAs per step; 32-row (and at 16^3 256-voxel) tiles put 4x / 2x as many CUs on the problem with a
   // 4x / 2x shorter chain per wave (B = 1: 114 -> 4x us at 16^3).  Same K order, same bits.
   const long long big_wgs = (long long)b * (r == 32 ? 64 : 8) * cdiv(cout, 64);
   const bool small = r != 8 && cout > 32 && big_wgs < 128;
   if (r == 32) { tx = 2; ty = 8; }
   else if (r == 16) { tx = small ? 1 : 2; ty = 16; }
-  else { tx = r8_small ? 2 : 4; ty = 8; }
+  else { tx = r8_tiny ? 1 : (r8_small ? 2 : 4); ty = 8; }
   mi = (cout > 32 && r != 8 && !small) ? 2 : 1;
   const size_t smem = 16 * ((size_t)2 * (tx + 2) * (ty + 2) * (r + 2) + (size_t)H2_PAIRS * 4 * 32 * mi);
   dim3 grid((r / tx) * (r / ty), cdiv(cout, 32 * mi), b);
@@ -348,29 +347,27 @@ static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, f
   if (gn_partial != nullptr) {
     BDM_REQUIRE(gn_cg >= 4 && (gn_cg & (gn_cg - 1)) == 0 && (32 * mi) % gn_cg == 0 && cout % gn_cg == 0 && (int)grid.x <= 64,
                 "conv3d_h2: GroupNorm statistics need a power-of-two channels-per-group dividing %d and <= 64 spatial tiles (got cg=%d)", 32 * mi, gn_cg);
-    // canonical slices (independent of the tile): 16^3 one per x-plane, 8^3 one per two x-planes, 32^3 one per 2 x 8 tile
-    if (slices_out) *slices_out = r == 16 ? 16 : (r == 8 ? 4 : (int)grid.x);
+    // canonical slices (independent of the tile): 16^3 and 8^3 one per x-plane, 32^3 one per 2 x 8 tile
+    if (slices_out) *slices_out = r == 16 ? 16 : (r == 8 ? 8 : (int)grid.x);
   }
-#define H2_LAUNCH(MI, NI, R, TX, TY, NW)                                                                        \
+#define H2Q_LAUNCH(MT, NT, R, TX, TY, NW)                                                                       \
   do {                                                                                                          \
-    BDM_ALLOW_LDS((conv3d_h2_kernel<MI, NI, R, TX, TY, NW>), smem);                                             \
-    hipLaunchKernelGGL((conv3d_h2_kernel<MI, NI, R, TX, TY, NW>), grid, dim3(NW * 64), smem, s, c8, cout,       \
+    BDM_ALLOW_LDS((conv3d_h2q_kernel<MT, NT, R, TX, TY, NW>), smem);                                            \
+    hipLaunchKernelGGL((conv3d_h2q_kernel<MT, NT, R, TX, TY, NW>), grid, dim3(NW * 64), smem, s, c8, cout,      \
                        (const float4 *)x_h2, (const float4 *)packed_w, inv_scale, x_inv_scale, bias, y, gn_cg,  \
                        gn_partial);                                                                             \
   } while (0)
-  const bool w8 = h2_waves() == 8;
-  if (r == 32) {
-    if (mi == 2) { if (w8) H2_LAUNCH(2, 2, 32, 2, 8, 8); else H2_LAUNCH(2, 4, 32, 2, 8, 4); }
-    else { if (w8) H2_LAUNCH(1, 2, 32, 2, 8, 8); else H2_LAUNCH(1, 4, 32, 2, 8, 4); }
-  } else if (r == 16) {
-    if (small) H2_LAUNCH(1, 1, 16, 1, 16, 8);
-    else if (mi == 2) { if (w8) H2_LAUNCH(2, 2, 16, 2, 16, 8); else H2_LAUNCH(2, 4, 16, 2, 16, 4); }
-    else { if (w8) H2_LAUNCH(1, 2, 16, 2, 16, 8); else H2_LAUNCH(1, 4, 16, 2, 16, 4); }
+  if (r == 32) { if (mi == 2) H2Q_LAUNCH(4, 4, 32, 2, 8, 8); else H2Q_LAUNCH(2, 4, 32, 2, 8, 8); }
+  else if (r == 16) {
+    if (small) H2Q_LAUNCH(2, 2, 16, 1, 16, 8);
+    else if (mi == 2) H2Q_LAUNCH(4, 4, 16, 2, 16, 8);
+    else H2Q_LAUNCH(2, 4, 16, 2, 16, 8);
   } else {
-    if (r8_small) H2_LAUNCH(1, 1, 8, 2, 8, 4);
-    else if (w8) H2_LAUNCH(1, 1, 8, 4, 8, 8); else H2_LAUNCH(1, 2, 8, 4, 8, 4);
+    if (r8_tiny) H2Q_LAUNCH(2, 1, 8, 1, 8, 4);
+    else if (r8_small) H2Q_LAUNCH(2, 2, 8, 2, 8, 4);
+    else H2Q_LAUNCH(2, 2, 8, 4, 8, 8);
   }
-#undef H2_LAUNCH
+#undef H2Q_LAUNCH
   return launch_status("conv3d_h2");
 }
 
