@@ -145,22 +145,26 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   const float4 *xb = x + (size_t)bi * C8 * 2 * R3;
   float *yb = y + (size_t)bi * Cout * R3;
 
-  int lbase[NT], gvox[NT];
-#pragma unroll
-  for (int q = 0; q < NT; ++q) {
-    const int v = (q * NW + wave) * 16 + l16;  // voxel of this lane inside the tile, (x-plane, y, z) order
-    const int tz = v % R, trow = v / R, tx = trow / TY, ty = trow % TY;
-    lbase[q] = ((tx + 1) * (TY + 2) + (ty + 1)) * RSV + 1 + tz;
-    gvox[q] = ((X0 + tx) * R + (Y0 + ty)) * R + tz;
-  }
+  // voxel of this lane in block q * NW + wave of the tile, (x-plane, y, z) order: the NW blocks of one q cover RQ whole rows, so
+  // the halo record of block q is the record of block 0 plus a COMPILE-TIME offset (one register instead of NT)
+  constexpr int RQ = NW * 16 / R;
+  static_assert(NW * 16 % R == 0 && (RQ % TY == 0 || TY % RQ == 0), "the blocks of one q are whole rows that tile the brick");
+  const int v0 = wave * 16 + l16, r0 = v0 / R, tz = v0 % R;
+  const int lbase0 = ((r0 / TY + 1) * (TY + 2) + (r0 % TY + 1)) * RSV + 1 + tz;
+  auto row_of = [&](int q, int &tx, int &ty) {  // brick row (tx, ty) of block q, relative to the lane's row of block 0
+    if (RQ % TY == 0) { tx = q * (RQ / TY); ty = 0; }
+    else { tx = (q * RQ) / TY; ty = (q * RQ) % TY; }
+  };
+  auto lbase = [&](int q) { int tx, ty; row_of(q, tx, ty); return lbase0 + (tx * (TY + 2) + ty) * RSV; };
   // record offset of this lane group's tap in every quad (pad tap 27 reuses tap 26's address: its weights are zero)
-  int toff[NQ], woff[NQ];
+  int toff[NQ];
 #pragma unroll
   for (int Q = 0; Q < NQ; ++Q) {
     const int t = min(4 * Q + kg, 26);
     toff[Q] = ((t / 9 - 1) * (TY + 2) + ((t / 3) % 3 - 1)) * RSV + (t % 3 - 1);
-    woff[Q] = ((2 * Q + (kg >> 1)) * 4 + (kg & 1)) * BM + l16;  // + s * 2 * BM + mt * 16
   }
+  // weight record of (quad Q, split s, channel tile mt): wbase + Q * 8 BM + s * 2 BM + mt * 16   (pair 2Q + kg/2, half kg&1)
+  const float4 *wbase = Ws + ((kg >> 1) * 4 + (kg & 1)) * BM + l16;
   f32x4a acc[MT][NT];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -220,12 +224,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       for (int s = 0; s < 2; ++s) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const float4 t = Ws[woff[Q] + s * 2 * BM + mt * 16];
+          const float4 t = wbase[Q * 8 * BM + s * 2 * BM + mt * 16];
           fa[buf][mt][s] = *reinterpret_cast<const f16x8 *>(&t);
         }
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
-          const float4 t = Xs[s * HALO + lbase[q] + toff[Q]];
+          const float4 t = Xs[s * HALO + lbase(q) + toff[Q]];
           fb[buf][q][s] = *reinterpret_cast<const f16x8 *>(&t);
         }
       }
@@ -260,13 +264,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
+      int qx, qy;
+      row_of(q, qx, qy);
+      const int gvox = ((X0 + r0 / TY + qx) * R + (Y0 + r0 % TY + qy)) * R + tz;
       float bs = 0.f, bq = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + mt * 16 + 4 * kg + i;
         if (m < Cout) {
           const float v = acc[mt][q][i] * (inv_scale[m] * x_inv_scale) + (bias ? bias[m] : 0.f);
-          yb[(size_t)m * R3 + gvox[q]] = v;
+          yb[(size_t)m * R3 + gvox] = v;
           bs += v;
           bq = __builtin_fmaf(v, v, bq);  // explicitly fused: the same rounding in every tile variant
         }

@@ -5,12 +5,12 @@ import csv, json, sys
 B = 16
 # (ABI key as bench.py prints it, rocprof kernel name prefix, grid threads, algorithmic bytes per launch)
 TABLE = [
-    (f"bdm_conv3d_3x3x3_h2({B}, 64, 64, 32)", "conv3d_h2_kernel<2, 2, 32", 64 * 1 * B * 512, 4 * B * 32768 * (64 + 64)),
-    (f"bdm_conv3d_3x3x3_h2({B}, 32, 32, 32)", "conv3d_h2_kernel<1, 2, 32", 64 * 1 * B * 512, 4 * B * 32768 * (32 + 32)),
-    (f"bdm_conv3d_3x3x3_h2({B}, 128, 128, 16)", "conv3d_h2_kernel<2, 2, 16", 8 * 2 * B * 512, 4 * B * 4096 * (128 + 128)),
-    (f"bdm_conv3d_3x3x3_h2({B}, 64, 64, 16)", "conv3d_h2_kernel<2, 2, 16", 8 * 1 * B * 512, 4 * B * 4096 * (64 + 64)),
-    (f"bdm_conv3d_3x3x3_h2({B}, 256, 256, 8)", "conv3d_h2_kernel<1, 1, 8", 2 * 8 * B * 512, 4 * B * 512 * (256 + 256)),
-    (f"bdm_conv3d_3x3x3_h2({B}, 128, 128, 8)", "conv3d_h2_kernel<1, 1, 8", 2 * 4 * B * 512, 4 * B * 512 * (128 + 128)),
+    (f"bdm_conv3d_3x3x3_h2({B}, 64, 64, 32)", "conv3d_h2q_kernel<4, 4, 32", 64 * 1 * B * 512, 4 * B * 32768 * (64 + 64)),
+    (f"bdm_conv3d_3x3x3_h2({B}, 32, 32, 32)", "conv3d_h2q_kernel<2, 4, 32", 64 * 1 * B * 512, 4 * B * 32768 * (32 + 32)),
+    (f"bdm_conv3d_3x3x3_h2({B}, 128, 128, 16)", "conv3d_h2q_kernel<4, 4, 16", 8 * 2 * B * 512, 4 * B * 4096 * (128 + 128)),
+    (f"bdm_conv3d_3x3x3_h2({B}, 64, 64, 16)", "conv3d_h2q_kernel<4, 4, 16", 8 * 1 * B * 512, 4 * B * 4096 * (64 + 64)),
+    (f"bdm_conv3d_3x3x3_h2({B}, 256, 256, 8)", "conv3d_h2q_kernel<2, 2, 8", 2 * 8 * B * 512, 4 * B * 512 * (256 + 256)),
+    (f"bdm_conv3d_3x3x3_h2({B}, 128, 128, 8)", "conv3d_h2q_kernel<2, 2, 8", 2 * 4 * B * 512, 4 * B * 512 * (128 + 128)),
     (f"bdm_sparse_conv_gemm_s3({B}, 4096, 390, 864)", "sparse_gemm_s3_kernel", 7 * 32 * B * 256, None),
     (f"bdm_sparse_conv_gemm_s3({B}, 4096, 32, 864)", "sparse_gemm_s3_kernel", 7 * 32 * B * 256, None),
     (f"bdm_sparse_conv_gemm_s3({B}, 4096, 64, 1728)", "sparse_gemm_s3_kernel", 14 * 32 * B * 256, None),
@@ -20,7 +20,7 @@ TABLE = [
     (f"bdm_sparse_conv_gather({B}, 32, 32, 4096)", "sparse_gather_v4_kernel", 1024 * B * 256, 4 * B * 32 * 32768),
     (f"bdm_sparse_conv_gather({B}, 128, 16, 1024)", "sparse_gather_v4_kernel", 256 * B * 256, 4 * B * 128 * 4096),
     (f"bdm_group_norm({B}, 64, 32768, 8)", "gn_apply_vec_kernel", None, 8 * B * 64 * 32768),
-    (f"bdm_attention_core({B}, 64, 4096)", "attn_flash_s3_kernel", None, 4 * 4 * B * 64 * 4096),
+    (f"bdm_attention_core({B}, 64, 4096)", "attn_flash_h2_kernel", None, 4 * 4 * B * 64 * 4096),
 ]
 rows = list(csv.DictReader(open(sys.argv[1])))
 out = {"commit": sys.argv[2], "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over tools/trace_forward.py "
