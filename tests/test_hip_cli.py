@@ -116,3 +116,13 @@ def test_rccl_init_branch_two_gpus(hip, tmp_path):
            f"run.save_dir={tmp_path}", "run.rng=per_shape", "dataset.num_shapes=4"] + COMMON
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
+
+
+def test_rccl_collectives_of_the_sampling_path_world_size_one(hip):
+    """The backend the 8-GPU run uses, on the one GPU a box has: an NCCL (= RCCL) group of world size 1 runs the collectives of
+    bdm_amd.distributed (barrier, max all_reduce, all_gather of clouds, broadcast_object_list).  The rank logic itself is covered by
+    the gloo tests (tests/test_sampler_host.py, the two-rank test above)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29745")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_world1_check.py")], capture_output=True, text=True, env=env,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "backend nccl ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
