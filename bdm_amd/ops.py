@@ -841,6 +841,18 @@ def voxel_plan(coords, r, eps=0.0):
 HOIST_CONDITIONING = os.environ.get("BDM_HOIST", "1") == "1"
 
 
+def three_nn_search(points_coords, centers_coords):
+    """(idx (B, 3, n) int32, w (B, 3, n)): the three nearest centres of every point and their inverse-distance weights
+    (neighbor_interpolate.cu:19-92), searched ONCE for features and t_emb (the reference searches twice: same result)."""
+    pc, cc = points_coords.contiguous(), centers_coords.contiguous()
+    B, _, n = pc.shape
+    m = cc.shape[2]
+    idx = torch.empty(B, 3, n, dtype=torch.int32, device=pc.device)
+    w = torch.empty(B, 3, n, dtype=torch.float32, device=pc.device)
+    L.check(L.lib().bdm_three_nn_search(B, m, n, L.ptr(pc), L.ptr(cc), L.ptr(idx), L.ptr(w), L.stream()), "three_nn_search")
+    return idx, w
+
+
 def _fill_conditioning_map(feat, wf, out):
     xt = wf.t().contiguous()[None]                                     # (1, C, M): the "activation" operand of the GEMM below
     for b in range(feat.shape[0]):                                      # y (HW x M) = F[b] (HW x C) . Wf^T: pixels on the GEMM's row axis

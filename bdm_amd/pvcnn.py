@@ -126,6 +126,8 @@ SIDE_PLAN = True  # voxel plans of levels 1.. on the sampler's side stream (tool
 # furthest point sampling is a fifth of the forward.  (The PVConv point branch keeps its 8192-point threshold: measured slower below.)
 SIDE_STREAM_MIN_POINTS = 0
 DEFER_CHAIN = True  # levels 1.. of the sampler chain enqueued when the first SA module is reached
+SIDE_NN = True      # 3-NN searches of the FP modules on the sampler's stream (False: each FP module searches on the main stream)
+NN_PLANS = {}       # (points ptr, centres ptr) -> (points, centres, idx, w, event): both tensors are held, so a key cannot alias
 
 
 def plan_sampling_chain(sa_layers, coords):
@@ -168,6 +170,15 @@ def plan_sampling_chain(sa_layers, coords):
                     plan = ops.voxel_plan(c, *args)
                     plan.ready = torch.cuda.Event()
                     tape.record_event(plan.ready, side)
+            # the 3-NN searches of the feature-propagation modules are geometry too (level i's points against level i + 1's
+            # centres): four launches that leave the main stream's critical path; an FP module finds its pair in NN_PLANS
+            if SIDE_NN:
+                chain = [c0] + [(b[-1] if isinstance(b, nn.Sequential) else b)._planned[0] for b in sa_layers]
+                for pts, ctr in zip(chain[:-1], chain[1:]):
+                    idx, w = ops.three_nn_search(pts, ctr)
+                    ev = torch.cuda.Event()
+                    tape.record_event(ev, side)
+                    NN_PLANS[(pts.data_ptr(), ctr.data_ptr())] = (pts, ctr, idx, w, ev)
         return first._planned
 
     if DEFER_CHAIN:
@@ -180,6 +191,7 @@ def encode(sa_layers, global_att, inputs, t_emb):
     """Down path (pvcnn.py:90-110)."""
     coords = inputs[:, :3, :].contiguous()
     ops.clear_plan_cache()  # voxel plans are valid within one encoder/decoder pass
+    NN_PLANS.clear()
     for blocks in sa_layers:  # sampler plans too: never inherit one from an aborted or foreign forward
         (blocks[-1] if isinstance(blocks, nn.Sequential) else blocks)._planned = None
     # also inside a hipGraph capture: the side stream forks from and joins the capturing stream.  Small problems (one
