@@ -299,7 +299,7 @@ int bdm_avg_voxelize_s3(int b, int c, int n, int r, const float *features, long 
 
 /* fp16x3 form of the dense convolution (default for the second convolution of every PVConv): operands stored as two
  * fp16 terms (hi, lo) after exact power-of-two scaling, three partial products per fp32 product on
- * v_mfma_f32_32x32x16_f16 -- half the matrix work of bf16x6 at the same accuracy (csrc/conv3d_h2.hip).
+ * v_mfma_f32_16x16x32_f16 -- half the matrix work of bf16x6 at the same accuracy (csrc/conv3d_h2.hip).
  *   packed_w : bdm_conv3d_h2_weight_elems(cout, cin) fp16; inv_scale (cout floats) = 2^-e[co] for the epilogue;
  *              scale_ws (cout floats) is scratch of the pack.
  *   x_h2     : (b, ceil(c/8), 2, v, 8) fp16 = act_scale * swish(group_norm(x)) split in two, from
