@@ -264,7 +264,8 @@ class PVConv(nn.Module):
                 # The gather runs HERE, on the branch's stream: its output is allocated on the stream that consumes it (a block of
                 # the main stream freed at return could be handed out again while the branch still reads it)
                 conv = self.point_features.layers[0]
-                fmap = cond.map("point_branch", conv.weight, lambda: conv.weight.detach().reshape(conv.out_channels, -1)[:, 3:3 + cond.C])
+                fmap = cond.map("point_branch", conv.weight,
+                                lambda conv=conv, C=cond.C: conv.weight.detach().reshape(conv.out_channels, -1)[:, 3:3 + C])  # (holds no step tensors: the closure is cached)
                 gathered = cond.gather(fmap)                         # (B, 3 + M, N): rows 0..2 = xyz, the rest = map rows
                 x, first_add = gathered[:, :3], gathered[:, 3:]
                 first_weight = hoisted_first_weight(self.point_features, conv, 3)
@@ -544,7 +545,8 @@ class PointNetFPModule(nn.Module):
             if (cond is not None and skip_src.shape[1] == cond.C and skip_src.data_ptr() == cond.x_cf[:, 3:].data_ptr()):
                 # the skip channels are F[pix]: their share of the first layer, (F . W_skip^T)[pix], is gathered from the hoisted map
                 conv = self.mlp.layers[0]
-                fmap = cond.map("fp_skip", conv.weight, lambda: conv.weight.detach().reshape(conv.out_channels, -1)[:, c_int:c_int + cond.C])
+                fmap = cond.map("fp_skip", conv.weight,
+                                lambda conv=conv, lo=c_int, C=cond.C: conv.weight.detach().reshape(conv.out_channels, -1)[:, lo:lo + C])
                 g = cond.gather(fmap)
                 return self.mlp.run(buf, first_weight=hoisted_first_weight(self.mlp, conv, c_int), first_add=g[:, 3:]), points_coords, interpolated_temb
             return self.mlp.run(buf, x2=skip_src), points_coords, interpolated_temb

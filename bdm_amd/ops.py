@@ -910,7 +910,7 @@ def sparse_first_conv_from_map(cond, plan, conv, cout, gn_groups=None):
     w = conv.weight
     n27 = 27 * cout
     C = cond.C
-    hmap = cond.map("conv1", w, lambda: w.detach()[:, 3:3 + C].reshape(cout, C, 27).permute(2, 0, 1).reshape(n27, C))  # row tap*cout+co
+    hmap = cond.map("conv1", w, lambda w=w, C=C, cout=cout, n27=n27: w.detach()[:, 3:3 + C].reshape(cout, C, 27).permute(2, 0, 1).reshape(n27, C))  # row tap*cout+co
     key = ("conv1_wx", w.data_ptr())
     hit = cond.maps.get(key)
     if hit is None or hit[0] != w._version:
