@@ -134,6 +134,24 @@ def test_forward_is_run_to_run_deterministic(hip):
         assert torch.equal(net(x, t), a)
 
 
+def test_geometry_on_the_sampler_stream_changes_no_bit(hip, monkeypatch):
+    """Everything that depends on coordinates only runs ahead on the sampler's stream (FPS / ball query of all levels, the next
+    levels' voxel plans, the FP modules' 3-NN searches: pvcnn.plan_sampling_chain).  Inline on the main stream, or with the 3-NN
+    searches left to the FP modules, the forward gives the same bits."""
+    from bdm_amd import pvcnn
+    from bdm_amd.pvcnn import PVCNN2_PC2
+    from bdm_amd.utils.procedural import fill_module_
+    net = fill_module_(PVCNN2_PC2(3, 64, extra_feature_channels=387).eval(), seed=4).cuda()
+    x = point_cloud_inputs(3, 390, 4096, seed=78).cuda()
+    t = torch.tensor([20, 400, 980]).cuda()
+    ahead = net(x, t).clone()
+    assert not pvcnn.NN_PLANS, "every planned 3-NN search is consumed by its FP module"
+    monkeypatch.setattr(pvcnn, "SIDE_NN", False)
+    assert torch.equal(net(x, t), ahead)
+    monkeypatch.setattr(pvcnn, "SIDE_STREAM", False)
+    assert torch.equal(net(x, t), ahead)
+
+
 def test_hoisted_projection_conditioning_equals_the_generic_path(hip, monkeypatch):
     """ops.Conditioning: x_in = [xyz, F[pix]] lets the first linear maps of the PC^2 denoiser (SA0 point branch, first sparse
     convolution, last FP module's first layer) be applied to the conditioning IMAGE once and gathered per step.  Same forward as the
