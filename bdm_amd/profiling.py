@@ -84,6 +84,8 @@ SPEC = {
                              lambda a: ("mfma_aux", 2.0 * a[0] * a[1] * OCCUPANCY.get(a[1], 1.0) * a[2] * a[3], MFMA32_PEAK_TFLOPS)),
     "bdm_sparse_conv_gather": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] ** 3)),
     "bdm_sparse_conv_gather_gn": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] ** 3)),
+    # hoisted conditioning (ops.Conditioning): rows of the occupied cells from the per-pixel map; algorithmic = the map rows of the points
+    "bdm_sparse_conv_rows_from_map": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[4]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[4])),
     "bdm_sparse_voxel_features_s3": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2])),
     "bdm_sparse_voxel_features": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2])),
     "bdm_sparse_voxel_features_f32": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2])),
@@ -91,6 +93,7 @@ SPEC = {
     # 1x1 convolutions / linear layers
     "bdm_pointwise_conv": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:4], _pw),
     "bdm_pointwise_conv_gn": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:4], _pw),  # + GroupNorm statistics / folded input GroupNorm
+    "bdm_pointwise_conv_gn_add": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:4], _pw),  # + per-element addend (hoisted conditioning share)
     "bdm_pointwise_conv_s3": ("1x1 conv GEMM (bf16x6)", lambda a: a[:4], _pw_s3),
     "bdm_pointwise_conv_gn_s3": ("1x1 conv GEMM (bf16x6)", lambda a: a[:4], _pw_s3),
     # normalisation and operand repacks: 1 read + 1 write of the tensor
