@@ -150,6 +150,27 @@ __global__ __launch_bounds__(256) void probe_brim_kernel(int words, int iters, i
   }
 }
 
+// trivial VICTIM with the access pattern of the global-memory devoxelisation and nothing else: eight scattered 4-byte loads per
+// (point, channel) from a static grid, a weighted sum, one store.  No LDS, no transcendental, no parameter tables.
+__global__ void gather8_kernel(int c, int n, int r, const float *__restrict__ coords, const float *__restrict__ grid, float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, ci = blockIdx.y, bi = blockIdx.z;
+  if (i >= n) return;
+  const float *pc = coords + (size_t)bi * 3 * n;
+  const float x = pc[i], y = pc[n + i], z = pc[2 * n + i];
+  const float xl = floorf(x), yl = floorf(y), zl = floorf(z), x1 = x - xl, y1 = y - yl, z1 = z - zl;
+  const int r2 = r * r, base = (int)xl * r2 + (int)yl * r + (int)zl, sx = x1 > 0 ? r2 : 0, sy = y1 > 0 ? r : 0, sz = z1 > 0 ? 1 : 0;
+  const float *g = grid + ((size_t)bi * c + ci) * r2 * r;
+  float acc = (1 - x1) * (1 - y1) * (1 - z1) * g[base];
+  acc += (1 - x1) * (1 - y1) * z1 * g[base + sz];
+  acc += (1 - x1) * y1 * (1 - z1) * g[base + sy];
+  acc += (1 - x1) * y1 * z1 * g[base + sy + sz];
+  acc += x1 * (1 - y1) * (1 - z1) * g[base + sx];
+  acc += x1 * (1 - y1) * z1 * g[base + sx + sz];
+  acc += x1 * y1 * (1 - z1) * g[base + sx + sy];
+  acc += x1 * y1 * z1 * g[base + sx + sy + sz];
+  out[((size_t)bi * c + ci) * n + i] = acc;
+}
+
 struct Case {
   const char *name;
   std::function<void()> launch;
@@ -254,7 +275,7 @@ static int aggress(const char *kind, double seconds) {
   { const int h[2] = {150, 90}; HIP_OK(hipMemcpy(live, h, sizeof(h), hipMemcpyHostToDevice)); }
   const int exit_mode = !strcmp(kind, "exit48k") ? 1 : !strcmp(kind, "noexit48k") ? 0 : !strcmp(kind, "exit48k_mfma") ? 3 :
                         !strcmp(kind, "noexit48k_mfma") ? 2 : !strcmp(kind, "exit8k") ? 5 : -1;
-  SparseSetup *sp = (!strcmp(kind, "features") || !strcmp(kind, "gemm_s3") || !strcmp(kind, "gather")) ? new SparseSetup() : nullptr;
+  SparseSetup *sp = (!strcmp(kind, "features") || !strcmp(kind, "gemm_s3") || !strcmp(kind, "gemm_s3_all") || !strcmp(kind, "gather")) ? new SparseSetup() : nullptr;
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
   HIP_OK(hipEventRecord(e0, g_agg_stream));
@@ -269,6 +290,14 @@ static int aggress(const char *kind, double seconds) {
       else if (!strcmp(kind, "features")) sp->features();
       else if (!strcmp(kind, "gemm_s3")) sp->gemm();
       else if (!strcmp(kind, "gather")) sp->gather();
+      else if (!strcmp(kind, "pw")) {  // the library's fp32-MFMA 1x1 GEMM (64 -> 64 channels, 2 x 32768 columns): another LDS + MFMA kernel
+        static float *pw_w = dev_random(64 * 64, 0.15f), *pw_b = dev_random(64, 0.1f);
+        ABI_OK(bdm_pointwise_conv(2, 64, 64, 32768, pw_w, 64, x, 64ll * 32768, 32768, pw_b, nullptr, 0, nullptr, 0, 0, y, 64ll * 32768, 32768, 0, 0.f,
+                                  (void *)g_agg_stream));
+      }
+      else if (!strcmp(kind, "gemm_s3_all")) {  // the same GEMM with every row block live (no early exit)
+        ABI_OK(bdm_sparse_conv_gemm_s3(sp->B, sp->n_max, sp->C, 27 * sp->cout, sp->xs, sp->wpk, nullptr, sp->y, (void *)g_agg_stream));
+      }
       else hipLaunchKernelGGL(copy_kernel, dim3((n4 + 255) / 256), dim3(256), 0, g_agg_stream, (const float4 *)x, (float4 *)y, n4);
     }
     iters += 50;
@@ -330,6 +359,13 @@ int main(int argc, char **argv) {
   float *add = dev_random((size_t)B * C * NP), *dout = dev_alloc<float>((size_t)B * C * NP);
   cases.push_back({"lib devoxelize_gn_gate_add (128 channels, 1024 points, 16^3)", [&] {
     ABI_OK(bdm_devoxelize_gn_gate_add(B, C, NP, R, coords, grid, coef, gate, add, (long long)C * NP, NP, dout, (long long)C * NP, NP, nullptr)); },
+    dout, (size_t)B * C * NP * 4});
+  // snapshots of the victim's static inputs: are they still intact at the end (an out-of-bounds WRITE of a neighbour would change them)?
+  std::vector<uint32_t> grid0((size_t)B * C * R * R * R), coords0((size_t)B * 3 * NP);
+  HIP_OK(hipMemcpy(grid0.data(), grid, grid0.size() * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(coords0.data(), coords, coords0.size() * 4, hipMemcpyDeviceToHost));
+  cases.push_back({"trivial gather8 (devoxelisation's 8 scattered loads per output, no LDS, no parameters)", [&] {
+    hipLaunchKernelGGL(gather8_kernel, dim3((NP + 255) / 256, C, B), dim3(256), 0, 0, C, NP, R, (const float *)coords, (const float *)grid, dout); },
     dout, (size_t)B * C * NP * 4});
   // ---- library: the three calls back to back, 40 rounds without any synchronisation in between (the shape of a real forward)
   cases.push_back({"lib chain: 40 x [gemm+stats -> folded gemm+stats -> devoxelize] without synchronisation", [&] {
@@ -410,6 +446,15 @@ int main(int argc, char **argv) {
     printf("%-92s %4d / %d repetitions differ from the first\n", c.name, bad, reps);
     fflush(stdout);
     total_bad += bad;
+  }
+  {
+    std::vector<uint32_t> g1(grid0.size()), c1(coords0.size());
+    HIP_OK(hipMemcpy(g1.data(), grid, g1.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(c1.data(), coords, c1.size() * 4, hipMemcpyDeviceToHost));
+    size_t gd = 0, cd = 0;
+    for (size_t i = 0; i < g1.size(); ++i) gd += g1[i] != grid0[i];
+    for (size_t i = 0; i < c1.size(); ++i) cd += c1[i] != coords0[i];
+    printf("static inputs of the devoxelisation / gather8 victims at the end: %zu grid words and %zu coordinate words changed\n", gd, cd);
   }
   if (bg) { bg->join(); }
   return total_bad ? 1 : 0;
