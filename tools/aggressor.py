@@ -52,6 +52,11 @@ elif family == "sparse":
     ops.clear_plan_cache()
     plan, ws3 = ops.voxel_plan(pts, 16), ops.sparse_conv_pack_s3(w)
     fn = lambda: ops.sparse_first_conv_planned(f, plan, ws3, None, 64)
+elif family == "sparse_h2":
+    pts, f, w = rnd(B, 3, 1024, scale=0.3), rnd(B, 64, 1024), rnd(64, 64, 3, 3, 3, scale=1 / 40)
+    ops.clear_plan_cache()
+    plan, wh2 = ops.voxel_plan(pts, 16), ops.sparse_conv_pack_h2(w)
+    fn = lambda: ops.sparse_first_conv_planned(f, plan, wh2, None, 64)
 elif family == "pw":
     x, w, b = rnd(B, 64, 32768), rnd(64, 64, scale=0.15), rnd(64)
     fn = lambda: ops.pointwise_conv(x, w, b)
