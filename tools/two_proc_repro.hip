@@ -231,6 +231,55 @@ __global__ __launch_bounds__(256) void lds_exit_kernel(int mode, const int *__re
   y[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x * 256 + blockIdx.x * 256 + tid] = s;
 }
 
+// Ablation stand-in for sparse_gemm_s3_kernel: the same grid, LDS footprint, load / store patterns and MFMA count, each part behind a mode
+// bit (1: global operand loads, 2: LDS staging + barriers, 4: MFMAs, 8: the output stores) -- which part disturbs the neighbour?
+__global__ __launch_bounds__(256) void agg_gemm_kernel(int mode, int M, int G, int N, const uint4 *__restrict__ A, const uint4 *__restrict__ Bw,
+                                                       float *__restrict__ Y) {
+  constexpr int BM = 128, BN = 128, AI = 12 * BM / 256, BI = 12 * BN / 256;
+  __shared__ uint4 As[12 * BM], Bs[12 * BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5, wr = wave >> 1, wc = wave & 1;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, bi = blockIdx.z;
+  const uint4 *Ab = A + (size_t)bi * G * 3 * M;
+  t_f32x16 acc[2][2];
+  for (int x = 0; x < 2; ++x) for (int y = 0; y < 2; ++y) for (int r = 0; r < 16; ++r) acc[x][y][r] = (float)(tid + r);
+  uint4 ar[AI], br[BI];
+  for (int i = 0; i < AI; ++i) ar[i] = make_uint4(tid, i, 1u, 2u);
+  for (int i = 0; i < BI; ++i) br[i] = make_uint4(tid, i, 3u, 4u);
+  for (int g0 = 0; g0 < G; g0 += 4) {
+    if (mode & 1) {
+      for (int i = 0; i < AI; ++i) { const int e = tid + i * 256, row = e % BM, gs = e / BM, g = min(g0 + gs / 3, G - 1), sp = gs % 3; ar[i] = Ab[(unsigned)((g * 3 + sp) * M + min(m0 + row, M - 1))]; }
+      for (int i = 0; i < BI; ++i) { const int e = tid + i * 256, col = e % BN, gs = e / BN, g = min(g0 + gs / 3, G - 1), sp = gs % 3; br[i] = Bw[(unsigned)((g * 3 + sp) * N + min(n0 + col, N - 1))]; }
+    }
+    if (mode & 2) {
+      __syncthreads();
+      for (int i = 0; i < AI; ++i) As[tid + i * 256] = ar[i];
+      for (int i = 0; i < BI; ++i) Bs[tid + i * 256] = br[i];
+      __syncthreads();
+    }
+    if (mode & 4) {
+      for (int kk = 0; kk < 2; ++kk)
+        for (int x = 0; x < 2; ++x)
+          for (int y = 0; y < 2; ++y) {
+            const uint4 a = (mode & 2) ? As[((2 * kk + lh) * 3) * BM + (wr * 2 + x) * 32 + li] : ar[(kk + x) % AI];
+            const uint4 b = (mode & 2) ? Bs[((2 * kk + lh) * 3) * BN + (wc * 2 + y) * 32 + li] : br[(kk + y) % BI];
+            for (int t = 0; t < 6; ++t)
+              acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const t_bf16x8 *>(&a), *reinterpret_cast<const t_bf16x8 *>(&b), acc[x][y], 0, 0, 0);
+          }
+    }
+  }
+  if (mode & 8) {
+    float *Yb = Y + (size_t)bi * M * N;
+    for (int x = 0; x < 2; ++x)
+      for (int y = 0; y < 2; ++y) {
+        const int nn = n0 + (wc * 2 + y) * 32 + li;
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wr * 2 + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < M && nn < N) Yb[(size_t)m * N + nn] = acc[x][y][r];
+        }
+      }
+  } else if (acc[0][0][0] == 12345.678f) Y[tid] = acc[1][1][3];  // keep the work alive
+}
+
 // The library's sparse first convolution, kernel by kernel (torch-free set-up of a voxel plan for B = 2 clouds of 1024 points, 16^3)
 static hipStream_t g_agg_stream = 0;  // stream of the aggressor's launches (null stream unless --inproc)
 
@@ -294,6 +343,11 @@ static int aggress(const char *kind, double seconds) {
         static float *pw_w = dev_random(64 * 64, 0.15f), *pw_b = dev_random(64, 0.1f);
         ABI_OK(bdm_pointwise_conv(2, 64, 64, 32768, pw_w, 64, x, 64ll * 32768, 32768, pw_b, nullptr, 0, nullptr, 0, 0, y, 64ll * 32768, 32768, 0, 0.f,
                                   (void *)g_agg_stream));
+      }
+      else if (!strncmp(kind, "agg", 3) && kind[3] >= '0' && kind[3] <= '9') {  // agg<mode>: the ablation stand-in above
+        static SparseSetup *sq = new SparseSetup();
+        hipLaunchKernelGGL(agg_gemm_kernel, dim3(14, 8, 2), dim3(256), 0, g_agg_stream, atoi(kind + 3), sq->n_max, sq->C / 8, 27 * sq->cout,
+                           (const uint4 *)sq->xs, (const uint4 *)sq->wpk, sq->y);
       }
       else if (!strcmp(kind, "gemm_s3_all")) {  // the same GEMM with every row block live (no early exit)
         ABI_OK(bdm_sparse_conv_gemm_s3(sp->B, sp->n_max, sp->C, 27 * sp->cout, sp->xs, sp->wpk, nullptr, sp->y, (void *)g_agg_stream));
