@@ -1027,6 +1027,42 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None):
     return (out, stats) if gn_groups else out
 
 
+def sparse_conv_pack_os(weight):
+    """(Cout, Cin, 3,3,3) fp32 -> ("os", fp16 weight image of the dense fp16x3 convolution, inv_scale) for sparse_first_conv_os."""
+    return ("os",) + tuple(conv3d_h2_pack(weight))
+
+
+def sparse_first_conv_os(features, plan, packed, bias, cout, gn_groups=None):
+    """Conv3d(k3, p1)(avg_voxelize(features)) as ONE output-stationary implicit GEMM with tap skipping (csrc/sparse_conv_os.hip):
+    occupied cells' fp32 feature records + per-shape maximum (one launch), then the convolution (one launch) -- no 27x intermediate.
+    packed = conv3d_h2_pack(weight).  gn_groups: -> (out, (workspace, slices, groups)) with the GroupNorm statistics of the output."""
+    f, B, C, n, bs_f, ld_f = _bcl(features)
+    dev, lib, r = f.device, L.lib(), plan.r
+    packed_w, inv_scale = packed
+    xr = torch.empty(B, (C + 7) // 8, plan.n_max, 8, dtype=torch.float32, device=dev)
+    amax = amax_slots(dev, B)
+    L.check(lib.bdm_sparse_voxel_features_f32(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),
+                                              L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()),
+            "sparse_voxel_features_f32")
+    out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
+    if gn_groups:
+        ws = torch.empty(lib.bdm_group_norm_workspace_bytes(B, gn_groups), dtype=torch.uint8, device=dev)
+        slices = ctypes.c_int(0)
+        L.check(lib.bdm_sparse_conv_os_gn(B, C, cout, r, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index), L.ptr(packed_w),
+                                          L.ptr(inv_scale), L.ptr(bias), L.ptr(out), int(gn_groups), L.ptr(ws), ctypes.byref(slices),
+                                          L.stream()), "sparse_conv_os_gn")
+        return out, (ws, slices.value, int(gn_groups))
+    L.check(lib.bdm_sparse_conv_os(B, C, cout, r, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index), L.ptr(packed_w),
+                                   L.ptr(inv_scale), L.ptr(bias), L.ptr(out), L.stream()), "sparse_conv_os")
+    return out
+
+
+def sparse_os_gn_ok(cout, groups, r):
+    cg = cout // groups if groups and cout % groups == 0 else 0
+    tile = 64 if (cout > 32 and r != 8) else 32
+    return cg >= 4 and (cg & (cg - 1)) == 0 and tile % cg == 0
+
+
 def sparse_first_conv(features, vox_coords, r, wt, bias, cout):
     """Conv3d(k3, p1)(avg_voxelize(features, vox_coords, r)) evaluated on the occupied voxels: (B, cout, r^3) fp32.
     Builds a one-off plan from integer voxel coordinates (the modules share cached plans: voxel_plan)."""
@@ -1047,4 +1083,6 @@ def sparse_first_conv(features, vox_coords, r, wt, bias, cout):
     L.check(lib.bdm_voxel_compact(B, r, p.n_max, L.ptr(p.cnt), L.ptr(p.occ_index), L.ptr(p.occ_list), L.ptr(p.n_occ), L.stream()),
             "voxel_compact")
     L.check(lib.bdm_voxel_row_occupancy(B, r, L.ptr(p.cnt), L.ptr(p.rowocc), L.stream()), "voxel_row_occupancy")
+    if isinstance(wt, tuple) and wt[0] == "os":
+        return sparse_first_conv_os(features, p, wt[1:], bias, cout)
     return sparse_first_conv_planned(features, p, wt, bias, cout)

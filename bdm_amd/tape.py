@@ -35,8 +35,9 @@ _active = None  # the LaunchTape being recorded (None: not recording)
 
 
 def _host_only(name):
+    # (bdm_tape_*: the executor's own management calls -- e.g. another tape's __del__ running during a recording -- are never steps)
     return (not name.startswith("bdm_") or name.endswith("_bytes") or name.endswith("_elems") or name.endswith("_slices")
-            or name in ("bdm_last_error", "bdm_abi_version"))
+            or name.startswith("bdm_tape_") or name in ("bdm_last_error", "bdm_abi_version"))
 
 
 class _RecordingLib:
@@ -101,6 +102,13 @@ class _TorchOps(TorchDispatchMode):
         touched = _tensors((args, kwargs, out), [])
         if not any(t.is_cuda for t in touched):
             return out
+        if tape.pool is not None:
+            # storages that appear as an operator's result without being one of its inputs were allocated during the recording,
+            # i.e. inside the tape's private pool (views share their base's storage and so inherit its status)
+            ins = {t.untyped_storage().data_ptr() for t in _tensors((args, kwargs), []) if t.is_cuda}
+            for t in _tensors(out, []):
+                if t.is_cuda and t.untyped_storage().data_ptr() not in ins:
+                    tape.pool_storages.add(t.untyped_storage().data_ptr())
         name = func._schema.name
         if func.is_view or name in _ALLOC_ONLY:
             return out
@@ -150,7 +158,7 @@ _U64 = (1 << 64) - 1
 def _slots(name, args):
     """8-byte argument slots of a recorded C-ABI call (include/bdm_hip.h section 5): integers and pointers as they are (two's
     complement), float arguments as the bit pattern of a double."""
-    argtypes = L.abi_signatures()[name][1] if name not in _slots.cache else _slots.cache[name]
+    argtypes = L.abi_signatures(experimental=L.has_experimental())[name][1] if name not in _slots.cache else _slots.cache[name]
     _slots.cache[name] = argtypes
     if len(argtypes) != len(args):
         raise L.BdmHipError(f"launch tape: {name} recorded with {len(args)} arguments, the header declares {len(argtypes)}")
@@ -178,7 +186,8 @@ class LaunchTape:
         self.native = {}     # index into calls -> native form of a non-C-ABI entry: ("memset", tensor, raw stream) | ...
         self.main_stream = None
         self.handle, self.program, self.python_entries = None, None, None
-        self.pool = None     # the private memory pool the step was recorded in (owns every address the tape holds)
+        self.pool = None     # the private memory pool the step was recorded in (owns every address allocated while recording)
+        self.pool_storages = set()   # storage addresses allocated during the recording (inside the pool)
 
     def __len__(self):
         return len(self.calls)
@@ -270,6 +279,22 @@ class LaunchTape:
                 self._fail(getattr(fn, "__name__", fn), rc)
 
 
+class _PinOutsiders:
+    """`_lib._keep` while a step is recorded into a private pool: the pool owns every buffer allocated DURING the recording, but the
+    step also bakes in addresses of longer-lived buffers allocated outside it -- `ops._ws_cache` workspaces (re-allocated when a
+    larger request arrives), the packed cameras, hoisted conditioning maps, amax rings, weights packs.  Those are pinned by the
+    tape, so a later eager call that replaces one of them can never free memory a recorded step still reads or writes."""
+
+    def __init__(self, tape):
+        self.tape, self.seen = tape, set()
+
+    def append(self, t):
+        sp = t.untyped_storage().data_ptr()
+        if sp not in self.tape.pool_storages and sp not in self.seen:
+            self.seen.add(sp)
+            self.tape.keep.append(t)
+
+
 class record:
     """`with record() as tape:` -- run one step eagerly and record it.  Check `tape.broken` afterwards."""
 
@@ -289,7 +314,8 @@ class record:
             self.tape.pool = torch.cuda.MemPool()
             self._pool_ctx = torch.cuda.use_mem_pool(self.tape.pool)
             self._pool_ctx.__enter__()
-            L._keep = None            # the pool owns the addresses; intermediates may be recycled inside the step, as in the eager loop
+            # the pool owns what is allocated inside the step (recycled within it, as in the eager loop); buffers from OUTSIDE are pinned
+            L._keep = _PinOutsiders(self.tape)
         else:
             L._keep = self.tape.keep  # no pool: the tape owns every buffer whose address it holds
         self._mode = _TorchOps(self.tape)
@@ -308,7 +334,10 @@ class record:
         if et is not None:
             self.tape.broken = f"exception while recording: {ev!r}"
         else:
-            self.tape.finalize()
+            try:
+                self.tape.finalize()
+            except (KeyError, L.BdmHipError) as e:   # an entry point without a thunk / prototype: stay on the eager path
+                self.tape.broken = f"finalize: {e!r}"
         return False
 
 

@@ -433,6 +433,21 @@ int bdm_sparse_split_h2(int b, int cin, int n_max, const void *xr, const float *
 int bdm_sparse_conv_gemm_h2(int b, int n_max, int cin, int cout, const void *xh, const float *amax, const void *packed_w,
                             const float *inv_scale, const int *n_occ, float *y, void *stream);
 
+/* The same first convolution as ONE output-stationary implicit GEMM with tap skipping (sparse_conv_os.hip, round 4; the default
+ * wherever the input is not the hoisted conditioning map): no (n_occ x 27*cout) intermediate, no gather, no operand-split pass.
+ *   xr / amax     bdm_sparse_voxel_features_f32: fp32 records (b, ceil(cin/8), n_max) x 8 channels + per-shape max |value|
+ *   occ_index     (b, r^3) compact row of every cell, -1 = empty (bdm_voxelize_plan_full / bdm_voxel_compact)
+ *   packed_w / inv_scale   bdm_conv3d_h2_pack_weights (the dense fp16x3 convolution's weight image)
+ *   y             (b, cout, r^3) fp32 = bias + conv; every cell is written.  r in {8, 16, 32}, n_max < 2^18.
+ * A workgroup owns a brick of output voxels (the dense kernel's tiles), builds its halo in LDS from the occupied cells only and
+ * skips every (16-voxel block, tap quad) MFMA group whose 64 neighbours are all empty.  fp16x3 arithmetic, activation scale per
+ * shape.  _gn: also leaves GroupNorm(groups) slice partials of y exactly as bdm_conv3d_3x3x3_h2_gn does. */
+int bdm_sparse_conv_os(int b, int cin, int cout, int r, int n_max, const void *xr, const float *amax, const int *occ_index,
+                       const void *packed_w, const float *inv_scale, const float *bias, float *y, void *stream);
+int bdm_sparse_conv_os_gn(int b, int cin, int cout, int r, int n_max, const void *xr, const float *amax, const int *occ_index,
+                          const void *packed_w, const float *inv_scale, const float *bias, float *y, int groups,
+                          void *gn_workspace, int *slices_out, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * 3. Per-step glue of the coupled DDPM loop
  * ---------------------------------------------------------------------------------- */

@@ -1,0 +1,78 @@
+"""Golden vectors of the full-length coupled trajectories: the CPU ORACLE's final clouds, written once in the build container
+so that the `-m gpu` parity tests do not spend minutes of host time per run re-deriving them.
+
+    python -m oracle.gen_golden_traj [blending_n1024] [merging_n1024] [c2_b16_shape11]      (no argument: all three)
+
+writes tests/golden/traj_<name>.npz = the case description (seeds, sizes, schedule, head scale: everything
+`tests/trajectory_case.build` needs to rebuild the identical weights / inputs / random draws procedurally), the oracle's final
+(1, N, 3) cloud and its clouds at every milestone boundary (for diagnosis when a test fails).  Nothing of /root/reference is read:
+the oracle is this repository's own restatement (oracle/ref_sampler.py, ref_net.py, pvcnn_ops_ref.c), pinned by the network
+and module goldens.  A fixture is host-independent enough for the 1e-3 bound it is used with: the oracle's own 1-ulp
+self-sensitivity over the full schedule at head scale 0.1 is 3.5e-5, and the live-oracle forms of the
+same tests stay available under the `gpu_slow` marker (tests/test_hip_full_trajectory.py, tests/test_hip_full_size.py).
+
+Test infrastructure: only tests/ read these files.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HEAD_SCALE = 0.1
+
+CASES = {
+    # name: (N, B, merging, seed of the per-shape Philox streams or None = injected KeyedNoise draws, sampled row)
+    "blending_n1024": dict(N=1024, B=1, merging=False, philox_seed=None, row=0),
+    "merging_n1024": dict(N=1024, B=1, merging=True, philox_seed=None, row=0),
+    "c2_b16_shape11": dict(N=4096, B=16, merging=False, philox_seed=42, row=11),
+}
+
+
+def oracle_case(name):
+    import trajectory_case as case
+    d = CASES[name]
+    c = case.build(d["N"], head_scale=HEAD_SCALE, merging=d["merging"], B=d["B"])
+    if d["philox_seed"] is not None:
+        return c, case.philox_shape_case(c, d["philox_seed"], d["row"], d["row"])
+    return c, c
+
+
+def generate(name):
+    import trajectory_case as case
+    from oracle import ops, ref_sampler as R
+    ops.build()
+    d = CASES[name]
+    c, oc = oracle_case(name)
+    order = case.program_order(c.milestones, c.roll_step, c.merging)
+    snaps, t0, n = {}, time.time(), [0]
+
+    def trace(kind, t, x):
+        n[0] += 1
+        if kind == "recon" and t in c.milestones[1:]:
+            snaps[f"recon_after_t{t}"] = x.detach().clone().numpy()
+        if n[0] % 100 == 0:
+            print(f"  [{name}] {n[0]:5d} / {len(order)} steps, {time.time() - t0:6.0f} s", flush=True)
+    R.TRACE = trace
+    try:
+        final = case.run_oracle(oc)
+    finally:
+        R.TRACE = None
+    out = os.path.join(ROOT, "tests", "golden", f"traj_{name}.npz")
+    np.savez_compressed(out, final=final.numpy().astype(np.float32), N=d["N"], B=d["B"], merging=d["merging"],
+                        philox_seed=-1 if d["philox_seed"] is None else d["philox_seed"], row=d["row"],
+                        head_scale=HEAD_SCALE, milestones=np.asarray(c.milestones), roll_step=c.roll_step,
+                        forwards=len(order), torch_version=torch.__version__, threads=torch.get_num_threads(),
+                        **{k: v.astype(np.float32) for k, v in snaps.items()})
+    print(f"{name}: {len(order)} forwards in {time.time() - t0:.0f} s -> {out} ({os.path.getsize(out) / 1024:.0f} KB)")
+
+
+if __name__ == "__main__":
+    for nm in (sys.argv[1:] or list(CASES)):
+        generate(nm)

@@ -24,3 +24,10 @@ def point_cloud_inputs(B, C, N, seed):
 
 def rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def golden_trajectory(name):
+    """tests/golden/traj_<name>.npz (oracle/gen_golden_traj.py): case description + the oracle's final cloud."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"traj_{name}.npz"))
+    return {k: g[k] for k in g.files}

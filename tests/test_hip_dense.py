@@ -448,6 +448,48 @@ def test_sparse_first_conv_equals_dense(ops, oracle_ops, cin, cout, r, npts):
         assert torch.equal(gotf, ops.sparse_first_conv(big[:, 3:3 + cin], vc.cuda(), r, ops.sparse_conv_pack_fused(w.cuda()), bias.cuda(), cout).cpu())
 
 
+@pytest.mark.parametrize("cin,cout,r,npts", [(35, 32, 32, 4096), (64, 64, 32, 1100), (64, 64, 32, 4096), (128, 64, 16, 1024), (128, 128, 16, 1024),
+                                             (256, 256, 8, 64), (192, 128, 8, 256), (16, 8, 8, 2000), (390, 32, 32, 700)])
+def test_sparse_first_conv_output_stationary_equals_dense(ops, oracle_ops, cin, cout, r, npts):
+    """The one-kernel output-stationary form with tap skipping (sparse_conv_os.hip, the default first convolution): == the dense
+    evaluation at fp32 grade, bit-reproducible, strided features accepted, and its GroupNorm partials == the statistics of its output."""
+    from bdm_amd import _lib as L
+    import ctypes
+    B = 3
+    g = torch.Generator().manual_seed(cin + r + npts)
+    vc = (torch.randn(B, 3, npts, generator=g) * r / 8 + r / 2).round().clamp(0, r - 1).to(torch.int32)
+    vc[1, :, : npts // 2] = 0            # many points in one corner voxel, incl. the grid boundary
+    vc[2] = r - 1                        # a shape with ONE occupied voxel, at the far corner: almost every brick is pure bias
+    f = torch.randn(B, cin, npts, generator=g)
+    f[:, : min(8, cin)] *= 300.0         # channels of very different magnitude share the shape's power-of-two scale
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    vox = oracle_ops.avg_voxelize_forward(f, vc, r)[0]
+    ref = TF.conv3d(vox.double().view(B, cin, r, r, r), w.double(), bias.double(), padding=1).float().reshape(B, cout, -1)
+    wt = ops.sparse_conv_pack_os(w.cuda())
+    got = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, wt, bias.cuda(), cout).cpu()
+    for b in range(B):
+        assert rel(got[b], ref[b]) < 2e-6, b
+    assert torch.equal(got, ops.sparse_first_conv(f.cuda(), vc.cuda(), r, wt, bias.cuda(), cout).cpu())
+    big = torch.randn(B, cin + 6, npts, generator=g).cuda()
+    big[:, 3:3 + cin] = f.cuda()
+    assert torch.equal(got, ops.sparse_first_conv(big[:, 3:3 + cin], vc.cuda(), r, wt, bias.cuda(), cout).cpu())
+    # a shape alone gives the bits it gives inside the batch (per-shape activation scale, one tile choice per resolution)
+    alone = ops.sparse_first_conv(f[1:2].contiguous().cuda(), vc[1:2].contiguous().cuda(), r, wt, bias.cuda(), cout).cpu()
+    assert torch.equal(alone, got[1:2])
+    groups = 8
+    if cout % groups == 0 and ops.sparse_os_gn_ok(cout, groups, r):
+        ops.clear_plan_cache()
+        pts = (torch.randn(B, 3, npts, generator=g) * 0.3).cuda()
+        plan = ops.voxel_plan(pts, r)
+        out, (ws, slices, gg) = ops.sparse_first_conv_os(f.cuda(), plan, wt[1:], bias.cuda(), cout, gn_groups=groups)
+        assert torch.equal(out, ops.sparse_first_conv_os(f.cuda(), plan, wt[1:], bias.cuda(), cout))
+        part = ws.view(torch.float64)[: B * groups * slices * 2].view(B, groups, slices, 2).sum(2).cpu()
+        o = out.double().cpu().view(B, groups, -1)
+        assert torch.allclose(part[..., 0], o.sum(-1), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(part[..., 1], (o * o).sum(-1), rtol=1e-5, atol=1e-3)
+
+
 @experimental
 def test_sparse_fused_conv_wide_dynamic_range_and_empty_shape(ops, oracle_ops):
     """channels of very different magnitude (the activation scale is ONE power of two from max |x|), a shape whose points

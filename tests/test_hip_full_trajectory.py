@@ -14,15 +14,32 @@ pass/fail at 1e-3 is a statement about the kernels and not about chaos.  Every l
 the per-step teacher-forced tests (tests/test_hip_teacher_forced.py) cover the head at scale 1.
 """
 import pytest
+import torch
 
-from helpers import rel_l2
+from helpers import golden_trajectory, rel_l2
 import trajectory_case as case
 
-pytestmark = pytest.mark.gpu
 HEAD_SCALE = 0.1
 NORTH_STAR = 1e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["blending_n1024", "merging_n1024"])
+def test_full_trajectory_vs_oracle_fixture(hip, name):
+    """The default (`-m gpu`) form: the oracle's final cloud comes from tests/golden/traj_<name>.npz, written by
+    oracle/gen_golden_traj.py (the same case, the same oracle, run once in the build container: ~3 min of host time each that the
+    GPU suite no longer pays per run).  The HIP side is the full 1080- / 1075-forward trajectory, nothing shortened."""
+    g = golden_trajectory(name)
+    c = case.build(int(g["N"]), head_scale=float(g["head_scale"]), merging=bool(g["merging"]), B=int(g["B"]))
+    assert list(g["milestones"]) == list(c.milestones) and int(g["roll_step"]) == c.roll_step
+    assert len(case.program_order(c.milestones, c.roll_step, c.merging)) == int(g["forwards"])
+    got = case.run_hip(c)
+    err = rel_l2(got, torch.from_numpy(g["final"]))
+    print(f"full trajectory {name} ({int(g['forwards'])} forwards, N={int(g['N'])}) vs the oracle fixture: final rel-L2 {err:.3e}")
+    assert err <= NORTH_STAR
+
+
+@pytest.mark.gpu_slow
 def test_full_blending_trajectory_literal_bound(hip, oracle_ops):
     c = case.build(1024, head_scale=HEAD_SCALE, merging=False)
     assert len(case.program_order(c.milestones, c.roll_step)) == 1080
@@ -33,6 +50,7 @@ def test_full_blending_trajectory_literal_bound(hip, oracle_ops):
     assert err <= NORTH_STAR
 
 
+@pytest.mark.gpu_slow
 def test_full_merging_trajectory_literal_bound(hip, oracle_ops):
     c = case.build(1024, head_scale=HEAD_SCALE, merging=True)
     order = case.program_order(c.milestones, c.roll_step, merging=True)

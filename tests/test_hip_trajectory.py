@@ -193,3 +193,60 @@ def test_saturation_reroute_reaches_a_recorded_step(hip, monkeypatch):
     assert tape1 is not tape0, "the recorded step with the clamped fp16x3 kernels was replayed"
     assert sum(n == "bdm_conv3d_3x3x3_s3" for n in names(tape1)) == n_s3_before + 1   # the flagged layer's second convolution
     assert float((after - before).norm() / before.norm()) < 1e-3                       # same sampler, bf16x6 in one layer
+
+
+def test_recorded_step_pins_the_buffers_it_did_not_allocate(hip, monkeypatch):
+    """a step recorded into the tape's private pool also bakes in addresses of buffers allocated OUTSIDE the
+    recording -- `ops._ws_cache` workspaces (replaced when a larger request arrives), the packed cameras (a single-entry cache
+    replaced by any call with another camera), weight packs.  The tape pins them: after an eager call has replaced the rasteriser
+    workspace and the camera pack, replaying the OLD recording still gives the eager loop's bits."""
+    import bdm_amd.model as M
+    from bdm_amd import ops
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.utils.procedural import fill_module_
+    B, N, steps = 2, 1024, 10
+    cfg = ProjectConfig()
+    cfg.dataset.max_points = N
+    model = fill_module_(M.get_model(cfg).eval(), seed=3).cuda()
+    batch = next(iter(SyntheticShapes(range(B), B, num_points=N))).to("cuda")
+    other = next(iter(SyntheticShapes(range(7, 7 + 2 * B), 2 * B, num_points=N))).to("cuda")   # another camera, a larger batch
+    x0 = torch.randn(B, N, 3, generator=torch.Generator().manual_seed(5)).cuda()
+
+    def run(mode, b=batch, x=x0, n=steps):
+        monkeypatch.setattr(M, "TAPE_STEPS", mode)
+        it = iter(torch.randn(x.shape, generator=torch.Generator().manual_seed(100 + i)).cuda() for i in range(n))
+        model.scheduler.noise_source = lambda shape, device: next(it)
+        try:
+            return model.interaction_sample(x.clone(), b.camera, b.image_rgb, None, start_time=500, end_time=500 - n).cpu()
+        finally:
+            model.scheduler.noise_source = None
+
+    eager = run("0")
+    taped = run("1")
+    tp = model._tape_cache["tape"]
+    assert tp is not None and tp.pool is not None and torch.equal(eager, taped)
+    pinned = {t.untyped_storage().data_ptr() for t in tp.keep if isinstance(t, torch.Tensor)}
+    cam_ptr = model._cam_cache[1].untyped_storage().data_ptr()
+    ws_ptrs = {k: v.untyped_storage().data_ptr() for k, v in ops._ws_cache.items()}
+    assert cam_ptr in pinned, "the packed cameras' address is baked into the step but not pinned by the tape"
+    assert pinned & set(ws_ptrs.values()), "no cached workspace is pinned although the step's kernels use them"
+    assert not (pinned & tp.pool_storages)
+    g = model._tape_cache
+
+    def replay_once():   # the recorded step by hand, on its own static buffers
+        g["x"].copy_(x0)
+        g["t"].fill_(400)
+        tp.replay()
+        torch.cuda.synchronize()
+        return g["eps"].clone()
+    eps_before = replay_once()
+    # an eager call with another camera and twice the batch: replaces the camera pack and outgrows the workspaces
+    x_big = torch.randn(2 * B, N, 3, generator=torch.Generator().manual_seed(9)).cuda()
+    run("0", b=other, x=x_big, n=3)
+    assert model._cam_cache[1].untyped_storage().data_ptr() != cam_ptr
+    assert any(v.untyped_storage().data_ptr() != ws_ptrs.get(k) for k, v in ops._ws_cache.items())
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(64)]   # whatever was freed is overwritten
+    del junk
+    # the OLD recording still reads and writes only memory it owns or pinned
+    assert torch.equal(replay_once(), eps_before) and bool(torch.isfinite(eps_before).all())
