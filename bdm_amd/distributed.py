@@ -34,10 +34,12 @@ import contextlib
 def gpu_turn(device=None):
     """Test aid for BDM_SHARE_GPU=1 (several ranks driving ONE GPU, used to exercise the multi-rank code on a 1-GPU box):
     the ranks take turns on the device (an flock'ed file; the GPU is drained before the turn ends).  Measured on MI355X /
-    ROCm 7.2: when two PROCESSES run kernels on the same GPU at the same time, a kernel occasionally returns a wrong
-    64-byte sector (16 consecutive floats of one row; all inputs bit-identical, the same launch alone or in a single
-    process is always right -- tools/determinism_trace.py).  One process per GPU, the production layout, never shares a
-    device, so this only matters for the shared-GPU test mode.  No-op otherwise."""
+    ROCm 7.2 (round 3): a kernel CO-RESIDENT with `sparse_gemm_s3_kernel` -- in another process or on another
+    stream of the same process -- occasionally reads a wrong 64-byte sector (16 consecutive floats; all inputs bit-identical,
+    the same launch alone is always right).  Round 4: the default forward no longer launches that GEMM (the first convolution is
+    one output-stationary kernel), and the side-stream kernels were run as victims next to both kernels
+    (tools/coresidency/side_stream_victims.sh, profiles/r04_side_stream_victims.txt).  The lock stays the default of this TEST
+    mode because two whole samplers sharing a GPU interleave every kernel pair, not only the pairs a forward produces.  No-op otherwise."""
     if os.environ.get("BDM_SHARE_GPU") != "1" or os.environ.get("BDM_GPU_TURN", "1") == "0":
         yield
         return
@@ -87,6 +89,60 @@ def gather_clouds(local, num_shapes, rank, world):
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+
+
+def per_rank_values(value: float, device):
+    """[value of rank 0, ..., value of rank world-1] on every rank (one all_gather of a double; bench.py's `per_rank_s`)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa_node(local_rank, sysfs="/sys"):
+    """Pin this worker to the host cores of the NUMA node its GPU hangs off (before any GPU call): the enqueue thread of a rank
+    then never runs across the socket from its device.  The node comes from the PCI device behind the local_rank-th DRM render
+    node that belongs to an amdgpu device (sorted by PCI address: the order ROCm enumerates them in when no *_VISIBLE_DEVICES
+    is set); the affinity is intersected with the mask the process already has (cgroup / taskset).  Returns a dict for the
+    bench line ({"numa_node", "cpus"}), or {"numa_node": None, "why": ...} when the topology cannot be read -- never raises."""
+    import glob
+    try:
+        cards = []
+        for dev in glob.glob(os.path.join(sysfs, "class/drm/renderD*/device")):
+            real = os.path.realpath(dev)
+            try:
+                vendor = open(os.path.join(real, "vendor")).read().strip()
+            except OSError:
+                continue
+            if vendor == "0x1002":
+                cards.append(real)
+        cards = sorted(set(cards), key=os.path.basename)
+        if local_rank >= len(cards):
+            return {"numa_node": None, "why": f"{len(cards)} amdgpu render nodes, local rank {local_rank}"}
+        node = int(open(os.path.join(cards[local_rank], "numa_node")).read().strip())
+        if node < 0:
+            return {"numa_node": None, "why": "device reports no NUMA node"}
+        cpus = _cpulist(open(os.path.join(sysfs, f"devices/system/node/node{node}/cpulist")).read())
+        allowed = os.sched_getaffinity(0)
+        mine = sorted(cpus & allowed)
+        if not mine:
+            return {"numa_node": node, "why": "no allowed CPU on that node", "cpus": 0}
+        os.sched_setaffinity(0, mine)
+        return {"numa_node": node, "cpus": len(mine), "pci": os.path.basename(cards[local_rank])}
+    except (OSError, ValueError) as e:
+        return {"numa_node": None, "why": repr(e)}
 
 
 def max_over_ranks(value: float, device) -> float:

@@ -235,7 +235,7 @@ class PVConv(nn.Module):
     se_in_devox = False  # SE block's FC layers inside the devoxelisation kernel: measured slower (DESIGN.md negative results)
     fold_gn1 = True  # GroupNorm-1 statistics from the sparse gather's epilogue
     fold_pf = True  # point branch's GroupNorm folded into the devoxelisation kernel
-    point_stream = True  # the point branch of a PVConv on its own stream (False: inline; tests and tools/two_proc_race.py flip it)
+    point_stream = True  # the point branch of a PVConv on its own stream (False: inline; tests and tools/coresidency/two_proc_race.py flip it)
     point_stream_min = 8192  # B * N below which the branch stays on the main stream
     _streams = {}
 

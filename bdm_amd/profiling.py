@@ -84,6 +84,10 @@ SPEC = {
                              lambda a: ("mfma_aux", 2.0 * a[0] * a[1] * OCCUPANCY.get(a[1], 1.0) * a[2] * a[3], MFMA32_PEAK_TFLOPS)),
     "bdm_sparse_conv_gather": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] ** 3)),
     "bdm_sparse_conv_gather_gn": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] ** 3)),
+    # round 4: the same convolution as ONE output-stationary implicit GEMM with tap skipping (sparse_conv_os.hip): algorithmic bytes =
+    # the dense output grid written once; its matrix work (live fragments only) rides along as mfma_aux
+    "bdm_sparse_conv_os": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[2] * a[3] ** 3)),
+    "bdm_sparse_conv_os_gn": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[2] * a[3] ** 3)),
     # hoisted conditioning (ops.Conditioning): rows of the occupied cells from the per-pixel map; algorithmic = the map rows of the points
     "bdm_sparse_conv_rows_from_map": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[4]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[4])),
     "bdm_sparse_voxel_features_s3": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2])),

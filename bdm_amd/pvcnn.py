@@ -120,7 +120,7 @@ def embed_time(embedf, t, embed_dim, n):
 
 _side_streams = {}
 SIDE_STREAM = os.environ.get("BDM_SIDE_STREAM", "1") == "1"  # sampler chain on its own stream (0: inline, for experiments)
-SIDE_PLAN = True  # voxel plans of levels 1.. on the sampler's side stream (tools/two_proc_race.py flips it)
+SIDE_PLAN = True  # voxel plans of levels 1.. on the sampler's side stream (tools/coresidency/two_proc_race.py flips it)
 # B * N below which the sampler chain stays on the main stream.  0: always on its own stream -- since the launch count and the
 # per-launch host cost came down it pays even for one small shape (B=1, N=1024: 3.48 -> 3.30 ms; B=4: 3.86 -> 3.42 ms), where
 # furthest point sampling is a fifth of the forward.  (The PVConv point branch keeps its 8192-point threshold: measured slower below.)

@@ -210,12 +210,15 @@ def main():
     from bdm_amd import _lib
     from bdm_amd.config import ProjectConfig
     from bdm_amd.data import SyntheticShapes
-    from bdm_amd.distributed import barrier, init_from_env, max_over_ranks, shard_indices
+    from bdm_amd.distributed import barrier, init_from_env, max_over_ranks, per_rank_values, pin_to_gpu_numa_node, shard_indices
     from bdm_amd.model import get_fusion_model, get_model
     from bdm_amd.pvd import prepare_pvd_model
     from bdm_amd.sampling import batch_streams, bdm_blending, bdm_merging, count_forwards
     from bdm_amd.utils.procedural import fill_module_
 
+    # before anything touches the GPU: this worker onto the host cores next to ITS GPU (no-op when the topology cannot be read)
+    lr_env = 0 if os.environ.get("BDM_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    affinity = pin_to_gpu_numa_node(lr_env) if os.environ.get("BDM_PIN_NUMA", "1") == "1" else {"numa_node": None, "why": "BDM_PIN_NUMA=0"}
     rank, local_rank, world = init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     rccl_ranks = torch.distributed.get_world_size() if world > 1 else 1  # the world size the process group really has
@@ -281,7 +284,10 @@ def main():
         out = trajectory()
     torch.cuda.synchronize()
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, device)
+    mine = time.perf_counter() - t0
+    elapsed = max_over_ranks(mine, device)
+    per_rank_s = per_rank_values(mine, device)          # after the timed region: which rank was the slow one, and by how much
+    per_rank_numa = per_rank_values(float(-1 if affinity.get("numa_node") is None else affinity["numa_node"]), device)
     prof.remove()
     assert torch.isfinite(out).all()
 
@@ -292,9 +298,12 @@ def main():
             "metric": f"sampled shapes/sec ({args.points} pts, 1000 DDPM steps)", "value": value, "unit": "shapes/s",
             "n_gpus": world, "rccl_ranks": rccl_ranks, "dist_backend": dist_backend, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "per_rank_s": [round(v, 4) for v in per_rank_s], "rank_spread": max(per_rank_s) / max(min(per_rank_s), 1e-9),
+            "per_rank_numa_node": [int(v) for v in per_rank_numa], "affinity_rank0": affinity,
             "rng": "per-shape Philox4x32-10 streams keyed by (seed, global shape index), noise generated inside the step kernels",
             "conv_arithmetic": CONV_IMPL + (" (fp32-grade: operands as two fp16 terms after power-of-two scaling, three partial "
-                                                    "products, fp32 accumulate; first conv of each PVConv: sparse, bf16x6)"
+                                                    "products, fp32 accumulate; first conv of each PVConv: on the occupied voxels only, fp16x3 too -- "
+                                                    "output-stationary implicit GEMM with tap skipping, or the hoisted fp32 map at SA0.0)"
                                                     if CONV_IMPL == "fp16x3" else " (fp32-grade: exact 3-way bf16 operand split, "
                                                     "six partial products, fp32 accumulate)"),
             "config": {"workload": conf["label"] + ", synthetic R2N2-style inputs, procedural random-init PC2 + PVD"

@@ -108,7 +108,7 @@ def test_two_rank_gloo_sharding_equivalence(tmp_path):
 import sys, torch
 sys.path.insert(0, {ROOT!r})
 from bdm_amd.data import SyntheticShapes, shape_generator
-from bdm_amd.distributed import init_from_env, shard_indices, gather_clouds, barrier, max_over_ranks
+from bdm_amd.distributed import init_from_env, shard_indices, gather_clouds, barrier, max_over_ranks, per_rank_values
 rank, local_rank, world = init_from_env(backend="gloo")
 N, TOTAL = 64, 5
 idx = shard_indices(TOTAL, rank, world)
@@ -121,6 +121,7 @@ full = gather_clouds(local, TOTAL, rank, world)
 ref = torch.stack([torch.randn(N, 3, generator=shape_generator(42, j)) for j in range(TOTAL)])
 assert torch.equal(full, ref), "gathered result differs from the single-rank result"
 assert max_over_ranks(float(rank), torch.device("cpu")) == world - 1
+assert per_rank_values(10.0 + rank, torch.device("cpu")) == [10.0 + r for r in range(world)]   # bench.py's per_rank_s
 print("OK", rank)
 """)
     import socket
@@ -133,6 +134,48 @@ print("OK", rank)
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.count("OK") == 2
+
+
+def test_worker_pins_itself_to_its_gpus_numa_node(tmp_path):
+    """bench.py's workers pin themselves to the host cores of the NUMA node their GPU hangs off (distributed.pin_to_gpu_numa_node),
+    read from sysfs: exercised on a fake tree (two amdgpu render nodes on nodes 0 / 1, one foreign device), in a child process so
+    that this test process keeps its affinity.  An unreadable topology is reported, never raised."""
+    sysfs = tmp_path / "sys"
+    allowed = sorted(os.sched_getaffinity(0))
+    half = max(1, len(allowed) // 2)
+    nodes = {0: allowed[:half], 1: allowed[half:] or allowed[:half]}
+    for n, cpus in nodes.items():
+        d = sysfs / "devices" / "system" / "node" / f"node{n}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    for i, (pci, vendor, node) in enumerate([("0000:05:00.0", "0x1002", 0), ("0000:85:00.0", "0x1002", 1), ("0000:01:00.0", "0x10de", 0)]):
+        dev = sysfs / "devices" / "pci" / pci
+        dev.mkdir(parents=True)
+        (dev / "vendor").write_text(vendor + "\n")
+        (dev / "numa_node").write_text(f"{node}\n")
+        rd = sysfs / "class" / "drm" / f"renderD{128 + i}"
+        rd.mkdir(parents=True)
+        os.symlink(dev, rd / "device")
+    code = f"""
+import os, sys, json
+sys.path.insert(0, {ROOT!r})
+from bdm_amd.distributed import pin_to_gpu_numa_node
+out = []
+for lr in (0, 1, 2):
+    info = pin_to_gpu_numa_node(lr, sysfs={str(sysfs)!r})
+    out.append((info, sorted(os.sched_getaffinity(0))))
+    os.sched_setaffinity(0, {allowed!r})
+out.append((pin_to_gpu_numa_node(0, sysfs="/nonexistent"), None))
+print(json.dumps(out))
+"""
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    import json
+    r0, r1, r2, r3 = json.loads(res.stdout.strip().splitlines()[-1])
+    assert r0[0]["numa_node"] == 0 and r0[1] == nodes[0] and r0[0]["pci"] == "0000:05:00.0"
+    assert r1[0]["numa_node"] == 1 and r1[1] == nodes[1]
+    assert r2[0]["numa_node"] is None and r2[1] == allowed          # only two amdgpu devices: rank 2 is left alone
+    assert r3[0]["numa_node"] is None
 
 
 def test_windowed_rasterizer_equals_bruteforce():

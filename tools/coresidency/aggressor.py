@@ -1,9 +1,9 @@
 """Background load for the two-process experiments: loops ONE kernel family of the library (or a whole denoiser forward) for a
-number of seconds, so that tools/two_proc_aggressors.sh can find out WHICH concurrent kernel of a second process disturbs a
+number of seconds, so that tools/coresidency/two_proc_aggressors.sh can find out WHICH concurrent kernel of a second process disturbs a
 victim process (tools/bin/two_proc_repro).   usage: aggressor.py <family> <seconds>"""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bdm_amd import ops
 from bdm_amd.functional.backend import _backend
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3: sparse_gemm_s3_kernel is the aggressor (tools/two_proc_aggressors2.sh).  Which of its properties is it -- reproduced with
+# Round 3: sparse_gemm_s3_kernel is the aggressor (tools/coresidency/two_proc_aggressors2.sh).  Which of its properties is it -- reproduced with
 # TRIVIAL kernels (48 KB static LDS, workgroups that return at once, matrix cores), and does it need a second process at all?
 REPS=${1:-100}; SECS=${2:-25}
 victim() { tools/bin/two_proc_repro $REPS "$1" 2>&1 | grep -v "^ *first differing" | awk '{print "      " $0}' | cut -c1-170; }

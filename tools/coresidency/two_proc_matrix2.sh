@@ -1,12 +1,12 @@
 #!/bin/bash
-# Second round of the two-process experiments (after tools/two_proc_matrix.sh showed that neither the side streams nor the absence
+# Second round of the two-process experiments (after tools/coresidency/two_proc_matrix.sh showed that neither the side streams nor the absence
 # of synchronisation matter): does the difference need the SAME program in both processes (same kernels on the same virtual
-# addresses)?  usage: tools/two_proc_matrix2.sh [reps]   (repo root, GPU box)
+# addresses)?  usage: tools/coresidency/two_proc_matrix2.sh [reps]   (repo root, GPU box)
 REPS=${1:-16}
 pair() {  # label, "env of A", "env of B"
   echo "=== $1"
-  (env $3 timeout 600 python tools/two_proc_race.py $REPS > /tmp/race_b.log 2>&1 &)
-  env $2 timeout 600 python tools/two_proc_race.py $REPS 2>&1 | grep -v "^$" | grep "traced calls\|first differing" | cut -c1-300
+  (env $3 timeout 600 python tools/coresidency/two_proc_race.py $REPS > /tmp/race_b.log 2>&1 &)
+  env $2 timeout 600 python tools/coresidency/two_proc_race.py $REPS 2>&1 | grep -v "^$" | grep "traced calls\|first differing" | cut -c1-300
   sleep 2; echo "--- second process"; grep "traced calls\|first differing" /tmp/race_b.log | cut -c1-300
 }
 pair "same program, same sizes (baseline)" "X=1" "X=1"

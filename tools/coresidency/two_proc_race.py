@@ -5,7 +5,7 @@ of bdm_amd.ops and the plugin backend) and compares each repetition with the fir
 output differs it prints: the operator, which elements differ (shape, index ranges, run lengths), the good and the bad values,
 and where else in the first repetition's outputs the bad bytes occur (a stale or foreign buffer shows up there).
 
-Run two copies at the same time on one GPU (tools/two_proc_matrix.sh) under different switches:
+Run two copies at the same time on one GPU (tools/coresidency/two_proc_matrix.sh) under different switches:
    BDM_SIDE_STREAM=0   sampler chain inline (no second stream)      RACE_POINT_STREAM=0  PVConv point branch inline
    RACE_SIDE_PLAN=0    voxel plans on the main stream               RACE_SYNC=1          device-wide sync after every operator
    RACE_MODEL=pc2|pvd  which denoiser                               RACE_B / RACE_N      batch and points
@@ -18,7 +18,7 @@ import types
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from bdm_amd import ops  # noqa: E402
 from bdm_amd.functional.backend import _backend, _Backend  # noqa: E402

@@ -1,6 +1,6 @@
 // two_proc_repro.hip -- torch-free reproduction of the two-process difference.
 //
-//   hipcc --offload-arch=gfx950 -O2 -I include tools/two_proc_repro.hip -o /tmp/two_proc_repro -L bdm_amd -l:libbdm_hip.so \
+//   hipcc --offload-arch=gfx950 -O2 -I include tools/coresidency/two_proc_repro.hip -o /tmp/two_proc_repro -L bdm_amd -l:libbdm_hip.so \
 //         -Wl,-rpath,$PWD/bdm_amd
 //   /tmp/two_proc_repro 300            # alone: every line must report 0 differing repetitions
 //   /tmp/two_proc_repro 300 & /tmp/two_proc_repro 300   # two PROCESSES on one GPU at the same time
@@ -206,7 +206,7 @@ __global__ void f32div_kernel(const float *x, float *y, size_t n) {
   }
 }
 
-// Trivial stand-ins for what distinguishes the library's sparse_gemm_s3_kernel (the kernel tools/two_proc_aggressors2.sh named):
+// Trivial stand-ins for what distinguishes the library's sparse_gemm_s3_kernel (the kernel tools/coresidency/two_proc_aggressors2.sh named):
 // 48 KB of static LDS, 256 threads, bf16 MFMA, and WHOLE WORKGROUPS THAT RETURN AT ONCE (rows beyond a shape's occupied count).
 //   mode bit 0: most workgroups exit before touching anything      bit 1: use the matrix cores      bit 2: only 8 KB of LDS
 typedef __attribute__((ext_vector_type(16))) float t_f32x16;
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void agg_gemm_kernel(int mode, int M, int G, i
 
 // The library's sparse first convolution, kernel by kernel (torch-free set-up of a voxel plan for B = 2 clouds of 1024 points, 16^3)
 static hipStream_t g_agg_stream = 0;  // stream of the aggressor's launches (null stream unless --inproc)
+static volatile bool g_stop = false;  // --inproc: the victim side is done, the aggressor thread may leave before its time is up
 
 struct SparseSetup {
   int B = 2, n = 1024, r = 16, C = 64, cout = 64, n_max = 1024;
@@ -306,8 +307,18 @@ struct SparseSetup {
     y = dev_alloc<float>((size_t)B * n_max * 27 * cout);
     out = dev_alloc<float>((size_t)B * cout * r3);
     features(); gemm(); gather();
+    xr = dev_alloc<float>((size_t)B * (C / 8) * n_max * 8); amax = dev_alloc<float>(B);
+    wh2 = dev_alloc<unsigned short>(bdm_conv3d_h2_weight_elems(cout, C)); inv_scale = dev_alloc<float>(cout);
+    float *scale_ws = dev_alloc<float>(cout);
+    ABI_OK(bdm_conv3d_h2_pack_weights(cout, C, w, wh2, scale_ws, inv_scale, nullptr));
+    ABI_OK(bdm_sparse_voxel_features_f32(B, C, n, r, n_max, feat, (long long)C * n, n, cnt, ws, occ_list, n_occ, xr, amax, nullptr));
+    conv_os();
     HIP_OK(hipDeviceSynchronize());
   }
+  float *xr, *amax, *inv_scale;
+  void *wh2;
+  // round 4: the output-stationary first convolution (sparse_conv_os.hip) -- the kernel that replaced GEMM + gather in the default forward
+  void conv_os() { ABI_OK(bdm_sparse_conv_os(B, C, cout, r, n_max, xr, amax, occ_index, wh2, inv_scale, nullptr, out, (void *)g_agg_stream)); }
   void features() { ABI_OK(bdm_sparse_voxel_features_s3(B, C, n, r, n_max, feat, (long long)C * n, n, cnt, ws, occ_list, n_occ, xs, (void *)g_agg_stream)); }
   void gemm() { ABI_OK(bdm_sparse_conv_gemm_s3(B, n_max, C, 27 * cout, xs, wpk, n_occ, y, (void *)g_agg_stream)); }
   void gather() { ABI_OK(bdm_sparse_conv_gather(B, cout, r, n_max, y, occ_index, rowocc, nullptr, out, (void *)g_agg_stream)); }
@@ -324,7 +335,7 @@ static int aggress(const char *kind, double seconds) {
   { const int h[2] = {150, 90}; HIP_OK(hipMemcpy(live, h, sizeof(h), hipMemcpyHostToDevice)); }
   const int exit_mode = !strcmp(kind, "exit48k") ? 1 : !strcmp(kind, "noexit48k") ? 0 : !strcmp(kind, "exit48k_mfma") ? 3 :
                         !strcmp(kind, "noexit48k_mfma") ? 2 : !strcmp(kind, "exit8k") ? 5 : -1;
-  SparseSetup *sp = (!strcmp(kind, "features") || !strcmp(kind, "gemm_s3") || !strcmp(kind, "gemm_s3_all") || !strcmp(kind, "gather")) ? new SparseSetup() : nullptr;
+  SparseSetup *sp = (!strcmp(kind, "features") || !strcmp(kind, "gemm_s3") || !strcmp(kind, "gemm_s3_all") || !strcmp(kind, "gather") || !strcmp(kind, "conv_os")) ? new SparseSetup() : nullptr;
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
   HIP_OK(hipEventRecord(e0, g_agg_stream));
@@ -339,6 +350,7 @@ static int aggress(const char *kind, double seconds) {
       else if (!strcmp(kind, "features")) sp->features();
       else if (!strcmp(kind, "gemm_s3")) sp->gemm();
       else if (!strcmp(kind, "gather")) sp->gather();
+      else if (!strcmp(kind, "conv_os")) sp->conv_os();
       else if (!strcmp(kind, "pw")) {  // the library's fp32-MFMA 1x1 GEMM (64 -> 64 channels, 2 x 32768 columns): another LDS + MFMA kernel
         static float *pw_w = dev_random(64 * 64, 0.15f), *pw_b = dev_random(64, 0.1f);
         ABI_OK(bdm_pointwise_conv(2, 64, 64, 32768, pw_w, 64, x, 64ll * 32768, 32768, pw_b, nullptr, 0, nullptr, 0, 0, y, 64ll * 32768, 32768, 0, 0.f,
@@ -358,7 +370,7 @@ static int aggress(const char *kind, double seconds) {
     HIP_OK(hipEventRecord(e1, g_agg_stream)); HIP_OK(hipEventSynchronize(e1));
     float ms = 0;
     HIP_OK(hipEventElapsedTime(&ms, e0, e1));
-    if (ms > seconds * 1e3) break;
+    if (ms > seconds * 1e3 || g_stop) break;
   }
   printf("aggressor %s: %ld launches\n", kind, iters);
   return 0;
@@ -430,6 +442,33 @@ int main(int argc, char **argv) {
                                    beta, 1e-5f, G, p2, nullptr, 0, nullptr));
       ABI_OK(bdm_devoxelize_gn_gate_add(B, C, NP, R, coords, grid, coef, gate, add, (long long)C * NP, NP, dout, (long long)C * NP, NP, nullptr));
     } }, y2, (size_t)B * M * N * 4});
+  // ---- library: what the SIDE STREAMS of a forward run beside the main stream's sparse GEMMs: the sampler chain
+  //      (FPS, ball query, 3-NN search, voxel plan at 32^3) at the bench's batch
+  {
+    const int SB = 16, SN = 4096, SM = 1024, SU = 32;
+    float *sc = dev_random((size_t)SB * 3 * SN, 0.5f), *cen = dev_alloc<float>((size_t)SB * 3 * SM);
+    int *fidx = dev_alloc<int>((size_t)SB * SM), *nbr = dev_alloc<int>((size_t)SB * SM * SU);
+    ABI_OK(bdm_furthest_point_sampling(SB, SN, SM, sc, fidx, cen, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    cases.push_back({"lib sampler: furthest_point_sampling (16 x 4096 -> 1024)", [=] {
+      ABI_OK(bdm_furthest_point_sampling(SB, SN, SM, sc, fidx, nullptr, nullptr)); }, fidx, (size_t)SB * SM * 4});
+    cases.push_back({"lib sampler: ball_query (16 x 1024 centres, 4096 points, r = 0.1, 32 neighbours)", [=] {
+      ABI_OK(bdm_ball_query(SB, SN, SM, 0.1f, SU, cen, sc, nbr, nullptr)); }, nbr, (size_t)SB * SM * SU * 4});
+    int *nn_i = dev_alloc<int>((size_t)SB * 3 * SN);
+    float *nn_w = dev_alloc<float>((size_t)SB * 3 * SN);
+    cases.push_back({"lib sampler: three_nn_search (16 x 4096 points, 1024 centres)", [=] {
+      ABI_OK(bdm_three_nn_search(SB, SM, SN, sc, cen, nn_i, nn_w, nullptr)); }, nn_w, (size_t)SB * 3 * SN * 4});
+    const int PR = 32, pr3 = PR * PR * PR;
+    float *pnorm = dev_alloc<float>((size_t)SB * 3 * SN);
+    int *pvox = dev_alloc<int>((size_t)SB * 3 * SN), *pind = dev_alloc<int>((size_t)SB * SN), *pcnt = dev_alloc<int>((size_t)SB * pr3);
+    int *pocc = dev_alloc<int>((size_t)SB * pr3), *plist = dev_alloc<int>((size_t)SB * SN), *pn = dev_alloc<int>(SB);
+    unsigned char *prow = dev_alloc<unsigned char>((size_t)SB * PR * PR);
+    void *pws = dev_alloc<unsigned char>(bdm_voxelize_workspace_bytes(SB, SN, PR));
+    ABI_OK(bdm_voxel_coords(SB, SN, PR, 0.f, sc, pnorm, pvox, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    cases.push_back({"lib sampler: voxelize_plan_full (16 x 4096 points, 32^3)", [=] {
+      ABI_OK(bdm_voxelize_plan_full(SB, SN, PR, SN, pvox, pind, pcnt, pws, pocc, plist, pn, prow, nullptr)); }, pocc, (size_t)SB * pr3 * 4});
+  }
   // ---- trivial kernels of this file
   const size_t n4 = (size_t)B * M * N / 4;
   cases.push_back({"trivial copy (float4 per thread)", [&] { hipLaunchKernelGGL(copy_kernel, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const float4 *)y1, (float4 *)y3, n4); }, y3, n4 * 16});
@@ -510,6 +549,6 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < c1.size(); ++i) cd += c1[i] != coords0[i];
     printf("static inputs of the devoxelisation / gather8 victims at the end: %zu grid words and %zu coordinate words changed\n", gd, cd);
   }
-  if (bg) { bg->join(); }
+  if (bg) { g_stop = true; bg->join(); }
   return total_bad ? 1 : 0;
 }

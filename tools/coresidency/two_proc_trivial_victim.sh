@@ -1,5 +1,5 @@
 #!/bin/bash
-# The trivial gather8 victim of tools/two_proc_repro.hip next to every aggressor kind, aggressor in a SECOND PROCESS (and alone).
+# The trivial gather8 victim of tools/coresidency/two_proc_repro.hip next to every aggressor kind, aggressor in a SECOND PROCESS (and alone).
 export LD_LIBRARY_PATH=$PWD/bdm_amd:$LD_LIBRARY_PATH
 R=tools/bin/two_proc_repro
 echo "--- alone"; timeout 120 $R 100 gather8 2>&1 | grep "gather8\|static inputs"

@@ -11,6 +11,7 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/trf -o fwd -- p
 python3 $R/tools/trace_summary.py $(find /tmp/trf -name "*kernel_trace.csv" | head -1) 80 > $R/gpurun_out/${TAG}_forward_launches.txt
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p1 -o f -- python3 $R/tools/trace_forward.py pc2 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p2 -o w -- python3 $R/tools/trace_forward.py pc2 > /dev/null 2>&1
-python3 $R/tools/pmc_summary.py $(find /tmp/p1 -name "*counter_collection.csv" | head -1) $(find /tmp/p2 -name "*counter_collection.csv" | head -1) $R/gpurun_out/${TAG}_pmc_hbm_traffic.csv
-python3 $R/tools/pmc_to_json.py $R/gpurun_out/${TAG}_pmc_hbm_traffic.csv $COMMIT $R/gpurun_out/${TAG}_pmc_traffic.json
+python3 $R/tools/pmc_summary.py $(find /tmp/p1 -name "*counter_collection.csv" | head -1) $(find /tmp/p2 -name "*counter_collection.csv" | head -1) $R/gpurun_out/${TAG}_pmc_hbm_traffic.csv $R/gpurun_out/${TAG}_pmc_dispatches.csv
+BDM_ABI_LOG=$R/gpurun_out/${TAG}_abi_log.json python3 $R/tools/trace_forward.py pc2 > /dev/null 2>&1
+python3 $R/tools/pmc_to_json.py $R/gpurun_out/${TAG}_pmc_dispatches.csv $R/gpurun_out/${TAG}_abi_log.json $COMMIT $R/gpurun_out/${TAG}_pmc_traffic.json
 head -3 $R/gpurun_out/${TAG}_bench.json | cut -c1-600

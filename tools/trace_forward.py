@@ -23,6 +23,36 @@ fn = (lambda: model.point_cloud_model(xin, t)) if which == "pc2" else (lambda: p
 for _ in range(2): fn()
 torch.cuda.synchronize()
 marker = torch.zeros(7, device="cuda")
+abi_log = os.environ.get("BDM_ABI_LOG")   # path: the ordered (function, integer arguments) list of the marked forward (tools/pmc_to_json.py)
+calls = []
+if abi_log:
+    from bdm_amd import _lib as L
+
+    class _Log:
+        def __init__(self, h):
+            self._h = h
+
+        def __getattr__(self, name):
+            f = getattr(self._h, name)
+            if not name.startswith("bdm_") or name.endswith(("_bytes", "_elems", "_slices")) or name == "bdm_last_error":
+                return f
+
+            def call(*a):
+                from bdm_amd import profiling as P
+                spec = P.SPEC.get(name)
+                try:     # the shape signature bench.py's roofline rows are keyed by (profiling.SPEC)
+                    ints = [int(P._plain(v)) for v in spec[1](a)] if spec else []
+                except (TypeError, ValueError):
+                    ints = []
+                calls.append((name, ints))
+                return f(*a)
+            return call
+    saved = L.lib()
+    L._lib = _Log(saved)
 torch.cumsum(marker, 0); torch.cuda.synchronize()   # marker kernel 1
 fn(); torch.cuda.synchronize()
 torch.cumsum(marker, 0); torch.cuda.synchronize()   # marker kernel 2
+if abi_log:
+    import json
+    L._lib = saved
+    json.dump(calls, open(abi_log, "w"))
