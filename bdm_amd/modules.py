@@ -213,8 +213,9 @@ class PVConv(nn.Module):
     # SLOWER on MI355X -- DESIGN.md section 7 -- so it is opt-in)
     sparse_gemm = {"fp32": "sparse", "bf16x6": "sparse_s3", "fused": "sparse_fused"}.get(os.environ.get("BDM_SPARSE_GEMM", "fp16x3"), "sparse_h2")
 
-    # formulation of the first convolution: "os" = output-stationary implicit GEMM with tap skipping (sparse_conv_os.hip, one
-    # launch after the feature records) | "gemm" = batched GEMM over the occupied rows + output-stationary gather (27x intermediate)
+    # formulation of the first convolution: "dil" = output-stationary implicit GEMM over compact tiles of the once-dilated voxel list,
+    # tap skipping (sparse_conv_os.hip, one launch after the feature records) | "os" = the same over fixed bricks of the grid |
+    # "gemm" = batched GEMM over the occupied rows + output-stationary gather (27x intermediate)
     sparse_conv = os.environ.get("BDM_SPARSE_CONV", "gemm")
 
     def _packed_weight(self, conv, impl):
@@ -327,11 +328,11 @@ class PVConv(nn.Module):
                 cond = self._hoisted(features)
                 if cond is not None and 27 * conv1.out_channels <= 1024:  # hoisted map instead of feature gather + K = 390 GEMM
                     v = ops.sparse_first_conv_from_map(cond, plan, conv1, conv1.out_channels, gn_groups=gn1.num_groups if want_stats else None)
-                elif self.sparse_conv == "os" and self.conv_impl == "fp16x3" and self.sparse_gemm == "sparse_h2":
+                elif self.sparse_conv in ("dil", "os") and self.conv_impl == "fp16x3" and self.sparse_gemm == "sparse_h2":
                     # one output-stationary implicit GEMM with tap skipping: no 27x intermediate (sparse_conv_os.hip)
                     want_stats = want_stats and ops.sparse_os_gn_ok(conv1.out_channels, gn1.num_groups, r)
                     v = ops.sparse_first_conv_os(features, plan, self._packed_weight(conv1, "fp16x3"), conv1.bias, conv1.out_channels,
-                                                 gn_groups=gn1.num_groups if want_stats else None)
+                                                 gn_groups=gn1.num_groups if want_stats else None, form=self.sparse_conv)
                 else:
                     v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, impl), conv1.bias, conv1.out_channels,
                                                       gn_groups=gn1.num_groups if want_stats else None)

@@ -788,7 +788,7 @@ class VoxelPlan:
     """Everything that depends on (coords, r) only: normalised / integer voxel coordinates, per-voxel point lists,
     occupied-cell compaction and row occupancy.  PVConvs of one level share it (exactly the same values)."""
     __slots__ = ("r", "n", "n_max", "norm_coords", "vox_coords", "ind", "cnt", "ws", "occ_index", "occ_list", "n_occ", "rowocc",
-                 "ready", "stream")
+                 "ready", "stream", "dil_list", "plane_start", "tile_start", "n_dil_max")
 
 
 _plan_cache = {}
@@ -826,8 +826,31 @@ def voxel_plan(coords, r, eps=0.0):
     L.check(lib.bdm_voxelize_plan_full(B, n, r, p.n_max, L.ptr(p.vox_coords), L.ptr(p.ind), L.ptr(p.cnt), L.ptr(p.ws),
                                        L.ptr(p.occ_index), L.ptr(p.occ_list), L.ptr(p.n_occ), L.ptr(p.rowocc), L.stream()),
             "voxelize_plan_full")
+    plan_dilation(p)
     p.stream = torch.cuda.current_stream(dev) if coords.is_cuda else None
     _plan_cache[key] = p
+    return p
+
+
+DILATED_PLAN = True   # voxel plans carry the once-dilated voxel list + tile table of the compact first convolution (sparse_conv_os.hip)
+
+
+def plan_dilation(p):
+    """dil_list / plane_start / tile_start of a plan (bdm_voxel_dilate): the output voxels of the first convolution that can differ from
+    the bias, in voxel order, cut into tiles.  One launch on the plan's stream; depends on (coords, r) only."""
+    if getattr(p, "dil_list", None) is not None or not DILATED_PLAN or p.r not in (8, 16, 32):
+        if getattr(p, "dil_list", None) is None:
+            p.dil_list = p.plane_start = p.tile_start = None
+            p.n_dil_max = 0
+        return p
+    lib, B, r = L.lib(), p.cnt.shape[0], p.r
+    dev = p.cnt.device
+    p.n_dil_max = r ** 3
+    p.dil_list = torch.empty(B, p.n_dil_max, dtype=torch.int32, device=dev)
+    p.plane_start = torch.empty(B, r + 2, dtype=torch.int32, device=dev)
+    p.tile_start = torch.empty(B, lib.bdm_voxel_dilate_slices(r) + 2, dtype=torch.int32, device=dev)
+    L.check(lib.bdm_voxel_dilate(B, r, p.n_dil_max, L.ptr(p.cnt), L.ptr(p.dil_list), L.ptr(p.plane_start), L.ptr(p.tile_start), L.stream()),
+            "voxel_dilate")
     return p
 
 
@@ -1027,15 +1050,20 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None):
     return (out, stats) if gn_groups else out
 
 
-def sparse_conv_pack_os(weight):
-    """(Cout, Cin, 3,3,3) fp32 -> ("os", fp16 weight image of the dense fp16x3 convolution, inv_scale) for sparse_first_conv_os."""
-    return ("os",) + tuple(conv3d_h2_pack(weight))
+def sparse_conv_pack_os(weight, form="dil"):
+    """(Cout, Cin, 3,3,3) fp32 -> (form, fp16 weight image of the dense fp16x3 convolution, inv_scale) for sparse_first_conv_os."""
+    return (form,) + tuple(conv3d_h2_pack(weight))
 
 
-def sparse_first_conv_os(features, plan, packed, bias, cout, gn_groups=None):
+def sparse_first_conv_os(features, plan, packed, bias, cout, gn_groups=None, form="dil"):
     """Conv3d(k3, p1)(avg_voxelize(features)) as ONE output-stationary implicit GEMM with tap skipping (csrc/sparse_conv_os.hip):
     occupied cells' fp32 feature records + per-shape maximum (one launch), then the convolution (one launch) -- no 27x intermediate.
-    packed = conv3d_h2_pack(weight).  gn_groups: -> (out, (workspace, slices, groups)) with the GroupNorm statistics of the output."""
+    form "dil" (default): compact tiles of the once-dilated voxel list (needs plan_dilation); "os": fixed bricks of the grid.
+    packed = conv3d_h2_pack(weight).  gn_groups: -> (out, (partials, slices, groups)) with the GroupNorm statistics of the output."""
+    if form == "dil" and getattr(plan, "dil_list", None) is None:
+        plan_dilation(plan)
+        if plan.dil_list is None:
+            form = "os"
     f, B, C, n, bs_f, ld_f = _bcl(features)
     dev, lib, r = f.device, L.lib(), plan.r
     packed_w, inv_scale = packed
@@ -1045,6 +1073,18 @@ def sparse_first_conv_os(features, plan, packed, bias, cout, gn_groups=None):
                                               L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()),
             "sparse_voxel_features_f32")
     out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
+    if form == "dil":
+        args = (B, C, cout, r, plan.n_max, plan.n_dil_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index), L.ptr(plan.dil_list),
+                L.ptr(plan.tile_start), L.ptr(plan.plane_start), L.ptr(packed_w), L.ptr(inv_scale), L.ptr(bias), L.ptr(out))
+        if gn_groups:
+            tiles = plan.tile_start.shape[1] - 2
+            partial = torch.empty(B, gn_groups, tiles, 2, dtype=torch.float64, device=dev)
+            slices = ctypes.c_int(0)
+            L.check(lib.bdm_sparse_conv_dil_gn(*args, int(gn_groups), L.ptr(partial), ctypes.byref(slices), L.stream()), "sparse_conv_dil_gn")
+            assert slices.value == tiles
+            return out, (partial, tiles, int(gn_groups))
+        L.check(lib.bdm_sparse_conv_dil(*args, L.stream()), "sparse_conv_dil")
+        return out
     if gn_groups:
         ws = torch.empty(lib.bdm_group_norm_workspace_bytes(B, gn_groups), dtype=torch.uint8, device=dev)
         slices = ctypes.c_int(0)
@@ -1083,6 +1123,7 @@ def sparse_first_conv(features, vox_coords, r, wt, bias, cout):
     L.check(lib.bdm_voxel_compact(B, r, p.n_max, L.ptr(p.cnt), L.ptr(p.occ_index), L.ptr(p.occ_list), L.ptr(p.n_occ), L.stream()),
             "voxel_compact")
     L.check(lib.bdm_voxel_row_occupancy(B, r, L.ptr(p.cnt), L.ptr(p.rowocc), L.stream()), "voxel_row_occupancy")
-    if isinstance(wt, tuple) and wt[0] == "os":
-        return sparse_first_conv_os(features, p, wt[1:], bias, cout)
+    p.dil_list = None
+    if isinstance(wt, tuple) and wt[0] in ("os", "dil"):
+        return sparse_first_conv_os(features, plan_dilation(p), wt[1:], bias, cout, form=wt[0])
     return sparse_first_conv_planned(features, p, wt, bias, cout)

@@ -88,6 +88,9 @@ SPEC = {
     # the dense output grid written once; its matrix work (live fragments only) rides along as mfma_aux
     "bdm_sparse_conv_os": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[2] * a[3] ** 3)),
     "bdm_sparse_conv_os_gn": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[2] * a[3] ** 3)),
+    "bdm_sparse_conv_dil": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[2] * a[3] ** 3)),
+    "bdm_sparse_conv_dil_gn": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[2] * a[3] ** 3)),
+    "bdm_voxel_dilate": ("voxelize / devoxelize", lambda a: a[:2], lambda a: ("hbm", 4.0 * a[0] * 2 * a[1] ** 3)),
     # hoisted conditioning (ops.Conditioning): rows of the occupied cells from the per-pixel map; algorithmic = the map rows of the points
     "bdm_sparse_conv_rows_from_map": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[4]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[4])),
     "bdm_sparse_voxel_features_s3": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2])),

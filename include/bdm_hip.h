@@ -448,6 +448,26 @@ int bdm_sparse_conv_os_gn(int b, int cin, int cout, int r, int n_max, const void
                           const void *packed_w, const float *inv_scale, const float *bias, float *y, int groups,
                           void *gn_workspace, int *slices_out, void *stream);
 
+/* Compact output-stationary form of the same convolution (sparse_conv_os.hip; the default): only the voxels that can differ from
+ * the bias -- the once-dilated occupied set, listed in voxel order -- are computed, in tiles of consecutive list entries whose
+ * occupied neighbours are ONE contiguous range of compact rows (staged in LDS per 8-channel chunk); everything else is bias.
+ *   bdm_voxel_dilate        cnt (b, r^3) -> dil_list (b, n_dil_max) voxel ids of the dilated set in ascending order (n_dil_max = r^3
+ *                           always suffices), plane_start (b, r + 2): occupied cells in x-planes < x, tile_start
+ *                           (b, bdm_voxel_dilate_slices(r) + 2): first list entry of every tile, then the tile count in the last slot.
+ *                           Depends on (coords, r) only: part of the voxel plan, shared by the PVConvs of a level.
+ *   bdm_sparse_conv_dil     y (b, cout, r^3) = bias + conv; xr / amax / occ_index / packed_w / inv_scale as bdm_sparse_conv_os.
+ *   bdm_sparse_conv_dil_gn  also leaves GroupNorm(groups) partials of y: gn_partial (b, groups, tiles, 2 doubles),
+ *                           *slices_out = tiles = bdm_voxel_dilate_slices(r); consumed by bdm_group_norm_to_h2_stats. */
+int bdm_voxel_dilate_slices(int r);
+int bdm_voxel_dilate(int b, int r, int n_dil_max, const int *cnt, int *dil_list, int *plane_start, int *tile_start, void *stream);
+int bdm_sparse_conv_dil(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
+                        const int *occ_index, const int *dil_list, const int *tile_start, const int *plane_start,
+                        const void *packed_w, const float *inv_scale, const float *bias, float *y, void *stream);
+int bdm_sparse_conv_dil_gn(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
+                           const int *occ_index, const int *dil_list, const int *tile_start, const int *plane_start,
+                           const void *packed_w, const float *inv_scale, const float *bias, float *y, int groups,
+                           void *gn_partial, int *slices_out, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * 3. Per-step glue of the coupled DDPM loop
  * ---------------------------------------------------------------------------------- */

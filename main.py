@@ -45,15 +45,19 @@ def main(argv=None):
                 stem = f"{name}-{sample_idx}" if cfg.run.num_samples > 1 else f"{name}"
                 for sub in ("metadata", "evolutions"):
                     (out_root / sub / cat).mkdir(parents=True, exist_ok=True)
-                cam = batch.camera[i] if isinstance(batch.camera, (list, tuple)) else batch.camera
+                # the reference stores the BATCH's camera in every sample's metadata (experiments/main.py:577)
+                cam = [c.to("cpu") if hasattr(c, "to") else c for c in batch.camera] if isinstance(batch.camera, (list, tuple)) else batch.camera.to("cpu")
                 torch.save(dict(index=i, sequence_name=batch.sequence_name, sequence_category=batch.sequence_category,
-                                frame_timestamp=batch.frame_timestamp, camera=cam.to("cpu") if hasattr(cam, "to") else cam,
+                                frame_timestamp=batch.frame_timestamp, camera=cam,
                                 image_size_hw=batch.image_size_hw, image_path=batch.image_path, depth_path=batch.depth_path,
                                 mask_path=batch.mask_path, bbox_xywh=batch.bbox_xywh, crop_bbox_xywh=batch.crop_bbox_xywh,
                                 sequence_point_cloud_path=batch.sequence_point_cloud_path, meta=batch.meta),
                            out_root / "metadata" / cat / f"{stem}.pth")
                 if cfg.run.sample_save_evolutions:
-                    torch.save(torch.stack([o.points_padded()[i].cpu() for o in all_outputs]), out_root / "evolutions" / cat / f"{stem}.pth")
+                    # experiments/main.py:590-599 saves all_outputs[i]: ONE Pointclouds whose batch axis is the recorded steps
+                    from bdm_amd.cameras import Pointclouds
+                    torch.save(Pointclouds(points=torch.stack([o.points_padded()[i].cpu() for o in all_outputs])),
+                               out_root / "evolutions" / cat / f"{stem}.pth")
     barrier()
     if rank == 0:
         print("Saved samples to:", out_root.absolute())

@@ -61,8 +61,10 @@ def test_main_sample_writes_the_reference_tree(hip, tmp_path):
     clouds = _check_tree(out, 3, 1024)
     for j in range(3):
         meta = torch.load(out / "metadata" / "chair" / f"synthetic_{j:06d}.pth", weights_only=False)
-        assert meta["sequence_category"][meta["index"]] == "chair" and meta["camera"] is not None
+        assert meta["sequence_category"][meta["index"]] == "chair"
+        assert len(meta["camera"]) == len(meta["sequence_name"])     # the BATCH's camera, as experiments/main.py:577 stores it
         evo = torch.load(out / "evolutions" / "chair" / f"synthetic_{j:06d}.pth", weights_only=False)
+        evo = evo.points_padded()                 # a Pointclouds whose batch axis is the recorded steps (experiments/main.py:590-599)
         assert evo.shape == (4, 1024, 3)          # steps 0, 10, 20 and the last (24) of 25
         assert np.allclose(evo[-1].numpy(), clouds[j], atol=1e-6)
     with pytest.raises(NotImplementedError):

@@ -450,7 +450,8 @@ def test_sparse_first_conv_equals_dense(ops, oracle_ops, cin, cout, r, npts):
 
 @pytest.mark.parametrize("cin,cout,r,npts", [(35, 32, 32, 4096), (64, 64, 32, 1100), (64, 64, 32, 4096), (128, 64, 16, 1024), (128, 128, 16, 1024),
                                              (256, 256, 8, 64), (192, 128, 8, 256), (16, 8, 8, 2000), (390, 32, 32, 700)])
-def test_sparse_first_conv_output_stationary_equals_dense(ops, oracle_ops, cin, cout, r, npts):
+@pytest.mark.parametrize("form", ["dil", "os"])
+def test_sparse_first_conv_output_stationary_equals_dense(ops, oracle_ops, cin, cout, r, npts, form):
     """The one-kernel output-stationary form with tap skipping (sparse_conv_os.hip, the default first convolution): == the dense
     evaluation at fp32 grade, bit-reproducible, strided features accepted, and its GroupNorm partials == the statistics of its output."""
     from bdm_amd import _lib as L
@@ -460,14 +461,18 @@ def test_sparse_first_conv_output_stationary_equals_dense(ops, oracle_ops, cin, 
     vc = (torch.randn(B, 3, npts, generator=g) * r / 8 + r / 2).round().clamp(0, r - 1).to(torch.int32)
     vc[1, :, : npts // 2] = 0            # many points in one corner voxel, incl. the grid boundary
     vc[2] = r - 1                        # a shape with ONE occupied voxel, at the far corner: almost every brick is pure bias
+    if npts >= r * r:                    # shape 0: half of the points fill consecutive x-planes densely (tiles cut at plane boundaries)
+        e = torch.arange(npts // 2)
+        vc[0, :, : npts // 2] = torch.stack([(r // 2 - 1 + e // (r * r)).clamp(max=r - 1), (e // r) % r, e % r]).to(torch.int32)
     f = torch.randn(B, cin, npts, generator=g)
     f[:, : min(8, cin)] *= 300.0         # channels of very different magnitude share the shape's power-of-two scale
     w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5
     bias = torch.randn(cout, generator=g)
     vox = oracle_ops.avg_voxelize_forward(f, vc, r)[0]
     ref = TF.conv3d(vox.double().view(B, cin, r, r, r), w.double(), bias.double(), padding=1).float().reshape(B, cout, -1)
-    wt = ops.sparse_conv_pack_os(w.cuda())
+    wt = ops.sparse_conv_pack_os(w.cuda(), form)
     got = ops.sparse_first_conv(f.cuda(), vc.cuda(), r, wt, bias.cuda(), cout).cpu()
+    assert bool(torch.isfinite(got).all())
     for b in range(B):
         assert rel(got[b], ref[b]) < 2e-6, b
     assert torch.equal(got, ops.sparse_first_conv(f.cuda(), vc.cuda(), r, wt, bias.cuda(), cout).cpu())
@@ -482,12 +487,63 @@ def test_sparse_first_conv_output_stationary_equals_dense(ops, oracle_ops, cin, 
         ops.clear_plan_cache()
         pts = (torch.randn(B, 3, npts, generator=g) * 0.3).cuda()
         plan = ops.voxel_plan(pts, r)
-        out, (ws, slices, gg) = ops.sparse_first_conv_os(f.cuda(), plan, wt[1:], bias.cuda(), cout, gn_groups=groups)
-        assert torch.equal(out, ops.sparse_first_conv_os(f.cuda(), plan, wt[1:], bias.cuda(), cout))
-        part = ws.view(torch.float64)[: B * groups * slices * 2].view(B, groups, slices, 2).sum(2).cpu()
+        out, (ws, slices, gg) = ops.sparse_first_conv_os(f.cuda(), plan, wt[1:], bias.cuda(), cout, gn_groups=groups, form=form)
+        assert torch.equal(out, ops.sparse_first_conv_os(f.cuda(), plan, wt[1:], bias.cuda(), cout, form=form))
+        part = ws.view(-1).view(torch.float64)[: B * groups * slices * 2].view(B, groups, slices, 2).sum(2).cpu()
         o = out.double().cpu().view(B, groups, -1)
         assert torch.allclose(part[..., 0], o.sum(-1), rtol=1e-5, atol=1e-3)
         assert torch.allclose(part[..., 1], (o * o).sum(-1), rtol=1e-5, atol=1e-3)
+
+
+def test_dilated_voxel_list_and_tile_table(ops):
+    """bdm_voxel_dilate against a host restatement: the once-dilated occupied set in ascending voxel order, the per-plane prefix of
+    the occupied cells, and a tile table whose tiles (a) partition the list, (b) hold <= the tile size, (c) need <= 3 r^2 compact rows
+    (planes x0-1 .. x1+1) -- including a dense slab that forces cuts at plane boundaries."""
+    import numpy as np
+    from bdm_amd import _lib as L
+    for r, n, tile in ((32, 4096, 512), (16, 1024, 256), (8, 300, 128)):
+        B = 3
+        g = torch.Generator().manual_seed(r + n)
+        vc = (torch.randn(B, 3, n, generator=g) * r / 8 + r / 2).round().clamp(0, r - 1).to(torch.int32)
+        e = torch.arange(n - 1)                                                                   # a dense slab: consecutive FULL x-planes from r/2 - 2 on,
+        vc[1, :, : n - 1] = torch.stack([r // 2 - 2 + e // (r * r), (e // r) % r, e % r]).to(torch.int32)
+        vc[1, :, n - 1] = 0                                                                         # and a lone cell that shifts the tiles off the plane boundaries
+        vc[2] = 0                                                                                   # one occupied cell, at the grid corner
+        f = torch.zeros(B, 1, n)
+        ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack_os(torch.zeros(4, 1, 3, 3, 3).cuda()), torch.zeros(4).cuda(), 4)
+        p = ops.VoxelPlan(); p.r, p.n = r, n
+        lib, r3 = L.lib(), r ** 3
+        cnt = torch.zeros(B, r3, dtype=torch.int32)
+        lin = (vc[:, 0].long() * r + vc[:, 1].long()) * r + vc[:, 2].long()
+        for b in range(B):
+            cnt[b].index_add_(0, lin[b], torch.ones(n, dtype=torch.int32))
+        cnt = cnt.cuda()
+        tiles = lib.bdm_voxel_dilate_slices(r)
+        dl = torch.full((B, r3), -1, dtype=torch.int32, device="cuda")
+        ps = torch.empty(B, r + 2, dtype=torch.int32, device="cuda")
+        ts = torch.empty(B, tiles + 2, dtype=torch.int32, device="cuda")
+        L.check(lib.bdm_voxel_dilate(B, r, r3, L.ptr(cnt), L.ptr(dl), L.ptr(ps), L.ptr(ts), L.stream()))
+        dl, ps, ts, occ = dl.cpu().numpy(), ps.cpu().numpy(), ts.cpu().numpy(), (cnt.cpu().numpy() > 0).reshape(B, r, r, r)
+        for b in range(B):
+            P = np.zeros((r + 2,) * 3, bool); P[1:-1, 1:-1, 1:-1] = occ[b]
+            D = np.zeros((r, r, r), bool)
+            for dx in range(3):
+                for dy in range(3):
+                    for dz in range(3):
+                        D |= P[dx:dx + r, dy:dy + r, dz:dz + r]
+            want = np.flatnonzero(D.reshape(-1))
+            nt = int(ts[b, tiles + 1])
+            assert int(ts[b, nt]) == len(want) and np.array_equal(dl[b, :len(want)], want), (r, b)
+            per_plane = occ[b].reshape(r, -1).sum(1)
+            assert np.array_equal(ps[b, :r + 1], np.concatenate([[0], np.cumsum(per_plane)])) and ps[b, r + 1] == ps[b, r]
+            assert ts[b, 0] == 0 and 1 <= nt <= tiles
+            for t in range(nt):
+                j0, j1 = int(ts[b, t]), int(ts[b, t + 1])
+                assert 0 < j1 - j0 <= tile
+                x0, x1 = want[j0] // (r * r), want[j1 - 1] // (r * r)
+                assert ps[b, min(x1 + 2, r)] - ps[b, max(x0 - 1, 0)] <= 3 * r * r
+            if b == 1:
+                assert nt > -(-len(want) // tile), "the dense slab did not force a cut at a plane boundary"
 
 
 @experimental

@@ -15,6 +15,8 @@ KERNEL_OF = {
     "bdm_conv3d_3x3x3_h2": ("conv3d_h2q_kernel", lambda a: 4 * a[0] * a[3] ** 3 * (a[1] + a[2])),
     "bdm_sparse_conv_os_gn": ("sconv_os_kernel", lambda a: 4 * a[0] * a[3] ** 3 * a[2]),       # output grid written once (+ occupied rows, small)
     "bdm_sparse_conv_os": ("sconv_os_kernel", lambda a: 4 * a[0] * a[3] ** 3 * a[2]),
+    "bdm_sparse_conv_dil_gn": ("sconv_dil_kernel", lambda a: 4 * a[0] * a[3] ** 3 * a[2]),
+    "bdm_sparse_conv_dil": ("sconv_dil_kernel", lambda a: 4 * a[0] * a[3] ** 3 * a[2]),
     "bdm_sparse_conv_gemm_s3": ("sparse_gemm_s3_kernel", None),
     "bdm_sparse_conv_gemm_h2": ("sparse_gemm_h2_kernel", None),
     "bdm_sparse_conv_gather_gn": ("sparse_gather_v4_kernel", lambda a: 4 * a[0] * a[1] * a[2] ** 3),

@@ -43,10 +43,11 @@ for name, cin, cout, r, n in LAYERS:
     t_old = t(lambda: ops.sparse_first_conv_planned(f, plan, w_old, bias, cout))
     t_new = t(lambda: ops.sparse_first_conv_planned(f, plan, w_new, bias, cout))
     w_os = ops.sparse_conv_pack_os(w)[1:]
-    c = ops.sparse_first_conv_os(f, plan, w_os, bias, cout)
+    form = os.environ.get("OS_FORM", "dil")
+    c = ops.sparse_first_conv_os(f, plan, w_os, bias, cout, form=form)
     err_os = float((c - b).norm() / b.norm())
-    t_os = t(lambda: ops.sparse_first_conv_os(f, plan, w_os, bias, cout))
-    t_os_gn = t(lambda: ops.sparse_first_conv_os(f, plan, w_os, bias, cout, gn_groups=8))
+    t_os = t(lambda: ops.sparse_first_conv_os(f, plan, w_os, bias, cout, form=form))
+    t_os_gn = t(lambda: ops.sparse_first_conv_os(f, plan, w_os, bias, cout, gn_groups=8, form=form))
     t_k = t_new
     tot_old += MULT[name] * t_old; tot_new += MULT[name] * t_new; tot_os += MULT[name] * t_os_gn
     fl = 2 * occ * 27 * cin * cout * B

@@ -40,7 +40,13 @@ for name, cin, cout, r, n in LAYERS:
     out = torch.empty(B, cout, r ** 3, device="cuda")
     conv = lambda: L.check(lib.bdm_sparse_conv_os(B, cin, cout, r, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index), L.ptr(packed_w),
                                                  L.ptr(inv_scale), L.ptr(bias), L.ptr(out), L.stream()))
-    row = [f"{name} {cin:4d}->{cout:4d} r={r:2d} n_occ={float(plan.n_occ.float().mean()):7.1f} features {t(feat):6.1f} us | conv"]
+    dil = lambda: L.check(lib.bdm_sparse_conv_dil(B, cin, cout, r, plan.n_max, plan.n_dil_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index),
+                                                 L.ptr(plan.dil_list), L.ptr(plan.tile_start), L.ptr(plan.plane_start), L.ptr(packed_w),
+                                                 L.ptr(inv_scale), L.ptr(bias), L.ptr(out), L.stream()))
+    ntl = plan.tile_start[:, -1].float().mean().item()
+    tdil = t(lambda: L.check(lib.bdm_voxel_dilate(B, r, plan.n_dil_max, L.ptr(plan.cnt), L.ptr(plan.dil_list), L.ptr(plan.plane_start), L.ptr(plan.tile_start), L.stream())))
+    row = [f"{name} {cin:4d}->{cout:4d} r={r:2d} n_occ={float(plan.n_occ.float().mean()):7.1f} features {t(feat):6.1f} us | dilate {tdil:5.1f} us, "
+           f"{ntl:4.1f} tiles/shape, compact conv {t(dil):6.1f} us | brick conv"]
     for mode in ("0", "1", "2", "3", "4", "5"):
         os.environ["BDM_OS_DBG"] = mode
         row.append(f"dbg{mode} {t(conv):6.1f}")
