@@ -530,6 +530,121 @@ extern "C" int bdm_group_norm_to_h2_stats(int b, int c, int v, int groups, const
   return launch_status("group_norm_to_h2_stats");
 }
 
+// The same producer for the COMPACT output of the first convolution (sparse_conv_os.hip): x holds one row of C floats per entry
+// of the dilated voxel list, (B, n_dil_max, C); dil_index[v] = row of voxel v or -1, and every voxel outside the list is `bias`
+// (the convolution of zeros) -- its record is the same for the whole grid and is formed once per thread.  Reads 23 % of the grid
+// (32^3, Gaussian-like cloud) instead of all of it; the dense fp32 grid is never written.
+template <int VB>
+__global__ __launch_bounds__(256) void to_h2_stats_compact_kernel(int C, int V, int G, int S, int n_dil_max, const float *__restrict__ xc,
+                                                                  const int *__restrict__ dil_index, const float *__restrict__ bias,
+                                                                  const double *__restrict__ partial, const float *__restrict__ gamma,
+                                                                  const float *__restrict__ beta, float eps, int act, float act_scale,
+                                                                  unsigned short *__restrict__ out, unsigned *__restrict__ saturated) {
+  __shared__ float s_mean[2], s_rstd[2];
+  __shared__ double s_red[2][4][2];
+  const int bi = blockIdx.z, c8 = blockIdx.y, C8 = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = C / G;
+  const int g_lo = (c8 * 8) / cg, g_hi = min((c8 * 8 + 7) / cg, G - 1);
+  for (int gi = g_lo; gi <= g_hi; ++gi) {
+    const double *pp = partial + ((size_t)bi * G + gi) * S * 2;
+    double a = 0.0, q = 0.0;
+    for (int sl = tid; sl < S; sl += 256) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    if (lane == 0) { s_red[gi - g_lo][wave][0] = a; s_red[gi - g_lo][wave][1] = q; }
+  }
+  __syncthreads();
+  if (tid <= g_hi - g_lo) {
+    const double a = ((s_red[tid][0][0] + s_red[tid][1][0]) + s_red[tid][2][0]) + s_red[tid][3][0];
+    const double q = ((s_red[tid][0][1] + s_red[tid][1][1]) + s_red[tid][2][1]) + s_red[tid][3][1];
+    const double cnt = (double)cg * V, mean = a / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0) var = 0;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  __shared__ float s_ab[8][3];   // affine form (a, b) of the GroupNorm per channel, and the channel's bias
+  if (tid < 8) {
+    const int ch = c8 * 8 + tid;
+    float a = 0.f, bsh = 0.f, bv = 0.f;
+    if (ch < C) {
+      const int g = ch / cg - g_lo;
+      a = gamma[ch] * s_rstd[g];
+      bsh = beta[ch] - s_mean[g] * a;
+      bv = bias ? bias[ch] : 0.f;
+    }
+    s_ab[tid][0] = a;
+    s_ab[tid][1] = bsh;
+    s_ab[tid][2] = bv;
+  }
+  __syncthreads();
+  float ca[8], cb[8], fill[8];
+  bool sat = false;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ca[j] = s_ab[j][0]; cb[j] = s_ab[j][1];
+    float t = s_ab[j][2] * ca[j] + cb[j];
+    if (act == 1) t = swishf(t);
+    fill[j] = t * act_scale;
+    sat |= !(fabsf(fill[j]) <= 65504.f);
+  }
+  const int nch = min(8, C - c8 * 8);
+  const bool vec = (C & 3) == 0 && nch == 8;   // 16-byte pieces of a row
+  const int *di = dil_index + (size_t)bi * V;
+  const float *xb = xc + (size_t)bi * n_dil_max * C + c8 * 8;
+#pragma unroll 2
+  for (int it = 0; it < VB / 256; ++it) {
+    const int v = blockIdx.x * VB + it * 256 + tid;
+    if (v >= V) break;
+    const int j = di[v];
+    float val[8];
+    if (j >= 0) {
+      const float *row = xb + (size_t)j * C;
+      float in[8];
+      if (vec) {
+        const float4 p = *reinterpret_cast<const float4 *>(row), q = *reinterpret_cast<const float4 *>(row + 4);
+        in[0] = p.x; in[1] = p.y; in[2] = p.z; in[3] = p.w; in[4] = q.x; in[5] = q.y; in[6] = q.z; in[7] = q.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) in[u] = row[min(u, nch - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float t = in[u] * ca[u] + cb[u];   // channels >= C: a = b = 0
+        if (act == 1) t = swishf(t);
+        val[u] = t * act_scale;
+        sat |= !(fabsf(val[u]) <= 65504.f);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) val[u] = fill[u];
+    }
+    store_h2(out + ((size_t)bi * C8 + c8) * 2 * (size_t)V * 8, (size_t)v, (size_t)V, val);
+  }
+  if (saturated != nullptr && __ballot(sat) != 0ull && lane == __ffsll((long long)__ballot(sat)) - 1) atomicOr(saturated, 1u);
+}
+
+extern "C" int bdm_group_norm_to_h2_stats_compact(int b, int c, int v, int groups, const float *xc, int n_dil_max, const int *dil_index,
+                                                  const float *bias, const float *gamma, const float *beta, float eps, int act,
+                                                  float act_scale, void *out_h2, const void *partial, int slices,
+                                                  unsigned int *saturated, void *stream) {
+  BDM_REQUIRE(b >= 0 && c >= 1 && v >= 1 && groups >= 1 && c % groups == 0 && (c / groups) >= 4 && partial != nullptr && slices >= 1 &&
+                  xc != nullptr && dil_index != nullptr && n_dil_max >= 1,
+              "group_norm_to_h2_stats_compact: bad arguments");
+  {
+    int ex = 0;
+    BDM_REQUIRE(act_scale > 0.f && act_scale < INFINITY && frexpf(act_scale, &ex) == 0.5f,
+                "group_norm_to_h2_stats_compact: act_scale must be a power of two (got %g)", (double)act_scale);
+  }
+  if (b == 0) return BDM_OK;
+  constexpr int VB = 1024;
+  dim3 grid(cdiv(v, VB), (c + 7) / 8, b);
+  hipLaunchKernelGGL(to_h2_stats_compact_kernel<VB>, grid, dim3(256), 0, (hipStream_t)stream, c, v, groups, slices, n_dil_max, xc, dil_index,
+                     bias, (const double *)partial, gamma, beta, eps, act, act_scale, (unsigned short *)out_h2, saturated);
+  return launch_status("group_norm_to_h2_stats_compact");
+}
+
 extern "C" int bdm_group_norm_stats(int b, int c, int l, int groups, const float *x, long long bs_x, void *workspace,
                                     int *slices_out, void *stream);
 

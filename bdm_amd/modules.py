@@ -213,10 +213,15 @@ class PVConv(nn.Module):
     # SLOWER on MI355X -- DESIGN.md section 7 -- so it is opt-in)
     sparse_gemm = {"fp32": "sparse", "bf16x6": "sparse_s3", "fused": "sparse_fused"}.get(os.environ.get("BDM_SPARSE_GEMM", "fp16x3"), "sparse_h2")
 
-    # formulation of the first convolution: "dil" = output-stationary implicit GEMM over compact tiles of the once-dilated voxel list,
-    # tap skipping (sparse_conv_os.hip, one launch after the feature records) | "os" = the same over fixed bricks of the grid |
+    # formulation of the first convolution: "dil" = output-stationary implicit GEMM over tiles of the once-dilated voxel list, tap
+    # skipping, compact output (sparse_conv_os.hip, one launch after the feature records) |
     # "gemm" = batched GEMM over the occupied rows + output-stationary gather (27x intermediate)
-    sparse_conv = os.environ.get("BDM_SPARSE_CONV", "gemm")
+    # The output-stationary form computes every (dilated voxel, tap) pair -- ~3.5x the matrix work of the GEMM over the occupied
+    # (cell, tap) pairs -- and wins where the GEMM's 27x intermediate is what costs: the 32^3 levels (measured at B = 16,
+    # profiles/r04_sparse_dil_probe.txt: 64 -> 64: 188 vs 235 us with the operand split, 32 -> 32: 85 vs 128; 16^3: 127 vs 127;
+    # 8^3: 114 vs 62 -- the small grids stay on GEMM + gather)
+    sparse_conv = os.environ.get("BDM_SPARSE_CONV", "dil")
+    sparse_dil_resolutions = {int(v) for v in os.environ.get("BDM_SPARSE_DIL_R", "32,16").split(",") if v}
 
     def _packed_weight(self, conv, impl):
         key = (id(conv), impl)
@@ -328,11 +333,14 @@ class PVConv(nn.Module):
                 cond = self._hoisted(features)
                 if cond is not None and 27 * conv1.out_channels <= 1024:  # hoisted map instead of feature gather + K = 390 GEMM
                     v = ops.sparse_first_conv_from_map(cond, plan, conv1, conv1.out_channels, gn_groups=gn1.num_groups if want_stats else None)
-                elif self.sparse_conv in ("dil", "os") and self.conv_impl == "fp16x3" and self.sparse_gemm == "sparse_h2":
-                    # one output-stationary implicit GEMM with tap skipping: no 27x intermediate (sparse_conv_os.hip)
+                elif (self.sparse_conv == "dil" and r in self.sparse_dil_resolutions and self.conv_impl == "fp16x3"
+                      and self.sparse_gemm == "sparse_h2" and not getattr(self, "h2_saturated", False)):
+                    # one output-stationary implicit GEMM with tap skipping over the dilated voxel list: no 27x intermediate; with the
+                    # statistics in its epilogue the output stays COMPACT (rows of the dilated voxels) and the operand split of the
+                    # second convolution reads it through the plan's index -- the dense fp32 grid is never written (sparse_conv_os.hip)
                     want_stats = want_stats and ops.sparse_os_gn_ok(conv1.out_channels, gn1.num_groups, r)
                     v = ops.sparse_first_conv_os(features, plan, self._packed_weight(conv1, "fp16x3"), conv1.bias, conv1.out_channels,
-                                                 gn_groups=gn1.num_groups if want_stats else None, form=self.sparse_conv)
+                                                 gn_groups=gn1.num_groups if want_stats else None, compact=want_stats)
                 else:
                     v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, impl), conv1.bias, conv1.out_channels,
                                                       gn_groups=gn1.num_groups if want_stats else None)

@@ -583,6 +583,17 @@ def to_h2(x, gn=None, swish=False, scale=None, saturated=None, stats=None):
     """x (B, C, V) fp32 contiguous -> (H2 tensor (B, ceil(C/8), 2, V, 8) fp16 of scale * [swish(group_norm(x))], 1 / scale).
     scale: power of two; default from the GroupNorm parameters, or (no GroupNorm: test path, host sync) from max |x|.
     saturated: optional 1-element int32 device tensor, OR-ed with 1 when a scaled value left fp16's range."""
+    if isinstance(x, CompactGrid):            # first convolution in compact form: rows of the dilated voxels + bias everywhere else
+        assert gn is not None and stats is not None, "a compact grid comes with its producer's statistics"
+        B, C, V = x.rows.shape[0], x.channels, x.plan.r ** 3
+        s = float(scale if scale is not None else h2_activation_scale(gn))
+        out = torch.empty(B, (C + 7) // 8, 2, V, 8, dtype=torch.float16, device=x.rows.device)
+        partial, slices, groups = stats
+        L.check(L.lib().bdm_group_norm_to_h2_stats_compact(B, C, V, groups, L.ptr(x.rows), x.plan.n_dil_max, L.ptr(x.plan.dil_index),
+                                                           L.ptr(x.bias), L.ptr(gn.weight), L.ptr(gn.bias), L.c_float(gn.eps),
+                                                           1 if swish else 0, L.c_float(s), L.ptr(out), L.ptr(partial), slices,
+                                                           L.ptr(saturated), L.stream()), "group_norm_to_h2_stats_compact")
+        return out, 1.0 / s
     x = x.contiguous()
     B, C = x.shape[:2]
     V = x.numel() // (B * C)
@@ -788,7 +799,7 @@ class VoxelPlan:
     """Everything that depends on (coords, r) only: normalised / integer voxel coordinates, per-voxel point lists,
     occupied-cell compaction and row occupancy.  PVConvs of one level share it (exactly the same values)."""
     __slots__ = ("r", "n", "n_max", "norm_coords", "vox_coords", "ind", "cnt", "ws", "occ_index", "occ_list", "n_occ", "rowocc",
-                 "ready", "stream", "dil_list", "plane_start", "tile_start", "n_dil_max")
+                 "ready", "stream", "dil_list", "dil_index", "plane_start", "tile_start", "n_dil_max")
 
 
 _plan_cache = {}
@@ -836,21 +847,23 @@ DILATED_PLAN = True   # voxel plans carry the once-dilated voxel list + tile tab
 
 
 def plan_dilation(p):
-    """dil_list / plane_start / tile_start of a plan (bdm_voxel_dilate): the output voxels of the first convolution that can differ from
-    the bias, in voxel order, cut into tiles.  One launch on the plan's stream; depends on (coords, r) only."""
-    if getattr(p, "dil_list", None) is not None or not DILATED_PLAN or p.r not in (8, 16, 32):
-        if getattr(p, "dil_list", None) is None:
-            p.dil_list = p.plane_start = p.tile_start = None
-            p.n_dil_max = 0
+    """dil_list / dil_index / plane_start / tile_start of a plan (bdm_voxel_dilate): the output voxels of the first convolution that
+    can differ from the bias, in voxel order, cut into tiles.  One launch on the plan's stream; depends on (coords, r) only."""
+    if getattr(p, "dil_list", None) is not None:
+        return p
+    p.dil_list = p.dil_index = p.plane_start = p.tile_start = None
+    p.n_dil_max = 0
+    if not DILATED_PLAN or p.r not in (8, 16, 32):
         return p
     lib, B, r = L.lib(), p.cnt.shape[0], p.r
     dev = p.cnt.device
     p.n_dil_max = r ** 3
     p.dil_list = torch.empty(B, p.n_dil_max, dtype=torch.int32, device=dev)
+    p.dil_index = torch.empty(B, r ** 3, dtype=torch.int32, device=dev)
     p.plane_start = torch.empty(B, r + 2, dtype=torch.int32, device=dev)
-    p.tile_start = torch.empty(B, lib.bdm_voxel_dilate_slices(r) + 2, dtype=torch.int32, device=dev)
-    L.check(lib.bdm_voxel_dilate(B, r, p.n_dil_max, L.ptr(p.cnt), L.ptr(p.dil_list), L.ptr(p.plane_start), L.ptr(p.tile_start), L.stream()),
-            "voxel_dilate")
+    p.tile_start = torch.empty(B, lib.bdm_voxel_dilate_slices(r), 8, dtype=torch.int32, device=dev)
+    L.check(lib.bdm_voxel_dilate(B, r, p.n_dil_max, L.ptr(p.cnt), L.ptr(p.dil_list), L.ptr(p.dil_index), L.ptr(p.plane_start),
+                                 L.ptr(p.tile_start), L.stream()), "voxel_dilate")
     return p
 
 
@@ -1055,15 +1068,35 @@ def sparse_conv_pack_os(weight, form="dil"):
     return (form,) + tuple(conv3d_h2_pack(weight))
 
 
-def sparse_first_conv_os(features, plan, packed, bias, cout, gn_groups=None, form="dil"):
-    """Conv3d(k3, p1)(avg_voxelize(features)) as ONE output-stationary implicit GEMM with tap skipping (csrc/sparse_conv_os.hip):
-    occupied cells' fp32 feature records + per-shape maximum (one launch), then the convolution (one launch) -- no 27x intermediate.
-    form "dil" (default): compact tiles of the once-dilated voxel list (needs plan_dilation); "os": fixed bricks of the grid.
-    packed = conv3d_h2_pack(weight).  gn_groups: -> (out, (partials, slices, groups)) with the GroupNorm statistics of the output."""
-    if form == "dil" and getattr(plan, "dil_list", None) is None:
-        plan_dilation(plan)
-        if plan.dil_list is None:
-            form = "os"
+class CompactGrid:
+    """Output of the first convolution in compact form: rows (B, n_dil_max, C), one per entry of the plan's dilated voxel list; every
+    other voxel of the (B, C, r^3) grid equals bias.  to_h2 consumes it directly; dense() materialises the grid (tests)."""
+
+    def __init__(self, rows, plan, bias, channels):
+        self.rows, self.plan, self.bias, self.channels = rows, plan, bias, channels
+
+    is_cuda = property(lambda self: self.rows.is_cuda)
+    device = property(lambda self: self.rows.device)
+
+    def dense(self):
+        B, r3, C = self.rows.shape[0], self.plan.r ** 3, self.channels
+        out = self.bias.detach().view(1, C, 1).expand(B, C, r3).contiguous()
+        idx = self.plan.dil_index.long()
+        for b in range(B):
+            v = torch.nonzero(idx[b] >= 0).squeeze(1)
+            out[b, :, v] = self.rows[b, idx[b, v]].t()
+        return out
+
+
+def sparse_first_conv_os(features, plan, packed, bias, cout, gn_groups=None, compact=False):
+    """Conv3d(k3, p1)(avg_voxelize(features)) as ONE output-stationary implicit GEMM with tap skipping over the once-dilated voxel
+    list of the plan (csrc/sparse_conv_os.hip): occupied cells' fp32 feature records + per-shape maximum (one launch), then the
+    convolution (one launch) -- no 27x intermediate.  packed = conv3d_h2_pack(weight).
+    compact: -> CompactGrid (rows per list entry; the dense grid is never written) instead of the (B, cout, r^3) tensor.
+    gn_groups: -> (out, (partials, slices, groups)) with the GroupNorm statistics of the (dense) output."""
+    plan_dilation(plan)
+    if plan.dil_list is None:
+        raise L.BdmHipError(f"sparse_first_conv_os: resolution {plan.r} has no dilated plan (8, 16, 32)")
     f, B, C, n, bs_f, ld_f = _bcl(features)
     dev, lib, r = f.device, L.lib(), plan.r
     packed_w, inv_scale = packed
@@ -1072,34 +1105,26 @@ def sparse_first_conv_os(features, plan, packed, bias, cout, gn_groups=None, for
     L.check(lib.bdm_sparse_voxel_features_f32(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),
                                               L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()),
             "sparse_voxel_features_f32")
-    out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
-    if form == "dil":
-        args = (B, C, cout, r, plan.n_max, plan.n_dil_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index), L.ptr(plan.dil_list),
-                L.ptr(plan.tile_start), L.ptr(plan.plane_start), L.ptr(packed_w), L.ptr(inv_scale), L.ptr(bias), L.ptr(out))
-        if gn_groups:
-            tiles = plan.tile_start.shape[1] - 2
-            partial = torch.empty(B, gn_groups, tiles, 2, dtype=torch.float64, device=dev)
-            slices = ctypes.c_int(0)
-            L.check(lib.bdm_sparse_conv_dil_gn(*args, int(gn_groups), L.ptr(partial), ctypes.byref(slices), L.stream()), "sparse_conv_dil_gn")
-            assert slices.value == tiles
-            return out, (partial, tiles, int(gn_groups))
-        L.check(lib.bdm_sparse_conv_dil(*args, L.stream()), "sparse_conv_dil")
-        return out
+    if compact:
+        y = torch.empty(B, plan.n_dil_max, cout, dtype=torch.float32, device=dev)
+        out = CompactGrid(y, plan, bias, cout)
+    else:
+        y = out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
+    args = (B, C, cout, r, plan.n_max, plan.n_dil_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index), L.ptr(plan.dil_list),
+            L.ptr(plan.dil_index), L.ptr(plan.tile_start), L.ptr(packed_w), L.ptr(inv_scale), L.ptr(bias), L.ptr(y), 1 if compact else 0)
     if gn_groups:
-        ws = torch.empty(lib.bdm_group_norm_workspace_bytes(B, gn_groups), dtype=torch.uint8, device=dev)
+        tiles = plan.tile_start.shape[1]
+        partial = torch.empty(B, gn_groups, tiles, 2, dtype=torch.float64, device=dev)
         slices = ctypes.c_int(0)
-        L.check(lib.bdm_sparse_conv_os_gn(B, C, cout, r, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index), L.ptr(packed_w),
-                                          L.ptr(inv_scale), L.ptr(bias), L.ptr(out), int(gn_groups), L.ptr(ws), ctypes.byref(slices),
-                                          L.stream()), "sparse_conv_os_gn")
-        return out, (ws, slices.value, int(gn_groups))
-    L.check(lib.bdm_sparse_conv_os(B, C, cout, r, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index), L.ptr(packed_w),
-                                   L.ptr(inv_scale), L.ptr(bias), L.ptr(out), L.stream()), "sparse_conv_os")
+        L.check(lib.bdm_sparse_conv_dil_gn(*args, int(gn_groups), L.ptr(partial), ctypes.byref(slices), L.stream()), "sparse_conv_dil_gn")
+        return out, (partial, tiles, int(gn_groups))
+    L.check(lib.bdm_sparse_conv_dil(*args, L.stream()), "sparse_conv_dil")
     return out
 
 
 def sparse_os_gn_ok(cout, groups, r):
     cg = cout // groups if groups and cout % groups == 0 else 0
-    tile = 64 if (cout > 32 and r != 8) else 32
+    tile = 64 if cout > 32 else 32
     return cg >= 4 and (cg & (cg - 1)) == 0 and tile % cg == 0
 
 
@@ -1124,6 +1149,7 @@ def sparse_first_conv(features, vox_coords, r, wt, bias, cout):
             "voxel_compact")
     L.check(lib.bdm_voxel_row_occupancy(B, r, L.ptr(p.cnt), L.ptr(p.rowocc), L.stream()), "voxel_row_occupancy")
     p.dil_list = None
-    if isinstance(wt, tuple) and wt[0] in ("os", "dil"):
-        return sparse_first_conv_os(features, plan_dilation(p), wt[1:], bias, cout, form=wt[0])
+    if isinstance(wt, tuple) and wt[0] in ("dil", "dil_compact"):
+        out = sparse_first_conv_os(features, plan_dilation(p), wt[1:], bias, cout, compact=wt[0] == "dil_compact")
+        return out.dense() if wt[0] == "dil_compact" else out
     return sparse_first_conv_planned(features, p, wt, bias, cout)

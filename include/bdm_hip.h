@@ -320,6 +320,13 @@ int bdm_group_norm_to_h2(int b, int c, int v, int groups, const float *x, const 
 int bdm_group_norm_to_h2_stats(int b, int c, int v, int groups, const float *x, const float *gamma, const float *beta,
                                float eps, int act, float act_scale, void *out_h2, const void *partial, int slices,
                                unsigned int *saturated, void *stream);
+/* bdm_group_norm_to_h2_stats for the COMPACT output of the first convolution (bdm_sparse_conv_dil, compact = 1): xc (b, n_dil_max, c)
+ * one row per entry of the dilated voxel list, dil_index (b, v) row of voxel v or -1; every voxel outside the list has the value
+ * bias[channel] (NULL: 0).  Same result as densifying xc first; the dense fp32 grid is never written or read. */
+int bdm_group_norm_to_h2_stats_compact(int b, int c, int v, int groups, const float *xc, int n_dil_max, const int *dil_index,
+                                       const float *bias, const float *gamma, const float *beta, float eps, int act,
+                                       float act_scale, void *out_h2, const void *partial, int slices,
+                                       unsigned int *saturated, void *stream);
 int bdm_conv3d_3x3x3_h2(int b, int cin, int cout, int r, const void *x_h2, float x_inv_scale, const void *packed_w,
                         const float *inv_scale, const float *bias, float *y, void *stream);
 
@@ -434,38 +441,31 @@ int bdm_sparse_conv_gemm_h2(int b, int n_max, int cin, int cout, const void *xh,
                             const float *inv_scale, const int *n_occ, float *y, void *stream);
 
 /* The same first convolution as ONE output-stationary implicit GEMM with tap skipping (sparse_conv_os.hip, round 4; the default
- * wherever the input is not the hoisted conditioning map): no (n_occ x 27*cout) intermediate, no gather, no operand-split pass.
- *   xr / amax     bdm_sparse_voxel_features_f32: fp32 records (b, ceil(cin/8), n_max) x 8 channels + per-shape max |value|
- *   occ_index     (b, r^3) compact row of every cell, -1 = empty (bdm_voxelize_plan_full / bdm_voxel_compact)
- *   packed_w / inv_scale   bdm_conv3d_h2_pack_weights (the dense fp16x3 convolution's weight image)
- *   y             (b, cout, r^3) fp32 = bias + conv; every cell is written.  r in {8, 16, 32}, n_max < 2^18.
- * A workgroup owns a brick of output voxels (the dense kernel's tiles), builds its halo in LDS from the occupied cells only and
- * skips every (16-voxel block, tap quad) MFMA group whose 64 neighbours are all empty.  fp16x3 arithmetic, activation scale per
- * shape.  _gn: also leaves GroupNorm(groups) slice partials of y exactly as bdm_conv3d_3x3x3_h2_gn does. */
-int bdm_sparse_conv_os(int b, int cin, int cout, int r, int n_max, const void *xr, const float *amax, const int *occ_index,
-                       const void *packed_w, const float *inv_scale, const float *bias, float *y, void *stream);
-int bdm_sparse_conv_os_gn(int b, int cin, int cout, int r, int n_max, const void *xr, const float *amax, const int *occ_index,
-                          const void *packed_w, const float *inv_scale, const float *bias, float *y, int groups,
-                          void *gn_workspace, int *slices_out, void *stream);
-
-/* Compact output-stationary form of the same convolution (sparse_conv_os.hip; the default): only the voxels that can differ from
- * the bias -- the once-dilated occupied set, listed in voxel order -- are computed, in tiles of consecutive list entries whose
- * occupied neighbours are ONE contiguous range of compact rows (staged in LDS per 8-channel chunk); everything else is bias.
+ * wherever the input is not the hoisted conditioning map): no (n_occ x 27*cout) intermediate, no gather, no operand-split pass.  Only
+ * the voxels that can differ from the bias -- the once-dilated occupied set, listed in voxel order -- are computed, in tiles of
+ * consecutive list entries whose occupied neighbours are ONE contiguous range of compact rows (staged in LDS per 8-channel chunk).
  *   bdm_voxel_dilate        cnt (b, r^3) -> dil_list (b, n_dil_max) voxel ids of the dilated set in ascending order (n_dil_max = r^3
- *                           always suffices), plane_start (b, r + 2): occupied cells in x-planes < x, tile_start
- *                           (b, bdm_voxel_dilate_slices(r) + 2): first list entry of every tile, then the tile count in the last slot.
- *                           Depends on (coords, r) only: part of the voxel plan, shared by the PVConvs of a level.
- *   bdm_sparse_conv_dil     y (b, cout, r^3) = bias + conv; xr / amax / occ_index / packed_w / inv_scale as bdm_sparse_conv_os.
- *   bdm_sparse_conv_dil_gn  also leaves GroupNorm(groups) partials of y: gn_partial (b, groups, tiles, 2 doubles),
- *                           *slices_out = tiles = bdm_voxel_dilate_slices(r); consumed by bdm_group_norm_to_h2_stats. */
+ *                           always suffices), dil_index (b, r^3) rank in that list or -1, plane_start (b, r + 2): occupied cells in
+ *                           x-planes < x, tile_start (b, bdm_voxel_dilate_slices(r), 8): per tile [first entry, end entry, first voxel of
+ *                           the linear range it owns, its end, first compact row of its input range, rows, 0, live tiles of the
+ *                           shape].  Depends on (coords, r) only: part of the voxel plan of a level.  r in {8, 16, 32}.
+ *   bdm_sparse_conv_dil     xr / amax: bdm_sparse_voxel_features_f32 (fp32 records (b, ceil(cin/8), n_max) x 8 channels + per-shape
+ *                           max |value|); occ_index (b, r^3) compact row of every cell or -1; packed_w / inv_scale:
+ *                           bdm_conv3d_h2_pack_weights (the dense fp16x3 convolution's weight image).  fp16x3 arithmetic, activation
+ *                           scale per shape.  compact = 1: y (b, n_dil_max, cout), one row per list entry (every other voxel of the
+ *                           grid equals bias: bdm_group_norm_to_h2_stats_compact consumes this form); compact = 0: y (b, cout, r^3),
+ *                           every cell written.
+ *   bdm_sparse_conv_dil_gn  also leaves GroupNorm(groups) partials of the DENSE output (bias voxels included) in gn_partial
+ *                           (b, groups, tiles, 2 doubles), *slices_out = tiles = bdm_voxel_dilate_slices(r). */
 int bdm_voxel_dilate_slices(int r);
-int bdm_voxel_dilate(int b, int r, int n_dil_max, const int *cnt, int *dil_list, int *plane_start, int *tile_start, void *stream);
+int bdm_voxel_dilate(int b, int r, int n_dil_max, const int *cnt, int *dil_list, int *dil_index, int *plane_start, int *tile_start,
+                     void *stream);
 int bdm_sparse_conv_dil(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
-                        const int *occ_index, const int *dil_list, const int *tile_start, const int *plane_start,
-                        const void *packed_w, const float *inv_scale, const float *bias, float *y, void *stream);
+                        const int *occ_index, const int *dil_list, const int *dil_index, const int *tile_start,
+                        const void *packed_w, const float *inv_scale, const float *bias, float *y, int compact, void *stream);
 int bdm_sparse_conv_dil_gn(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
-                           const int *occ_index, const int *dil_list, const int *tile_start, const int *plane_start,
-                           const void *packed_w, const float *inv_scale, const float *bias, float *y, int groups,
+                           const int *occ_index, const int *dil_list, const int *dil_index, const int *tile_start,
+                           const void *packed_w, const float *inv_scale, const float *bias, float *y, int compact, int groups,
                            void *gn_partial, int *slices_out, void *stream);
 
 /* ------------------------------------------------------------------------------------

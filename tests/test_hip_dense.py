@@ -450,7 +450,7 @@ def test_sparse_first_conv_equals_dense(ops, oracle_ops, cin, cout, r, npts):
 
 @pytest.mark.parametrize("cin,cout,r,npts", [(35, 32, 32, 4096), (64, 64, 32, 1100), (64, 64, 32, 4096), (128, 64, 16, 1024), (128, 128, 16, 1024),
                                              (256, 256, 8, 64), (192, 128, 8, 256), (16, 8, 8, 2000), (390, 32, 32, 700)])
-@pytest.mark.parametrize("form", ["dil", "os"])
+@pytest.mark.parametrize("form", ["dil", "dil_compact"])
 def test_sparse_first_conv_output_stationary_equals_dense(ops, oracle_ops, cin, cout, r, npts, form):
     """The one-kernel output-stationary form with tap skipping (sparse_conv_os.hip, the default first convolution): == the dense
     evaluation at fp32 grade, bit-reproducible, strided features accepted, and its GroupNorm partials == the statistics of its output."""
@@ -487,12 +487,53 @@ def test_sparse_first_conv_output_stationary_equals_dense(ops, oracle_ops, cin, 
         ops.clear_plan_cache()
         pts = (torch.randn(B, 3, npts, generator=g) * 0.3).cuda()
         plan = ops.voxel_plan(pts, r)
-        out, (ws, slices, gg) = ops.sparse_first_conv_os(f.cuda(), plan, wt[1:], bias.cuda(), cout, gn_groups=groups, form=form)
-        assert torch.equal(out, ops.sparse_first_conv_os(f.cuda(), plan, wt[1:], bias.cuda(), cout, form=form))
-        part = ws.view(-1).view(torch.float64)[: B * groups * slices * 2].view(B, groups, slices, 2).sum(2).cpu()
+        compact = form == "dil_compact"
+        out, (ws, slices, gg) = ops.sparse_first_conv_os(f.cuda(), plan, wt[1:], bias.cuda(), cout, gn_groups=groups, compact=compact)
+        plain = ops.sparse_first_conv_os(f.cuda(), plan, wt[1:], bias.cuda(), cout, compact=compact)
+        if compact:
+            for b in range(B):   # (rows beyond a shape's list length are never written)
+                nd = int(plan.tile_start[b, :, 1].max())
+                assert torch.equal(out.rows[b, :nd], plain.rows[b, :nd])
+            out = out.dense()
+            assert torch.equal(out, ops.sparse_first_conv_os(f.cuda(), plan, wt[1:], bias.cuda(), cout))   # compact == dense form, bit for bit
+        else:
+            assert torch.equal(out, plain)
+        part = ws.sum(2).cpu()
         o = out.double().cpu().view(B, groups, -1)
-        assert torch.allclose(part[..., 0], o.sum(-1), rtol=1e-5, atol=1e-3)
-        assert torch.allclose(part[..., 1], (o * o).sum(-1), rtol=1e-5, atol=1e-3)
+        err_s = float((part[..., 0] - o.sum(-1)).abs().max() / o.abs().sum(-1).max())
+        err_q = float((part[..., 1] - (o * o).sum(-1)).abs().max() / (o * o).sum(-1).max())
+        assert err_s < 2e-6 and err_q < 2e-6, (err_s, err_q)   # fp32 partial sums of <= 512 values, fp64 above
+
+
+def test_compact_grid_operand_split_equals_the_dense_one(ops):
+    """The operand split of the second convolution fed with the COMPACT output of the first (rows of the dilated voxels + bias
+    everywhere else, read through the plan's index) gives the H2 grid of the dense path bit for bit, saturation word included."""
+    import torch.nn as nn
+    for cin, cout, r, n in ((32, 32, 32, 4096), (64, 64, 32, 3000), (128, 128, 16, 1024), (256, 256, 8, 64), (192, 128, 8, 256)):
+        g = torch.Generator().manual_seed(cin + n)
+        B = 3
+        f = torch.randn(B, cin, n, generator=g).cuda()
+        pts = (torch.randn(B, 3, n, generator=g) * 0.3).cuda()
+        w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).cuda()
+        bias = torch.randn(cout, generator=g).cuda()
+        gn = nn.GroupNorm(8, cout).cuda()
+        with torch.no_grad():
+            gn.weight.copy_(torch.randn(cout, generator=g) * 0.3 + 1.0)
+            gn.bias.copy_(torch.randn(cout, generator=g) * 0.2)
+        ops.clear_plan_cache()
+        plan = ops.voxel_plan(pts, r)
+        pk = ops.conv3d_h2_pack(w)
+        dense, st_d = ops.sparse_first_conv_os(f, plan, pk, bias, cout, gn_groups=8)
+        comp, st_c = ops.sparse_first_conv_os(f, plan, pk, bias, cout, gn_groups=8, compact=True)
+        assert torch.equal(st_d[0], st_c[0])
+        sat_d, sat_c = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+        h_d, s_d = ops.to_h2(dense, gn, swish=True, saturated=sat_d, stats=st_d)
+        h_c, s_c = ops.to_h2(comp, gn, swish=True, saturated=sat_c, stats=st_c)
+        assert s_d == s_c and torch.equal(h_d.view(torch.int16), h_c.view(torch.int16)) and int(sat_d) == int(sat_c) == 0
+        # a scale that saturates: both routes raise the word
+        h_d, _ = ops.to_h2(dense, gn, swish=True, saturated=sat_d, stats=st_d, scale=2.0 ** 20)
+        h_c, _ = ops.to_h2(comp, gn, swish=True, saturated=sat_c, stats=st_c, scale=2.0 ** 20)
+        assert int(sat_d) == 1 and int(sat_c) == 1 and torch.equal(h_d.view(torch.int16), h_c.view(torch.int16))
 
 
 def test_dilated_voxel_list_and_tile_table(ops):
@@ -509,9 +550,6 @@ def test_dilated_voxel_list_and_tile_table(ops):
         vc[1, :, : n - 1] = torch.stack([r // 2 - 2 + e // (r * r), (e // r) % r, e % r]).to(torch.int32)
         vc[1, :, n - 1] = 0                                                                         # and a lone cell that shifts the tiles off the plane boundaries
         vc[2] = 0                                                                                   # one occupied cell, at the grid corner
-        f = torch.zeros(B, 1, n)
-        ops.sparse_first_conv(f.cuda(), vc.cuda(), r, ops.sparse_conv_pack_os(torch.zeros(4, 1, 3, 3, 3).cuda()), torch.zeros(4).cuda(), 4)
-        p = ops.VoxelPlan(); p.r, p.n = r, n
         lib, r3 = L.lib(), r ** 3
         cnt = torch.zeros(B, r3, dtype=torch.int32)
         lin = (vc[:, 0].long() * r + vc[:, 1].long()) * r + vc[:, 2].long()
@@ -520,10 +558,12 @@ def test_dilated_voxel_list_and_tile_table(ops):
         cnt = cnt.cuda()
         tiles = lib.bdm_voxel_dilate_slices(r)
         dl = torch.full((B, r3), -1, dtype=torch.int32, device="cuda")
+        di = torch.full((B, r3), -7, dtype=torch.int32, device="cuda")
         ps = torch.empty(B, r + 2, dtype=torch.int32, device="cuda")
-        ts = torch.empty(B, tiles + 2, dtype=torch.int32, device="cuda")
-        L.check(lib.bdm_voxel_dilate(B, r, r3, L.ptr(cnt), L.ptr(dl), L.ptr(ps), L.ptr(ts), L.stream()))
+        ts = torch.empty(B, tiles, 8, dtype=torch.int32, device="cuda")
+        L.check(lib.bdm_voxel_dilate(B, r, r3, L.ptr(cnt), L.ptr(dl), L.ptr(di), L.ptr(ps), L.ptr(ts), L.stream()))
         dl, ps, ts, occ = dl.cpu().numpy(), ps.cpu().numpy(), ts.cpu().numpy(), (cnt.cpu().numpy() > 0).reshape(B, r, r, r)
+        di = di.cpu().numpy()
         for b in range(B):
             P = np.zeros((r + 2,) * 3, bool); P[1:-1, 1:-1, 1:-1] = occ[b]
             D = np.zeros((r, r, r), bool)
@@ -532,18 +572,22 @@ def test_dilated_voxel_list_and_tile_table(ops):
                     for dz in range(3):
                         D |= P[dx:dx + r, dy:dy + r, dz:dz + r]
             want = np.flatnonzero(D.reshape(-1))
-            nt = int(ts[b, tiles + 1])
-            assert int(ts[b, nt]) == len(want) and np.array_equal(dl[b, :len(want)], want), (r, b)
+            nt = int(ts[b, 0, 7])
+            assert int(ts[b, nt - 1, 1]) == len(want) and np.array_equal(dl[b, :len(want)], want), (r, b)
+            rank = np.full(r3, -1, np.int32); rank[want] = np.arange(len(want))
+            assert np.array_equal(di[b], rank)
             per_plane = occ[b].reshape(r, -1).sum(1)
             assert np.array_equal(ps[b, :r + 1], np.concatenate([[0], np.cumsum(per_plane)])) and ps[b, r + 1] == ps[b, r]
-            assert ts[b, 0] == 0 and 1 <= nt <= tiles
+            assert ts[b, 0, 0] == 0 and 1 <= nt <= tiles and (ts[b, :, 7] == nt).all()
             for t in range(nt):
-                j0, j1 = int(ts[b, t]), int(ts[b, t + 1])
-                assert 0 < j1 - j0 <= tile
+                j0, j1, vf, ve, klo, nr = (int(v) for v in ts[b, t, :6])
+                assert 0 < j1 - j0 <= tile and (t == 0 or j0 == ts[b, t - 1, 1])
                 x0, x1 = want[j0] // (r * r), want[j1 - 1] // (r * r)
-                assert ps[b, min(x1 + 2, r)] - ps[b, max(x0 - 1, 0)] <= 3 * r * r
-            if b == 1:
-                assert nt > -(-len(want) // tile), "the dense slab did not force a cut at a plane boundary"
+                assert klo == ps[b, max(x0 - 1, 0)] and nr == ps[b, min(x1 + 2, r)] - klo and nr <= 3 * r * r
+                assert vf == (0 if t == 0 else want[j0]) and ve == (want[j1] if t + 1 < nt else r3)   # the linear ranges partition the grid
+            assert (ts[b, nt:, 0] == len(want)).all() and (ts[b, nt:, 1] == len(want)).all()
+            if b == 1:   # the dense slab: some tile other than the last is short, i.e. was cut at a plane boundary
+                assert any(int(ts[b, t, 1] - ts[b, t, 0]) < tile for t in range(nt - 1)), "the dense slab did not force a cut"
 
 
 @experimental

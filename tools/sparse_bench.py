@@ -43,14 +43,13 @@ for name, cin, cout, r, n in LAYERS:
     t_old = t(lambda: ops.sparse_first_conv_planned(f, plan, w_old, bias, cout))
     t_new = t(lambda: ops.sparse_first_conv_planned(f, plan, w_new, bias, cout))
     w_os = ops.sparse_conv_pack_os(w)[1:]
-    form = os.environ.get("OS_FORM", "dil")
-    c = ops.sparse_first_conv_os(f, plan, w_os, bias, cout, form=form)
+    c = ops.sparse_first_conv_os(f, plan, w_os, bias, cout)
     err_os = float((c - b).norm() / b.norm())
-    t_os = t(lambda: ops.sparse_first_conv_os(f, plan, w_os, bias, cout, form=form))
-    t_os_gn = t(lambda: ops.sparse_first_conv_os(f, plan, w_os, bias, cout, gn_groups=8, form=form))
+    t_os = t(lambda: ops.sparse_first_conv_os(f, plan, w_os, bias, cout))
+    t_os_gn = t(lambda: ops.sparse_first_conv_os(f, plan, w_os, bias, cout, gn_groups=8, compact=True))
     t_k = t_new
     tot_old += MULT[name] * t_old; tot_new += MULT[name] * t_new; tot_os += MULT[name] * t_os_gn
     fl = 2 * occ * 27 * cin * cout * B
     print(f"{name} {cin:4d}->{cout:4d} r={r:2d} n={n:5d} n_occ={occ:7.1f}  bf16x6 {t_old:7.1f} us  fp16x3 {t_new:7.1f} us ("
-          f"{fl / t_k / 1e6:6.1f} TF/s alg.)  rel diff {err:.1e} | output-stationary {t_os:7.1f} us (+GN stats {t_os_gn:7.1f}) rel diff {err_os:.1e}", flush=True)
+          f"{fl / t_k / 1e6:6.1f} TF/s alg.)  rel diff {err:.1e} | output-stationary, dense out {t_os:7.1f} us; compact out + GN stats {t_os_gn:7.1f} us; rel diff {err_os:.1e}", flush=True)
 print(f"per forward (14 PVConvs): bf16x6 {tot_old:.0f} us, fp16x3 {tot_new:.0f} us, output-stationary {tot_os:.0f} us")

@@ -1,8 +1,9 @@
-"""Timing probe of the output-stationary sparse first convolution (sparse_conv_os.hip) per layer shape; BDM_OS_DBG selects a debug mode of
-the kernel (1: skip every MFMA group, 2: skip none, 3: prologue + epilogue only).  usage: sparse_os_probe.py [B]"""
+"""Timing probe of the output-stationary sparse first convolution (sparse_conv_os.hip) per layer shape at the bench's batch: feature records,
+dilated plan, the convolution in its compact and dense output forms, and the operand split that consumes each.  usage: sparse_os_probe.py [B]"""
 import os, sys, torch
+import torch.nn as nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bdm_amd import ops
+from bdm_amd import ops, _lib as L
 from bdm_amd import functional as F
 
 
@@ -22,7 +23,6 @@ for m in (1024, 256, 64):
     clouds[m] = F.furthest_point_sample(clouds[m * 4], m)
 LAYERS = [("SA0.1", 32, 32, 32, 4096), ("SA1.0", 128, 64, 16, 1024), ("SA2.0", 192, 128, 8, 256),
           ("FP0.x", 256, 256, 8, 64), ("FP1.x", 256, 256, 8, 256), ("FP2.x", 128, 128, 16, 1024), ("FP3.x", 64, 64, 32, 4096)]
-from bdm_amd import _lib as L
 lib = L.lib()
 for name, cin, cout, r, n in LAYERS:
     pts = clouds[n]
@@ -31,37 +31,31 @@ for name, cin, cout, r, n in LAYERS:
     f = torch.randn(B, cin, n, generator=g).cuda()
     w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).cuda()
     bias = torch.zeros(cout).cuda()
-    packed_w, inv_scale = ops.conv3d_h2_pack(w)
+    gn = nn.GroupNorm(8, cout).cuda()
+    pk = ops.conv3d_h2_pack(w)
     xr = torch.empty(B, (cin + 7) // 8, plan.n_max, 8, dtype=torch.float32, device="cuda")
     amax = torch.zeros(B, device="cuda")
     feat = lambda: L.check(lib.bdm_sparse_voxel_features_f32(B, cin, n, r, plan.n_max, L.ptr(f), cin * n, n, L.ptr(plan.cnt), L.ptr(plan.ws),
                                                             L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()))
     feat()
-    out = torch.empty(B, cout, r ** 3, device="cuda")
-    conv = lambda: L.check(lib.bdm_sparse_conv_os(B, cin, cout, r, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index), L.ptr(packed_w),
-                                                 L.ptr(inv_scale), L.ptr(bias), L.ptr(out), L.stream()))
-    dil = lambda: L.check(lib.bdm_sparse_conv_dil(B, cin, cout, r, plan.n_max, plan.n_dil_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index),
-                                                 L.ptr(plan.dil_list), L.ptr(plan.tile_start), L.ptr(plan.plane_start), L.ptr(packed_w),
-                                                 L.ptr(inv_scale), L.ptr(bias), L.ptr(out), L.stream()))
-    ntl = plan.tile_start[:, -1].float().mean().item()
-    tdil = t(lambda: L.check(lib.bdm_voxel_dilate(B, r, plan.n_dil_max, L.ptr(plan.cnt), L.ptr(plan.dil_list), L.ptr(plan.plane_start), L.ptr(plan.tile_start), L.stream())))
-    row = [f"{name} {cin:4d}->{cout:4d} r={r:2d} n_occ={float(plan.n_occ.float().mean()):7.1f} features {t(feat):6.1f} us | dilate {tdil:5.1f} us, "
-           f"{ntl:4.1f} tiles/shape, compact conv {t(dil):6.1f} us | brick conv"]
-    for mode in ("0", "1", "2", "3", "4", "5"):
-        os.environ["BDM_OS_DBG"] = mode
-        row.append(f"dbg{mode} {t(conv):6.1f}")
-    os.environ["BDM_OS_DBG"] = "0"
-    print("  ".join(row), flush=True)
-    # activity of the (16-voxel block, tap quad) fragments on THIS plan, computed on the host from occ_index
-    occ = (plan.occ_index.view(B, r, r, r) >= 0).cpu().numpy()
-    import numpy as np
-    zb = min(16, r)
-    acts = []
-    for b in range(min(B, 4)):
-        P = np.zeros((r + 2,) * 3, bool); P[1:-1, 1:-1, 1:-1] = occ[b]
-        act = np.zeros((r, r, r // zb, 27), bool)
-        for tp in range(27):
-            dx, dy, dz = tp // 9 - 1, (tp // 3) % 3 - 1, tp % 3 - 1
-            act[..., tp] = P[1 + dx:1 + dx + r, 1 + dy:1 + dy + r, 1 + dz:1 + dz + r].reshape(r, r, r // zb, zb).any(-1)
-        acts.append(np.stack([act[..., 4 * Q:min(4 * Q + 4, 27)].any(-1) for Q in range(7)], -1).mean())
-    print(f"      host-side fragment activity {100 * np.mean(acts):.1f} %  occupied {100 * occ.mean():.1f} %")
+    yd = torch.empty(B, cout, r ** 3, device="cuda")
+    yc = torch.empty(B, plan.n_dil_max, cout, device="cuda")
+    part = torch.empty(B, 8, plan.tile_start.shape[1], 2, dtype=torch.float64, device="cuda")
+    import ctypes
+    sl = ctypes.c_int(0)
+
+    def conv(y, compact):
+        return lambda: L.check(lib.bdm_sparse_conv_dil_gn(B, cin, cout, r, plan.n_max, plan.n_dil_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index),
+                                                          L.ptr(plan.dil_list), L.ptr(plan.dil_index), L.ptr(plan.tile_start),
+                                                          L.ptr(pk[0]), L.ptr(pk[1]), L.ptr(bias), L.ptr(y), compact, 8, L.ptr(part), ctypes.byref(sl), L.stream()))
+    tdil = t(lambda: L.check(lib.bdm_voxel_dilate(B, r, plan.n_dil_max, L.ptr(plan.cnt), L.ptr(plan.dil_list), L.ptr(plan.dil_index), L.ptr(plan.plane_start),
+                                                  L.ptr(plan.tile_start), L.stream())))
+    ntl = plan.tile_start[:, 0, 7].float().mean().item()
+    nd = plan.tile_start[:, :, 1].max(1).values.float().mean().item()
+    tc, td = t(conv(yc, 1)), t(conv(yd, 0))
+    st = (part, part.shape[2], 8)
+    comp = ops.CompactGrid(yc, plan, bias, cout)
+    th_c = t(lambda: ops.to_h2(comp, gn, swish=True, stats=st))
+    th_d = t(lambda: ops.to_h2(yd, gn, swish=True, stats=st))
+    print(f"{name} {cin:4d}->{cout:4d} r={r:2d} n_occ={float(plan.n_occ.float().mean()):7.1f} n_dil={nd:7.1f} ({ntl:4.1f} tiles) | features {t(feat):6.1f} us, "
+          f"dilate {tdil:5.1f} us | conv compact {tc:6.1f} us + split {th_c:5.1f} us | conv dense {td:6.1f} us + split {th_d:5.1f} us", flush=True)
