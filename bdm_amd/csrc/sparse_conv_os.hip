@@ -60,7 +60,7 @@ __global__ __launch_bounds__(1024) void vox_dilate_kernel(int r, int n_dil_max, 
   //   tile_start[t]   8 ints per tile (see the end of this kernel); a tile holds <= `tile` consecutive entries and is cut at an x-plane
   //                   boundary where the compact rows of planes [x0 - 1, x1 + 1] would exceed `xcap` (xcap >= 3 r^2, so a tile inside
   //                   one plane always fits)
-  extern __shared__ unsigned bits[];   // [r*r] occupancy rows, 2 x 16 wave totals, 2 x (r + 2) plane prefixes
+  extern __shared__ unsigned bits[];   // [r*r] occupancy rows, 2 x 16 wave totals, 2 x (r + 2) plane prefixes, [r*r] dilated rows, [r*r] their prefix
   const int bi = blockIdx.x, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int r2 = r * r, r3 = r2 * r;
   unsigned *occ = bits;
@@ -103,18 +103,26 @@ __global__ __launch_bounds__(1024) void vox_dilate_kernel(int r, int n_dil_max, 
     if (w < wave) { off_d += wtot[w]; off_o += wtot[16 + w]; }
     tot_d += wtot[w]; tot_o += wtot[16 + w];
   }
+  unsigned *drow = bits + r2 + 32 + 2 * (r + 2);          // [r*r] dilated bit rows
+  int *drun = reinterpret_cast<int *>(drow + r2);         // [r*r] dilated cells before the row
   if (tid < r2) {
-    int run = off_d + incl_d - mine_d;
+    const int run = off_d + incl_d - mine_d;
     if (tid % r == 0) { ps_o[tid / r] = off_o + incl_o - mine_o; ps_d[tid / r] = run; }
+    drow[tid] = d;
+    drun[tid] = run;
+  }
+  __syncthreads();
+  {   // ranks and list, one voxel per thread and step: coalesced index writes (a thread walking its own row wrote 32 separate lines)
     int *dl = dil_list + (size_t)bi * n_dil_max;
-    int *di = dil_index + (size_t)bi * r3 + (size_t)tid * r;
-    for (int z = 0; z < r; ++z) {
-      const bool in = (d >> z) & 1u;
-      di[z] = in && run < n_dil_max ? run : -1;
-      if (in) {
-        if (run < n_dil_max) dl[run] = tid * r + z;
-        ++run;
-      }
+    int *di = dil_index + (size_t)bi * r3;
+    for (int v = tid; v < r3; v += T) {
+      const int row = v / r, z = v - row * r;
+      const unsigned m = drow[row];
+      const bool in = (m >> z) & 1u;
+      const int rank = drun[row] + __popc(m & ((1u << z) - 1u));
+      const bool ok = in && rank < n_dil_max;
+      di[v] = ok ? rank : -1;
+      if (ok) dl[rank] = v;
     }
   }
   if (tid == 0) { ps_o[r] = ps_o[r + 1] = tot_o; ps_d[r] = ps_d[r + 1] = tot_d; }
@@ -171,7 +179,7 @@ extern "C" int bdm_voxel_dilate(int b, int r, int n_dil_max, const int *cnt, int
   if (b == 0) return BDM_OK;
   int tile, xcap, tiles_max;
   sconv_dil_geometry(r, &tile, &xcap, &tiles_max);
-  const size_t smem = sizeof(unsigned) * ((size_t)r * r + 32 + 2 * (r + 2));
+  const size_t smem = sizeof(unsigned) * (3 * (size_t)r * r + 32 + 2 * (r + 2));
   hipLaunchKernelGGL(vox_dilate_kernel, dim3(b), dim3(1024), smem, (hipStream_t)stream, r, n_dil_max, tile, xcap, tiles_max, cnt,
                      dil_list, dil_index, plane_start, tile_start);
   return launch_status("voxel_dilate");
@@ -180,13 +188,21 @@ extern "C" int bdm_voxel_dilate(int b, int r, int n_dil_max, const int *cnt, int
 // ---------------------------------------------------------------------------------------------------------------------
 // the convolution
 // ---------------------------------------------------------------------------------------------------------------------
+#ifdef DIL_TIMING   // phase timestamps of every live workgroup (wall_clock64: 100 MHz), a debug build for tools/sparse_os_probe.py only
+__device__ long long *g_dil_ts = nullptr;
+extern "C" int bdm_debug_dil_timestamps(long long *buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_dil_ts), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; }
+#define DIL_STAMP(i) do { if (g_dil_ts && tid == 0) g_dil_ts[(size_t)item * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define DIL_STAMP(i)
+#endif
+
 template <int MT, int NT, int NW, int R>
 __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
     int C8, int Cout, int n_max, int n_dil_max, int xcap, const float4 *__restrict__ xr, const float *__restrict__ amax,
     const int *__restrict__ occ_index, const int *__restrict__ dil_list, const int *__restrict__ dil_index,
     const int *__restrict__ tile_start, const float4 *__restrict__ wq,
     const float *__restrict__ inv_scale, const float *__restrict__ bias, float *__restrict__ y, int compact, int gn_cg,
-    double *__restrict__ gn_partial) {
+    double *__restrict__ gn_partial, int nb_shapes, int ncb, int tiles_max, int *__restrict__ work_counter) {
   extern __shared__ __align__(16) float4 smem4[];
   constexpr int BM = 16 * MT, TILE = NT * NW * 16;   // a tile holds <= TILE voxels (sconv_dil_geometry)
   constexpr int R2 = R * R, R3 = R2 * R;
@@ -197,18 +213,35 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
   constexpr int NBLK = NT * NW, NB = MT * 4 * 2;
   float4 *Ws = smem4;                 // [14][2][2][BM]
   float4 *Xs = smem4 + WV;            // [2][xcap + 64]: records xcap .. xcap + 63 of each split are zero, one per lane -- absent neighbours are
-  const int XS = xcap + 64;           // the common case, and 64 lanes reading ONE 16-byte record serialise on its four banks (measured: 19 us per chunk)
+  const int XS = xcap + 64;           // the common case, and 64 lanes reading ONE 16-byte record serialise on its four banks
+  __shared__ int s_item;
+  __shared__ float s_osc[64], s_obi[64];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kg = lane >> 4;
-  // grid = (shapes, channel blocks, tiles): tile index slowest, so the tiles no shape has (most of the grid) are dispatched after
-  // every live workgroup is running -- a workgroup needs the whole CU's LDS, and in tile-fastest order the dead ones of shape k
-  // queue in front of the live ones of shape k + 1
-  const int bi = blockIdx.x, m0 = blockIdx.y * BM, tile = blockIdx.z, tiles_max = gridDim.z;
+  const int tid0 = threadIdx.x;
+  const int G = gn_partial != nullptr ? Cout / gn_cg : 0, S = tiles_max;
+  const int items = tiles_max * ncb * nb_shapes;
+  // PERSISTENT workgroups (one per CU: a workgroup needs the CU's whole LDS) pull work items -- (tile, channel block, shape), tile
+  // slowest, so the live tiles come first -- from a device-side counter.  With one workgroup per item the ~250 live tiles of a
+  // B = 16 batch had to land on 256 CUs in ONE round; workgroups go round-robin over the 8 XCDs by index, a few XCDs got 33 of them
+  // for their 32 CUs, and those stragglers started when the first round ended: the kernel took two workgroup lifetimes (measured
+  // with wall-clock stamps, tools/sparse_dil_timeline.py: 159 us for an 84 us workgroup).  The counter is zero on entry
+  // (caller) and is not reset: which workgroup computes a tile does not change any result.
+  for (;;) {
+    // the thread index is laundered once per item: everything derived from it (staging offsets, fragment addresses, ...) would
+    // otherwise be hoisted out of the item loop and held in registers across it (+50 VGPRs: the 64 x 64 wave tile spilled)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kg = lane >> 4;
+    __syncthreads();                  // the previous item's LDS (operand tiles, reduction scratch, s_item) is dead
+    if (tid == 0) s_item = atomicAdd(work_counter, 1);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= items) break;
+    const int bi = item % nb_shapes, m0 = ((item / nb_shapes) % ncb) * BM, tile = item / (nb_shapes * ncb);
   const int4 *te = reinterpret_cast<const int4 *>(tile_start + ((size_t)bi * tiles_max + tile) * 8);
   const int4 ta = te[0], tb = te[1];
   const int j0 = ta.x, jn = ta.y, v_first = ta.z, v_end = ta.w, k_lo = tb.x;   // entries [j0, jn) of the list; linear range owned; input rows
   const int tiles_live = tb.w;
-  const int G = gn_partial != nullptr ? Cout / gn_cg : 0, S = tiles_max;
   if (tile >= max(tiles_live, 1)) {   // nothing to compute here: an empty slice of the statistics
     if (gn_partial != nullptr) {
       const int ngt = BM / gn_cg;
@@ -217,38 +250,21 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
         dst[0] = 0.0; dst[1] = 0.0;
       }
     }
-    return;
+    continue;
   }
+  DIL_STAMP(0);
   const int *dl = dil_list + (size_t)bi * n_dil_max;
   const bool nothing = jn <= j0;                                // (a grid without an occupied cell: tile 0 is all bias)
   const int nrows = nothing ? 0 : tb.y;                         // compact rows [k_lo, k_lo + nrows): planes x0-1 .. x1+1 (<= xcap by construction)
 
-  // ---- tile set-up: per-lane neighbour records, skip mask ----------------------------------------------------------------------
-  int rec[NT][NQ];                    // LDS record of this lane's (voxel, tap) neighbour; xcap + lane = this lane's zero record
-  unsigned amask = 0u;
-  {
-    const int *oi = occ_index + (size_t)bi * R3;
-#pragma unroll
-    for (int q = 0; q < NT; ++q) {
-      const int j = j0 + (q * NW + wave) * 16 + l16;
-      const int v = j < jn ? dl[j] : -1;
-      const int vx = v / R2, vy = (v / R) % R, vz = v % R;
-#pragma unroll
-      for (int Q = 0; Q < NQ; ++Q) {
-        const int t = 4 * Q + kg;
-        int k = -1;
-        if (v >= 0 && t < 27) {
-          const int gx = vx + t / 9 - 1, gy = vy + (t / 3) % 3 - 1, gz = vz + t % 3 - 1;
-          if (gx >= 0 && gx < R && gy >= 0 && gy < R && gz >= 0 && gz < R) k = oi[(gx * R + gy) * R + gz];
-        }
-        const bool here = k >= k_lo && k - k_lo < nrows;       // (always, for a present neighbour: the range covers its plane)
-        if (__ballot(here) != 0ull) amask |= 1u << (Q * NT + q);
-        rec[q][Q] = here ? k - k_lo : xcap + lane;
-      }
-    }
-    amask = __builtin_amdgcn_readfirstlane(amask);
-  }
   const float sx = act_scale_from_max(amax[bi]);
+  // the tile's BM output channels: scale and bias once, in LDS (the epilogue's MT * NT (tile, block) pairs read them from there: the
+  // 64 x 64 wave tile has no registers to spare, and per-use global loads made the epilogue the longest phase)
+  if (tid < BM) {
+    const int m = min(m0 + tid, Cout - 1);
+    s_osc[tid] = inv_scale[m] * (1.0f / sx);
+    s_obi[tid] = bias ? bias[m] : 0.f;
+  }
   const float4 *wbase = Ws + ((kg >> 1) * 4 + (kg & 1)) * BM + l16;
   f32x4a acc[MT][NT];
 #pragma unroll
@@ -301,12 +317,42 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
     }
   };
 
+  if (!nothing) load_chunk(0);   // chunk 0's operands are in flight while the neighbour records are looked up
+
+  // ---- tile set-up: per-lane neighbour records, skip mask ----------------------------------------------------------------------
+  int rec[NT][NQ];                    // LDS record of this lane's (voxel, tap) neighbour; xcap + lane = this lane's zero record
+  unsigned amask = 0u;
+  {
+    const int *oi = occ_index + (size_t)bi * R3;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int j = j0 + (q * NW + wave) * 16 + l16;
+      const int v = j < jn ? dl[j] : -1;
+      const int vx = v / R2, vy = (v / R) % R, vz = v % R;
+#pragma unroll
+      for (int Q = 0; Q < NQ; ++Q) {
+        const int t = 4 * Q + kg;
+        int k = -1;
+        if (v >= 0 && t < 27) {
+          const int gx = vx + t / 9 - 1, gy = vy + (t / 3) % 3 - 1, gz = vz + t % 3 - 1;
+          if (gx >= 0 && gx < R && gy >= 0 && gy < R && gz >= 0 && gz < R) k = oi[(gx * R + gy) * R + gz];
+        }
+        const bool here = k >= k_lo && k - k_lo < nrows;       // (always, for a present neighbour: the range covers its plane)
+        if (__ballot(here) != 0ull) amask |= 1u << (Q * NT + q);
+        rec[q][Q] = here ? k - k_lo : xcap + lane;
+      }
+    }
+    amask = __builtin_amdgcn_readfirstlane(amask);
+  }
+  DIL_STAMP(1);
   if (!nothing) {   // (uniform per workgroup)
-    load_chunk(0);
     for (int c8 = 0; c8 < C8; ++c8) {
       __syncthreads();
+      if (c8 == 0) DIL_STAMP(2);
       store_chunk(c8);
       __syncthreads();
+      if (c8 == 0) DIL_STAMP(3);
+      if (c8 == 1) DIL_STAMP(4);
       if (c8 + 1 < C8) load_chunk(c8 + 1);
 #pragma unroll
       for (int Q = 0; Q < NQ; ++Q) {
@@ -320,9 +366,11 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
             const float4 t = wbase[Q * 8 * BM + s * 2 * BM + mt * 16];
             fa[mt][s] = *reinterpret_cast<const f16x8 *>(&t);
           }
+        // block by block (an absent neighbour reads the lane's zero record; blocks are almost always live in a compact tile, so they
+        // are not skipped one by one).  Reading all NT blocks' fragments first, as the dense kernel does, was measured no faster
+        // and costs the 64 x 64 wave tile 24 registers it does not have
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
-          if ((qm & (1u << q)) == 0u) continue;
           f16x8 fb[2];
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
@@ -341,8 +389,8 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
   }
 
   // ---- epilogue: scale + bias, GroupNorm partials, output ----------------------------------------------------------------------
+  DIL_STAMP(5);
   __syncthreads();                                          // the operand tiles are dead (LDS is reused below)
-  const float x_inv_scale = 1.0f / sx;
   float *red = reinterpret_cast<float *>(smem4);            // [NBLK][NB], then [NB]
   float *otile = red + (NBLK + 1) * NB;                     // dense form: [BM][TILE] results of the tile (fits: checked by the launcher)
 #pragma unroll
@@ -357,7 +405,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + mt * 16 + 4 * kg + i;
         if (m < Cout && live) {
-          const float v = acc[mt][q][i] * (inv_scale[m] * x_inv_scale) + (bias ? bias[m] : 0.f);
+          const float v = acc[mt][q][i] * s_osc[mt * 16 + 4 * kg + i] + s_obi[mt * 16 + 4 * kg + i];
           o[i] = v;
           bs += v;
           bq = __builtin_fmaf(v, v, bq);
@@ -432,14 +480,16 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
       dst[1] = qq;
     }
   }
+  DIL_STAMP(6);
+  }   // work items
 }
 
 static int sconv_dil_launch(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
                             const int *occ_index, const int *dil_list, const int *dil_index, const int *tile_start,
                             const void *packed_w, const float *inv_scale, const float *bias, float *y,
-                            int compact, int gn_cg, double *gn_partial, int *slices_out, void *stream) {
+                            int compact, int gn_cg, double *gn_partial, int *slices_out, int *work_counter, void *stream) {
   BDM_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && n_max >= 1 && n_dil_max >= 1 && xr && amax && occ_index && dil_list && dil_index &&
-                  tile_start && inv_scale && y,
+                  tile_start && inv_scale && y && work_counter,
               "sparse_conv_dil: bad arguments");
   if (r != 8 && r != 16 && r != 32) {
     set_error("sparse_conv_dil: resolution %d unsupported (8, 16, 32)", r);
@@ -450,11 +500,22 @@ static int sconv_dil_launch(int b, int cin, int cout, int r, int n_max, int n_di
   const int mi = cout > 32 ? 2 : 1;                     // 64 or 32 output channels per workgroup
   int tile, xcap, tiles;
   sconv_dil_geometry(r, &tile, &xcap, &tiles);
-  const int bm = 32 * mi, nblk = tile / 16, nb = (bm / 16) * 8;
+  const int bm = 32 * mi, nblk = tile / 16, nb = (bm / 16) * 8, ncb = cdiv(cout, bm);
   size_t smem = 16 * ((size_t)OS_PAIRS * 4 * bm + 2 * ((size_t)xcap + 64));
   const size_t smem_out = sizeof(float) * ((size_t)(nblk + 1) * nb + (compact ? 0 : (size_t)bm * tile));
   if (smem_out > smem) smem = smem_out;
-  dim3 grid(b, cdiv(cout, bm), tiles);
+  // one persistent workgroup per CU (or per item, when there are fewer)
+  static int cus[16] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || cus[dev] == 0) {
+    hipDeviceProp_t prop;
+    const int n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    if (dev >= 0 && dev < 16) cus[dev] = n > 0 ? n : 256;
+  }
+  const int ncu = (dev >= 0 && dev < 16) ? cus[dev] : 256;
+  const long long items = (long long)tiles * ncb * b;
+  dim3 grid((unsigned)(items < ncu ? items : ncu));
   hipStream_t s = (hipStream_t)stream;
   if (gn_partial != nullptr) {
     BDM_REQUIRE(gn_cg >= 4 && (gn_cg & (gn_cg - 1)) == 0 && bm % gn_cg == 0 && cout % gn_cg == 0,
@@ -466,7 +527,8 @@ static int sconv_dil_launch(int b, int cin, int cout, int r, int n_max, int n_di
     BDM_ALLOW_LDS((sconv_dil_kernel<MT, NT, NW, R>), smem);                                                               \
     hipLaunchKernelGGL((sconv_dil_kernel<MT, NT, NW, R>), grid, dim3(NW * 64), smem, s, c8, cout, n_max, n_dil_max, xcap, \
                        (const float4 *)xr, amax, occ_index, dil_list, dil_index, tile_start,                              \
-                       (const float4 *)packed_w, inv_scale, bias, y, compact, gn_cg, gn_partial);                         \
+                       (const float4 *)packed_w, inv_scale, bias, y, compact, gn_cg, gn_partial, b, ncb, tiles,           \
+                       work_counter);                                                                                     \
   } while (0)
   if (r == 32) { if (mi == 2) DIL_LAUNCH(4, 4, 8, 32); else DIL_LAUNCH(2, 4, 8, 32); }
   else if (r == 16) { if (mi == 2) DIL_LAUNCH(4, 2, 8, 16); else DIL_LAUNCH(2, 2, 8, 16); }
@@ -478,16 +540,17 @@ static int sconv_dil_launch(int b, int cin, int cout, int r, int n_max, int n_di
 extern "C" int bdm_sparse_conv_dil(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
                                    const int *occ_index, const int *dil_list, const int *dil_index, const int *tile_start,
                                    const void *packed_w, const float *inv_scale, const float *bias, float *y,
-                                   int compact, void *stream) {
+                                   int compact, int *work_counter, void *stream) {
   return sconv_dil_launch(b, cin, cout, r, n_max, n_dil_max, xr, amax, occ_index, dil_list, dil_index, tile_start, packed_w,
-                          inv_scale, bias, y, compact, 0, nullptr, nullptr, stream);
+                          inv_scale, bias, y, compact, 0, nullptr, nullptr, work_counter, stream);
 }
 
 extern "C" int bdm_sparse_conv_dil_gn(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
                                       const int *occ_index, const int *dil_list, const int *dil_index, const int *tile_start,
                                       const void *packed_w, const float *inv_scale, const float *bias,
-                                      float *y, int compact, int groups, void *gn_partial, int *slices_out, void *stream) {
+                                      float *y, int compact, int groups, void *gn_partial, int *slices_out, int *work_counter,
+                                      void *stream) {
   BDM_REQUIRE(groups >= 1 && cout % groups == 0 && gn_partial != nullptr && slices_out != nullptr, "sparse_conv_dil_gn: bad arguments");
   return sconv_dil_launch(b, cin, cout, r, n_max, n_dil_max, xr, amax, occ_index, dil_list, dil_index, tile_start, packed_w,
-                          inv_scale, bias, y, compact, cout / groups, (double *)gn_partial, slices_out, stream);
+                          inv_scale, bias, y, compact, cout / groups, (double *)gn_partial, slices_out, work_counter, stream);
 }

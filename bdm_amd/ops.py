@@ -1101,7 +1101,8 @@ def sparse_first_conv_os(features, plan, packed, bias, cout, gn_groups=None, com
     dev, lib, r = f.device, L.lib(), plan.r
     packed_w, inv_scale = packed
     xr = torch.empty(B, (C + 7) // 8, plan.n_max, 8, dtype=torch.float32, device=dev)
-    amax = amax_slots(dev, B)
+    slots = amax_slots(dev, B + 1)            # B activation-scale maxima + the convolution's work counter (zero bits = int 0)
+    amax, counter = slots[:B], slots[B:]
     L.check(lib.bdm_sparse_voxel_features_f32(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),
                                               L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()),
             "sparse_voxel_features_f32")
@@ -1116,9 +1117,10 @@ def sparse_first_conv_os(features, plan, packed, bias, cout, gn_groups=None, com
         tiles = plan.tile_start.shape[1]
         partial = torch.empty(B, gn_groups, tiles, 2, dtype=torch.float64, device=dev)
         slices = ctypes.c_int(0)
-        L.check(lib.bdm_sparse_conv_dil_gn(*args, int(gn_groups), L.ptr(partial), ctypes.byref(slices), L.stream()), "sparse_conv_dil_gn")
+        L.check(lib.bdm_sparse_conv_dil_gn(*args, int(gn_groups), L.ptr(partial), ctypes.byref(slices), L.ptr(counter), L.stream()),
+                "sparse_conv_dil_gn")
         return out, (partial, tiles, int(gn_groups))
-    L.check(lib.bdm_sparse_conv_dil(*args, L.stream()), "sparse_conv_dil")
+    L.check(lib.bdm_sparse_conv_dil(*args, L.ptr(counter), L.stream()), "sparse_conv_dil")
     return out
 
 

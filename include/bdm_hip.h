@@ -455,6 +455,8 @@ int bdm_sparse_conv_gemm_h2(int b, int n_max, int cin, int cout, const void *xh,
  *                           scale per shape.  compact = 1: y (b, n_dil_max, cout), one row per list entry (every other voxel of the
  *                           grid equals bias: bdm_group_norm_to_h2_stats_compact consumes this form); compact = 0: y (b, cout, r^3),
  *                           every cell written.
+ *                           work_counter: one int, ZERO on entry (left non-zero): the persistent workgroups (one per CU) pull their
+ *                           (tile, channel block, shape) items from it.
  *   bdm_sparse_conv_dil_gn  also leaves GroupNorm(groups) partials of the DENSE output (bias voxels included) in gn_partial
  *                           (b, groups, tiles, 2 doubles), *slices_out = tiles = bdm_voxel_dilate_slices(r). */
 int bdm_voxel_dilate_slices(int r);
@@ -462,11 +464,12 @@ int bdm_voxel_dilate(int b, int r, int n_dil_max, const int *cnt, int *dil_list,
                      void *stream);
 int bdm_sparse_conv_dil(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
                         const int *occ_index, const int *dil_list, const int *dil_index, const int *tile_start,
-                        const void *packed_w, const float *inv_scale, const float *bias, float *y, int compact, void *stream);
+                        const void *packed_w, const float *inv_scale, const float *bias, float *y, int compact, int *work_counter,
+                        void *stream);
 int bdm_sparse_conv_dil_gn(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
                            const int *occ_index, const int *dil_list, const int *dil_index, const int *tile_start,
                            const void *packed_w, const float *inv_scale, const float *bias, float *y, int compact, int groups,
-                           void *gn_partial, int *slices_out, void *stream);
+                           void *gn_partial, int *slices_out, int *work_counter, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * 3. Per-step glue of the coupled DDPM loop

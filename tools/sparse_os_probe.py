@@ -44,10 +44,12 @@ for name, cin, cout, r, n in LAYERS:
     import ctypes
     sl = ctypes.c_int(0)
 
+    ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
+
     def conv(y, compact):
-        return lambda: L.check(lib.bdm_sparse_conv_dil_gn(B, cin, cout, r, plan.n_max, plan.n_dil_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index),
+        return lambda: (ctr.zero_(), L.check(lib.bdm_sparse_conv_dil_gn(B, cin, cout, r, plan.n_max, plan.n_dil_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index),
                                                           L.ptr(plan.dil_list), L.ptr(plan.dil_index), L.ptr(plan.tile_start),
-                                                          L.ptr(pk[0]), L.ptr(pk[1]), L.ptr(bias), L.ptr(y), compact, 8, L.ptr(part), ctypes.byref(sl), L.stream()))
+                                                          L.ptr(pk[0]), L.ptr(pk[1]), L.ptr(bias), L.ptr(y), compact, 8, L.ptr(part), ctypes.byref(sl), L.ptr(ctr), L.stream())))
     tdil = t(lambda: L.check(lib.bdm_voxel_dilate(B, r, plan.n_dil_max, L.ptr(plan.cnt), L.ptr(plan.dil_list), L.ptr(plan.dil_index), L.ptr(plan.plane_start),
                                                   L.ptr(plan.tile_start), L.stream())))
     ntl = plan.tile_start[:, 0, 7].float().mean().item()
