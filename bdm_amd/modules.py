@@ -222,6 +222,7 @@ class PVConv(nn.Module):
     # 8^3: 114 vs 62 -- the small grids stay on GEMM + gather)
     sparse_conv = os.environ.get("BDM_SPARSE_CONV", "dil")
     sparse_dil_resolutions = {int(v) for v in os.environ.get("BDM_SPARSE_DIL_R", "32,16").split(",") if v}
+    sparse_dil_always = os.environ.get("BDM_SPARSE_DIL_ALWAYS", "0") == "1"   # ignore ops.sparse_dil_pays (tests, A/B timing)
 
     def _packed_weight(self, conv, impl):
         key = (id(conv), impl)
@@ -250,6 +251,14 @@ class PVConv(nn.Module):
         if self.conv_impl in ("bf16x6", "fp16x3") and self.sparse_first_conv and self.resolution in self.sparse_resolutions:
             return self.resolution, self.voxelization.eps
         return None
+
+    def wants_dilated_plan(self, batch, n_points):
+        """Will this module's first convolution run in the compact output-stationary form for (batch, n_points)?  (the side-stream
+        planner then builds the dilated list with the plan, off the main stream)"""
+        conv1 = self.voxel_layers[0]
+        return (self.sparse_conv == "dil" and self.resolution in self.sparse_dil_resolutions and self.conv_impl == "fp16x3"
+                and self.sparse_gemm == "sparse_h2" and not getattr(self, "h2_saturated", False) and self.sparse_first_conv
+                and (self.sparse_dil_always or ops.sparse_dil_pays(batch, n_points, self.resolution, conv1.out_channels)))
 
     _cond = None  # ops.Conditioning of this forward when the input is the raw conditioned cloud (set by PVCNN2Base.forward)
 
@@ -333,8 +342,7 @@ class PVConv(nn.Module):
                 cond = self._hoisted(features)
                 if cond is not None and 27 * conv1.out_channels <= 1024:  # hoisted map instead of feature gather + K = 390 GEMM
                     v = ops.sparse_first_conv_from_map(cond, plan, conv1, conv1.out_channels, gn_groups=gn1.num_groups if want_stats else None)
-                elif (self.sparse_conv == "dil" and r in self.sparse_dil_resolutions and self.conv_impl == "fp16x3"
-                      and self.sparse_gemm == "sparse_h2" and not getattr(self, "h2_saturated", False)):
+                elif self.wants_dilated_plan(features.shape[0], plan.n):
                     # one output-stationary implicit GEMM with tap skipping over the dilated voxel list: no 27x intermediate; with the
                     # statistics in its epilogue the output stays COMPACT (rows of the dilated voxels) and the operand split of the
                     # second convolution reads it through the plan's index -- the dense fp32 grid is never written (sparse_conv_os.hip)

@@ -809,7 +809,9 @@ def clear_plan_cache():
     _plan_cache.clear()
 
 
-def voxel_plan(coords, r, eps=0.0):
+def voxel_plan(coords, r, eps=0.0, dilate=False):
+    """dilate: also build the dilated voxel list of the compact first convolution now, on this stream (plan_dilation; a consumer that
+    finds it missing builds it on ITS stream)."""
     key = (coords.data_ptr(), coords._version, tuple(coords.shape), int(r))
     p = _plan_cache.get(key)
     if p is not None:
@@ -837,7 +839,9 @@ def voxel_plan(coords, r, eps=0.0):
     L.check(lib.bdm_voxelize_plan_full(B, n, r, p.n_max, L.ptr(p.vox_coords), L.ptr(p.ind), L.ptr(p.cnt), L.ptr(p.ws),
                                        L.ptr(p.occ_index), L.ptr(p.occ_list), L.ptr(p.n_occ), L.ptr(p.rowocc), L.stream()),
             "voxelize_plan_full")
-    plan_dilation(p)
+    p.dil_list = None
+    if dilate:
+        plan_dilation(p)
     p.stream = torch.cuda.current_stream(dev) if coords.is_cuda else None
     _plan_cache[key] = p
     return p
@@ -1122,6 +1126,25 @@ def sparse_first_conv_os(features, plan, packed, bias, cout, gn_groups=None, com
         return out, (partial, tiles, int(gn_groups))
     L.check(lib.bdm_sparse_conv_dil(*args, L.ptr(counter), L.stream()), "sparse_conv_dil")
     return out
+
+
+SPARSE_DIL_MIN_ITEMS = 160   # tiles x channel blocks x shapes below which the compact convolution cannot fill the chip
+
+
+def sparse_dil_pays(batch, n_points, r, cout):
+    """Does the compact output-stationary convolution beat GEMM + gather for this layer?  Its persistent workgroups take one tile
+    (<= 512 / 256 / 128 dilated voxels x 64 or 32 channels) through ALL channel chunks: ~85 us per tile at 64 -> 64 channels whatever
+    the batch, so it needs about a tile per CU to pay (measured on one box, B = 16, N = 4096: step 6.39 -> 6.13 ms; B = 4: 3.84 ->
+    4.23 ms, C1 0.279 -> 0.306 s; profiles/r04_sparse_dil_small_batch.txt).  Tiles per shape are estimated from the sizes alone
+    (a Gaussian-like cloud of n points dilates to ~2 n voxels at 32^3, ~1.8 n at 16^3), so the choice depends on the configuration,
+    never on the data."""
+    if r == 32:
+        tiles = min(64, max(1, (2 * n_points) // 512))
+    elif r == 16:
+        tiles = min(16, max(1, (2 * n_points) // 256))
+    else:
+        return False          # 8^3: the GEMM over <= 256 occupied rows per shape wins at every batch measured
+    return batch * tiles * (2 if cout > 64 else 1) >= SPARSE_DIL_MIN_ITEMS
 
 
 def sparse_os_gn_ok(cout, groups, r):

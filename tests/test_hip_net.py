@@ -74,6 +74,33 @@ def test_fuse_full_golden(hip):
     assert rel_l2(y, torch.from_numpy(g["out"])) < TOL
 
 
+@pytest.mark.parametrize("which", ["pc2", "pvd"])
+def test_network_goldens_with_the_compact_first_convolution_on_every_level(hip, monkeypatch, which):
+    """The default picks the first convolution's form per layer from (batch, points, resolution, channels) (ops.sparse_dil_pays: the
+    compact output-stationary kernel where a batch fills the chip with tiles, GEMM + gather elsewhere); the goldens run at B <= 2,
+    i.e. on GEMM + gather.  Here the compact form (dilated plan -> sparse_conv_dil -> compact operand split) is forced on EVERY PVConv
+    of both denoisers, 8^3 levels included, against the reference's own outputs."""
+    from bdm_amd.modules import PVConv
+    from bdm_amd.pvcnn import PVCNN2_PC2, PVCNN2_PVD
+    monkeypatch.setattr(PVConv, "sparse_dil_always", True)
+    monkeypatch.setattr(PVConv, "sparse_dil_resolutions", {8, 16, 32})
+    seen = []
+    from bdm_amd import ops
+    real = ops.sparse_first_conv_os
+    monkeypatch.setattr(ops, "sparse_first_conv_os", lambda *a, **k: (seen.append(a[1].r), real(*a, **k))[1])
+    if which == "pc2":
+        g = load("pc2_full_n1024.npz")
+        net = build(PVCNN2_PC2, g, extra_feature_channels=387)
+        x = point_cloud_inputs(1, 390, 1024, int(g["input_seed"]))
+    else:
+        g = load("pvd_full_n1024.npz")
+        net = build(PVCNN2_PVD, g, extra_feature_channels=0)
+        x = point_cloud_inputs(2, 3, 1024, int(g["input_seed"]))
+    y = net(x.cuda(), torch.from_numpy(g["t"]).cuda()).cpu()
+    assert rel_l2(y, torch.from_numpy(g["out"])) < TOL
+    assert sorted(set(seen)) == [8, 16, 32] and len(seen) >= 13   # (PC^2: SA0.0 takes the hoisted map)
+
+
 @pytest.mark.parametrize("N,B", [(4096, 2), (2048, 1), (8192, 1), (1100, 3)])
 def test_pvd_vs_oracle_fresh_inputs(hip, oracle_ops, N, B):
     """level-0 sizes of the benchmark (N = 4096) against the oracle."""
