@@ -40,6 +40,7 @@ using namespace bdm;
 #define OS_PAIRS 14  // the dense kernel's weight image: [C8][14 tap pairs][2 splits][2 halves][Cout] records of 8 fp16
 
 typedef __attribute__((ext_vector_type(4))) float f32x4a;
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------------------
 // plan side: dilated voxel list, ranks, plane prefixes, tile table
@@ -51,9 +52,9 @@ static void sconv_dil_geometry(int r, int *tile, int *xcap, int *tiles_max) {
 }
 
 __global__ __launch_bounds__(1024) void vox_dilate_kernel(int r, int n_dil_max, int tile, int xcap, int tiles_max,
-                                                          const int *__restrict__ cnt, int *__restrict__ dil_list,
+                                                          const int *__restrict__ cnt, int thr, int *__restrict__ dil_list,
                                                           int *__restrict__ dil_index, int *__restrict__ plane_start,
-                                                          int *__restrict__ tile_start) {
+                                                          int *__restrict__ tile_start, int *__restrict__ class_count) {
   // one workgroup per shape: occupancy bit rows (x, y) -> dilated bit rows -> ordered compaction -> tile table
   //   dil_index[v]    rank of voxel v in dil_list, -1 outside the dilated set
   //   plane_start[x]  occupied cells in planes < x (r + 2 entries: [r] = [r + 1] = n_occ): compact rows of planes [a, b) = [ps[a], ps[b])
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(1024) void vox_dilate_kernel(int r, int n_dil_max, 
   const int *c = cnt + (size_t)bi * r3;
   // a wave turns 64 consecutive cells into bits with one ballot (coalesced reads): r = 32: two rows, r = 16: four, r = 8: eight
   for (int v0 = wave * 64; v0 < r3; v0 += T) {
-    const unsigned long long m = __ballot(c[v0 + lane] > 0);
+    const unsigned long long m = __ballot(c[v0 + lane] > thr);   // a cell of the input set (thr = 0: point counts, -1: ranks of a list)
     const int rows = 64 / r;
     if (lane < rows) occ[v0 / r + lane] = (unsigned)((m >> (lane * r)) & (r == 32 ? 0xffffffffull : ((1ull << r) - 1ull)));
   }
@@ -125,6 +126,24 @@ __global__ __launch_bounds__(1024) void vox_dilate_kernel(int r, int n_dil_max, 
       if (ok) dl[rank] = v;
     }
   }
+  if (class_count != nullptr) {
+    // cells OUTSIDE the dilated set per boundary class (class = 9 cx + 3 cy + cz, c = 0 / 1 / 2: first plane, interior, last plane of
+    // the axis): the convolution of a constant field takes one value per class there (bdm_conv3d_class_constants)
+    __shared__ int s_cls[27];
+    if (tid < 27) s_cls[tid] = 0;
+    __syncthreads();
+    if (tid < r2) {
+      const int x = tid / r, y = tid % r;
+      const int cx = x == 0 ? 0 : (x == r - 1 ? 2 : 1), cy = y == 0 ? 0 : (y == r - 1 ? 2 : 1);
+      const unsigned out = ~d & full;
+      const int lo = out & 1u, hi = (out >> (r - 1)) & 1u, mid = __popc(out) - lo - hi;
+      if (lo) atomicAdd(&s_cls[(cx * 3 + cy) * 3 + 0], lo);
+      if (mid) atomicAdd(&s_cls[(cx * 3 + cy) * 3 + 1], mid);
+      if (hi) atomicAdd(&s_cls[(cx * 3 + cy) * 3 + 2], hi);
+    }
+    __syncthreads();
+    if (tid < 27) class_count[(size_t)bi * 27 + tid] = s_cls[tid];
+  }
   if (tid == 0) { ps_o[r] = ps_o[r + 1] = tot_o; ps_d[r] = ps_d[r + 1] = tot_d; }
   __syncthreads();
   for (int x = tid; x < r + 2; x += T) plane_start[(size_t)bi * (r + 2) + x] = ps_o[x];
@@ -172,17 +191,30 @@ extern "C" int bdm_voxel_dilate_slices(int r) {
   return tiles_max;
 }
 
-extern "C" int bdm_voxel_dilate(int b, int r, int n_dil_max, const int *cnt, int *dil_list, int *dil_index, int *plane_start,
-                                int *tile_start, void *stream) {
-  BDM_REQUIRE(b >= 0 && (r == 8 || r == 16 || r == 32) && n_dil_max >= 1 && cnt && dil_list && dil_index && plane_start && tile_start,
+static int voxel_dilate_launch(int b, int r, int n_dil_max, const int *src, int thr, int *dil_list, int *dil_index, int *plane_start,
+                               int *tile_start, int *class_count, void *stream) {
+  BDM_REQUIRE(b >= 0 && (r == 8 || r == 16 || r == 32) && n_dil_max >= 1 && src && dil_list && dil_index && plane_start && tile_start,
               "voxel_dilate: bad arguments (r in {8, 16, 32})");
   if (b == 0) return BDM_OK;
   int tile, xcap, tiles_max;
   sconv_dil_geometry(r, &tile, &xcap, &tiles_max);
   const size_t smem = sizeof(unsigned) * (3 * (size_t)r * r + 32 + 2 * (r + 2));
-  hipLaunchKernelGGL(vox_dilate_kernel, dim3(b), dim3(1024), smem, (hipStream_t)stream, r, n_dil_max, tile, xcap, tiles_max, cnt,
-                     dil_list, dil_index, plane_start, tile_start);
+  hipLaunchKernelGGL(vox_dilate_kernel, dim3(b), dim3(1024), smem, (hipStream_t)stream, r, n_dil_max, tile, xcap, tiles_max, src, thr,
+                     dil_list, dil_index, plane_start, tile_start, class_count);
   return launch_status("voxel_dilate");
+}
+
+extern "C" int bdm_voxel_dilate(int b, int r, int n_dil_max, const int *cnt, int *dil_list, int *dil_index, int *plane_start,
+                                int *tile_start, void *stream) {
+  return voxel_dilate_launch(b, r, n_dil_max, cnt, 0, dil_list, dil_index, plane_start, tile_start, nullptr, stream);
+}
+
+// The same for a set given by the RANKS of a previous list (cells with index >= 0): the dilation of the once-dilated set is where the
+// SECOND convolution of a PVConv can differ from its per-class constants; its tiles' input ranges are rows of the FIRST list.
+extern "C" int bdm_voxel_dilate_again(int b, int r, int n_dil_max, const int *dil_index_in, int *dil_list, int *dil_index,
+                                      int *plane_start, int *tile_start, int *class_count, void *stream) {
+  BDM_REQUIRE(class_count != nullptr, "voxel_dilate_again: class_count is NULL");
+  return voxel_dilate_launch(b, r, n_dil_max, dil_index_in, -1, dil_list, dil_index, plane_start, tile_start, class_count, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -196,29 +228,38 @@ extern "C" int bdm_debug_dil_timestamps(long long *buf) { return hipMemcpyToSymb
 #define DIL_STAMP(i)
 #endif
 
-template <int MT, int NT, int NW, int R>
+// H2IN = false: FIRST convolution -- rows are fp32 records of the occupied cells (scaled by the shape's power of two and split here),
+//               an absent neighbour is zero.
+// H2IN = true : SECOND convolution over the twice-dilated set -- rows are the (hi, lo) fp16 records of the once-dilated voxels
+//               (bdm_group_norm_to_h2_rows: (b, C8, 2, n_max) records), a neighbour inside the grid but outside that set holds the
+//               shape's CONSTANT record of the chunk (`xconst` (b, C8, 2): GroupNorm + Swish of the first convolution's bias), one
+//               outside the grid is zero; `amax` is unused, the activation scale is x_inv_scale.  No closed-form bias share in
+//               the GroupNorm partials: the voxels outside the list take per-class constants (bdm_conv3d_class_constants).
+template <int MT, int NT, int NW, int R, bool H2IN>
 __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
     int C8, int Cout, int n_max, int n_dil_max, int xcap, const float4 *__restrict__ xr, const float *__restrict__ amax,
+    const float4 *__restrict__ xconst, float x_inv_scale,
     const int *__restrict__ occ_index, const int *__restrict__ dil_list, const int *__restrict__ dil_index,
     const int *__restrict__ tile_start, const float4 *__restrict__ wq,
     const float *__restrict__ inv_scale, const float *__restrict__ bias, float *__restrict__ y, int compact, int gn_cg,
-    double *__restrict__ gn_partial, int nb_shapes, int ncb, int tiles_max, int *__restrict__ work_counter) {
+    double *__restrict__ gn_partial, int gn_slices, int nb_shapes, int ncb, int tiles_max, int *__restrict__ work_counter) {
   extern __shared__ __align__(16) float4 smem4[];
   constexpr int BM = 16 * MT, TILE = NT * NW * 16;   // a tile holds <= TILE voxels (sconv_dil_geometry)
   constexpr int R2 = R * R, R3 = R2 * R;
   constexpr int NT_ = NW * 64;
   constexpr int WV = OS_PAIRS * 2 * 2 * BM, WI = (WV + NT_ - 1) / NT_;
   constexpr int NQ = OS_PAIRS / 2;
-  constexpr int PF = 2;                              // rows per thread whose records are register-prefetched one chunk ahead
+  constexpr int PF = MT * NT >= 16 ? 1 : 2;          // rows per thread whose records are register-prefetched one chunk ahead (the
+                                                     // 64 x 64 wave tile has registers for one)
   constexpr int NBLK = NT * NW, NB = MT * 4 * 2;
   float4 *Ws = smem4;                 // [14][2][2][BM]
-  float4 *Xs = smem4 + WV;            // [2][xcap + 64]: records xcap .. xcap + 63 of each split are zero, one per lane -- absent neighbours are
-  const int XS = xcap + 64;           // the common case, and 64 lanes reading ONE 16-byte record serialise on its four banks
+  float4 *Xs = smem4 + WV;            // [2][xcap + 128]: records xcap .. xcap + 63 of each split are zero -- absent neighbours are
+  const int XS = xcap + 128;          // the common case (one copy per lane); xcap + 64 .. xcap + 127: the chunk's CONSTANT record (H2IN), per lane
   __shared__ int s_item;
   __shared__ float s_osc[64], s_obi[64];
 
   const int tid0 = threadIdx.x;
-  const int G = gn_partial != nullptr ? Cout / gn_cg : 0, S = tiles_max;
+  const int G = gn_partial != nullptr ? Cout / gn_cg : 0, S = gn_slices;   // (H2IN: 27 more slices follow the tiles': the class constants')
   const int items = tiles_max * ncb * nb_shapes;
   // PERSISTENT workgroups (one per CU: a workgroup needs the CU's whole LDS) pull work items -- (tile, channel block, shape), tile
   // slowest, so the live tiles come first -- from a device-side counter.  With one workgroup per item the ~250 live tiles of a
@@ -257,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
   const bool nothing = jn <= j0;                                // (a grid without an occupied cell: tile 0 is all bias)
   const int nrows = nothing ? 0 : tb.y;                         // compact rows [k_lo, k_lo + nrows): planes x0-1 .. x1+1 (<= xcap by construction)
 
-  const float sx = act_scale_from_max(amax[bi]);
+  const float sx = H2IN ? 1.0f / x_inv_scale : act_scale_from_max(amax[bi]);
   // the tile's BM output channels: scale and bias once, in LDS (the epilogue's MT * NT (tile, block) pairs read them from there: the
   // 64 x 64 wave tile has no registers to spare, and per-use global loads made the epilogue the longest phase)
   if (tid < BM) {
@@ -272,18 +313,26 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
 #pragma unroll
     for (int q = 0; q < NT; ++q) acc[a][q] = f32x4a{0.f, 0.f, 0.f, 0.f};
   if (tid < 128) Xs[(tid >> 6) * XS + xcap + (tid & 63)] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero records of both splits
+  f32x4v_t cr = {0.f, 0.f, 0.f, 0.f};                                                            // (H2IN) this thread's copy of the constant record
 
   const float4 *xb = xr + (size_t)bi * C8 * n_max * 2;
-  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  typedef f32x4v_t f32x4v;
   f32x4v xa[PF][2], wr[WI];
   auto load_chunk = [&](int c8) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {   // clamped rows re-read a valid record: never stored
       const int row = min(tid + u * NT_, max(nrows - 1, 0));
-      const f32x4v *src = reinterpret_cast<const f32x4v *>(xb + ((size_t)c8 * n_max + k_lo + row) * 2);
-      xa[u][0] = src[0];
-      xa[u][1] = src[1];
+      if (H2IN) {
+        const f32x4v *src = reinterpret_cast<const f32x4v *>(xr + (((size_t)bi * C8 + c8) * 2) * n_max + k_lo + row);
+        xa[u][0] = src[0];
+        xa[u][1] = src[n_max];
+      } else {
+        const f32x4v *src = reinterpret_cast<const f32x4v *>(xb + ((size_t)c8 * n_max + k_lo + row) * 2);
+        xa[u][0] = src[0];
+        xa[u][1] = src[1];
+      }
     }
+    if (H2IN && tid < 128) cr = *reinterpret_cast<const f32x4v *>(xconst + ((size_t)bi * C8 + c8) * 2 + (tid >> 6));
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       const int e = tid + i * NT_;
@@ -293,10 +342,15 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
     }
   };
   auto put = [&](int row, const float4 &p, const float4 &q) {
-    f16x8 hi, lo;
-    split_record(p, q, sx, hi, lo);
-    *reinterpret_cast<f16x8 *>(&Xs[row]) = hi;
-    *reinterpret_cast<f16x8 *>(&Xs[XS + row]) = lo;
+    if (H2IN) {   // already (hi, lo) records
+      Xs[row] = p;
+      Xs[XS + row] = q;
+    } else {
+      f16x8 hi, lo;
+      split_record(p, q, sx, hi, lo);
+      *reinterpret_cast<f16x8 *>(&Xs[row]) = hi;
+      *reinterpret_cast<f16x8 *>(&Xs[XS + row]) = lo;
+    }
   };
   auto store_chunk = [&](int c8) {
 #pragma unroll
@@ -306,10 +360,20 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
         const float4 q = make_float4(xa[u][1][0], xa[u][1][1], xa[u][1][2], xa[u][1][3]);
         put(tid + u * NT_, p, q);
       }
-    for (int row = tid + PF * NT_; row < nrows; row += NT_) {   // ranges beyond PF * NT_ rows: unprefetched
-      const float4 *src = xb + ((size_t)c8 * n_max + k_lo + row) * 2;
-      put(row, src[0], src[1]);
+    for (int row0 = tid + PF * NT_; row0 < nrows; row0 += 2 * NT_) {   // ranges beyond PF * NT_ rows: unprefetched, two rows in flight
+      const int row1 = row0 + NT_, rc1 = min(row1, nrows - 1);
+      float4 a0, a1, b0, b1;
+      if (H2IN) {
+        const float4 *src = xr + (((size_t)bi * C8 + c8) * 2) * n_max + k_lo;
+        a0 = src[row0]; a1 = src[n_max + row0]; b0 = src[rc1]; b1 = src[n_max + rc1];
+      } else {
+        const float4 *src = xb + ((size_t)c8 * n_max + k_lo) * 2;
+        a0 = src[2 * row0]; a1 = src[2 * row0 + 1]; b0 = src[2 * rc1]; b1 = src[2 * rc1 + 1];
+      }
+      put(row0, a0, a1);
+      if (row1 < nrows) put(row1, b0, b1);
     }
+    if (H2IN && tid < 128) *reinterpret_cast<f32x4v *>(&Xs[(tid >> 6) * XS + xcap + 64 + (tid & 63)]) = cr;
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       const int e = tid + i * NT_;
@@ -333,13 +397,16 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
       for (int Q = 0; Q < NQ; ++Q) {
         const int t = 4 * Q + kg;
         int k = -1;
+        bool inside = false;
         if (v >= 0 && t < 27) {
           const int gx = vx + t / 9 - 1, gy = vy + (t / 3) % 3 - 1, gz = vz + t % 3 - 1;
-          if (gx >= 0 && gx < R && gy >= 0 && gy < R && gz >= 0 && gz < R) k = oi[(gx * R + gy) * R + gz];
+          inside = gx >= 0 && gx < R && gy >= 0 && gy < R && gz >= 0 && gz < R;
+          if (inside) k = oi[(gx * R + gy) * R + gz];
         }
         const bool here = k >= k_lo && k - k_lo < nrows;       // (always, for a present neighbour: the range covers its plane)
-        if (__ballot(here) != 0ull) amask |= 1u << (Q * NT + q);
-        rec[q][Q] = here ? k - k_lo : xcap + lane;
+        const bool live = here || (H2IN && inside);            // a constant neighbour contributes too
+        if (__ballot(live) != 0ull) amask |= 1u << (Q * NT + q);
+        rec[q][Q] = here ? k - k_lo : ((H2IN && inside) ? xcap + 64 + lane : xcap + lane);
       }
     }
     amask = __builtin_amdgcn_readfirstlane(amask);
@@ -469,7 +536,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
         qq += (double)red2[(tid * nb4 + j) * 2 + 1];
       }
       // the bias voxels of the owned range, in closed form
-      const double nfill = (double)((v_end - v_first) - (jn - j0));
+      const double nfill = H2IN ? 0.0 : (double)((v_end - v_first) - (jn - j0));
       for (int c = 0; c < gn_cg; ++c) {
         const double bv = bias ? (double)bias[m0 + tid * gn_cg + c] : 0.0;
         a += nfill * bv;
@@ -484,12 +551,12 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
   }   // work items
 }
 
-static int sconv_dil_launch(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
-                            const int *occ_index, const int *dil_list, const int *dil_index, const int *tile_start,
-                            const void *packed_w, const float *inv_scale, const float *bias, float *y,
+static int sconv_dil_launch(bool h2in, int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
+                            const void *xconst, float x_inv_scale, const int *in_index, const int *dil_list, const int *dil_index,
+                            const int *tile_start, const void *packed_w, const float *inv_scale, const float *bias, float *y,
                             int compact, int gn_cg, double *gn_partial, int *slices_out, int *work_counter, void *stream) {
-  BDM_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && n_max >= 1 && n_dil_max >= 1 && xr && amax && occ_index && dil_list && dil_index &&
-                  tile_start && inv_scale && y && work_counter,
+  BDM_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && n_max >= 1 && n_dil_max >= 1 && xr && (h2in ? xconst != nullptr : amax != nullptr) &&
+                  in_index && dil_list && dil_index && tile_start && inv_scale && y && work_counter,
               "sparse_conv_dil: bad arguments");
   if (r != 8 && r != 16 && r != 32) {
     set_error("sparse_conv_dil: resolution %d unsupported (8, 16, 32)", r);
@@ -501,7 +568,7 @@ static int sconv_dil_launch(int b, int cin, int cout, int r, int n_max, int n_di
   int tile, xcap, tiles;
   sconv_dil_geometry(r, &tile, &xcap, &tiles);
   const int bm = 32 * mi, nblk = tile / 16, nb = (bm / 16) * 8, ncb = cdiv(cout, bm);
-  size_t smem = 16 * ((size_t)OS_PAIRS * 4 * bm + 2 * ((size_t)xcap + 64));
+  size_t smem = 16 * ((size_t)OS_PAIRS * 4 * bm + 2 * ((size_t)xcap + 128));
   const size_t smem_out = sizeof(float) * ((size_t)(nblk + 1) * nb + (compact ? 0 : (size_t)bm * tile));
   if (smem_out > smem) smem = smem_out;
   // one persistent workgroup per CU (or per item, when there are fewer)
@@ -517,23 +584,26 @@ static int sconv_dil_launch(int b, int cin, int cout, int r, int n_max, int n_di
   const long long items = (long long)tiles * ncb * b;
   dim3 grid((unsigned)(items < ncu ? items : ncu));
   hipStream_t s = (hipStream_t)stream;
+  const int slices = h2in ? tiles + 27 : tiles;
   if (gn_partial != nullptr) {
     BDM_REQUIRE(gn_cg >= 4 && (gn_cg & (gn_cg - 1)) == 0 && bm % gn_cg == 0 && cout % gn_cg == 0,
                 "sparse_conv_dil: GroupNorm statistics need a power-of-two channels-per-group dividing %d (got cg=%d)", bm, gn_cg);
-    if (slices_out) *slices_out = tiles;
+    if (slices_out) *slices_out = slices;
   }
-#define DIL_LAUNCH(MT, NT, NW, R)                                                                                         \
-  do {                                                                                                                    \
-    BDM_ALLOW_LDS((sconv_dil_kernel<MT, NT, NW, R>), smem);                                                               \
-    hipLaunchKernelGGL((sconv_dil_kernel<MT, NT, NW, R>), grid, dim3(NW * 64), smem, s, c8, cout, n_max, n_dil_max, xcap, \
-                       (const float4 *)xr, amax, occ_index, dil_list, dil_index, tile_start,                              \
-                       (const float4 *)packed_w, inv_scale, bias, y, compact, gn_cg, gn_partial, b, ncb, tiles,           \
-                       work_counter);                                                                                     \
+#define DIL_LAUNCH_(MT, NT, NW, R, H)                                                                                      \
+  do {                                                                                                                     \
+    BDM_ALLOW_LDS((sconv_dil_kernel<MT, NT, NW, R, H>), smem);                                                             \
+    hipLaunchKernelGGL((sconv_dil_kernel<MT, NT, NW, R, H>), grid, dim3(NW * 64), smem, s, c8, cout, n_max, n_dil_max,     \
+                       xcap, (const float4 *)xr, amax, (const float4 *)xconst, x_inv_scale, in_index, dil_list, dil_index, \
+                       tile_start, (const float4 *)packed_w, inv_scale, bias, y, compact, gn_cg, gn_partial, slices, b,    \
+                       ncb, tiles, work_counter);                                                                          \
   } while (0)
+#define DIL_LAUNCH(MT, NT, NW, R) do { if (h2in) DIL_LAUNCH_(MT, NT, NW, R, true); else DIL_LAUNCH_(MT, NT, NW, R, false); } while (0)
   if (r == 32) { if (mi == 2) DIL_LAUNCH(4, 4, 8, 32); else DIL_LAUNCH(2, 4, 8, 32); }
   else if (r == 16) { if (mi == 2) DIL_LAUNCH(4, 2, 8, 16); else DIL_LAUNCH(2, 2, 8, 16); }
   else { if (mi == 2) DIL_LAUNCH(4, 1, 8, 8); else DIL_LAUNCH(2, 1, 8, 8); }
 #undef DIL_LAUNCH
+#undef DIL_LAUNCH_
   return launch_status("sparse_conv_dil");
 }
 
@@ -541,8 +611,8 @@ extern "C" int bdm_sparse_conv_dil(int b, int cin, int cout, int r, int n_max, i
                                    const int *occ_index, const int *dil_list, const int *dil_index, const int *tile_start,
                                    const void *packed_w, const float *inv_scale, const float *bias, float *y,
                                    int compact, int *work_counter, void *stream) {
-  return sconv_dil_launch(b, cin, cout, r, n_max, n_dil_max, xr, amax, occ_index, dil_list, dil_index, tile_start, packed_w,
-                          inv_scale, bias, y, compact, 0, nullptr, nullptr, work_counter, stream);
+  return sconv_dil_launch(false, b, cin, cout, r, n_max, n_dil_max, xr, amax, nullptr, 0.f, occ_index, dil_list, dil_index, tile_start,
+                          packed_w, inv_scale, bias, y, compact, 0, nullptr, nullptr, work_counter, stream);
 }
 
 extern "C" int bdm_sparse_conv_dil_gn(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
@@ -551,6 +621,22 @@ extern "C" int bdm_sparse_conv_dil_gn(int b, int cin, int cout, int r, int n_max
                                       float *y, int compact, int groups, void *gn_partial, int *slices_out, int *work_counter,
                                       void *stream) {
   BDM_REQUIRE(groups >= 1 && cout % groups == 0 && gn_partial != nullptr && slices_out != nullptr, "sparse_conv_dil_gn: bad arguments");
-  return sconv_dil_launch(b, cin, cout, r, n_max, n_dil_max, xr, amax, occ_index, dil_list, dil_index, tile_start, packed_w,
-                          inv_scale, bias, y, compact, cout / groups, (double *)gn_partial, slices_out, work_counter, stream);
+  return sconv_dil_launch(false, b, cin, cout, r, n_max, n_dil_max, xr, amax, nullptr, 0.f, occ_index, dil_list, dil_index, tile_start,
+                          packed_w, inv_scale, bias, y, compact, cout / groups, (double *)gn_partial, slices_out, work_counter, stream);
+}
+
+// SECOND convolution of a PVConv on the twice-dilated set (H2IN form of the kernel): rows_h2 / xconst / x_inv_scale from
+// bdm_group_norm_to_h2_rows, in_index = the FIRST list's ranks (dil_index of bdm_voxel_dilate), lists / tiles of
+// bdm_voxel_dilate_again; y (b, n_dil_max, cout) compact rows.  The partials cover the listed voxels only: slices =
+// bdm_voxel_dilate_slices(r) + 27, the last 27 are written by bdm_conv3d_class_constants.
+extern "C" int bdm_sparse_conv_dil_h2_gn(int b, int cin, int cout, int r, int n_rows_max, int n_dil_max, const void *rows_h2,
+                                         const void *xconst, float x_inv_scale, const int *in_index, const int *dil_list,
+                                         const int *dil_index, const int *tile_start, const void *packed_w, const float *inv_scale,
+                                         const float *bias, float *y, int groups, void *gn_partial, int *slices_out,
+                                         int *work_counter, void *stream) {
+  BDM_REQUIRE(groups >= 1 && cout % groups == 0 && gn_partial != nullptr && slices_out != nullptr && x_inv_scale > 0.f,
+              "sparse_conv_dil_h2_gn: bad arguments");
+  return sconv_dil_launch(true, b, cin, cout, r, n_rows_max, n_dil_max, rows_h2, nullptr, xconst, x_inv_scale, in_index, dil_list,
+                          dil_index, tile_start, packed_w, inv_scale, bias, y, 1, cout / groups, (double *)gn_partial, slices_out,
+                          work_counter, stream);
 }

@@ -229,7 +229,7 @@ class PVConv(nn.Module):
         sig = (conv.weight._version, conv.weight.data_ptr())
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
-            pack = {"bf16x6": ops.conv3d_s3_pack, "fp16x3": ops.conv3d_h2_pack, "sparse": ops.sparse_conv_pack,
+            pack = {"bf16x6": ops.conv3d_s3_pack, "fp16x3": ops.conv3d_h2_pack, "sparse": ops.sparse_conv_pack, "class": ops.conv_class_pack,
                     "sparse_s3": ops.sparse_conv_pack_s3, "sparse_fused": ops.sparse_conv_pack_fused, "sparse_h2": ops.sparse_conv_pack_h2,
                     "fp32": ops.conv3d_pack}[impl]
             hit = (sig, pack(conv.weight.detach()))
@@ -259,6 +259,23 @@ class PVConv(nn.Module):
         return (self.sparse_conv == "dil" and self.resolution in self.sparse_dil_resolutions and self.conv_impl == "fp16x3"
                 and self.sparse_gemm == "sparse_h2" and not getattr(self, "h2_saturated", False) and self.sparse_first_conv
                 and (self.sparse_dil_always or ops.sparse_dil_pays(batch, n_points, self.resolution, conv1.out_channels)))
+
+    # The whole voxel branch on voxel lists (pvconv_compact.hip): second convolution on the twice-dilated list, SE means and
+    # devoxelisation from its rows + 27 class constants -- no dense grid is written.  "1": where ops.compact_tail_pays; "always"; "0".
+    compact_tail = os.environ.get("BDM_COMPACT_TAIL", "1")
+    compact_tail_resolutions = {int(v) for v in os.environ.get("BDM_COMPACT_TAIL_R", "32,16").split(",") if v}
+
+    def wants_compact_tail(self, batch, n_points):
+        conv2 = self.voxel_layers[4] if isinstance(self.voxel_layers[3], nn.Dropout) else self.voxel_layers[3]
+        if not isinstance(conv2, nn.Conv3d):
+            conv2 = next(m for m in list(self.voxel_layers)[1:] if isinstance(m, nn.Conv3d))
+        c = conv2.out_channels
+        has_att = any(isinstance(m, Attention) for m in self.voxel_layers)
+        has_se = any(isinstance(m, SE3d) for m in self.voxel_layers)
+        return (self.compact_tail != "0" and self.resolution in self.compact_tail_resolutions and self.conv_impl == "fp16x3"
+                and self.sparse_first_conv and self.fold_gn1 and self.fold_gn2 and not self.se_in_devox and not has_att and has_se
+                and not getattr(self, "h2_saturated", False) and c % 4 == 0 and c <= 256 and (c // 8) in (4, 8, 16, 32)
+                and (self.compact_tail == "always" or ops.compact_tail_pays(batch, n_points, self.resolution, c)))
 
     _cond = None  # ops.Conditioning of this forward when the input is the raw conditioned cloud (set by PVCNN2Base.forward)
 
@@ -359,6 +376,24 @@ class PVConv(nn.Module):
                 x3 = ops.avg_voxelize_s3(features, vox_coords, r)
                 v = ops.conv3d_s3(x3, self._packed_weight(conv1, "bf16x6"), conv1.bias, conv1.in_channels,
                                   conv1.out_channels, r)
+            if gn1_stats is not None and folded_tail and self.wants_compact_tail(features.shape[0], features.shape[2]):
+                # the rest of the branch on voxel lists: operand split on the once-dilated rows, second convolution on the
+                # twice-dilated list, SE means and devoxelisation from its rows + the 27 class constants (pvconv_compact.hip)
+                sat = ops.saturation_slot(self, features.device)
+                rows_h2, const_h2, const_f32, inv_s = ops.to_h2_rows(v, plan, gn1, gn1_stats, saturated=sat, bias=conv1.bias)
+                y2, cvals, st2 = ops.second_conv_rows(rows_h2, const_h2, const_f32, inv_s, plan, self._packed_weight(conv2, "fp16x3"),
+                                                      self._packed_weight(conv2, "class"), conv2.bias, conv2.in_channels,
+                                                      conv2.out_channels, gn2.num_groups)
+                w1, w2 = se.fc[0].weight, se.fc[2].weight
+                if pf_pending is not None:
+                    if pf_ready is not None:
+                        tape.wait_event(pf_ready)  # the branch's statistics are read by the SE kernel
+                    gate, coef, pf_coef = ops.se_gate_gn_rows(y2, cvals, plan, st2, gn2, w1, w2, pf=pf_pending, n_points=pf.shape[2])
+                    return ops.devoxelize_gn_gate_add_rows(norm_coords, y2, cvals, plan, coef, gate=gate, add=pf, add_coef=pf_coef), coords, temb
+                gate, coef = ops.se_gate_gn_rows(y2, cvals, plan, st2, gn2, w1, w2)
+                if pf_ready is not None:
+                    tape.wait_event(pf_ready)
+                return ops.devoxelize_gn_gate_add_rows(norm_coords, y2, cvals, plan, coef, gate=gate, add=pf), coords, temb
             # GroupNorm + Swish fused into the operand split of the second conv
             if self.conv_impl == "fp16x3" and not getattr(self, "h2_saturated", False):
                 # saturation guard: to_h2 raises this layer's sticky device word when a scaled activation leaves fp16's

@@ -799,7 +799,8 @@ class VoxelPlan:
     """Everything that depends on (coords, r) only: normalised / integer voxel coordinates, per-voxel point lists,
     occupied-cell compaction and row occupancy.  PVConvs of one level share it (exactly the same values)."""
     __slots__ = ("r", "n", "n_max", "norm_coords", "vox_coords", "ind", "cnt", "ws", "occ_index", "occ_list", "n_occ", "rowocc",
-                 "ready", "stream", "dil_list", "dil_index", "plane_start", "tile_start", "n_dil_max")
+                 "ready", "stream", "dil_list", "dil_index", "plane_start", "tile_start", "n_dil_max",
+                 "d2_list", "d2_index", "d2_tiles", "d2_class_count")
 
 
 _plan_cache = {}
@@ -839,9 +840,11 @@ def voxel_plan(coords, r, eps=0.0, dilate=False):
     L.check(lib.bdm_voxelize_plan_full(B, n, r, p.n_max, L.ptr(p.vox_coords), L.ptr(p.ind), L.ptr(p.cnt), L.ptr(p.ws),
                                        L.ptr(p.occ_index), L.ptr(p.occ_list), L.ptr(p.n_occ), L.ptr(p.rowocc), L.stream()),
             "voxelize_plan_full")
-    p.dil_list = None
+    p.dil_list = p.d2_list = None
     if dilate:
         plan_dilation(p)
+        if dilate == 2:
+            plan_dilation2(p)
     p.stream = torch.cuda.current_stream(dev) if coords.is_cuda else None
     _plan_cache[key] = p
     return p
@@ -868,6 +871,27 @@ def plan_dilation(p):
     p.tile_start = torch.empty(B, lib.bdm_voxel_dilate_slices(r), 8, dtype=torch.int32, device=dev)
     L.check(lib.bdm_voxel_dilate(B, r, p.n_dil_max, L.ptr(p.cnt), L.ptr(p.dil_list), L.ptr(p.dil_index), L.ptr(p.plane_start),
                                  L.ptr(p.tile_start), L.stream()), "voxel_dilate")
+    return p
+
+
+def plan_dilation2(p):
+    """The TWICE-dilated voxel list of a plan (bdm_voxel_dilate_again): where the second convolution of a PVConv can differ from its
+    per-class constants; tiles whose input ranges are rows of the first list; voxels outside it counted per boundary class."""
+    if getattr(p, "d2_list", None) is not None:
+        return p
+    plan_dilation(p)
+    p.d2_list = p.d2_index = p.d2_tiles = p.d2_class_count = None
+    if p.dil_list is None:
+        return p
+    lib, B, r = L.lib(), p.cnt.shape[0], p.r
+    dev = p.cnt.device
+    p.d2_list = torch.empty(B, p.n_dil_max, dtype=torch.int32, device=dev)
+    p.d2_index = torch.empty(B, r ** 3, dtype=torch.int32, device=dev)
+    ps = torch.empty(B, r + 2, dtype=torch.int32, device=dev)
+    p.d2_tiles = torch.empty(B, lib.bdm_voxel_dilate_slices(r), 8, dtype=torch.int32, device=dev)
+    p.d2_class_count = torch.empty(B, 27, dtype=torch.int32, device=dev)
+    L.check(lib.bdm_voxel_dilate_again(B, r, p.n_dil_max, L.ptr(p.dil_index), L.ptr(p.d2_list), L.ptr(p.d2_index), L.ptr(ps),
+                                       L.ptr(p.d2_tiles), L.ptr(p.d2_class_count), L.stream()), "voxel_dilate_again")
     return p
 
 
@@ -1128,6 +1152,120 @@ def sparse_first_conv_os(features, plan, packed, bias, cout, gn_groups=None, com
     return out
 
 
+# ---- the PVConv voxel branch on voxel lists only (csrc/pvconv_compact.hip) ---------------------------------------------------------
+def to_h2_rows(x, plan, gn, stats, swish=True, saturated=None, bias=None):
+    """GroupNorm + Swish + fp16 split of the first convolution's output on the rows of the plan's dilated list.  x: CompactGrid or the
+    dense (B, C, r^3) grid (then `bias` = the convolution's bias).  -> (rows_h2, const_h2, const_f32, 1 / scale)."""
+    plan_dilation(plan)
+    lib = L.lib()
+    compact = isinstance(x, CompactGrid)
+    src = x.rows if compact else x.contiguous()
+    bias = x.bias if compact else bias
+    B, C, V = src.shape[0], (x.channels if compact else src.shape[1]), plan.r ** 3
+    dev = src.device
+    s = float(h2_activation_scale(gn))
+    C8 = (C + 7) // 8
+    rows = torch.empty(B, C8, 2, plan.n_dil_max, 8, dtype=torch.float16, device=dev)
+    const_h2 = torch.empty(B, C8, 2, 8, dtype=torch.float16, device=dev)
+    const_f32 = torch.empty(B, C, dtype=torch.float32, device=dev)
+    partial, slices, groups = stats
+    L.check(lib.bdm_group_norm_to_h2_rows(B, C, V, groups, L.ptr(src), 0 if compact else 1, plan.n_dil_max, L.ptr(plan.dil_list),
+                                          L.ptr(plan.tile_start), plan.tile_start.shape[1], L.ptr(bias), L.ptr(gn.weight), L.ptr(gn.bias),
+                                          L.c_float(gn.eps), 1 if swish else 0, L.c_float(s), L.ptr(rows), L.ptr(const_h2), L.ptr(const_f32),
+                                          L.ptr(partial), slices, L.ptr(saturated), L.stream()), "group_norm_to_h2_rows")
+    return rows, const_h2, const_f32, 1.0 / s
+
+
+def conv_class_pack(weight):
+    """(Cout, Cin, 3,3,3) fp32 -> (27, Cin, Cout) fp64: per boundary class the sum of the taps that stay inside the grid."""
+    cout, cin = weight.shape[:2]
+    lib = L.lib()
+    wsum = torch.empty(lib.bdm_conv3d_class_weight_elems(cout, cin), dtype=torch.float64, device=weight.device)
+    L.check(lib.bdm_conv3d_class_weight_sums(cout, cin, L.ptr(weight.contiguous()), L.ptr(wsum), L.stream()), "conv3d_class_weight_sums")
+    return wsum
+
+
+def second_conv_rows(rows_h2, const_h2, const_f32, x_inv_scale, plan, packed, wsum, bias, cin, cout, groups=8):
+    """The second convolution of a PVConv on the plan's twice-dilated list: -> (rows (B, n_dil_max, cout), class_vals (B, 27, cout),
+    (partials, slices)) -- every voxel outside the list has the value of its boundary class."""
+    plan_dilation2(plan)
+    lib, B, r = L.lib(), rows_h2.shape[0], plan.r
+    dev = rows_h2.device
+    packed_w, inv_scale = packed
+    y = torch.empty(B, plan.n_dil_max, cout, dtype=torch.float32, device=dev)
+    tiles = plan.d2_tiles.shape[1]
+    partial = torch.empty(B, groups, tiles + 27, 2, dtype=torch.float64, device=dev)
+    counter = amax_slots(dev, 1)
+    slices = ctypes.c_int(0)
+    L.check(lib.bdm_sparse_conv_dil_h2_gn(B, cin, cout, r, plan.n_dil_max, plan.n_dil_max, L.ptr(rows_h2), L.ptr(const_h2), L.c_float(x_inv_scale),
+                                          L.ptr(plan.dil_index), L.ptr(plan.d2_list), L.ptr(plan.d2_index), L.ptr(plan.d2_tiles), L.ptr(packed_w),
+                                          L.ptr(inv_scale), L.ptr(bias), L.ptr(y), int(groups), L.ptr(partial), ctypes.byref(slices),
+                                          L.ptr(counter), L.stream()), "sparse_conv_dil_h2_gn")
+    assert slices.value == tiles + 27
+    class_vals = torch.empty(B, 27, cout, dtype=torch.float32, device=dev)
+    L.check(lib.bdm_conv3d_class_constants(B, cin, cout, L.ptr(wsum), L.ptr(bias), L.ptr(const_f32), L.ptr(plan.d2_class_count), L.ptr(class_vals),
+                                           int(groups), L.ptr(partial), tiles + 27, tiles, L.stream()), "conv3d_class_constants")
+    return y, class_vals, (partial, tiles + 27)
+
+
+def se_gate_gn_rows(rows, class_vals, plan, stats, gn, w1, w2, pf=None, n_points=0):
+    """se_gate_gn from the rows of the twice-dilated list + counts x class constants: (gate, coef[, pf_coef])."""
+    partial, slices = stats
+    B, C = rows.shape[0], rows.shape[2]
+    dev, lib = rows.device, L.lib()
+    V = plan.r ** 3
+    mean = torch.empty(B, C, dtype=torch.float32, device=dev)
+    coef = torch.empty(B, C, 2, dtype=torch.float32, device=dev)
+    gate = torch.empty(B, C, dtype=torch.float32, device=dev)
+    part = torch.empty(lib.bdm_se_gate_gn_rows_workspace_elems(B, C), dtype=torch.float32, device=dev)
+    args = (B, C, w1.shape[0], V, gn.num_groups, L.ptr(rows), plan.n_dil_max, L.ptr(plan.d2_tiles), plan.d2_tiles.shape[1], L.ptr(class_vals),
+            L.ptr(plan.d2_class_count), L.ptr(partial), slices, L.ptr(gn.weight), L.ptr(gn.bias), L.c_float(gn.eps), L.ptr(w1), L.ptr(w2), L.ptr(part),
+            L.ptr(mean), L.ptr(coef), L.ptr(gate))
+    if pf is not None:
+        (pp, ps, pg), pgn = pf
+        pf_coef = torch.empty(B, C, 2, dtype=torch.float32, device=dev)
+        L.check(lib.bdm_se_gate_gn_rows_pf(*args, L.ptr(pp), ps, pg, int(n_points), L.ptr(pgn.weight), L.ptr(pgn.bias), L.c_float(pgn.eps),
+                                           L.ptr(pf_coef), L.stream()), "se_gate_gn_rows_pf")
+        return gate, coef, pf_coef
+    L.check(lib.bdm_se_gate_gn_rows(*args, L.stream()), "se_gate_gn_rows")
+    return gate, coef
+
+
+def devoxelize_gn_gate_add_rows(norm_coords, rows, class_vals, plan, coef, gate=None, add=None, add_coef=None):
+    B, C = rows.shape[0], rows.shape[2]
+    n = norm_coords.shape[2]
+    out = torch.empty(B, C, n, dtype=torch.float32, device=rows.device)
+    _, _, _, _, bs_o, ld_o = _bcl(out)
+    if add is not None:
+        aa, _, _, _, bs_a, ld_a = _bcl(add)
+        assert aa.data_ptr() == add.data_ptr()
+    else:
+        bs_a, ld_a = 0, 0
+    lib = L.lib()
+    args = (B, C, n, plan.r, L.ptr(norm_coords), L.ptr(rows), plan.n_dil_max, L.ptr(plan.d2_index), L.ptr(class_vals), L.ptr(coef), L.ptr(gate),
+            L.ptr(add), bs_a, ld_a)
+    if add_coef is not None:
+        L.check(lib.bdm_devoxelize_gn_gate_add_rows_pf(*args, L.ptr(add_coef), L.ptr(out), bs_o, ld_o, L.stream()), "devoxelize_gn_gate_add_rows_pf")
+    else:
+        L.check(lib.bdm_devoxelize_gn_gate_add_rows(*args, L.ptr(out), bs_o, ld_o, L.stream()), "devoxelize_gn_gate_add_rows")
+    return out
+
+
+def densify_rows(rows, class_vals, plan):
+    """(B, C, r^3) grid of a second convolution's compact result (tests): rows at the list's voxels, the class constant elsewhere."""
+    B, _, C = rows.shape
+    r = plan.r
+    ax = torch.arange(r, device=rows.device)
+    cls1 = torch.where(ax == 0, 0, torch.where(ax == r - 1, 2, 1))
+    cls = (cls1[:, None, None] * 9 + cls1[None, :, None] * 3 + cls1[None, None, :]).reshape(-1)
+    out = class_vals[:, cls].permute(0, 2, 1).contiguous()
+    idx = plan.d2_index.long()
+    for b in range(B):
+        v = torch.nonzero(idx[b] >= 0).squeeze(1)
+        out[b, :, v] = rows[b, idx[b, v]].t()
+    return out
+
+
 SPARSE_DIL_MIN_ITEMS = 160   # tiles x channel blocks x shapes below which the compact convolution cannot fill the chip
 
 
@@ -1144,6 +1282,20 @@ def sparse_dil_pays(batch, n_points, r, cout):
         tiles = min(16, max(1, (2 * n_points) // 256))
     else:
         return False          # 8^3: the GEMM over <= 256 occupied rows per shape wins at every batch measured
+    return batch * tiles * (2 if cout > 64 else 1) >= SPARSE_DIL_MIN_ITEMS
+
+
+def compact_tail_pays(batch, n_points, r, cout):
+    """Does the voxel branch on voxel lists (second convolution on the twice-dilated list, no dense grids: pvconv_compact.hip) beat the
+    dense-grid path?  Measured at B = 16 (tools/conv2_compact_estimate.py): 64 channels at 32^3 187 vs 358 us, 32 channels 84 vs 117,
+    64 channels at 16^3 56 vs 75, 128 channels at 16^3 176 vs 157 (the list covers 72 % of that grid: no).  As sparse_dil_pays: decided
+    from the sizes, never from the data."""
+    if r == 32:
+        tiles = min(64, max(1, (3 * n_points) // 512))
+    elif r == 16 and cout <= 64:
+        tiles = min(16, max(1, (3 * n_points) // 256))
+    else:
+        return False
     return batch * tiles * (2 if cout > 64 else 1) >= SPARSE_DIL_MIN_ITEMS
 
 

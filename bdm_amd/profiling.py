@@ -91,6 +91,16 @@ SPEC = {
     "bdm_sparse_conv_dil": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[2] * a[3] ** 3)),
     "bdm_sparse_conv_dil_gn": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[2] * a[3] ** 3)),
     "bdm_voxel_dilate": ("voxelize / devoxelize", lambda a: a[:2], lambda a: ("hbm", 4.0 * a[0] * 2 * a[1] ** 3)),
+    "bdm_voxel_dilate_again": ("voxelize / devoxelize", lambda a: a[:2], lambda a: ("hbm", 4.0 * a[0] * 2 * a[1] ** 3)),
+    # second convolution on the twice-dilated list: priced like the dense one (2 * 27 * cin * cout * r^3 fp32-equivalent flops per
+    # shape is what the operator computes; the list only removes the voxels whose result is a class constant)
+    "bdm_sparse_conv_dil_h2_gn": ("dense conv3d (fp16x3)", lambda a: a[:4], _conv_h2),
+    "bdm_conv3d_class_constants": ("dense conv3d (fp16x3)", lambda a: a[:3], lambda a: ("mfma", 0.0, MFMA16_PEAK_TFLOPS / 3)),
+    "bdm_group_norm_to_h2_rows": ("GroupNorm(+Swish)", lambda a: a[:4], lambda a: ("hbm", (4.0 + 4.0) * a[0] * a[1] * a[2])),
+    "bdm_se_gate_gn_rows": ("SE gate", lambda a: (a[0], a[1], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[3])),
+    "bdm_se_gate_gn_rows_pf": ("SE gate", lambda a: (a[0], a[1], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[3])),
+    "bdm_devoxelize_gn_gate_add_rows": ("voxelize / devoxelize", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 10 * a[1] * a[2]))),
+    "bdm_devoxelize_gn_gate_add_rows_pf": ("voxelize / devoxelize", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * (3 * a[2] + 10 * a[1] * a[2]))),
     # hoisted conditioning (ops.Conditioning): rows of the occupied cells from the per-pixel map; algorithmic = the map rows of the points
     "bdm_sparse_conv_rows_from_map": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[4]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[4])),
     "bdm_sparse_voxel_features_s3": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]), lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2])),

@@ -167,7 +167,8 @@ def plan_sampling_chain(sa_layers, coords):
                 pv = nxt[0] if isinstance(nxt, nn.Sequential) and hasattr(nxt[0], "voxel_plan_args") else None
                 args = pv.voxel_plan_args() if (pv is not None and SIDE_PLAN) else None
                 if args is not None:
-                    plan = ops.voxel_plan(c, *args, dilate=pv.wants_dilated_plan(c.shape[0], c.shape[2]))
+                    plan = ops.voxel_plan(c, *args, dilate=2 if pv.wants_compact_tail(c.shape[0], c.shape[2]) else
+                                          (1 if pv.wants_dilated_plan(c.shape[0], c.shape[2]) else 0))
                     plan.ready = torch.cuda.Event()
                     tape.record_event(plan.ready, side)
             # the 3-NN searches of the feature-propagation modules are geometry too (level i's points against level i + 1's

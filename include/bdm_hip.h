@@ -471,6 +471,58 @@ int bdm_sparse_conv_dil_gn(int b, int cin, int cout, int r, int n_max, int n_dil
                            const void *packed_w, const float *inv_scale, const float *bias, float *y, int compact, int groups,
                            void *gn_partial, int *slices_out, int *work_counter, void *stream);
 
+/* --- the whole voxel branch of a PVConv without dense grids (pvconv_compact.hip, sparse_conv_os.hip; pvconv.py:74-97) ---
+ * After GroupNorm + Swish the first convolution's output is a per-channel CONSTANT outside the once-dilated set D1, so the second
+ * convolution differs from one of 27 per-class constants (class = 9 cx + 3 cy + cz, c = 0 / 1 / 2: first plane / interior / last
+ * plane of the axis -- the zero padding removes taps there) only on the twice-dilated set D2, and the devoxelisation only reads D1.
+ *   bdm_voxel_dilate_again        D2 from D1's ranks (dil_index of bdm_voxel_dilate): list, ranks, tiles (input ranges = rows of D1),
+ *                                 class_count (b, 27): voxels outside D2 per class
+ *   bdm_group_norm_to_h2_rows     GroupNorm + Swish + fp16 split of the FIRST convolution's output on the rows of D1: x = compact rows
+ *                                 (b, n_rows_max, c) [dense_in = 0] or the grid (b, c, v) read at dil_list [dense_in = 1]; statistics
+ *                                 from `partial` (b, groups, slices, 2).  -> rows_h2 (b, ceil(c/8), 2, n_rows_max) records of 8 fp16,
+ *                                 const_h2 (b, ceil(c/8), 2) records and const_f32 (b, c): the value outside D1 (from bias)
+ *   bdm_sparse_conv_dil_h2_gn     the SECOND convolution on D2's tiles from those rows: y (b, n_dil_max, cout) compact rows; GroupNorm
+ *                                 partials (b, groups, slices, 2), *slices_out = bdm_voxel_dilate_slices(r) + 27 (the tiles'; the last 27
+ *                                 are left for bdm_conv3d_class_constants); work_counter as bdm_sparse_conv_dil
+ *   bdm_conv3d_class_weight_sums  (cout, cin, 3,3,3) -> wsum (27, cin, cout) doubles: per class, the sum of the taps inside the grid
+ *   bdm_conv3d_class_constants    class_vals (b, 27, cout) = bias + wsum[k] . const_f32[b] (fp64, rounded once) and slices
+ *                                 slice0 .. slice0 + 26 of gn_partial: class_count x (sum, sum of squares) per group
+ *   bdm_se_gate_gn_rows(_pf)      bdm_se_gate_gn(_pf) from the rows of D2 + counts x class constants: coef (b, c, 2), mean_ws (b, c),
+ *                                 gate (b, c) (w1 = NULL: no FC layers); part_ws: bdm_se_gate_gn_rows_workspace_elems(b, c) floats
+ *   bdm_devoxelize_gn_gate_add_rows(_pf)  bdm_devoxelize_gn_gate_add(_pf) reading the 8 corner rows through D2's ranks */
+int bdm_voxel_dilate_again(int b, int r, int n_dil_max, const int *dil_index_in, int *dil_list, int *dil_index, int *plane_start,
+                           int *tile_start, int *class_count, void *stream);
+int bdm_group_norm_to_h2_rows(int b, int c, int v, int groups, const float *x, int dense_in, int n_rows_max, const int *dil_list,
+                              const int *tile_start, int tiles_max, const float *bias, const float *gamma, const float *beta,
+                              float eps, int act, float act_scale, void *rows_h2, void *const_h2, float *const_f32,
+                              const void *partial, int slices, unsigned int *saturated, void *stream);
+int bdm_sparse_conv_dil_h2_gn(int b, int cin, int cout, int r, int n_rows_max, int n_dil_max, const void *rows_h2, const void *xconst,
+                              float x_inv_scale, const int *in_index, const int *dil_list, const int *dil_index,
+                              const int *tile_start, const void *packed_w, const float *inv_scale, const float *bias, float *y,
+                              int groups, void *gn_partial, int *slices_out, int *work_counter, void *stream);
+size_t bdm_conv3d_class_weight_elems(int cout, int cin);
+int bdm_conv3d_class_weight_sums(int cout, int cin, const float *w, void *wsum, void *stream);
+int bdm_conv3d_class_constants(int b, int cin, int cout, const void *wsum, const float *bias, const float *const_f32,
+                               const int *class_count, float *class_vals, int groups, void *gn_partial, int slices, int slice0,
+                               void *stream);
+size_t bdm_se_gate_gn_rows_workspace_elems(int b, int c);
+int bdm_se_gate_gn_rows(int b, int c, int hidden, int v, int groups, const float *rows, int n_rows_max, const int *tile_start,
+                        int tiles_max, const float *class_vals, const int *class_count, const void *gn_partial, int slices,
+                        const float *gamma, const float *beta, float eps, const float *w1, const float *w2, float *part_ws,
+                        float *mean_ws, float *coef, float *gate, void *stream);
+int bdm_se_gate_gn_rows_pf(int b, int c, int hidden, int v, int groups, const float *rows, int n_rows_max, const int *tile_start,
+                           int tiles_max, const float *class_vals, const int *class_count, const void *gn_partial, int slices,
+                           const float *gamma, const float *beta, float eps, const float *w1, const float *w2, float *part_ws,
+                           float *mean_ws, float *coef, float *gate, const void *pf_partial, int pf_slices, int pf_groups, int pf_n,
+                           const float *pf_gamma, const float *pf_beta, float pf_eps, float *pf_coef, void *stream);
+int bdm_devoxelize_gn_gate_add_rows(int b, int c, int n, int r, const float *coords, const float *rows, int n_rows_max,
+                                    const int *dil_index, const float *class_vals, const float *coef, const float *gate,
+                                    const float *add, long long bs_a, int ld_a, float *out, long long bs_o, int ld_o, void *stream);
+int bdm_devoxelize_gn_gate_add_rows_pf(int b, int c, int n, int r, const float *coords, const float *rows, int n_rows_max,
+                                       const int *dil_index, const float *class_vals, const float *coef, const float *gate,
+                                       const float *add, long long bs_a, int ld_a, const float *add_coef, float *out, long long bs_o,
+                                       int ld_o, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * 3. Per-step glue of the coupled DDPM loop
  * ---------------------------------------------------------------------------------- */

@@ -82,8 +82,16 @@ def test_network_goldens_with_the_compact_first_convolution_on_every_level(hip, 
     of both denoisers, 8^3 levels included, against the reference's own outputs."""
     from bdm_amd.modules import PVConv
     from bdm_amd.pvcnn import PVCNN2_PC2, PVCNN2_PVD
+    from bdm_amd import ops as ops_mod
     monkeypatch.setattr(PVConv, "sparse_dil_always", True)
     monkeypatch.setattr(PVConv, "sparse_dil_resolutions", {8, 16, 32})
+    # ... and the rest of the voxel branch on voxel lists (second convolution on the twice-dilated list, SE gate and devoxelisation
+    # from its rows + 27 class constants) wherever the module has no attention block
+    monkeypatch.setattr(PVConv, "compact_tail", "always")
+    monkeypatch.setattr(PVConv, "compact_tail_resolutions", {8, 16, 32})
+    tails = []
+    real_tail = ops_mod.second_conv_rows
+    monkeypatch.setattr(ops_mod, "second_conv_rows", lambda *a, **k: (tails.append(a[4].r), real_tail(*a, **k))[1])
     seen = []
     from bdm_amd import ops
     real = ops.sparse_first_conv_os
@@ -99,6 +107,7 @@ def test_network_goldens_with_the_compact_first_convolution_on_every_level(hip, 
     y = net(x.cuda(), torch.from_numpy(g["t"]).cuda()).cpu()
     assert rel_l2(y, torch.from_numpy(g["out"])) < TOL
     assert sorted(set(seen)) == [8, 16, 32] and len(seen) >= 13   # (PC^2: SA0.0 takes the hoisted map)
+    assert sorted(set(tails)) == [8, 16, 32] and len(tails) >= 12  # every PVConv but the ones with an attention block
 
 
 @pytest.mark.parametrize("N,B", [(4096, 2), (2048, 1), (8192, 1), (1100, 3)])
