@@ -42,26 +42,29 @@ __device__ __forceinline__ void split_rec(const float v[8], uint4 &ph, uint4 &pl
   pl.x = l[0] | (l[1] << 16); pl.y = l[2] | (l[3] << 16); pl.z = l[4] | (l[5] << 16); pl.w = l[6] | (l[7] << 16);
 }
 
-// mean / rstd of GroupNorm group `g` of shape `bi` from S slice partials (b, G, S, 2): thread t adds slices t, t + T, ..., wave
-// butterfly, waves in order -- a fixed order.  Call with all threads of the block; result valid in every thread.
-__device__ __forceinline__ void group_stats(const double *__restrict__ partial, int bi, int G, int g, int S, double count, float eps,
-                                            double (*s_red)[2], float &mean, float &rstd) {
-  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, NWV = T >> 6;
-  const double *pp = partial + ((size_t)bi * G + g) * S * 2;
-  double a = 0.0, q = 0.0;
-  for (int sl = tid; sl < S; sl += T) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
+// mean / rstd of ALL G <= 64 groups of shape `bi` at once: 32 lanes per group add slices l, l + 32, ... and butterfly (a fixed order);
+// 256 threads take 8 groups per round.  Results in s_mean / s_rstd (valid after the call's trailing barrier).
+__device__ __forceinline__ void all_group_stats(const double *__restrict__ partial, int bi, int G, int S, double count, float eps,
+                                                float *s_mean, float *s_rstd) {
+  const int tid = threadIdx.x, l = tid & 31, gq = tid >> 5, per = blockDim.x >> 5;
+  for (int g0 = 0; g0 < G; g0 += per) {
+    const int g = g0 + gq;
+    double a = 0.0, q = 0.0;
+    if (g < G) {
+      const double *pp = partial + ((size_t)bi * G + g) * S * 2;
+      for (int sl = l; sl < S; sl += 32) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
+    }
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    if (l == 0 && g < G) {
+      const double mu = a / count;
+      double var = q / count - mu * mu;
+      if (var < 0) var = 0;
+      s_mean[g] = (float)mu;
+      s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
   __syncthreads();
-  if (lane == 0) { s_red[wave][0] = a; s_red[wave][1] = q; }
-  __syncthreads();
-  a = 0.0; q = 0.0;
-  for (int w = 0; w < NWV; ++w) { a += s_red[w][0]; q += s_red[w][1]; }
-  const double mu = a / count;
-  double var = q / count - mu * mu;
-  if (var < 0) var = 0;
-  mean = (float)mu;
-  rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 }  // namespace
@@ -79,39 +82,37 @@ __global__ __launch_bounds__(256) void to_h2_rows_kernel(int C, int V, int G, in
                                                          const float *__restrict__ beta, float eps, int act, float act_scale,
                                                          uint4 *__restrict__ rows_h2, uint4 *__restrict__ const_h2,
                                                          float *__restrict__ const_f32, unsigned *__restrict__ saturated) {
-  __shared__ double s_red[4][2];
-  __shared__ float s_ab[8][3];
-  const int bi = blockIdx.z, c8 = blockIdx.y, C8 = gridDim.y, tid = threadIdx.x, lane = tid & 63;
+  // grid (row blocks of RB rows, shapes); a thread = (row, 8-channel chunk) with the chunk on the FAST lane axis: the lanes of a row
+  // read its C floats as one contiguous run (a thread per row and chunk-per-block read 32 bytes out of every 256: measured 35 us)
+  __shared__ float s_mean[64], s_rstd[64];
+  __shared__ float s_a[256], s_b[256];
+  const int bi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int C8 = (C + 7) / 8;
   const int nd = tile_start[((size_t)bi * tiles_max + tiles_max - 1) * 8 + 1];   // entries of this shape's list
-  if ((int)blockIdx.x * 1024 >= nd && blockIdx.x != 0) return;
+  constexpr int RB = 512;
+  if ((int)blockIdx.x * RB >= nd && blockIdx.x != 0) return;
   const int cg = C / G;
-  const int g_lo = (c8 * 8) / cg, g_hi = min((c8 * 8 + 7) / cg, G - 1);
-  float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
-  for (int gi = g_lo; gi <= g_hi; ++gi) group_stats(partial, bi, G, gi, S, (double)cg * V, eps, s_red, mean[gi - g_lo], rstd[gi - g_lo]);
-  if (tid < 8) {
-    const int ch = c8 * 8 + tid;
-    float a = 0.f, bsh = 0.f, bv = 0.f;
+  all_group_stats(partial, bi, G, S, (double)cg * V, eps, s_mean, s_rstd);
+  for (int ch = tid; ch < C8 * 8; ch += blockDim.x) {
+    float a = 0.f, bsh = 0.f;
     if (ch < C) {
-      const int g = ch / cg - g_lo;
-      a = gamma[ch] * rstd[g];
-      bsh = beta[ch] - mean[g] * a;
-      bv = bias ? bias[ch] : 0.f;
+      const int g = ch / cg;
+      a = gamma[ch] * s_rstd[g];
+      bsh = beta[ch] - s_mean[g] * a;
     }
-    s_ab[tid][0] = a; s_ab[tid][1] = bsh; s_ab[tid][2] = bv;
+    s_a[ch] = a; s_b[ch] = bsh;
   }
   __syncthreads();
-  float ca[8], cb[8];
   bool sat = false;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { ca[j] = s_ab[j][0]; cb[j] = s_ab[j][1]; }
-  const int nch = min(8, C - c8 * 8);
-  if (blockIdx.x == 0 && tid == 0) {   // the constant record: GroupNorm + Swish of the bias
+  if (blockIdx.x == 0 && tid < C8) {   // the constant records: GroupNorm + Swish of the bias
+    const int c8 = tid, nch = min(8, C - c8 * 8);
     float fill[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float t = s_ab[j][2] * ca[j] + cb[j];
+      const int ch = c8 * 8 + j;
+      float t = (ch < C && bias ? bias[ch] : 0.f) * s_a[ch] + s_b[ch];
       if (act == 1) t = swishf(t);
-      fill[j] = t * act_scale;
+      fill[j] = ch < C ? t * act_scale : 0.f;
       sat |= !(fabsf(fill[j]) <= 65504.f);
     }
     uint4 ph, pl;
@@ -121,39 +122,44 @@ __global__ __launch_bounds__(256) void to_h2_rows_kernel(int C, int V, int G, in
     const f16x8 hh = *reinterpret_cast<const f16x8 *>(&ph), ll = *reinterpret_cast<const f16x8 *>(&pl);
     for (int j = 0; j < nch; ++j) const_f32[(size_t)bi * C + c8 * 8 + j] = ((float)hh[j] + (float)ll[j]) * (1.0f / act_scale);
   }
+  const int per_pass = blockDim.x / C8;                       // rows per pass (C8 <= 32)
+  const int c8 = tid % C8, rl = tid / C8;
+  const int nch = min(8, C - c8 * 8);
   const bool vec = (C & 3) == 0 && nch == 8;
-#pragma unroll 2
-  for (int it = 0; it < 4; ++it) {
-    const int j = blockIdx.x * 1024 + it * 256 + tid;
-    if (j >= nd) break;
-    float in[8];
-    if (dense_in) {
-      const int v = dil_list[(size_t)bi * n_rows_max + j];
-      const float *xb = x + ((size_t)bi * C + c8 * 8) * V + v;
+  float ca[8], cb[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) in[u] = xb[(size_t)min(u, nch - 1) * V];
-    } else {
-      const float *row = x + ((size_t)bi * n_rows_max + j) * C + c8 * 8;
-      if (vec) {
-        const float4 p = *reinterpret_cast<const float4 *>(row), q = *reinterpret_cast<const float4 *>(row + 4);
-        in[0] = p.x; in[1] = p.y; in[2] = p.z; in[3] = p.w; in[4] = q.x; in[5] = q.y; in[6] = q.z; in[7] = q.w;
+  for (int j = 0; j < 8; ++j) { ca[j] = s_a[c8 * 8 + j]; cb[j] = s_b[c8 * 8 + j]; }
+  if (rl < per_pass) {
+    for (int j = blockIdx.x * RB + rl; j < min(nd, (int)(blockIdx.x + 1) * RB); j += per_pass) {
+      float in[8];
+      if (dense_in) {
+        const int v = dil_list[(size_t)bi * n_rows_max + j];
+        const float *xb = x + ((size_t)bi * C + c8 * 8) * V + v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) in[u] = xb[(size_t)min(u, nch - 1) * V];
       } else {
+        const float *row = x + ((size_t)bi * n_rows_max + j) * C + c8 * 8;
+        if (vec) {
+          const float4 p = *reinterpret_cast<const float4 *>(row), q = *reinterpret_cast<const float4 *>(row + 4);
+          in[0] = p.x; in[1] = p.y; in[2] = p.z; in[3] = p.w; in[4] = q.x; in[5] = q.y; in[6] = q.z; in[7] = q.w;
+        } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) in[u] = row[min(u, nch - 1)];
+          for (int u = 0; u < 8; ++u) in[u] = row[min(u, nch - 1)];
+        }
       }
-    }
-    float val[8];
+      float val[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      float t = in[u] * ca[u] + cb[u];   // channels >= C: a = b = 0
-      if (act == 1) t = swishf(t);
-      val[u] = t * act_scale;
-      sat |= !(fabsf(val[u]) <= 65504.f);
+      for (int u = 0; u < 8; ++u) {
+        float t = in[u] * ca[u] + cb[u];   // channels >= C: a = b = 0
+        if (act == 1) t = swishf(t);
+        val[u] = t * act_scale;
+        sat |= !(fabsf(val[u]) <= 65504.f);
+      }
+      uint4 ph, pl;
+      split_rec(val, ph, pl);
+      rows_h2[(((size_t)bi * C8 + c8) * 2 + 0) * n_rows_max + j] = ph;
+      rows_h2[(((size_t)bi * C8 + c8) * 2 + 1) * n_rows_max + j] = pl;
     }
-    uint4 ph, pl;
-    split_rec(val, ph, pl);
-    rows_h2[(((size_t)bi * C8 + c8) * 2 + 0) * n_rows_max + j] = ph;
-    rows_h2[(((size_t)bi * C8 + c8) * 2 + 1) * n_rows_max + j] = pl;
   }
   if (saturated != nullptr && __ballot(sat) != 0ull && lane == __ffsll((long long)__ballot(sat)) - 1) atomicOr(saturated, 1u);
 }
@@ -163,17 +169,17 @@ extern "C" int bdm_group_norm_to_h2_rows(int b, int c, int v, int groups, const 
                                          const float *gamma, const float *beta, float eps, int act, float act_scale, void *rows_h2,
                                          void *const_h2, float *const_f32, const void *partial, int slices,
                                          unsigned int *saturated, void *stream) {
-  BDM_REQUIRE(b >= 0 && c >= 1 && v >= 1 && groups >= 1 && c % groups == 0 && (c / groups) >= 4 && partial != nullptr && slices >= 1 &&
-                  x != nullptr && dil_list != nullptr && tile_start != nullptr && tiles_max >= 1 && n_rows_max >= 1 && rows_h2 && const_h2 &&
-                  const_f32,
-              "group_norm_to_h2_rows: bad arguments");
+  BDM_REQUIRE(b >= 0 && c >= 1 && c <= 256 && v >= 1 && groups >= 1 && groups <= 64 && c % groups == 0 && (c / groups) >= 4 &&
+                  partial != nullptr && slices >= 1 && x != nullptr && dil_list != nullptr && tile_start != nullptr && tiles_max >= 1 &&
+                  n_rows_max >= 1 && rows_h2 && const_h2 && const_f32,
+              "group_norm_to_h2_rows: bad arguments (<= 256 channels)");
   {
     int ex = 0;
     BDM_REQUIRE(act_scale > 0.f && act_scale < INFINITY && frexpf(act_scale, &ex) == 0.5f,
                 "group_norm_to_h2_rows: act_scale must be a power of two (got %g)", (double)act_scale);
   }
   if (b == 0) return BDM_OK;
-  dim3 grid(cdiv(n_rows_max, 1024), (c + 7) / 8, b);
+  dim3 grid(cdiv(n_rows_max, 512), b);
   hipLaunchKernelGGL(to_h2_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, v, groups, slices, n_rows_max, tiles_max, dense_in, x,
                      dil_list, tile_start, bias, (const double *)partial, gamma, beta, eps, act, act_scale, (uint4 *)rows_h2,
                      (uint4 *)const_h2, const_f32, saturated);
@@ -252,7 +258,7 @@ extern "C" int bdm_conv3d_class_constants(int b, int cin, int cout, const void *
 // ---------------------------------------------------------------------------------------------------------------------
 // SE gate from rows + class constants
 // ---------------------------------------------------------------------------------------------------------------------
-#define SE_SLABS 32
+#define SE_SLABS 64
 struct GnFoldC {
   const double *partial;  // (b, G, S, 2) or NULL
   int S, G, l;
@@ -267,19 +273,16 @@ __global__ __launch_bounds__(256) void se_rows_partial_kernel(int c, int V, int 
                                                               const double *__restrict__ partial, const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, float eps, float2 *__restrict__ coef,
                                                               float *__restrict__ part, GnFoldC pf, float2 *__restrict__ pf_coef) {
-  __shared__ double s_red[4][2];
+  __shared__ float s_mean[64], s_rstd[64];
   __shared__ float s_a[256], s_b[256];
   __shared__ float s_acc[256];
   const int slab = blockIdx.x, bi = blockIdx.y, tid = threadIdx.x;
   const int cg = c / G;
-  for (int g = 0; g < G; ++g) {
-    float mean, rstd;
-    group_stats(partial, bi, G, g, S, (double)cg * V, eps, s_red, mean, rstd);
-    for (int ch = g * cg + tid; ch < (g + 1) * cg; ch += blockDim.x) {
-      const float ga = gamma[ch] * rstd;
-      s_a[ch] = ga;
-      s_b[ch] = beta[ch] - mean * ga;
-    }
+  all_group_stats(partial, bi, G, S, (double)cg * V, eps, s_mean, s_rstd);
+  for (int ch = tid; ch < c; ch += blockDim.x) {
+    const float ga = gamma[ch] * s_rstd[ch / cg];
+    s_a[ch] = ga;
+    s_b[ch] = beta[ch] - s_mean[ch / cg] * ga;
   }
   __syncthreads();
   if (slab == 0) {
@@ -309,7 +312,14 @@ __global__ __launch_bounds__(256) void se_rows_partial_kernel(int c, int V, int 
     if (rl < RL && ch < c) {
       const float ga = s_a[ch], be = s_b[ch];
       const float *col = rows + (size_t)bi * n_rows_max * c + ch;
-      for (int j = j_lo + rl; j < j_hi; j += RL) acc += swishf(col[(size_t)j * c] * ga + be);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four rows in flight per thread (one dependent load per step was latency-bound)
+      int j = j_lo + rl;
+      for (; j + 3 * RL < j_hi; j += 4 * RL) {
+        const float v0 = col[(size_t)j * c], v1 = col[(size_t)(j + RL) * c], v2 = col[(size_t)(j + 2 * RL) * c], v3 = col[(size_t)(j + 3 * RL) * c];
+        a0 += swishf(v0 * ga + be); a1 += swishf(v1 * ga + be); a2 += swishf(v2 * ga + be); a3 += swishf(v3 * ga + be);
+      }
+      for (; j < j_hi; j += RL) a0 += swishf(col[(size_t)j * c] * ga + be);
+      acc = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
     s_acc[tid] = acc;

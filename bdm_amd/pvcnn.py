@@ -125,6 +125,7 @@ SIDE_PLAN = True  # voxel plans of levels 1.. on the sampler's side stream (tool
 # per-launch host cost came down it pays even for one small shape (B=1, N=1024: 3.48 -> 3.30 ms; B=4: 3.86 -> 3.42 ms), where
 # furthest point sampling is a fifth of the forward.  (The PVConv point branch keeps its 8192-point threshold: measured slower below.)
 SIDE_STREAM_MIN_POINTS = 0
+SIDE_STREAM_PRIORITY = int(os.environ.get("BDM_SIDE_PRIORITY", "-1"))  # torch: lower = higher priority (0 = default)
 DEFER_CHAIN = True  # levels 1.. of the sampler chain enqueued when the first SA module is reached
 SIDE_NN = True      # 3-NN searches of the FP modules on the sampler's stream (False: each FP module searches on the main stream)
 NN_PLANS = {}       # (points ptr, centres ptr) -> (points, centres, idx, w, event): both tensors are held, so a key cannot alias
@@ -142,7 +143,9 @@ def plan_sampling_chain(sa_layers, coords):
     key = (coords.device, cur.cuda_stream)  # one sampler stream per main stream: concurrent lanes do not queue behind each other
     side = _side_streams.get(key)
     if side is None:
-        side = _side_streams[key] = torch.cuda.Stream(device=coords.device)
+        # high priority: the sampler chain is the long pole of the step's first 0.8 ms, and its short kernels (ball query, 3-NN, plans)
+        # otherwise queue behind whatever the main stream has in flight when a CU frees up
+        side = _side_streams[key] = torch.cuda.Stream(device=coords.device, priority=SIDE_STREAM_PRIORITY)
     tape.wait_stream(side, cur)
     first = sa_layers[0][-1] if isinstance(sa_layers[0], nn.Sequential) else sa_layers[0]
     with torch.cuda.stream(side):
