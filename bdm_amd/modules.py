@@ -533,11 +533,16 @@ class PointNetSAModule(nn.Module):
         if planned is not None and callable(planned[0]):  # deferred rest of the sampler chain (pvcnn.plan_sampling_chain)
             planned = planned[0]() if planned[1] is coords else None
             self._planned = None
+            if planned is None:
+                self._more = None
         # a plan is valid for the very coordinate tensor it was computed from (a forward that aborted midway, or
         # sa_layers shared between networks, must never leave a plan behind for other coordinates)
         if planned is not None and planned[3] is coords:
             centers_coords, idx, event, _ = planned
             tape.wait_event(event)  # the current stream waits for the side stream's sampler
+            more, self._more = getattr(self, "_more", None), None
+            if more is not None:    # the rest of the sampler chain goes to the side stream AFTER this wait is queued (pvcnn.plan_sampling_chain)
+                more()
         else:
             centers_coords, idx = self.plan(coords)
         grouped, g_t = self.groupers[0](coords, centers_coords, temb, features, neighbor_indices=idx)

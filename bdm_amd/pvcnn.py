@@ -120,12 +120,13 @@ def embed_time(embedf, t, embed_dim, n):
 
 _side_streams = {}
 SIDE_STREAM = os.environ.get("BDM_SIDE_STREAM", "1") == "1"  # sampler chain on its own stream (0: inline, for experiments)
-SIDE_PLAN = True  # voxel plans of levels 1.. on the sampler's side stream (tools/coresidency/two_proc_race.py flips it)
+# voxel plans of levels 1.. on the sampler's side stream (tools/coresidency/two_proc_race.py flips it)
+SIDE_PLAN = os.environ.get("BDM_SIDE_PLAN", "1") == "1"
 # B * N below which the sampler chain stays on the main stream.  0: always on its own stream -- since the launch count and the
 # per-launch host cost came down it pays even for one small shape (B=1, N=1024: 3.48 -> 3.30 ms; B=4: 3.86 -> 3.42 ms), where
 # furthest point sampling is a fifth of the forward.  (The PVConv point branch keeps its 8192-point threshold: measured slower below.)
 SIDE_STREAM_MIN_POINTS = 0
-SIDE_STREAM_PRIORITY = int(os.environ.get("BDM_SIDE_PRIORITY", "-1"))  # torch: lower = higher priority (0 = default)
+SIDE_STREAM_PRIORITY = int(os.environ.get("BDM_SIDE_PRIORITY", "0"))  # torch: lower = higher priority; -1 measured no different (5.52 vs 5.53 ms per step)
 DEFER_CHAIN = True  # levels 1.. of the sampler chain enqueued when the first SA module is reached
 SIDE_NN = True      # 3-NN searches of the FP modules on the sampler's stream (False: each FP module searches on the main stream)
 NN_PLANS = {}       # (points ptr, centres ptr) -> (points, centres, idx, w, event): both tensors are held, so a key cannot alias
@@ -143,8 +144,7 @@ def plan_sampling_chain(sa_layers, coords):
     key = (coords.device, cur.cuda_stream)  # one sampler stream per main stream: concurrent lanes do not queue behind each other
     side = _side_streams.get(key)
     if side is None:
-        # high priority: the sampler chain is the long pole of the step's first 0.8 ms, and its short kernels (ball query, 3-NN, plans)
-        # otherwise queue behind whatever the main stream has in flight when a CU frees up
+        # (priority: see SIDE_STREAM_PRIORITY)
         side = _side_streams[key] = torch.cuda.Stream(device=coords.device, priority=SIDE_STREAM_PRIORITY)
     tape.wait_stream(side, cur)
     first = sa_layers[0][-1] if isinstance(sa_layers[0], nn.Sequential) else sa_layers[0]
@@ -152,43 +152,58 @@ def plan_sampling_chain(sa_layers, coords):
         c0 = coords.contiguous()
         centers0 = first.sample(c0)
 
-    def rest():
+    def level(li, c, centers):
+        """ball query of level li (+ its sampler for li > 0) and the next level's voxel plan, on the side stream; -> its centres"""
+        sa = sa_layers[li][-1] if isinstance(sa_layers[li], nn.Sequential) else sa_layers[li]
+        if li > 0:
+            centers = sa.sample(c)
+        idx = sa.query(c, centers)
+        ev = torch.cuda.Event()
+        tape.record_event(ev, side)
+        sa._planned = (centers, idx, ev, c if li > 0 else coords)
+        # the voxel plan of the NEXT level's PVConvs (sort of the centres into cells, occupied-cell lists) is geometry
+        # too: one single-workgroup-per-shape kernel that would otherwise sit on the main stream's critical path
+        nxt = sa_layers[li + 1] if li + 1 < len(sa_layers) else None
+        pv = nxt[0] if isinstance(nxt, nn.Sequential) and hasattr(nxt[0], "voxel_plan_args") else None
+        args = pv.voxel_plan_args() if (pv is not None and SIDE_PLAN) else None
+        if args is not None:
+            plan = ops.voxel_plan(centers, *args, dilate=2 if pv.wants_compact_tail(centers.shape[0], centers.shape[2]) else
+                                  (1 if pv.wants_dilated_plan(centers.shape[0], centers.shape[2]) else 0))
+            plan.ready = torch.cuda.Event()
+            tape.record_event(plan.ready, side)
+        return centers
+
+    def remaining(c):
         with torch.cuda.stream(side):
-            c, centers = c0, centers0
-            for li, blocks in enumerate(sa_layers):
-                sa = blocks[-1] if isinstance(blocks, nn.Sequential) else blocks
-                if li > 0:
-                    centers = sa.sample(c)
-                idx = sa.query(c, centers)
-                ev = torch.cuda.Event()
-                tape.record_event(ev, side)
-                sa._planned = (centers, idx, ev, c if li > 0 else coords)
-                c = centers
-                # the voxel plan of the NEXT level's PVConvs (sort of the centres into cells, occupied-cell lists) is geometry
-                # too: one single-workgroup-per-shape kernel that would otherwise sit on the main stream's critical path
-                nxt = sa_layers[li + 1] if li + 1 < len(sa_layers) else None
-                pv = nxt[0] if isinstance(nxt, nn.Sequential) and hasattr(nxt[0], "voxel_plan_args") else None
-                args = pv.voxel_plan_args() if (pv is not None and SIDE_PLAN) else None
-                if args is not None:
-                    plan = ops.voxel_plan(c, *args, dilate=2 if pv.wants_compact_tail(c.shape[0], c.shape[2]) else
-                                          (1 if pv.wants_dilated_plan(c.shape[0], c.shape[2]) else 0))
-                    plan.ready = torch.cuda.Event()
-                    tape.record_event(plan.ready, side)
+            cents = [c]
+            for li in range(1, len(sa_layers)):
+                c = level(li, c, None)
+                cents.append(c)
             # the 3-NN searches of the feature-propagation modules are geometry too (level i's points against level i + 1's
             # centres): four launches that leave the main stream's critical path; an FP module finds its pair in NN_PLANS
             if SIDE_NN:
-                chain = [c0] + [(b[-1] if isinstance(b, nn.Sequential) else b)._planned[0] for b in sa_layers]
+                chain = [c0] + cents
                 for pts, ctr in zip(chain[:-1], chain[1:]):
                     idx, w = ops.three_nn_search(pts, ctr)
                     ev = torch.cuda.Event()
                     tape.record_event(ev, side)
                     NN_PLANS[(pts.data_ptr(), ctr.data_ptr())] = (pts, ctr, idx, w, ev)
+
+    def rest():
+        # Level 0's ball query first; the REST of the chain is enqueued by the SA module after the main stream's wait on level 0's
+        # event is in its queue (first._more).  With the whole chain enqueued before that wait, the replayed step's main queue resumed
+        # ~160 us after the ball query had finished -- when the side queue reached its third sampler (profiles/r04_replayed_steps.txt).
+        with torch.cuda.stream(side):
+            c1 = level(0, c0, centers0)
+        first._more = lambda: remaining(c1)
         return first._planned
 
     if DEFER_CHAIN:
         first._planned = (rest, coords)
     else:
         rest()
+        more, first._more = first._more, None
+        more()
 
 
 def encode(sa_layers, global_att, inputs, t_emb):
@@ -198,6 +213,7 @@ def encode(sa_layers, global_att, inputs, t_emb):
     NN_PLANS.clear()
     for blocks in sa_layers:  # sampler plans too: never inherit one from an aborted or foreign forward
         (blocks[-1] if isinstance(blocks, nn.Sequential) else blocks)._planned = None
+        (blocks[-1] if isinstance(blocks, nn.Sequential) else blocks)._more = None
     # also inside a hipGraph capture: the side stream forks from and joins the capturing stream.  Small problems (one
     # small shape) are bound by kernel-to-kernel dispatch latency, where the extra events cost more than the overlap gains
     if coords.is_cuda and SIDE_STREAM and coords.shape[0] * coords.shape[2] >= SIDE_STREAM_MIN_POINTS:

@@ -79,7 +79,8 @@ def test_c3_mini_merging_batch16(hip, oracle_ops):
 def _forward_case(cls, B, N, extra, seed, row, monkeypatch):
     """-> (batch output, oracle output of shape `row`, that shape alone with the batch's kernel choice, alone with the default choice).
     The first convolution's FORM is picked per layer from (batch, points, resolution, channels) (ops.sparse_dil_pays: compact
-    output-stationary kernel for a batch that fills the chip with tiles, GEMM + gather below that), so a shape run alone takes the
+    output-stationary kernel for a batch that fills the chip with tiles, GEMM + gather below that; likewise ops.compact_tail_pays for the
+    rest of the voxel branch), so a shape run alone takes the
     other form on some layers -- same products, another fp32 summation order.  The batch-invariance property (no batch-dependent
     BUG: grid.z = B, workspace sizing, tile choices) is therefore tested with the form pinned to what the batch uses; the default
     choice at B = 1 is held to the forward tolerance class instead."""
@@ -94,8 +95,9 @@ def _forward_case(cls, B, N, extra, seed, row, monkeypatch):
     got = net(x.cuda(), t.cuda()).cpu()
     alone_default = net(x[row:row + 1].contiguous().cuda(), t[row:row + 1].cuda()).cpu()
     from bdm_amd import ops
-    pays = ops.sparse_dil_pays
-    monkeypatch.setattr(ops, "sparse_dil_pays", lambda b, n, r, c: pays(B, n, r, c))   # the batch's choice, whatever the batch
+    pays, tail = ops.sparse_dil_pays, ops.compact_tail_pays
+    monkeypatch.setattr(ops, "sparse_dil_pays", lambda b, n, r, c: pays(B, n, r, c))   # the batch's choices, whatever the batch
+    monkeypatch.setattr(ops, "compact_tail_pays", lambda b, n, r, c: tail(B, n, r, c))
     alone = net(x[row:row + 1].contiguous().cuda(), t[row:row + 1].cuda()).cpu()
     monkeypatch.undo()
     return got, ref, alone, alone_default

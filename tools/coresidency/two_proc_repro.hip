@@ -312,16 +312,28 @@ struct SparseSetup {
     float *scale_ws = dev_alloc<float>(cout);
     ABI_OK(bdm_conv3d_h2_pack_weights(cout, C, w, wh2, scale_ws, inv_scale, nullptr));
     ABI_OK(bdm_sparse_voxel_features_f32(B, C, n, r, n_max, feat, (long long)C * n, n, cnt, ws, occ_list, n_occ, xr, amax, nullptr));
+    const int tiles = bdm_voxel_dilate_slices(r);
+    dil_list = dev_alloc<int>((size_t)B * r3); dil_index = dev_alloc<int>((size_t)B * r3);
+    int *plane_start = dev_alloc<int>((size_t)B * (r + 2));
+    tile_start = dev_alloc<int>((size_t)B * tiles * 8); counter = dev_alloc<int>(1);
+    yc = dev_alloc<float>((size_t)B * r3 * cout);
+    ABI_OK(bdm_voxel_dilate(B, r, r3, cnt, dil_list, dil_index, plane_start, tile_start, nullptr));
     conv_os();
     HIP_OK(hipDeviceSynchronize());
   }
-  float *xr, *amax, *inv_scale;
-  void *wh2;
-  // round 4: the output-stationary first convolution (sparse_conv_os.hip) -- the kernel that replaced GEMM + gather in the default forward
-  void conv_os() { ABI_OK(bdm_sparse_conv_os(B, C, cout, r, n_max, xr, amax, occ_index, wh2, inv_scale, nullptr, out, (void *)g_agg_stream)); }
   void features() { ABI_OK(bdm_sparse_voxel_features_s3(B, C, n, r, n_max, feat, (long long)C * n, n, cnt, ws, occ_list, n_occ, xs, (void *)g_agg_stream)); }
   void gemm() { ABI_OK(bdm_sparse_conv_gemm_s3(B, n_max, C, 27 * cout, xs, wpk, n_occ, y, (void *)g_agg_stream)); }
   void gather() { ABI_OK(bdm_sparse_conv_gather(B, cout, r, n_max, y, occ_index, rowocc, nullptr, out, (void *)g_agg_stream)); }
+  float *xr, *amax, *inv_scale, *yc;
+  int *dil_list, *dil_index, *tile_start, *counter;
+  void *wh2;
+  // round 4: the compact output-stationary first convolution (sparse_conv_os.hip) -- the kernel that replaced GEMM + gather at the
+  // 32^3 / 16^3 levels of the default forward (persistent workgroups: its work counter is zeroed before every launch)
+  void conv_os() {
+    HIP_OK(hipMemsetAsync(counter, 0, sizeof(int), g_agg_stream));
+    ABI_OK(bdm_sparse_conv_dil(B, C, cout, r, n_max, r * r * r, xr, amax, occ_index, dil_list, dil_index, tile_start, wh2, inv_scale, nullptr, yc, 1,
+                               counter, (void *)g_agg_stream));
+  }
 };
 
 // usage: two_proc_repro --aggress <kind> <seconds>   kind: lds128k | lds32k | copy | f64div | f32div | features | gemm_s3 | gather |

@@ -7,6 +7,10 @@ from bdm_amd.data import SyntheticShapes
 from bdm_amd.model import get_model
 from bdm_amd.utils.procedural import fill_module_
 B, N = int(os.environ.get("TB", 16)), int(os.environ.get("TN", 4096))
+from bdm_amd import pvcnn as _pv
+for _k in ("SIDE_PLAN", "SIDE_NN", "DEFER_CHAIN"):          # experiments: TRACE_SIDE_PLAN=0 etc.
+    if os.environ.get("TRACE_" + _k) is not None:
+        setattr(_pv, _k, os.environ["TRACE_" + _k] == "1")
 cfg = ProjectConfig(); cfg.dataset.max_points = N
 model = fill_module_(get_model(cfg).eval(), seed=1).cuda()
 b = next(iter(SyntheticShapes(range(B), B, num_points=N))).to("cuda")
