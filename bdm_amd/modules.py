@@ -510,6 +510,9 @@ class PointNetSAModule(nn.Module):
         self.groupers = nn.ModuleList(groupers)
         self.mlps = nn.ModuleList(mlps)
 
+    # grouped MLP by recomputation where bdm_sa_mlp2_fused covers it (the first level); the equality tests flip it
+    fuse_mlp = os.environ.get("BDM_SA_FUSED", "1") != "0"
+
     def plan(self, coords):
         """Geometry-only part of the module (furthest point sampling + ball query): depends on the coordinates
         alone, so the denoiser's encoder runs it for all levels on a side stream while the first PVConvs compute."""
@@ -545,6 +548,12 @@ class PointNetSAModule(nn.Module):
                 more()
         else:
             centers_coords, idx = self.plan(coords)
+        if (self.fuse_mlp and coords.is_cuda and features is not None and ops.is_point_invariant(temb)
+                and ops.sa_mlp2_fusable(self.mlps[0], features.shape[1], idx.shape[2])):
+            # first level: grouping, both MLP layers and the max in three recompute passes over the packed points -- neither the
+            # grouped tensor nor a layer's output is written (sa_mlp_fused.hip)
+            out = ops.sa_mlp2_fused(coords, centers_coords.contiguous(), features, idx, self.mlps[0])
+            return out, centers_coords, temb[:, :, :1].expand(-1, -1, self.num_centers)
         grouped, g_t = self.groupers[0](coords, centers_coords, temb, features, neighbor_indices=idx)
         h, pending = self.mlps[0].run(grouped, fold_last=True)
         out = ops.max_over_neighbors(h, fold=pending)

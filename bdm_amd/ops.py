@@ -222,6 +222,37 @@ def sa_group(coords, centers, features, indices, point_major=None):
     return out
 
 
+def sa_mlp2_fusable(mlp, c_in, u):
+    """Does bdm_sa_mlp2_fused cover this SharedMLP (3 + c_in inputs, 1 <= c_in <= 32, -> 32 -> 64 channels, GroupNorm(8), 32 neighbours)?"""
+    layers = mlp.layers
+    if len(layers) != 6 or u != 32 or not 1 <= c_in <= 32:
+        return False
+    (c1, g1), (c2, g2) = (layers[0], layers[1]), (layers[3], layers[4])
+    return (c1.out_channels == 32 and c2.out_channels == 64 and c1.in_channels == c_in + 3 and g1.num_groups == 8 and g2.num_groups == 8
+            and c1.bias is not None and c2.bias is not None)
+
+
+def sa_mlp2_fused(coords, centers, features, indices, mlp):
+    """max over neighbours of SharedMLP(cat[grouping(coords) - centers, grouping(features)]) -> (B, 64, M), nothing of size M x U in
+    memory (bdm_sa_mlp2_fused: three recompute passes; pointnet.py:80-90 at the first level)."""
+    B, _, n = coords.shape
+    m, u = indices.shape[1], indices.shape[2]
+    f, _, C, _, bs_f, ld_f = _bcl(features)
+    dev = coords.device
+    c1, g1, c2, g2 = mlp.layers[0], mlp.layers[1], mlp.layers[3], mlp.layers[4]
+    rows = workspace(L.lib().bdm_sa_mlp2_fused_rows_bytes(B, C, n), dev, "sa_rows")
+    S = L.lib().bdm_sa_mlp2_fused_slices(B, m)
+    partial = torch.empty(2, B, 8, S, 2, dtype=torch.float64, device=dev)
+    out = torch.empty(B, c2.out_channels, m, dtype=torch.float32, device=dev)
+    _, _, _, _, bs_o, ld_o = _bcl(out)
+    L.check(L.lib().bdm_sa_mlp2_fused(B, C, n, m, u, c1.out_channels, c2.out_channels, L.ptr(coords), L.ptr(f), L.c_ll(bs_f), ld_f,
+                                      L.ptr(centers), L.ptr(indices), L.ptr(c1.weight), L.ptr(c1.bias), L.ptr(g1.weight), L.ptr(g1.bias),
+                                      L.c_float(g1.eps), L.ptr(c2.weight), L.ptr(c2.bias), L.ptr(g2.weight), L.ptr(g2.bias),
+                                      L.c_float(g2.eps), 8, L.ptr(rows), L.ptr(partial[0]), L.ptr(partial[1]), L.ptr(out), L.c_ll(bs_o),
+                                      ld_o, L.stream()), "sa_mlp2_fused")
+    return out
+
+
 def broadcast_rows(v, l, out=None):
     """v (B,C) -> (B,C,l) materialised (or written into the view `out`)."""
     B, C = v.shape

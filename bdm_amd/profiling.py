@@ -129,6 +129,10 @@ SPEC = {
                        lambda a: ("valu", 1.0 * a[0] * a[1] * a[2], VALU_TESTS_PEAK, "G tests/s")),
     "bdm_sa_group": ("grouping gather + max over neighbours", lambda a: a[:5],
                      lambda a: ("hbm", 4.0 * a[0] * ((3 + a[1]) * a[2] + a[3] * a[4] + (a[1] + 3) * a[3] * a[4]))),
+    # fused first set-abstraction MLP: algorithmic flops = the two layers ONCE (the three passes recompute: 3x layer 1, 2x layer 2);
+    # algorithmic bytes would be the features + indices + output only, so the class is priced as a GEMM
+    "bdm_sa_mlp2_fused": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:7],
+                          lambda a: ("mfma", 2.0 * a[0] * a[3] * a[4] * ((3 + a[1]) * a[5] + a[5] * a[6]), MFMA32_PEAK_TFLOPS)),
     "bdm_grouping_forward": ("grouping gather + max over neighbours", lambda a: a[:5],
                              lambda a: ("hbm", 4.0 * a[0] * (a[1] * a[2] + a[3] * a[4] + a[1] * a[3] * a[4]))),
     "bdm_max_over_neighbors": ("grouping gather + max over neighbours", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * a[1] * a[2] * (a[3] + 1))),

@@ -209,7 +209,22 @@ int bdm_sa_group(int b, int c, int n, int m, int u, const float *coords, const f
                  const float *features, long long bs_f, int ld_f, const int *indices, float *out,
                  void *workspace, void *stream);
 
-/* y[b][ci][:] = v[b][ci]   -- t_emb[:, :, None].expand(-1, -1, N) (pvcnn.py:88) written into a concat slice. */
+/* PointNetSAModule.forward (modules/pointnet.py:80-90) at the first level, WITHOUT the grouped tensor or either layer's output in
+ * memory: grouping ([xyz - centre ; features], 1 <= c <= 32 feature rows), two SharedMLP layers (shared_mlp.py:11-37: Conv2d k=1 ->
+ * GroupNorm(8) -> Swish; widths m1 = 32, m2 = 64), max over the u = 32 neighbours -> out (b, m2, m).  Four launches: the features
+ * repacked point-major into `rows` (bdm_sa_mlp2_fused_rows_bytes(b, c, n) bytes, 16-byte aligned), then three passes that each
+ * re-gather the neighbours' rows and recompute what they need (pass 1: GroupNorm-1 statistics; pass 2: GroupNorm-2 statistics;
+ * pass 3: the output).  w1 (m1, 3 + c), w2 (m2, m1) as the convolutions hold them.  partial1 / partial2: fp64 scratch,
+ * b * 8 * bdm_sa_mlp2_fused_slices(b, m) * 2 elements each.  Deterministic. */
+size_t bdm_sa_mlp2_fused_rows_bytes(int b, int c, int n);
+int bdm_sa_mlp2_fused_slices(int b, int m);
+int bdm_sa_mlp2_fused(int b, int c, int n, int m, int u, int m1, int m2, const float *coords, const float *features,
+                      long long bs_f, int ld_f, const float *centers, const int *indices, const float *w1, const float *b1,
+                      const float *g1w, const float *g1b, float eps1, const float *w2, const float *b2, const float *g2w,
+                      const float *g2b, float eps2, int groups, void *rows, void *partial1, void *partial2, float *out,
+                      long long bs_o, int ld_o, void *stream);
+
+/* y[b][ci][:] = v[b][ci]  -- t_emb[:, :, None].expand(-1, -1, N) (pvcnn.py:88) written into a concat slice. */
 int bdm_broadcast_rows(int b, int c, int l, const float *v, int ld_v, float *y, long long bs_y,
                        int ld_y, void *stream);
 /* strided row copy (building torch.cat operands in place) */
