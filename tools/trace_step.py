@@ -11,6 +11,9 @@ from bdm_amd import pvcnn as _pv
 for _k in ("SIDE_PLAN", "SIDE_NN", "DEFER_CHAIN"):          # experiments: TRACE_SIDE_PLAN=0 etc.
     if os.environ.get("TRACE_" + _k) is not None:
         setattr(_pv, _k, os.environ["TRACE_" + _k] == "1")
+if os.environ.get("TRACE_NO_WAIT") == "1":   # UNSAFE (stale inputs, timing experiment only): the main stream never waits for the side streams
+    from bdm_amd import tape as _tape
+    _tape.wait_event = lambda event: None
 cfg = ProjectConfig(); cfg.dataset.max_points = N
 model = fill_module_(get_model(cfg).eval(), seed=1).cuda()
 b = next(iter(SyntheticShapes(range(B), B, num_points=N))).to("cuda")
