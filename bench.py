@@ -334,7 +334,7 @@ def main():
             head = top_rows[0]
             traffic, traffic_commit = None, None
             try:  # HBM bytes per launch of that kernel from the committed PMC pass (separate rocprofv3 --pmc runs)
-                pm_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(p))
+                pm_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(p))
                 pm = json.load(open(pm_path))
                 key = f"{head['function']}{tuple(head['shape'])}"
                 ent = (pm["kernels"].get(key) or pm["kernels"].get(key.replace("_h2_gn(", "_h2("))  # same kernels + GN epilogue
@@ -365,6 +365,27 @@ def main():
                 return next((r for r in rows if r["function"] == fn and pred(r["shape"])), None)
             bq = _row("bdm_ball_query", lambda sh: sh[1] == args.points and sh[2] == 1024)
             sg = _row("bdm_sa_group", lambda sh: sh[2] == args.points and sh[3] == 1024)
+            fused = _row("bdm_sa_mlp2_fused", lambda sh: sh[2] == args.points and sh[3] == 1024)
+            in_path = sg is not None
+            if bq and sg is None and fused is not None:
+                # round 4: the first level's grouped MLP re-gathers the neighbours' rows inside its three passes (bdm_sa_mlp2_fused), so
+                # the standalone gather no longer runs there.  It still ships (levels 1-3, and level 0 with BDM_SA_FUSED=0): timed here
+                # OUTSIDE the timed region on the level-0 shape, 20 launches between two events on the launching stream.
+                b_, c_, n_, m_, u_ = fused["shape"][:5]
+                gq = torch.Generator().manual_seed(1)
+                pts_ = (torch.rand(b_, 3, n_, generator=gq) - 0.5).to(device)
+                fts_ = torch.randn(b_, c_, n_, generator=gq).to(device)
+                cen_ = BF.furthest_point_sample(pts_, m_)
+                idx_ = BF.ball_query(cen_, pts_, 0.1, u_)
+                for _ in range(3):
+                    bops.sa_group(pts_, cen_, fts_, idx_)
+                e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0_.record()
+                for _ in range(20):
+                    bops.sa_group(pts_, cen_, fts_, idx_)
+                e1_.record()
+                torch.cuda.synchronize()
+                sg = {"shape": (b_, c_, n_, m_, u_), "avg_us": e0_.elapsed_time(e1_) / 20 * 1e3}
             if bq and sg:
                 b_, c_, n_, m_, u_ = sg["shape"][:5]
                 gather_bytes = 4.0 * b_ * ((3 + c_) * n_ + m_ * u_ + (c_ + 3) * m_ * u_)
@@ -372,7 +393,7 @@ def main():
                 tests = 1.0 * b_ * m_ * n_
                 line["g1_ball_query_and_grouping"] = {
                     "level": f"SA0: {b_} x {n_} points -> {m_} centres x {u_} neighbours, {c_} feature channels",
-                    "grouping_gather": {"kernel": f"bdm_sa_group{tuple(sg['shape'])}", "avg_us": round(sg["avg_us"], 2),
+                    "grouping_gather": {"kernel": f"bdm_sa_group{tuple(sg['shape'])}", "avg_us": round(sg["avg_us"], 2), "in_timed_path": in_path,
                                         "algorithmic_mb": round(gather_bytes / 2 ** 20, 1), "achieved_gbs": round(gather_bytes / sg["avg_us"] / 1e3, 1),
                                         "hbm_frac": round(gather_bytes / sg["avg_us"] / 1e3 / profiling.HBM_PEAK_GBS, 3)},
                     "ball_query": {"kernel": f"bdm_ball_query{tuple(bq['shape'])}", "avg_us": round(bq["avg_us"], 2),
@@ -382,6 +403,17 @@ def main():
                     "pair_hbm_frac": round((gather_bytes + query_bytes - 4.0 * b_ * m_ * u_) / (sg["avg_us"] + bq["avg_us"]) / 1e3 / profiling.HBM_PEAK_GBS, 3),
                     "note": "the query is bound by VALU issue (6.7 instructions per distance test), not by its 3 MB of traffic; the gather meets "
                             "the 40 % target on its own, the pair cannot by memory tuning (DESIGN.md 7.6)"}
+                if fused is not None:
+                    fb_, fc_, fn_, fm_, fu_, f1_, f2_ = fused["shape"][:7]
+                    flops_ = 2.0 * fb_ * fm_ * fu_ * ((3 + fc_) * f1_ + f1_ * f2_)
+                    line["g1_ball_query_and_grouping"]["fused_grouped_mlp"] = {
+                        "kernel": f"bdm_sa_mlp2_fused{tuple(fused['shape'])}", "avg_us": round(fused["avg_us"], 2),
+                        "algorithmic_gflop": round(flops_ / 1e9, 2), "achieved_tflops": round(flops_ / fused["avg_us"] / 1e6, 1),
+                        "fp32_mfma_frac": round(flops_ / fused["avg_us"] / 1e6 / FP32_MFMA_PEAK_TFLOPS, 3),
+                        "bytes_not_moved_mb": round(4.0 * fb_ * fm_ * fu_ * (2 * (3 + fc_) + 2 * f1_ + f2_) / 2 ** 20, 1),
+                        "note": "grouping + 2-layer SharedMLP + max over neighbours in four launches (row repack + three recompute passes): the "
+                                "grouped tensor and both layer outputs (bytes_not_moved_mb: each written once and read once by the operator chain) "
+                                "never exist; replaces sa_group + two 1x1 GEMMs + the folded max at this level (204 -> 112 us at B = 16)"}
         # whole-path view: algorithmic FLOPs of SURVEY.md 8d per trajectory
         tflop_per_shape = (pc2_f * 103.64 + pvd_f * 81.22) / 1e3 if args.points == 4096 and not merging else None
         if tflop_per_shape:

@@ -1,9 +1,14 @@
-import sys, time, torch
+"""C1 (one shape, N = 1024, 100 steps) wall time, six runs.  C1_SE_IN_DEVOX=1: SE block's FC layers inside the devoxelisation kernel
+(one launch less per PVConv).  python tools/c1_ab.py"""
+import os, sys, time, torch
 sys.path.insert(0, '.')
 from bdm_amd.config import ProjectConfig
 from bdm_amd.data import SyntheticShapes
 from bdm_amd.model import get_model
 from bdm_amd.utils.procedural import fill_module_
+from bdm_amd import modules as _m
+if os.environ.get("C1_SE_IN_DEVOX") == "1":
+    _m.PVConv.se_in_devox = True
 dev = torch.device("cuda", 0)
 cfg = ProjectConfig(); cfg.dataset.max_points = 1024
 model = fill_module_(get_model(cfg).eval(), seed=11).to(dev)
