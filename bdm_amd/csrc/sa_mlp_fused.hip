@@ -23,15 +23,31 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
 
-// 32 lanes per group add slices l, l + 32, ... and butterfly; 8 groups per 256 threads (G <= 8 here)
+// GroupNorm statistics are summed along ONE binary tree over the centres (padded with zeros to a power of two), whatever the launch's
+// centres-per-wave: a centre's value is a fixed-order fp32 sum (registers, then lanes); centres -> wave -> workgroup (= slice) ->
+// shape are pairwise fp64 sums in tree order.  A shape's statistics therefore do not depend on the batch it is sampled in (the
+// centres-per-wave follow the batch size).  Here: the slices' part of the tree -- lane l of a group's 32 holds the aligned block
+// [l P / 32, (l + 1) P / 32) of the P = 2^k >= S slices (in-lane tree over <= 8 values), then the lanes pair up (xor 1, 2, 4, 8, 16).
 __device__ __forceinline__ void group_stats8(const double *__restrict__ partial, int bi, int G, int S, double count, float eps,
                                              float *s_mean, float *s_rstd) {
   const int tid = threadIdx.x, l = tid & 31, g = tid >> 5;
-  double a = 0.0, q = 0.0;
-  if (g < G) {
-    const double *pp = partial + ((size_t)bi * G + g) * S * 2;
-    for (int sl = l; sl < S; sl += 32) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
+  int P = 32;
+  while (P < S) P <<= 1;
+  const int per = P >> 5;   // 1, 2, 4 or 8 (S <= 256)
+  double va[8], vq[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int sl = l * per + i;
+    const bool ok = g < G && i < per && sl < S;
+    const double *pp = partial + (((size_t)bi * G + (ok ? g : 0)) * S + (ok ? sl : 0)) * 2;
+    va[i] = ok ? pp[0] : 0.0;
+    vq[i] = ok ? pp[1] : 0.0;
   }
+#pragma unroll
+  for (int span = 1; span < 8; span <<= 1)
+#pragma unroll
+    for (int i = 0; i + span < 8; i += 2 * span) { va[i] += va[i + span]; vq[i] += vq[i + span]; }
+  double a = va[0], q = vq[0];
 #pragma unroll
   for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
   if (l == 0 && g < G) {
@@ -67,7 +83,7 @@ struct SaTile {
 };
 
 template <int PASS, int TPW>
-__global__ __launch_bounds__(256) void sa_mlp2_kernel(int c, int n, int m, int nb, const float *__restrict__ rows,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void sa_mlp2_kernel(int c, int n, int m, int nb, const float *__restrict__ rows,
                                                       const float *__restrict__ coords, const float *__restrict__ centers,
                                                       const int *__restrict__ idx, const float *__restrict__ w1,
                                                       const float *__restrict__ b1, const float *__restrict__ g1w,
@@ -78,7 +94,7 @@ __global__ __launch_bounds__(256) void sa_mlp2_kernel(int c, int n, int m, int n
                                                       int ld_o) {
   __shared__ float s_mean[8], s_rstd[8];
   __shared__ float s_a1[32], s_c1[32];
-  __shared__ float s_red[4][8][2];
+  __shared__ double s_red[4][8][2];
   __shared__ float s_out[PASS == 3 ? 64 : 1][4 * TPW + 1];
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,12 +162,12 @@ __global__ __launch_bounds__(256) void sa_mlp2_kernel(int c, int n, int m, int n
     }
   }
   // per register r of a layer-1 tile: channel kr = (r & 3) + 8 (r >> 2) + 4 lh
-  float k_a[16], k_b[16];          // pass 1: (b1, unused); passes 2, 3: GroupNorm-1 (scale, shift)
+  float k_a[16], k_b[16];          // passes 2, 3: GroupNorm-1 (scale, shift)
   float wb[PASS >= 2 ? 2 : 1][16];  // layer-2 weights as the B operand: column = channel li + 32 mt, k = kr
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int ch = (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (PASS == 1) { k_a[r] = b1[ch]; k_b[r] = 0.f; }
+    if (PASS == 1) { k_a[r] = 0.f; k_b[r] = 0.f; }
     else { k_a[r] = s_a1[ch]; k_b[r] = s_c1[ch]; }
   }
   if (PASS >= 2) {
@@ -165,7 +181,20 @@ __global__ __launch_bounds__(256) void sa_mlp2_kernel(int c, int n, int m, int n
   }
   const float bias2[2] = {PASS == 2 ? b2[li] : 0.f, PASS == 2 ? b2[32 + li] : 0.f};
 
-  float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};   // pass 1: per register quad; pass 2: [mt] in slots 0, 1
+  // per centre of this wave: the statistics of ITS 32 columns (pass 1: group li / 4 in every lane; pass 2: groups li / 8 and 4 + li / 8)
+  // (each centre's value is an fp32 sum in a fixed order; fp64 from there on.)  The tree is built as the centres arrive: lvl[k] holds
+  // the finished LEFT subtree of 2^k centres until its right sibling is complete (a binary counter; t is a compile-time constant).
+  constexpr int NLVL = TPW >= 8 ? 4 : (TPW >= 4 ? 3 : (TPW >= 2 ? 2 : 1));
+  double lvl_s[NLVL][2], lvl_q[NLVL][2];
+  auto tree_push = [&](int t, int v, float sv, float qv) {
+    double a = (double)sv, q = (double)qv;
+#pragma unroll
+    for (int k = 0; k < NLVL - 1; ++k)
+      if ((t >> k) & 1) { a = lvl_s[k][v] + a; q = lvl_q[k][v] + q; }
+      else { lvl_s[k][v] = a; lvl_q[k][v] = q; return; }
+    lvl_s[NLVL - 1][v] = a; lvl_q[NLVL - 1][v] = q;
+  };
+  const float bias1 = PASS == 1 ? b1[li] : 0.f;
 
   auto compute = [&](const SaTile &x, int t) {
     const int j = j0 + t;
@@ -173,6 +202,26 @@ __global__ __launch_bounds__(256) void sa_mlp2_kernel(int c, int n, int m, int n
     f32x16 acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+    if (PASS == 1) {
+      // statistics only: the operands SWAPPED, C1^T[neighbour][channel] -- a channel's 32 neighbours are then 16 registers of two lanes
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.px - x.qx, wc0, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.py - x.qy, wc1, acc1, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < SA_Q; ++q) {
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.f[q].x, wa[q][0], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.f[q].y, wa[q][1], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.f[q].z, wa[q][2], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.f[q].w, wa[q][3], acc1, 0, 0, 0);
+      }
+      float sv = 0.f, qv = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float v = acc1[r] + bias1; sv += v; qv = __builtin_fmaf(v, v, qv); }
+      sv += __shfl_xor(sv, 32, 64); qv += __shfl_xor(qv, 32, 64);   // the other 16 neighbours
+#pragma unroll
+      for (int o = 1; o < 4; o <<= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }   // the group's 4 channels
+      tree_push(t, 0, live ? sv : 0.f, live ? qv : 0.f);
+      return;
+    }
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc0, x.px - x.qx, acc1, 0, 0, 0);   // lh = 0: dx, lh = 1: dz
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc1, x.py - x.qy, acc1, 0, 0, 0);   // lh = 0: dy, lh = 1: weight 0
 #pragma unroll
@@ -183,13 +232,6 @@ __global__ __launch_bounds__(256) void sa_mlp2_kernel(int c, int n, int m, int n
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[q][3], x.f[q].w, acc1, 0, 0, 0);
       }
     // C layout: register r of lane (li, lh) = channel (r & 3) + 8 (r >> 2) + 4 lh, neighbour li
-    if (PASS == 1) {
-      // GroupNorm-1 partials of y1 = acc + b1: group = 4 consecutive channels = register quad qd of half-wave lh -> group 2 qd + lh
-      if (live)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const float v = acc1[r] + k_a[r]; st_s[r >> 2] += v; st_q[r >> 2] = __builtin_fmaf(v, v, st_q[r >> 2]); }
-      return;
-    }
     // a1 = Swish(GN1(y1)) in place: the A operand of layer 2
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = swishf(__builtin_fmaf(acc1[r], k_a[r], k_b[r]));
@@ -204,11 +246,16 @@ __global__ __launch_bounds__(256) void sa_mlp2_kernel(int c, int n, int m, int n
       for (int mt = 0; mt < 2; ++mt) acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc1[r], wb[PASS >= 2 ? mt : 0][r], acc2[mt], 0, 0, 0);
     // C2 layout: register r of lane (li, lh) = neighbour (r & 3) + 8 (r >> 2) + 4 lh, channel li + 32 mt
     if (PASS == 2) {
-      if (live)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt) {
+        float sv = 0.f, qv = 0.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { const float v = acc2[mt][r] + bias2[mt]; st_s[mt] += v; st_q[mt] = __builtin_fmaf(v, v, st_q[mt]); }
+        for (int r = 0; r < 16; ++r) { const float v = acc2[mt][r] + bias2[mt]; sv += v; qv = __builtin_fmaf(v, v, qv); }
+        sv += __shfl_xor(sv, 32, 64); qv += __shfl_xor(qv, 32, 64);   // the other 16 neighbours
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { sv += __shfl_xor(sv, o, 64); qv += __shfl_xor(qv, o, 64); }   // the group's 8 channels
+        tree_push(t, mt, live ? sv : 0.f, live ? qv : 0.f);
+      }
     } else {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
@@ -237,31 +284,25 @@ __global__ __launch_bounds__(256) void sa_mlp2_kernel(int c, int n, int m, int n
     }
     return;
   }
-  if (PASS == 1) {
+  // centres -> wave (tree over TPW), waves -> workgroup (tree over 4): one fp64 slice per workgroup
+  if (PASS != 3) {
+    constexpr int NV = PASS == 1 ? 1 : 2;
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      float s = st_s[qd], q = st_q[qd];
-#pragma unroll
-      for (int o = 1; o < 32; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-      if (li == 0) { s_red[wave][2 * qd + lh][0] = s; s_red[wave][2 * qd + lh][1] = q; }
+    for (int v = 0; v < NV; ++v) {
+      const double sa = lvl_s[NLVL - 1][v], sq = lvl_q[NLVL - 1][v];
+      if (PASS == 1) {
+        if (lh == 0 && (li & 3) == 0) { s_red[wave][li >> 2][0] = sa; s_red[wave][li >> 2][1] = sq; }
+      } else {
+        if (lh == 0 && (li & 7) == 0) { s_red[wave][v * 4 + (li >> 3)][0] = sa; s_red[wave][v * 4 + (li >> 3)][1] = sq; }
+      }
     }
-  } else {
-    // group = 8 consecutive channels = 8 adjacent lanes (both half-waves: the other 16 neighbours)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float s = st_s[mt], q = st_q[mt];
-      s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
-#pragma unroll
-      for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-      if (lh == 0 && (li & 7) == 0) { s_red[wave][mt * 4 + (li >> 3)][0] = s; s_red[wave][mt * 4 + (li >> 3)][1] = q; }
+    __syncthreads();
+    if (tid < G) {
+      const double a = (s_red[0][tid][0] + s_red[1][tid][0]) + (s_red[2][tid][0] + s_red[3][tid][0]);
+      const double q = (s_red[0][tid][1] + s_red[1][tid][1]) + (s_red[2][tid][1] + s_red[3][tid][1]);
+      double *dst = (PASS == 1 ? partial1 : partial2) + (((size_t)bi * G + tid) * S + wg) * 2;
+      dst[0] = a; dst[1] = q;
     }
-  }
-  __syncthreads();
-  if (tid < G) {
-    double a = 0.0, q = 0.0;
-    for (int w = 0; w < 4; ++w) { a += (double)s_red[w][tid][0]; q += (double)s_red[w][tid][1]; }
-    double *dst = (PASS == 1 ? partial1 : partial2) + (((size_t)bi * G + tid) * S + wg) * 2;
-    dst[0] = a; dst[1] = q;
   }
 }
 
@@ -313,7 +354,7 @@ extern "C" int bdm_sa_mlp2_fused(int b, int c, int n, int m, int u, int m1, int 
   const int p = SA_P, tpw = sa_fused_tpw(b, m);
   const int S = (m + 4 * tpw - 1) / (4 * tpw);
   const long long total = (long long)S * b;
-  BDM_REQUIRE(total < (1ll << 28), "sa_mlp2_fused: too many workgroups");
+  BDM_REQUIRE(total < (1ll << 28) && S <= 256, "sa_mlp2_fused: at most 8192 centres per shape (got m=%d)", m);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(sa_rows_kernel, dim3(cdiv(n, 64), cdiv(p, 32), b), dim3(256), 0, s, c, n, p, features, bs_f, ld_f, (float *)rows);
   dim3 grid((unsigned)(8 * ((total + 7) / 8)));

@@ -64,3 +64,17 @@ def test_fused_form_is_declined_for_other_widths(hip):
     assert not ops.sa_mlp2_fusable(PointNetSAModule(256, 0.2, 16, in_channels=32, out_channels=[32, 64]).mlps[0], 32, 16)
     assert not ops.sa_mlp2_fusable(PointNetSAModule(16, 0.8, 32, in_channels=32, out_channels=[32, 64, 64]).mlps[0], 32, 32)
     assert not ops.sa_mlp2_fusable(PointNetSAModule(16, 0.8, 32, in_channels=61, out_channels=[32, 64]).mlps[0], 61, 32)
+
+
+def test_a_shapes_result_does_not_depend_on_its_batch(hip):
+    """The centres a wave walks follow the batch size (8 per wave at B = 16, 1 at B = 1); the GroupNorm statistics are summed along one
+    binary tree over the centres whatever that number is: same bits alone and in a batch."""
+    sa, features, coords, temb = _module(32, 1024, 2048, 16, seed=7)
+    with torch.no_grad():
+        sa.fuse_mlp = True
+        batch, _, _ = sa((features, coords, temb))
+        for row in (0, 5, 15):
+            alone, _, _ = sa((features[row:row + 1].contiguous(), coords[row:row + 1].contiguous(), temb[row:row + 1]))
+            assert torch.equal(alone[0], batch[row]), row
+        four, _, _ = sa((features[4:8].contiguous(), coords[4:8].contiguous(), temb[4:8]))
+        assert torch.equal(four, batch[4:8])
