@@ -223,6 +223,10 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
         feat, hw = self.conditioning_image(image_rgb, mask)
         if hw != tuple(image_rgb.shape[-2:]):
             raise ValueError(f"{hw=} and {image_rgb.shape=}")
+        early = None
+        if CHANNEL_FIRST_CONDITIONING and ops.HOIST_CONDITIONING and x_t.shape[2] == 3 and x_t.is_cuda:
+            from . import pvcnn
+            early = pvcnn.early_first_sampler(getattr(getattr(self, "point_cloud_model", None), "model", None), x_t)
         pix = self.surface_projection_indices(x_t[:, :, :3], camera, hw)
         C = feat.shape[2]
         if CHANNEL_FIRST_CONDITIONING:
@@ -234,6 +238,7 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
             res = out.transpose(1, 2)
             if ops.HOIST_CONDITIONING and x_t.shape[2] == 3:
                 res._bdm_cond = ops.Conditioning(feat, hw, pix, x_t, out, self._cond_cache[5])
+                res._bdm_cond.early = early
             return res
         out = torch.empty(B, N, 3 + C, dtype=torch.float32, device=x_t.device)
         L.check(L.lib().bdm_condition_gather(B, N, C, hw[0] * hw[1], L.ptr(x_t), L.ptr(feat), L.ptr(pix), L.ptr(out),

@@ -974,6 +974,7 @@ class Conditioning:
         # channel-first (rows 0..2 = xyz) forms of the step's cloud; maps: the per-image cache of hoisted maps
         self.feat, self.hw, self.pix, self.x_t, self.x_cf, self.maps = feat, hw, pix, x_t, x_cf, maps
         self.C = feat.shape[2]
+        self.early = None   # (centres of the first set-abstraction level, sampled from x_t while the conditioning ran; pvcnn.early_first_sampler)
 
     def map(self, kind, weight, build):
         """(B, HW, M) = F . Wf^T for the (M, C) matrix `build()` returns; cached per (kind, weight tensor, version) for the image batch."""

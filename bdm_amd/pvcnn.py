@@ -132,7 +132,38 @@ SIDE_NN = True      # 3-NN searches of the FP modules on the sampler's stream (F
 NN_PLANS = {}       # (points ptr, centres ptr) -> (points, centres, idx, w, event): both tensors are held, so a key cannot alias
 
 
-def plan_sampling_chain(sa_layers, coords):
+EARLY_SAMPLER = os.environ.get("BDM_EARLY_SAMPLER", "1") == "1"
+
+
+def _side_stream(device):
+    cur = torch.cuda.current_stream(device)
+    key = (device, cur.cuda_stream)  # one sampler stream per main stream: concurrent lanes do not queue behind each other
+    side = _side_streams.get(key)
+    if side is None:
+        # (priority: see SIDE_STREAM_PRIORITY)
+        side = _side_streams[key] = torch.cuda.Stream(device=device, priority=SIDE_STREAM_PRIORITY)
+    return cur, side
+
+
+def early_first_sampler(net, x_t):
+    """The first level's furthest point sampling needs the step's cloud only: started on the sampler's stream BEFORE the projection
+    conditioning of the step (raster + gather, ~140 us at B = 16), whose output the rest of the denoiser waits for.  x_t (B, N, 3)
+    point-major, as the conditioning receives it; -> the centres (B, 3, M), for plan_sampling_chain of THIS step's forward (the handle
+    travels with the conditioned input: ops.Conditioning.early), or None."""
+    sa_layers = getattr(net, "sa_layers", None)
+    if not (EARLY_SAMPLER and SIDE_STREAM and sa_layers is not None and x_t.is_cuda and x_t.dim() == 3 and x_t.shape[2] == 3
+            and x_t.shape[0] * x_t.shape[1] >= SIDE_STREAM_MIN_POINTS):
+        return None
+    first = sa_layers[0][-1] if isinstance(sa_layers[0], nn.Sequential) else sa_layers[0]
+    cur, side = _side_stream(x_t.device)
+    tape.wait_stream(side, cur)
+    with torch.cuda.stream(side):
+        c0 = x_t.transpose(1, 2).contiguous()   # the values of the denoiser's coordinate rows (model.get_input_with_conditioning)
+        centers0 = first.sample(c0)
+    return (c0, centers0, side)
+
+
+def plan_sampling_chain(sa_layers, coords, early=None):
     """Furthest point sampling + ball query of ALL set-abstraction levels depend on the input coordinates only
     (1 356 strictly sequential sampler rounds on 16 CUs).  They are enqueued on a side stream so that they overlap
     the level-0 PVConvs; each SA module waits on its own event.
@@ -140,17 +171,15 @@ def plan_sampling_chain(sa_layers, coords):
     Host order matters when the host, not the GPU, paces the step (one small shape): only the first level's sampler -- the
     long pole -- is enqueued up front; the other ~19 launches of the chain follow when the first SA module is reached, i.e.
     AFTER the host has fed the main stream its first PVConvs (they could not start before that sampler finishes anyway)."""
-    cur = torch.cuda.current_stream()
-    key = (coords.device, cur.cuda_stream)  # one sampler stream per main stream: concurrent lanes do not queue behind each other
-    side = _side_streams.get(key)
-    if side is None:
-        # (priority: see SIDE_STREAM_PRIORITY)
-        side = _side_streams[key] = torch.cuda.Stream(device=coords.device, priority=SIDE_STREAM_PRIORITY)
+    cur, side = _side_stream(coords.device)
     tape.wait_stream(side, cur)
     first = sa_layers[0][-1] if isinstance(sa_layers[0], nn.Sequential) else sa_layers[0]
-    with torch.cuda.stream(side):
-        c0 = coords.contiguous()
-        centers0 = first.sample(c0)
+    c0 = coords.contiguous()
+    if early is not None and early[2] is side and tuple(early[0].shape) == tuple(c0.shape) and early[1].shape[2] == first.num_centers:
+        centers0 = early[1]   # sampled from the same cloud on this very stream, ahead of the conditioning (early_first_sampler)
+    else:
+        with torch.cuda.stream(side):
+            centers0 = first.sample(c0)
 
     def level(li, c, centers):
         """ball query of level li (+ its sampler for li > 0) and the next level's voxel plan, on the side stream; -> its centres"""
@@ -206,7 +235,7 @@ def plan_sampling_chain(sa_layers, coords):
         more()
 
 
-def encode(sa_layers, global_att, inputs, t_emb):
+def encode(sa_layers, global_att, inputs, t_emb, early=None):
     """Down path (pvcnn.py:90-110)."""
     coords = inputs[:, :3, :].contiguous()
     ops.clear_plan_cache()  # voxel plans are valid within one encoder/decoder pass
@@ -217,7 +246,7 @@ def encode(sa_layers, global_att, inputs, t_emb):
     # also inside a hipGraph capture: the side stream forks from and joins the capturing stream.  Small problems (one
     # small shape) are bound by kernel-to-kernel dispatch latency, where the extra events cost more than the overlap gains
     if coords.is_cuda and SIDE_STREAM and coords.shape[0] * coords.shape[2] >= SIDE_STREAM_MIN_POINTS:
-        plan_sampling_chain(sa_layers, coords)
+        plan_sampling_chain(sa_layers, coords, early)
     features = inputs
     coords_list, in_features_list = [], []
     for i, sa_blocks in enumerate(sa_layers):
@@ -284,7 +313,9 @@ class PVCNN2Base(nn.Module):
         try:
             for m in hoisted:
                 m._cond = cond
-            features, coords, t_emb, coords_list, in_features_list = encode(self.sa_layers, self.global_att, inputs, t_emb)
+            # (the first level's centres, sampled ahead of the conditioning from this very cloud: the handle vouches for the tensor)
+            early = cond.early if (cond is not None and cond.x_cf.data_ptr() == inputs.data_ptr()) else None
+            features, coords, t_emb, coords_list, in_features_list = encode(self.sa_layers, self.global_att, inputs, t_emb, early)
             in_features_list[0] = inputs[:, 3:, :]
             return decode(self.fp_layers, self.classifier, features, coords, t_emb, coords_list, in_features_list)
         finally:

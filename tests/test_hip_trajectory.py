@@ -250,3 +250,44 @@ def test_recorded_step_pins_the_buffers_it_did_not_allocate(hip, monkeypatch):
     del junk
     # the OLD recording still reads and writes only memory it owns or pinned
     assert torch.equal(replay_once(), eps_before) and bool(torch.isfinite(eps_before).all())
+
+
+def test_first_level_sampled_ahead_of_the_conditioning_same_bits(hip, monkeypatch):
+    """pvcnn.early_first_sampler: the first set-abstraction level's furthest point sampling starts from x_t on the sampler's stream
+    before the step's projection conditioning; the forward that follows uses those centres.  Same bits as sampling inside the
+    encoder, eagerly and on a replayed tape; a forward whose input is NOT the conditioned tensor of that call samples for itself."""
+    import bdm_amd.model as M
+    import bdm_amd.pvcnn as PV
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.utils.procedural import fill_module_
+    B, N, steps = 2, 1024, 6
+    cfg = ProjectConfig()
+    cfg.dataset.max_points = N
+    model = fill_module_(M.get_model(cfg).eval(), seed=4).cuda()
+    batch = next(iter(SyntheticShapes(range(B), B, num_points=N))).to("cuda")
+    x0 = torch.randn(B, N, 3, generator=torch.Generator().manual_seed(6)).cuda()
+    noise = [torch.randn(B, N, 3, generator=torch.Generator().manual_seed(200 + i)).cuda() for i in range(steps)]
+
+    def run(early, mode):
+        monkeypatch.setattr(PV, "EARLY_SAMPLER", early)
+        monkeypatch.setattr(M, "TAPE_STEPS", mode)
+        model._tape_cache = None
+        it = iter(noise)
+        model.scheduler.noise_source = lambda shape, device: next(it)
+        try:
+            return model.interaction_sample(x0.clone(), batch.camera, batch.image_rgb, None, start_time=400, end_time=400 - steps).cpu()
+        finally:
+            model.scheduler.noise_source = None
+
+    ref = run(False, "0")
+    assert torch.equal(run(True, "0"), ref)
+    assert torch.equal(run(True, "1"), ref)
+    # the handle vouches for ONE tensor: a copy of the conditioned input carries no handle and is sampled inside the encoder
+    monkeypatch.setattr(PV, "EARLY_SAMPLER", True)
+    t = torch.full((B,), 300, dtype=torch.int64, device="cuda")
+    x_in = model.get_input_with_conditioning(x0, batch.camera, batch.image_rgb, None, t)
+    assert x_in._bdm_cond.early is not None
+    with_handle = model.point_cloud_model(x_in, t)
+    plain = model.point_cloud_model(x_in.clone(), t)
+    assert torch.allclose(with_handle, plain, rtol=0, atol=1e-5)   # (the clone also leaves the hoisted-conditioning path: not the same bits)
