@@ -373,7 +373,7 @@ def main():
                 # OUTSIDE the timed region on the level-0 shape, 20 launches between two events on the launching stream.
                 b_, c_, n_, m_, u_ = fused["shape"][:5]
                 gq = torch.Generator().manual_seed(1)
-                pts_ = (torch.rand(b_, 3, n_, generator=gq) - 0.5).to(device)
+                pts_ = out.transpose(1, 2).contiguous()   # the final clouds of this run (the neighbourhoods the path sees)
                 fts_ = torch.randn(b_, c_, n_, generator=gq).to(device)
                 cen_ = BF.furthest_point_sample(pts_, m_)
                 idx_ = BF.ball_query(cen_, pts_, 0.1, u_)
