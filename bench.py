@@ -283,10 +283,11 @@ def main():
     for _ in range(args.steps):
         out = trajectory()
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0                      # this rank's own work, BEFORE the closing barrier equalises the clocks
     barrier()
     mine = time.perf_counter() - t0
     elapsed = max_over_ranks(mine, device)
-    per_rank_s = per_rank_values(mine, device)          # after the timed region: which rank was the slow one, and by how much
+    per_rank_s = per_rank_values(own, device)           # after the timed region: which rank was the slow one, and by how much
     per_rank_numa = per_rank_values(float(-1 if affinity.get("numa_node") is None else affinity["numa_node"]), device)
     prof.remove()
     assert torch.isfinite(out).all()
