@@ -76,7 +76,7 @@ __global__ void attn_split_v_h2_kernel(int C, int CP, int L, int Lp, const float
 template <int CB>  // channel blocks of 32 (C <= 32 * CB)
 // amdgpu_waves_per_eu(3): 196 -> 142 VGPRs without spilling (a target of 4 spills 18): three waves per SIMD instead of two,
 // 334 -> 289 us at B = 16, L = 4096
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_flash_h2_kernel(int C, int L, int Lp, const uint4 *__restrict__ qs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_flash_h2_kernel(int C, int L, int Lp, int nb, const uint4 *__restrict__ qs,
                                                             const uint4 *__restrict__ ks,
                                                             const unsigned short *__restrict__ vt,
                                                             const float *__restrict__ amax, float *__restrict__ out,
@@ -86,8 +86,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
   __shared__ uint4 Ksh[KT];                                       // [c8][split][key]
   __shared__ __align__(16) unsigned short Vsh[2 * CP * VROW_H2];  // [split][c][VROW_H2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const int bi = blockIdx.y;
-  const int i0 = (blockIdx.x * 4 + wave) * 32;  // this wave's first query
+  // XCD-aware item order: workgroup ids are dealt round-robin to the 8 XCDs; XCD x takes the contiguous (shape, query tile) items
+  // [x * per, (x + 1) * per), so a shape's K / V stay in ONE XCD's L2 (they were fetched by all eight: 272 MB per launch at B = 16, PMC)
+  const int qtiles = (L + 127) / 128, total = qtiles * nb, per = (total + 7) >> 3;
+  const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (item >= total) return;
+  const int bi = item / qtiles;
+  const int i0 = ((item - bi * qtiles) * 4 + wave) * 32;  // this wave's first query
   const uint4 *qb = qs + (size_t)bi * C8 * 2 * L, *kb = ks + (size_t)bi * C8 * 2 * L;
   const unsigned short *vb = vt + (size_t)bi * 2 * CP * Lp;
   const float sq = h2_scale_from_max(amax[bi * 3]), sk = h2_scale_from_max(amax[bi * 3 + 1]), sv = h2_scale_from_max(amax[bi * 3 + 2]);
@@ -251,12 +256,14 @@ extern "C" int bdm_attention_core_h2(int b, int c, int l, const float *q, const 
   unsigned short *vt = reinterpret_cast<unsigned short *>(ks + qk_rec);
   hipLaunchKernelGGL(attn_split_qk_h2_kernel, dim3(cdiv(l, 128), c8, 2 * b), dim3(128), 0, s, c, l, q, k, bs_qkv, ld_qkv, amax, qs, ks);
   hipLaunchKernelGGL(attn_split_v_h2_kernel, dim3(cdiv(lp / 8, 64), cp, b), dim3(64), 0, s, c, cp, l, lp, v, bs_qkv, ld_qkv, amax, vt);
-  dim3 grid(cdiv(l, 128), b);
+  const long long total = (long long)cdiv(l, 128) * b;
+  BDM_REQUIRE(total < (1ll << 28), "attention_core_h2: too many workgroups");
+  dim3 grid((unsigned)(8 * ((total + 7) / 8)));
   if (cp == 32)
-    hipLaunchKernelGGL(attn_flash_h2_kernel<1>, grid, dim3(256), 0, s, c, l, lp, (const uint4 *)qs, (const uint4 *)ks, vt, amax, out,
+    hipLaunchKernelGGL(attn_flash_h2_kernel<1>, grid, dim3(256), 0, s, c, l, lp, b, (const uint4 *)qs, (const uint4 *)ks, vt, amax, out,
                        bs_o, ld_o);
   else
-    hipLaunchKernelGGL(attn_flash_h2_kernel<2>, grid, dim3(256), 0, s, c, l, lp, (const uint4 *)qs, (const uint4 *)ks, vt, amax, out,
+    hipLaunchKernelGGL(attn_flash_h2_kernel<2>, grid, dim3(256), 0, s, c, l, lp, b, (const uint4 *)qs, (const uint4 *)ks, vt, amax, out,
                        bs_o, ld_o);
   return launch_status("attention_core_h2");
 }
