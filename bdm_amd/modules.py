@@ -548,7 +548,7 @@ class PointNetSAModule(nn.Module):
                 more()
         else:
             centers_coords, idx = self.plan(coords)
-        if (self.fuse_mlp and coords.is_cuda and features is not None and ops.is_point_invariant(temb)
+        if (self.fuse_mlp and coords.is_cuda and features is not None and ops.is_point_invariant(temb) and idx.shape[1] <= 8192
                 and ops.sa_mlp2_fusable(self.mlps[0], features.shape[1], idx.shape[2])):
             # first level: grouping, both MLP layers and the max in three recompute passes over the packed points -- neither the
             # grouped tensor nor a layer's output is written (sa_mlp_fused.hip)
