@@ -585,7 +585,7 @@ static int pointwise_conv_gn_impl(int b, int m, int k, int n, const float *w, in
                                  long long bs_y, int ld_y, const void *in_partial, int in_slices, int in_groups,
                                  const float *in_gamma, const float *in_beta, float in_eps, int out_groups,
                                  void *out_partial, float *amax, int amax_rows, const float *add, long long bs_add, int ld_add,
-                                 void *stream) {
+                                 void *stream, const float *batch_bias = nullptr, int ld_bb = 0) {
   BDM_REQUIRE(b >= 0 && m >= 1 && k >= 1 && n >= 1, "pointwise_conv_gn: bad sizes m=%d k=%d n=%d", m, k, n);
   BDM_REQUIRE((long long)k * ld_x + n < (1ll << 31) && (long long)m * ldw + k < (1ll << 31),
               "pointwise_conv_gn: one operand spans more than 2^31 elements");
@@ -616,16 +616,16 @@ static int pointwise_conv_gn_impl(int b, int m, int k, int n, const float *w, in
   if (pw_skinny_shape(k, n)) {
 #define SK_LAUNCH(NB, FOLD)                                                                                                       \
     hipLaunchKernelGGL((pw_skinny_kernel<NB, FOLD>), dim3(cdiv(m, 32), b, cdiv(n, 32 * NB)), dim3(256), 0, (hipStream_t)stream, m, k, n, w, ldw, x, bs_x, \
-                       ld_x, bias, (const float *)nullptr, 0, (const float *)nullptr, 0ll, 0, y, bs_y, ld_y, 0, 0.f, gn)
+                       ld_x, bias, batch_bias, ld_bb, (const float *)nullptr, 0ll, 0, y, bs_y, ld_y, 0, 0.f, gn)
     if (in_partial != nullptr) { if (n <= 32) SK_LAUNCH(1, true); else SK_LAUNCH(2, true); }
     else { if (n <= 32) SK_LAUNCH(1, false); else SK_LAUNCH(2, false); }
 #undef SK_LAUNCH
     return launch_status("pointwise_conv_gn");
   }
   if (in_partial != nullptr)
-    pw_dispatch<true>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, nullptr, 0, add, bs_add, ld_add, y, bs_y, ld_y, 0, 0.f, gn, (hipStream_t)stream);
+    pw_dispatch<true>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, batch_bias, ld_bb, add, bs_add, ld_add, y, bs_y, ld_y, 0, 0.f, gn, (hipStream_t)stream);
   else
-    pw_dispatch<false>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, nullptr, 0, add, bs_add, ld_add, y, bs_y, ld_y, 0, 0.f, gn, (hipStream_t)stream);
+    pw_dispatch<false>(b, m, k, n, w, ldw, x, bs_x, ld_x, bias, batch_bias, ld_bb, add, bs_add, ld_add, y, bs_y, ld_y, 0, 0.f, gn, (hipStream_t)stream);
   return launch_status("pointwise_conv_gn");
 }
 
@@ -651,6 +651,21 @@ extern "C" int bdm_pointwise_conv_gn_add(int b, int m, int k, int n, const float
   BDM_REQUIRE(add != nullptr, "pointwise_conv_gn_add: add is NULL");
   return pointwise_conv_gn_impl(b, m, k, n, w, ldw, x, bs_x, ld_x, x2, bs_x2, ld_x2, k1, bias, y, bs_y, ld_y, in_partial, in_slices,
                                 in_groups, in_gamma, in_beta, in_eps, out_groups, out_partial, amax, amax_rows, add, bs_add, ld_add, stream);
+}
+
+// The same with a per-SHAPE bias batch_bias (b, ld_bb >= m): y = (W x' + bias) + batch_bias[shape] (+ add), statistics / amax over that y.
+// The share of a layer whose remaining input columns are constant along the points of a shape (the time embedding concatenated to the
+// features: W . [x ; t 1^T] = W_x . x + (W_t . t) 1^T, pvcnn.py:88 / pointnet.py:104-112).  add may be NULL.
+extern "C" int bdm_pointwise_conv_gn_bb(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x,
+                                        int ld_x, const float *x2, long long bs_x2, int ld_x2, int k1, const float *bias, float *y,
+                                        long long bs_y, int ld_y, const void *in_partial, int in_slices, int in_groups,
+                                        const float *in_gamma, const float *in_beta, float in_eps, int out_groups,
+                                        void *out_partial, float *amax, int amax_rows, const float *batch_bias, int ld_bb,
+                                        const float *add, long long bs_add, int ld_add, void *stream) {
+  BDM_REQUIRE(batch_bias != nullptr && ld_bb >= m, "pointwise_conv_gn_bb: batch_bias is NULL or its row stride is below m");
+  return pointwise_conv_gn_impl(b, m, k, n, w, ldw, x, bs_x, ld_x, x2, bs_x2, ld_x2, k1, bias, y, bs_y, ld_y, in_partial, in_slices,
+                                in_groups, in_gamma, in_beta, in_eps, out_groups, out_partial, amax, amax_rows, add, bs_add, ld_add, stream,
+                                batch_bias, ld_bb);
 }
 
 extern "C" int bdm_sparse_conv_gemm(int b, int n_max, int cin, int n27, const float *xc, const float *wt,

@@ -52,12 +52,13 @@ class SharedMLP(nn.Module):
     # Swishes on the fly -- no GroupNorm pass, the normalised tensor is never written
     fold_gn = True
 
-    def run(self, x, out_last=None, fold_last=False, x2=None, first_weight=None, first_add=None):
+    def run(self, x, out_last=None, fold_last=False, x2=None, first_weight=None, first_add=None, first_bias=None):
         """-> activations; with fold_last -> (raw output of the last convolution, (stats, gn) | None): the caller applies the
         last GroupNorm + Swish inside its own consumer kernel (None: already applied).  x2: the input is cat([x, x2], dim=1),
         read in place by the first convolution.  first_weight / first_add: the first convolution's weight restricted to the columns
         of `x` and the per-element addend that stands for its other columns (the hoisted projection conditioning:
-        W . [x, F[pix]] = W_x . x + (F . W_f^T)[pix], ops.Conditioning)."""
+        W . [x, F[pix]] = W_x . x + (F . W_f^T)[pix], ops.Conditioning).  first_bias (B, M): a per-shape bias of the first convolution
+        (the share of input columns that are constant along a shape's points: the time embedding)."""
         n = len(self.layers) // 3
         pending = None
         for i in range(n):
@@ -68,9 +69,10 @@ class SharedMLP(nn.Module):
             second = x2 if i == 0 else None
             weight = first_weight if (i == 0 and first_weight is not None) else conv.weight
             addend = first_add if i == 0 else None
-            if defer or pending is not None or second is not None or addend is not None:
+            bb = first_bias if i == 0 else None
+            if defer or pending is not None or second is not None or addend is not None or bb is not None:
                 r = ops.pointwise_conv_gn(x, weight, conv.bias, out=dst, fold_in=pending,
-                                          out_groups=gn.num_groups if defer else None, x2=second, add=addend)
+                                          out_groups=gn.num_groups if defer else None, x2=second, add=addend, batch_bias=bb)
                 if defer:
                     x, stats = r
                     pending = (stats, gn)
@@ -90,11 +92,14 @@ class SharedMLP(nn.Module):
 
 def hoisted_first_weight(owner, conv, keep_cols):
     """W[:, :keep_cols] (contiguous copy) of a 1x1 convolution whose remaining input columns were hoisted into a per-image map
-    (ops.Conditioning); the gathered map rows enter the layer as its addend.  Cached on `owner` per weight version."""
+    (ops.Conditioning); the gathered map rows enter the layer as its addend.  keep_cols may also be a tuple of (lo, hi) column ranges
+    (the columns that stay, in order).  Cached on `owner` per weight version."""
     w = conv.weight
     hit = getattr(owner, "_hoist_w", None)
     if hit is None or hit[0] != (w._version, w.data_ptr(), keep_cols):
-        hit = ((w._version, w.data_ptr(), keep_cols), w.detach().reshape(w.shape[0], -1)[:, :keep_cols].contiguous())
+        w2 = w.detach().reshape(w.shape[0], -1)
+        kept = w2[:, :keep_cols] if isinstance(keep_cols, int) else torch.cat([w2[:, lo:hi] for lo, hi in keep_cols], dim=1)
+        hit = ((w._version, w.data_ptr(), keep_cols), kept.contiguous())
         owner._hoist_w = hit
     return hit[1]
 
@@ -568,6 +573,45 @@ class PointNetFPModule(nn.Module):
     """pointnet.py:96-113."""
     two_source = True  # skip features read in place by the MLP's first convolution
     _cond = None       # ops.Conditioning of this forward when the skip features are the raw conditioning channels
+    _temb_bias = None  # (B, M) = W[:, t columns] . t of this forward, when pvcnn.decode has computed all modules' in one launch
+
+    def temb_weight(self, c_feat, c_t):
+        """W[:, c_feat : c_feat + c_t] of the first MLP layer (contiguous, cached per weight version): the time embedding's columns"""
+        w = self.mlp.layers[0].weight
+        hit = getattr(self, "_wt", None)
+        if hit is None or hit[0] != (w._version, w.data_ptr(), c_feat, c_t):
+            hit = ((w._version, w.data_ptr(), c_feat, c_t), w.detach().reshape(w.shape[0], -1)[:, c_feat:c_feat + c_t].contiguous())
+            self._wt = hit
+        return hit[1]
+
+    def _forward_split(self, pc, cc, idx, w, features, points_features, temb, points_coords):
+        from . import _lib as L
+        B, _, n = pc.shape
+        m, dev = cc.shape[2], pc.device
+        conv0 = self.mlp.layers[0]
+        c_feat, c_t = features.shape[1], temb.shape[1]
+        c_skip = 0 if points_features is None else points_features.shape[1]
+        bb, self._temb_bias = self._temb_bias, None
+        if bb is None or tuple(bb.shape) != (B, conv0.out_channels):
+            tvec = temb[:, :, 0].contiguous()
+            bb = ops.pointwise_conv(tvec[:, :, None], self.temb_weight(c_feat, c_t))[:, :, 0]
+        buf = torch.empty(B, c_feat, n, dtype=torch.float32, device=dev)
+        fa, _, _, _, bs_a, ld_a = ops._bcl(features)
+        _, _, _, _, bs_0, ld_0 = ops._bcl(buf)
+        L.check(L.lib().bdm_fp_assemble(B, m, n, L.ptr(idx), L.ptr(w), c_feat, L.ptr(fa), L.c_ll(bs_a), ld_a, 0, None, L.c_ll(0), 0,
+                                        0, None, L.c_ll(0), 0, L.ptr(buf), L.c_ll(bs_0), ld_0, None, L.c_ll(0), 0, L.stream()), "fp_assemble")
+        if c_skip == 0:
+            return self.mlp.run(buf, first_weight=hoisted_first_weight(self.mlp, conv0, c_feat), first_bias=bb), points_coords, temb
+        cond = self._cond
+        if cond is not None and points_features.shape[1] == cond.C and points_features.data_ptr() == cond.x_cf[:, 3:].data_ptr():
+            # the skip channels are F[pix]: their share of the first layer, (F . W_skip^T)[pix], is gathered from the hoisted map
+            fmap = cond.map("fp_skip", conv0.weight,
+                            lambda conv=conv0, lo=c_feat + c_t, C=cond.C: conv.weight.detach().reshape(conv.out_channels, -1)[:, lo:lo + C])
+            g = cond.gather(fmap)
+            return (self.mlp.run(buf, first_weight=hoisted_first_weight(self.mlp, conv0, c_feat), first_add=g[:, 3:], first_bias=bb),
+                    points_coords, temb)
+        keep = ((0, c_feat), (c_feat + c_t, c_feat + c_t + c_skip))
+        return self.mlp.run(buf, x2=points_features, first_weight=hoisted_first_weight(self.mlp, conv0, keep), first_bias=bb), points_coords, temb
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
@@ -594,6 +638,16 @@ class PointNetFPModule(nn.Module):
         else:
             idx, w = ops.three_nn_search(pc, cc)
 
+        # SPLIT form (pvcnn.decode): centers_features arrive WITHOUT the time embedding, which is constant along a shape's points
+        # (t_emb[:, :, None].expand): its interpolation is itself (the weights sum to one) and its share of the first MLP layer is a
+        # per-shape bias W[:, t columns] . t -- no concatenation, 64 channels less to interpolate (twice: the reference interpolates
+        # cat([features, t_emb]) AND t_emb) and 64 columns less in the first GEMM
+        c_t = temb.shape[1]
+        conv0 = self.mlp.layers[0]
+        split = (dev.type == "cuda" and ops.is_point_invariant(temb) and not ops.is_point_invariant(centers_features)
+                 and centers_features.shape[1] + c_t + (0 if points_features is None else points_features.shape[1]) == conv0.in_channels)
+        if split:
+            return self._forward_split(pc, cc, idx, w, centers_features, points_features, temb, points_coords)
         cf = ops.materialize(centers_features)
         c_int = cf.shape[1]
         c_skip = 0 if points_features is None else points_features.shape[1]

@@ -119,11 +119,11 @@ def gn_foldable(channels, groups):
     return groups <= 8 and cg >= 4 and (cg & (cg - 1)) == 0 and channels <= 1024
 
 
-def pointwise_conv_gn(x, weight, bias=None, out=None, fold_in=None, out_groups=None, x2=None, amax=None, amax_rows=0, add=None):
+def pointwise_conv_gn(x, weight, bias=None, out=None, fold_in=None, out_groups=None, x2=None, amax=None, amax_rows=0, add=None, batch_bias=None):
     """1x1 convolution with GroupNorm folding (bdm_pointwise_conv_gn).  fold_in = (stats, gn) of a previous call: x is that
     call's raw output and Swish(GroupNorm(x)) is applied on the fly.  out_groups: also return the statistics of the output
     -> (y, (partial, slices, groups)).  add (B, M, n): per-element addend, part of y before the statistics (the hoisted share of
-    the layer: ops.Conditioning).  shared_mlp.py:25-30."""
+    the layer: ops.Conditioning).  batch_bias (B, M[, 1]): per-shape bias, likewise (the time embedding's share).  shared_mlp.py:25-30."""
     x, B, K, n, bs_x, ld_x = _bcl(x)
     k1, x2p, bs_x2, ld_x2 = 0, None, 0, 0
     if x2 is not None:  # the operand is cat([x, x2], dim=1), read in place
@@ -151,6 +151,19 @@ def pointwise_conv_gn(x, weight, bias=None, out=None, fold_in=None, out_groups=N
         assert slices > 0
         out_p = torch.empty(B * og * slices * 2, dtype=torch.float64, device=x.device)
         stats = (out_p, slices, og)
+    if batch_bias is not None:
+        bb = batch_bias.reshape(B, -1)
+        assert bb.shape[1] == M and bb.stride(1) == 1, "batch_bias must be (B, M) with unit channel stride"
+        ap, bs_a, ld_a = None, 0, 0
+        if add is not None:
+            aa, Ba, Ma, na, bs_a, ld_a = _bcl(add)
+            assert aa.data_ptr() == add.data_ptr() and (Ba, Ma, na) == (B, M, n), "add must be a dense-row (B, M, n) view"
+            ap = add
+        L.check(lib.bdm_pointwise_conv_gn_bb(B, M, K, n, L.ptr(w), K, L.ptr(x), L.c_ll(bs_x), ld_x, L.ptr(x2p), L.c_ll(bs_x2), ld_x2, k1,
+                                             L.ptr(bias), L.ptr(out), L.c_ll(bs_y), ld_y, L.ptr(in_p), in_s, in_g, L.ptr(in_gamma), L.ptr(in_beta),
+                                             L.c_float(in_eps), og, L.ptr(out_p), L.ptr(amax), int(amax_rows), L.ptr(bb), bb.stride(0),
+                                             L.ptr(ap), L.c_ll(bs_a), ld_a, L.stream()), "pointwise_conv_gn_bb")
+        return (out, stats) if out_groups else out
     if add is not None:
         aa, Ba, Ma, na, bs_a, ld_a = _bcl(add)
         assert aa.data_ptr() == add.data_ptr() and (Ba, Ma, na) == (B, M, n), "add must be a dense-row (B, M, n) view"

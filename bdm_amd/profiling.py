@@ -110,6 +110,7 @@ SPEC = {
     # 1x1 convolutions / linear layers
     "bdm_pointwise_conv": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:4], _pw),
     "bdm_pointwise_conv_gn": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:4], _pw),  # + GroupNorm statistics / folded input GroupNorm
+    "bdm_pointwise_conv_gn_bb": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:4], _pw),   # + per-shape bias (the time embedding's share)
     "bdm_pointwise_conv_gn_add": ("1x1 conv GEMM (fp32 MFMA)", lambda a: a[:4], _pw),  # + per-element addend (hoisted conditioning share)
     "bdm_pointwise_conv_s3": ("1x1 conv GEMM (bf16x6)", lambda a: a[:4], _pw_s3),
     "bdm_pointwise_conv_gn_s3": ("1x1 conv GEMM (bf16x6)", lambda a: a[:4], _pw_s3),

@@ -261,12 +261,47 @@ def encode(sa_layers, global_att, inputs, t_emb, early=None):
     return features, coords, t_emb, coords_list, in_features_list
 
 
+FP_TEMB_SPLIT = os.environ.get("BDM_FP_TEMB_SPLIT", "1") == "1"  # FP modules take the point-invariant time embedding as a per-shape bias
+
+
+def _fp_temb_biases(fp_layers, in_features_list, c_feat0, t_emb):
+    """All FP modules' W[:, t columns] . t in ONE launch (the embedding is the same for all of them): module i gets its (B, M_i) view."""
+    mods = [(b[0] if isinstance(b, nn.Sequential) else b) for b in fp_layers]
+    c_t, c_feat, parts = t_emb.shape[1], c_feat0, []
+    for i, fp in enumerate(mods):
+        conv0 = fp.mlp.layers[0]
+        c_skip = in_features_list[-1 - i].shape[1]
+        if c_feat + c_t + c_skip != conv0.in_channels:
+            return  # not the denoisers' layout: every module computes its own
+        parts.append(fp.temb_weight(c_feat, c_t))
+        c_feat = fp.mlp.layers[-3].out_channels   # (this module's output feeds the next one; its PVConvs keep the width)
+        nxt = fp_layers[i]
+        if isinstance(nxt, nn.Sequential) and len(nxt) > 1:
+            last = nxt[-1]
+            c_feat = getattr(last, "out_channels", c_feat)
+    key = tuple((p.data_ptr(), p._version) for p in parts)
+    owner = mods[0]
+    hit = getattr(owner, "_wt_all", None)
+    if hit is None or hit[0] != key:
+        hit = (key, torch.cat(parts, dim=0).contiguous())
+        owner._wt_all = hit
+    tvec = t_emb[:, :, 0].contiguous()
+    bb = ops.pointwise_conv(tvec[:, :, None], hit[1])[:, :, 0]   # (B, sum M_i), row stride sum M_i
+    lo = 0
+    for fp, p in zip(mods, parts):
+        fp._temb_bias = bb[:, lo:lo + p.shape[0]]
+        lo += p.shape[0]
+
+
 def decode(fp_layers, classifier, features, coords, t_emb, coords_list, in_features_list):
     """Up path + head (pvcnn.py:112-127)."""
+    split = FP_TEMB_SPLIT and features.is_cuda and ops.is_point_invariant(t_emb)
+    if split:
+        _fp_temb_biases(fp_layers, in_features_list, features.shape[1], t_emb)
     for fp_idx, fp_blocks in enumerate(fp_layers):
-        features, coords, t_emb = run_blocks(
-            fp_blocks, (coords_list[-1 - fp_idx], coords, ops.cat_channels([features, t_emb]),
-                        in_features_list[-1 - fp_idx], t_emb))
+        # (split: the module takes the embedding's share of its first layer as a per-shape bias and hands the embedding on unchanged)
+        cf = features if (split and ops.is_point_invariant(t_emb)) else ops.cat_channels([features, t_emb])
+        features, coords, t_emb = run_blocks(fp_blocks, (coords_list[-1 - fp_idx], coords, cf, in_features_list[-1 - fp_idx], t_emb))
     return run_classifier(classifier, features)
 
 

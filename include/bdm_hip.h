@@ -177,6 +177,15 @@ int bdm_pointwise_conv_gn_add(int b, int m, int k, int n, const float *w, int ld
                               int ld_y, const void *in_partial, int in_slices, int in_groups, const float *in_gamma,
                               const float *in_beta, float in_eps, int out_groups, void *out_partial, float *amax, int amax_rows,
                               const float *add, long long bs_add, int ld_add, void *stream);
+/* The same with a per-SHAPE bias batch_bias (b, ld_bb >= m): y = (W x' + bias) + batch_bias[shape] (+ add; may be NULL), statistics and
+ * amax over that y.  The share of a layer whose remaining input columns are constant along a shape's points -- the time embedding
+ * concatenated to the features (pvcnn.py:88, pointnet.py:104-112): W . [x ; t 1^T] = W_x . x + (W_t . t) 1^T. */
+int bdm_pointwise_conv_gn_bb(int b, int m, int k, int n, const float *w, int ldw, const float *x, long long bs_x, int ld_x,
+                             const float *x2, long long bs_x2, int ld_x2, int k1, const float *bias, float *y, long long bs_y,
+                             int ld_y, const void *in_partial, int in_slices, int in_groups, const float *in_gamma,
+                             const float *in_beta, float in_eps, int out_groups, void *out_partial, float *amax, int amax_rows,
+                             const float *batch_bias, int ld_bb, const float *add, long long bs_add, int ld_add, void *stream);
+
 #ifdef BDM_EXPERIMENTAL
 /* bf16x6 form of the two entry points above (csrc/experimental/pointwise_s3.hip; measured: no faster, the GEMMs are staging-bound): the weights are split ONCE into exact bf16 triples
  * (bdm_pointwise_s3_pack_weights: packed = bdm_pointwise_s3_weight_elems(m, k) 16-bit elements), the activations while they are

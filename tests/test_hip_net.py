@@ -235,3 +235,27 @@ def test_hoisted_projection_conditioning_equals_the_generic_path(hip, monkeypatc
     ref3 = net(x_cf2, t).clone()
     x_cf2._bdm_cond = ops.Conditioning(feat, (H, H), pix2, x_t2, x_cf2, maps)
     assert rel_l2(net(x_cf2, t).cpu(), ref3.cpu()) < 5e-6 and rel_l2(ref3.cpu(), ref2.cpu()) > 1e-4
+
+
+@pytest.mark.parametrize("which", ["pc2", "pvd"])
+def test_time_embedding_as_a_per_shape_bias_of_the_fp_modules(hip, monkeypatch, which):
+    """pvcnn.decode in split form: the point-invariant time embedding is not concatenated to the features before a PointNetFPModule
+    (pointnet.py:104-112 interpolates cat([features, t_emb]) AND t_emb: both are t itself); its share of the first MLP layer enters as
+    a per-shape bias W[:, t columns] . t (all four modules' in one launch).  Same forward up to the reassociation of that share."""
+    import bdm_amd.pvcnn as PV
+    from bdm_amd.utils.procedural import fill_module_
+    B, N = 3, 2048
+    net = fill_module_((PV.PVCNN2_PC2(3, 64, extra_feature_channels=32) if which == "pc2" else PV.PVCNN2_PVD(3, 64, extra_feature_channels=0)).eval(),
+                       seed=9).cuda()
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.randn(B, 3, N, generator=g) * 0.4, torch.randn(B, 32 if which == "pc2" else 0, N, generator=g)], dim=1).cuda()
+    t = torch.tensor([900, 400, 3]).cuda()
+    monkeypatch.setattr(PV, "FP_TEMB_SPLIT", False)
+    ref = net(x, t).clone()
+    monkeypatch.setattr(PV, "FP_TEMB_SPLIT", True)
+    got = net(x, t)
+    assert rel_l2(got.cpu(), ref.cpu()) < 2e-6, rel_l2(got.cpu(), ref.cpu())
+    assert not torch.equal(got, ref)                       # really another route
+    assert torch.equal(net(x, t), got)                     # deterministic
+    alone = net(x[1:2].contiguous(), t[1:2])
+    assert torch.equal(alone[0], got[1])                   # and batch-invariant

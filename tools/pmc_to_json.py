@@ -24,7 +24,7 @@ FAMILIES = [
     (("sparse_rows_from_map_kernel",), 1, {"bdm_sparse_conv_rows_from_map": None}),
     (("attn_flash_h2_kernel",), 1, {"bdm_attention_core_h2": None}),
     (("ball_query_kernel",), 1, {"bdm_ball_query": None}),
-    (("pw_gemm_kernel", "pw_skinny_kernel"), 1, {"bdm_pointwise_conv_gn": _pw, "bdm_pointwise_conv_gn_add": _pw, "bdm_pointwise_conv": _pw}),
+    (("pw_gemm_kernel", "pw_skinny_kernel"), 1, {"bdm_pointwise_conv_gn": _pw, "bdm_pointwise_conv_gn_add": _pw, "bdm_pointwise_conv_gn_bb": _pw, "bdm_pointwise_conv": _pw}),
     # fused first set-abstraction level: row repack + three recompute passes per call; algorithmic = features + indices + output
     (("sa_rows_kernel", "sa_mlp2_kernel"), 4, {"bdm_sa_mlp2_fused": lambda a: 4 * a[0] * ((3 + a[1]) * a[2] + a[3] * a[4] + a[6] * a[3])}),
     (("to_h2_rows_kernel",), 1, {"bdm_group_norm_to_h2_rows": None}),
