@@ -298,20 +298,22 @@ extern "C" int bdm_condition_gather(int b, int n, int c, int hw, const float *x_
 // the point-major tensor first thing) -- the 100 MB transpose pass per step disappears.  Workgroup = 64 points; the
 // pixel-major feature rows are read as contiguous 256-byte pieces (64 channels of one point per wave step), transposed through
 // an LDS tile and written as 256-byte runs along the point axis.
-__global__ __launch_bounds__(256) void condition_gather_cf_kernel(int n, int C, int HW, const float *__restrict__ x_t,
+// Cw: feature channels actually written (C, or 0: the coordinate rows only -- every consumer of the feature rows takes its share from
+// a hoisted per-pixel map instead, bdm_condition_xyz_cf)
+__global__ __launch_bounds__(256) void condition_gather_cf_kernel(int n, int C, int Cw, int HW, const float *__restrict__ x_t,
                                                                   const float *__restrict__ feat,
                                                                   const int *__restrict__ pix, float *__restrict__ out) {
   __shared__ float tile[64][65];
   __shared__ int s_px[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, bi = blockIdx.y, n0 = blockIdx.x * 64;
   float *ob = out + (size_t)bi * (3 + C) * n;
-  if (tid < 64) s_px[tid] = (n0 + tid < n) ? pix[(size_t)bi * n + n0 + tid] : -1;
+  if (tid < 64) s_px[tid] = (Cw > 0 && n0 + tid < n) ? pix[(size_t)bi * n + n0 + tid] : -1;
   if (tid < 192) {  // x_t (B, N, 3) -> channels 0..2
     const int d = tid >> 6, pt = n0 + lane;
     if (pt < n) ob[(size_t)d * n + pt] = x_t[((size_t)bi * n + pt) * 3 + d];
   }
   __syncthreads();
-  for (int c0 = 0; c0 < C; c0 += 64) {
+  for (int c0 = 0; c0 < Cw; c0 += 64) {
     const int c = c0 + lane;
 #pragma unroll 4
     for (int k = 0; k < 16; ++k) {  // wave w reads the rows of points w*16 .. w*16+15, 64 channels each
@@ -331,9 +333,20 @@ extern "C" int bdm_condition_gather_cf(int b, int n, int c, int hw, const float 
                                        const int *pix_of_point, float *out, void *stream) {
   BDM_REQUIRE(b >= 0 && n >= 1 && c >= 0 && hw >= 1, "condition_gather_cf: bad sizes");
   if (b == 0) return BDM_OK;
-  hipLaunchKernelGGL(condition_gather_cf_kernel, dim3(cdiv(n, 64), b), dim3(256), 0, (hipStream_t)stream, n, c, hw, x_t,
+  hipLaunchKernelGGL(condition_gather_cf_kernel, dim3(cdiv(n, 64), b), dim3(256), 0, (hipStream_t)stream, n, c, c, hw, x_t,
                      feature_image, pix_of_point, out);
   return launch_status("condition_gather_cf");
+}
+
+// Rows 0..2 (the coordinates) of that tensor only: out (b, 3 + c, n) keeps its layout, rows 3.. are left UNWRITTEN.  For the reverse
+// loop when every consumer of the feature rows reads a hoisted per-pixel map instead (ops.Conditioning: 100 MB per step at B = 16 that
+// nothing would read); bdm_condition_gather_cf on the same tensor completes it.
+extern "C" int bdm_condition_xyz_cf(int b, int n, int c, const float *x_t, float *out, void *stream) {
+  BDM_REQUIRE(b >= 0 && n >= 1 && c >= 0 && x_t && out, "condition_xyz_cf: bad arguments");
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(condition_gather_cf_kernel, dim3(cdiv(n, 64), b), dim3(256), 0, (hipStream_t)stream, n, c, 0, 1, x_t,
+                     (const float *)nullptr, (const int *)nullptr, out);
+  return launch_status("condition_xyz_cf");
 }
 
 // -------------------------------------------------------------------------------------

@@ -77,6 +77,8 @@ class PointCloudModel(_DeviceMixin, nn.Module):
         cond = getattr(inputs, "_bdm_cond", None)  # projection conditioning in factored form (ops.Conditioning)
         if cond is not None and cond.x_cf.data_ptr() == x.data_ptr():
             x._bdm_cond = cond
+        elif cond is not None:
+            cond.ensure_features()  # (a lazy handle that does not travel on: complete its tensor first)
         return ops.transpose12(self.model(x, t))
 
 
@@ -214,8 +216,10 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
         return Pointclouds(points=x[:, :, :3] / (self.scale_factor if unscale else 1))
 
     @torch.no_grad()
-    def get_input_with_conditioning(self, x_t, camera, image_rgb, mask, t):
-        """projection_model.py:179-231 -> (B, N, in_channels)."""
+    def get_input_with_conditioning(self, x_t, camera, image_rgb, mask, t, lazy=False):
+        """projection_model.py:179-231 -> (B, N, in_channels).  lazy (the reverse loops only): the feature channels of the result may be
+        left unwritten -- the tensor then carries a handle (ops.Conditioning, features_ready False) and the denoiser either reads the
+        hoisted maps instead or completes it; nothing else may read it."""
         B, N = x_t.shape[:2]
         x_t = x_t.contiguous()
         if not self.use_local_conditioning:
@@ -233,12 +237,17 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
             # written channel-first and returned as its (B, N, 3 + C) transposed VIEW: the reference's shape and values, and the
             # denoiser's `inputs.transpose(1, 2)` (point_cloud_model.py:65) becomes free (ops.transpose12 sees the view)
             out = torch.empty(B, 3 + C, N, dtype=torch.float32, device=x_t.device)
-            L.check(L.lib().bdm_condition_gather_cf(B, N, C, hw[0] * hw[1], L.ptr(x_t), L.ptr(feat), L.ptr(pix), L.ptr(out),
-                                                    L.stream()), "condition_gather_cf")
+            lazy = bool(lazy and LAZY_CONDITIONING and ops.HOIST_CONDITIONING and x_t.shape[2] == 3 and x_t.is_cuda)
+            if lazy:
+                L.check(L.lib().bdm_condition_xyz_cf(B, N, C, L.ptr(x_t), L.ptr(out), L.stream()), "condition_xyz_cf")
+            else:
+                L.check(L.lib().bdm_condition_gather_cf(B, N, C, hw[0] * hw[1], L.ptr(x_t), L.ptr(feat), L.ptr(pix), L.ptr(out),
+                                                        L.stream()), "condition_gather_cf")
             res = out.transpose(1, 2)
             if ops.HOIST_CONDITIONING and x_t.shape[2] == 3:
                 res._bdm_cond = ops.Conditioning(feat, hw, pix, x_t, out, self._cond_cache[5])
                 res._bdm_cond.early = early
+                res._bdm_cond.features_ready = not lazy
             return res
         out = torch.empty(B, N, 3 + C, dtype=torch.float32, device=x_t.device)
         L.check(L.lib().bdm_condition_gather(B, N, C, hw[0] * hw[1], L.ptr(x_t), L.ptr(feat), L.ptr(pix), L.ptr(out),
@@ -246,6 +255,7 @@ class PointCloudProjectionModel(_DeviceMixin, nn.Module):
         return out
 
 
+LAZY_CONDITIONING = os.environ.get("BDM_LAZY_CONDITIONING", "1") == "1"  # reverse loops: feature rows of x_in written only if a layer reads them
 CHANNEL_FIRST_CONDITIONING = True  # the conditioning gather writes the denoiser's channel-first input directly (tests flip the attribute)
 
 
@@ -300,7 +310,7 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
         B = x_t.shape[0]
         for t in timesteps:
             tt = torch.full((B,), t, dtype=torch.int64, device=x_t.device)
-            x_in = self.get_input_with_conditioning(x_t, camera=camera, image_rgb=image_rgb, mask=mask, t=tt)
+            x_in = self.get_input_with_conditioning(x_t, camera=camera, image_rgb=image_rgb, mask=mask, t=tt, lazy=True)
             noise_pred = self.point_cloud_model(x_in, tt)
             x_t = scheduler.step(noise_pred, t, x_t, generator=generator, **self._step_kwargs).prev_sample
         return x_t
@@ -325,7 +335,7 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
         g["x"].copy_(x_t)
 
         def step():
-            x_in = self.get_input_with_conditioning(g["x"], camera=camera, image_rgb=image_rgb, mask=mask, t=g["t"])
+            x_in = self.get_input_with_conditioning(g["x"], camera=camera, image_rgb=image_rgb, mask=mask, t=g["t"], lazy=True)
             eps = self.point_cloud_model(x_in, g["t"])
             scheduler.step_dev(eps, g["coef"], g["x"], g["noise"], out=g["x"])
 
@@ -351,7 +361,7 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
         for i, t in enumerate(timesteps):                     # kernels can be timed with HIP events inside the loop
             if probe and i % probe == probe - 1:
                 tt = torch.full((x_t.shape[0],), t, dtype=torch.int64, device=x_t.device)
-                x_in = self.get_input_with_conditioning(g["x"], camera=camera, image_rgb=image_rgb, mask=mask, t=tt)
+                x_in = self.get_input_with_conditioning(g["x"], camera=camera, image_rgb=image_rgb, mask=mask, t=tt, lazy=True)
                 g["x"].copy_(scheduler.step(self.point_cloud_model(x_in, tt), t, g["x"], generator=generator).prev_sample)
                 continue
             g["t"].fill_(t)
@@ -382,7 +392,7 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
             self._tape_cache = g
 
         def denoise():  # conditioning + denoiser on the static buffers: everything between two scheduler steps
-            x_in = self.get_input_with_conditioning(g["x"], camera=camera, image_rgb=image_rgb, mask=mask, t=g["t"])
+            x_in = self.get_input_with_conditioning(g["x"], camera=camera, image_rgb=image_rgb, mask=mask, t=g["t"], lazy=True)
             return self.point_cloud_model(x_in, g["t"])
 
         g["x"].copy_(x_t)

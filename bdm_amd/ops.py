@@ -988,6 +988,17 @@ class Conditioning:
         self.feat, self.hw, self.pix, self.x_t, self.x_cf, self.maps = feat, hw, pix, x_t, x_cf, maps
         self.C = feat.shape[2]
         self.early = None   # (centres of the first set-abstraction level, sampled from x_t while the conditioning ran; pvcnn.early_first_sampler)
+        # LAZY form (model.get_input_with_conditioning(lazy=True), the reverse loops): only the coordinate rows of x_cf are written; the
+        # denoiser completes the tensor (ensure_features) unless every reader of rows 3.. takes its share from a hoisted map
+        self.features_ready = True
+
+    def ensure_features(self):
+        """Write the feature rows of x_cf if the lazy form left them out (one launch of the full conditioning gather)."""
+        if not self.features_ready:
+            B, _, N = self.x_cf.shape
+            L.check(L.lib().bdm_condition_gather_cf(B, N, self.C, self.feat.shape[1], L.ptr(self.x_t), L.ptr(self.feat), L.ptr(self.pix),
+                                                    L.ptr(self.x_cf), L.stream()), "condition_gather_cf")
+            self.features_ready = True
 
     def map(self, kind, weight, build):
         """(B, HW, M) = F . Wf^T for the (M, C) matrix `build()` returns; cached per (kind, weight tensor, version) for the image batch."""

@@ -160,6 +160,7 @@ SPEC = {
     "bdm_transpose": ("concat / broadcast / transpose copies", lambda a: a[:3], lambda a: ("hbm", 8.0 * a[0] * a[1] * a[2])),
     "bdm_rasterize_points": ("projection conditioning", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * 4 * a[1])),
     "bdm_condition_gather_cf": ("projection conditioning", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * a[1] * (2 * a[2] + 7))),
+    "bdm_condition_xyz_cf": ("projection conditioning", lambda a: a[:3], lambda a: ("hbm", 4.0 * a[0] * a[1] * 6)),
     "bdm_condition_gather": ("projection conditioning", lambda a: a[:4], lambda a: ("hbm", 4.0 * a[0] * a[1] * (2 * a[2] + 7))),
     "bdm_ddpm_step": ("scheduler step / blend", lambda a: a[:1], lambda a: ("hbm", 16.0 * a[0])),
     "bdm_ddpm_step_philox": ("scheduler step / blend", lambda a: a[:2], lambda a: ("hbm", 12.0 * a[0] * a[1])),

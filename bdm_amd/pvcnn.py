@@ -345,6 +345,8 @@ class PVCNN2Base(nn.Module):
         inputs = inputs.contiguous()
         t_emb = embed_time(self.embedf, t, self.embed_dim, inputs.shape[-1])
         hoisted = self._hoist_targets(cond, inputs)
+        if cond is not None and not cond.features_ready and not self._hoist_complete(hoisted, cond, inputs):
+            cond.ensure_features()   # a layer will read the feature rows of the lazily built input: write them now
         try:
             for m in hoisted:
                 m._cond = cond
@@ -356,6 +358,18 @@ class PVCNN2Base(nn.Module):
         finally:
             for m in hoisted:
                 m._cond = None
+
+    def _hoist_complete(self, hoisted, cond, inputs):
+        """True when NO layer of this forward reads rows 3.. of the conditioned input: its three readers -- the point branch and the
+        first convolution of the first PVConv, the skip input of the last FP module -- all take the hoisted maps (the conditions of
+        PVConv._point_branch, PVConv.forward and PointNetFPModule.forward, restated)."""
+        if len(hoisted) != 2 or cond.x_cf.data_ptr() != inputs.data_ptr():
+            return False
+        first, last = hoisted
+        conv1 = first.voxel_layers[0]
+        return (len(first.point_features.layers) == 3 and isinstance(conv1, nn.Conv3d) and 27 * conv1.out_channels <= 1024
+                and first.conv_impl in ("bf16x6", "fp16x3") and first.sparse_first_conv and first.resolution in first.sparse_resolutions
+                and getattr(last, "two_source", False) and inputs.shape[1] - 3 == cond.C)
 
     def _hoist_targets(self, cond, inputs):
         """Modules whose first linear map reads the raw conditioned input (ops.Conditioning): the first PVConv of the first

@@ -631,6 +631,9 @@ int bdm_condition_gather(int b, int n, int c, int hw, const float *x_t, const fl
 /* the same, written channel-first: out (b, 3 + c, n) -- the layout the denoiser consumes (no transpose pass) */
 int bdm_condition_gather_cf(int b, int n, int c, int hw, const float *x_t, const float *feature_image,
                             const int *pix_of_point, float *out, void *stream);
+/* rows 0..2 (the coordinates) of that tensor only; rows 3.. stay UNWRITTEN until bdm_condition_gather_cf completes the same tensor.  For
+ * the reverse loop when every consumer of the feature rows reads a hoisted per-pixel map instead (100 MB per step at b = 16). */
+int bdm_condition_xyz_cf(int b, int n, int c, const float *x_t, float *out, void *stream);
 
 /* Quality metrics of the evaluation scripts (evaluation/evaluation_cd.py:111-131, evaluation_f1.py:90-110):
  * out (b, n) = min over the m target points of the squared distance; src (b,n,3), tgt (b,m,3) point-major. */

@@ -291,3 +291,43 @@ def test_first_level_sampled_ahead_of_the_conditioning_same_bits(hip, monkeypatc
     with_handle = model.point_cloud_model(x_in, t)
     plain = model.point_cloud_model(x_in.clone(), t)
     assert torch.allclose(with_handle, plain, rtol=0, atol=1e-5)   # (the clone also leaves the hoisted-conditioning path: not the same bits)
+
+
+def test_lazily_conditioned_input_is_either_unread_or_completed(hip, monkeypatch):
+    """model.get_input_with_conditioning(lazy=True) (the reverse loops): only the coordinate rows of the (B, 3 + C, N) input are written.
+    (a) With every reader of the feature rows on a hoisted map the forward gives the bits of the complete input -- also when rows 3..
+    are poisoned with NaN, so nothing reads them; (b) when a reader is NOT hoisted (here: the hoisted first convolution switched off)
+    the denoiser completes the tensor first; (c) completing is idempotent."""
+    import bdm_amd.model as M
+    from bdm_amd import modules, ops
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.utils.procedural import fill_module_
+    B, N = 2, 1024
+    cfg = ProjectConfig()
+    cfg.dataset.max_points = N
+    model = fill_module_(M.get_model(cfg).eval(), seed=5).cuda()
+    batch = next(iter(SyntheticShapes(range(B), B, num_points=N))).to("cuda")
+    x0 = (torch.randn(B, N, 3, generator=torch.Generator().manual_seed(8)) * 0.5).cuda()
+    t = torch.full((B,), 321, dtype=torch.int64, device="cuda")
+    full = model.get_input_with_conditioning(x0, batch.camera, batch.image_rgb, None, t)
+    assert full._bdm_cond.features_ready
+    ref = model.point_cloud_model(full, t).clone()
+    lazy = model.get_input_with_conditioning(x0, batch.camera, batch.image_rgb, None, t, lazy=True)
+    cond = lazy._bdm_cond
+    assert not cond.features_ready and torch.equal(cond.x_cf[:, :3], full._bdm_cond.x_cf[:, :3])
+    cond.x_cf[:, 3:].fill_(float("nan"))                       # (a) poisoned: a reader would spread NaN
+    got = model.point_cloud_model(lazy, t)
+    assert not cond.features_ready and torch.equal(got, ref)
+    # (b) a generic reader: the tensor is completed, and the result is that of the complete input
+    lazy2 = model.get_input_with_conditioning(x0, batch.camera, batch.image_rgb, None, t, lazy=True)
+    monkeypatch.setattr(modules.PVConv, "sparse_first_conv", False)
+    ref_b = model.point_cloud_model(model.get_input_with_conditioning(x0, batch.camera, batch.image_rgb, None, t), t).clone()
+    got_b = model.point_cloud_model(lazy2, t)
+    assert lazy2._bdm_cond.features_ready and torch.equal(lazy2._bdm_cond.x_cf, full._bdm_cond.x_cf) and torch.equal(got_b, ref_b)
+    monkeypatch.setattr(modules.PVConv, "sparse_first_conv", True)
+    # (c) completing is idempotent and leaves the complete tensor
+    lazy3 = model.get_input_with_conditioning(x0, batch.camera, batch.image_rgb, None, t, lazy=True)
+    lazy3._bdm_cond.ensure_features()
+    lazy3._bdm_cond.ensure_features()
+    assert lazy3._bdm_cond.features_ready and torch.equal(lazy3._bdm_cond.x_cf, full._bdm_cond.x_cf)
