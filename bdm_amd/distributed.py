@@ -36,8 +36,8 @@ def gpu_turn(device=None):
     the ranks take turns on the device (an flock'ed file; the GPU is drained before the turn ends).  Measured on MI355X /
     ROCm 7.2 (round 3): a kernel CO-RESIDENT with `sparse_gemm_s3_kernel` -- in another process or on another
     stream of the same process -- occasionally reads a wrong 64-byte sector (16 consecutive floats; all inputs bit-identical,
-    the same launch alone is always right).  Round 4: the default forward no longer launches that GEMM (the first convolution is
-    one output-stationary kernel), and the side-stream kernels were run as victims next to both kernels
+    the same launch alone is always right).  Round 4: the default forward launches that GEMM ONCE per forward (the 128 -> 64 first convolution of the 16^3 level; the 32^3 levels
+    run one output-stationary kernel instead), and the side-stream kernels were run as victims next to both kernels
     (tools/coresidency/side_stream_victims.sh, profiles/r04_side_stream_victims.txt).  The lock stays the default of this TEST
     mode because two whole samplers sharing a GPU interleave every kernel pair, not only the pairs a forward produces.  No-op otherwise."""
     if os.environ.get("BDM_SHARE_GPU") != "1" or os.environ.get("BDM_GPU_TURN", "1") == "0":

@@ -23,7 +23,7 @@ Extra objects on the JSON line:
                     bytes) of its launches / their summed duration, against the peak that bounds it (dense 16-bit MFMA peak
                     / 3 partial products for the fp16x3 convolution); `kernel` names the heaviest (function, shape) row of
                     the class, whose avg_launch_us is the number to compare with the rocprofv3 summary under profiles/.
-                    `traffic` comes from the committed PMC pass profiles/r03_pmc_traffic.json (separate rocprofv3 --pmc runs of one
+                    `traffic` comes from the committed PMC pass profiles/r0N_pmc_traffic.json (newest round first; separate rocprofv3 --pmc runs of one
                     forward, same kernel; `traffic_commit` = the commit it was measured at -- not measured inside this run).
   roofline_table -- every kernel class: share of kernel time, launches, achieved vs peak.
   cpu_baseline   -- the CPU oracle ("port": oracle/ref_net.py + oracle/pvcnn_ops_ref.c, the reference has no CPU
@@ -303,8 +303,9 @@ def main():
             "per_rank_numa_node": [int(v) for v in per_rank_numa], "affinity_rank0": affinity,
             "rng": "per-shape Philox4x32-10 streams keyed by (seed, global shape index), noise generated inside the step kernels",
             "conv_arithmetic": CONV_IMPL + (" (fp32-grade: operands as two fp16 terms after power-of-two scaling, three partial "
-                                                    "products, fp32 accumulate; first conv of each PVConv: on the occupied voxels only, fp16x3 too -- "
-                                                    "output-stationary implicit GEMM with tap skipping, or the hoisted fp32 map at SA0.0)"
+                                                    "products, fp32 accumulate; first conv of each PVConv: on the occupied voxels only -- fp16x3 (list kernel or 8^3 GEMM) or "
+                                                    "bf16x6 (exact 3-way bf16 split, six products: the GEMM + gather form a layer takes when the batch is too "
+                                                    "small for the list kernel, ops.sparse_dil_pays), or the hoisted fp32 map at SA0.0)"
                                                     if CONV_IMPL == "fp16x3" else " (fp32-grade: exact 3-way bf16 operand split, "
                                                     "six partial products, fp32 accumulate)"),
             "config": {"workload": conf["label"] + ", synthetic R2N2-style inputs, procedural random-init PC2 + PVD"
