@@ -111,26 +111,70 @@ def _cpulist(text):
     return cpus
 
 
+def _amdgpu_devices_in_hip_order(sysfs):
+    """PCI device directories of the amdgpu GPUs in the order HIP numbers them with no *_VISIBLE_DEVICES set: the KFD topology's
+    GPU nodes (simd_count > 0) in node order, each mapped to its PCI device through its DRM render minor.  Falls back to the render
+    nodes sorted by PCI address when the KFD topology is not readable (-> (devices, "kfd" | "pci"))."""
+    import glob
+    by_minor = {}
+    for rd in glob.glob(os.path.join(sysfs, "class/drm/renderD*")):
+        real = os.path.realpath(os.path.join(rd, "device"))
+        try:
+            vendor = open(os.path.join(real, "vendor")).read().strip()
+            minor = int(os.path.basename(rd)[len("renderD"):])
+        except (OSError, ValueError):
+            continue
+        if vendor == "0x1002":
+            by_minor[minor] = real
+    kfd = []
+    nodes = glob.glob(os.path.join(sysfs, "class/kfd/kfd/topology/nodes/*/properties"))
+    for prop in sorted(nodes, key=lambda q: int(os.path.basename(os.path.dirname(q)))):
+        try:
+            kv = dict(line.split()[:2] for line in open(prop).read().splitlines() if len(line.split()) >= 2)
+            if int(kv.get("simd_count", "0")) > 0:
+                kfd.append(by_minor[int(kv["drm_render_minor"])])
+        except (OSError, ValueError, KeyError):
+            return sorted(set(by_minor.values()), key=os.path.basename), "pci"
+    if kfd:
+        return kfd, "kfd"
+    return sorted(set(by_minor.values()), key=os.path.basename), "pci"
+
+
+def _visible_ordinals(n_devices):
+    """The device list left by ROCR_VISIBLE_DEVICES (applied first, by the runtime) and then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
+    (applied on top, by HIP), as indices into the unrestricted HIP order; None when a list is set but is not plain ordinals (UUIDs)."""
+    order = list(range(n_devices))
+    for names in (("ROCR_VISIBLE_DEVICES",), ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+        text = next((os.environ[k] for k in names if os.environ.get(k, "") != ""), None)
+        if text is None:
+            continue
+        picked = []
+        for part in text.split(","):
+            part = part.strip()
+            if not part.isdigit():
+                return None
+            if int(part) >= len(order):
+                break   # (the runtimes stop at the first invalid ordinal)
+            picked.append(order[int(part)])
+        order = picked
+    return order
+
+
 def pin_to_gpu_numa_node(local_rank, sysfs="/sys"):
     """Pin this worker to the host cores of the NUMA node its GPU hangs off (before any GPU call): the enqueue thread of a rank
-    then never runs across the socket from its device.  The node comes from the PCI device behind the local_rank-th DRM render
-    node that belongs to an amdgpu device (sorted by PCI address: the order ROCm enumerates them in when no *_VISIBLE_DEVICES
-    is set); the affinity is intersected with the mask the process already has (cgroup / taskset).  Returns a dict for the
-    bench line ({"numa_node", "cpus"}), or {"numa_node": None, "why": ...} when the topology cannot be read -- never raises."""
-    import glob
+    then never runs across the socket from its device.  HIP ordinal -> PCI device: the KFD topology's GPU nodes in node order
+    (what HIP enumerates; PCI-address order only as a fallback when KFD is unreadable, reported as "order": "pci"), filtered by
+    ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES when they hold plain ordinals -- a list that cannot be interpreted (UUIDs) means NO pinning
+    rather than a guess.  The affinity is intersected with the mask the process already has (cgroup / taskset).  Returns a dict for
+    the bench line ({"numa_node", "cpus", "pci", "order"}), or {"numa_node": None, "why": ...} -- never raises."""
     try:
-        cards = []
-        for dev in glob.glob(os.path.join(sysfs, "class/drm/renderD*/device")):
-            real = os.path.realpath(dev)
-            try:
-                vendor = open(os.path.join(real, "vendor")).read().strip()
-            except OSError:
-                continue
-            if vendor == "0x1002":
-                cards.append(real)
-        cards = sorted(set(cards), key=os.path.basename)
+        cards, order = _amdgpu_devices_in_hip_order(sysfs)
+        visible = _visible_ordinals(len(cards))
+        if visible is None:
+            return {"numa_node": None, "why": "a *_VISIBLE_DEVICES list that is not plain ordinals: device order unknown, not pinning"}
+        cards = [cards[i] for i in visible]
         if local_rank >= len(cards):
-            return {"numa_node": None, "why": f"{len(cards)} amdgpu render nodes, local rank {local_rank}"}
+            return {"numa_node": None, "why": f"{len(cards)} visible amdgpu devices, local rank {local_rank}"}
         node = int(open(os.path.join(cards[local_rank], "numa_node")).read().strip())
         if node < 0:
             return {"numa_node": None, "why": "device reports no NUMA node"}
@@ -140,7 +184,7 @@ def pin_to_gpu_numa_node(local_rank, sysfs="/sys"):
         if not mine:
             return {"numa_node": node, "why": "no allowed CPU on that node", "cpus": 0}
         os.sched_setaffinity(0, mine)
-        return {"numa_node": node, "cpus": len(mine), "pci": os.path.basename(cards[local_rank])}
+        return {"numa_node": node, "cpus": len(mine), "pci": os.path.basename(cards[local_rank]), "order": order}
     except (OSError, ValueError) as e:
         return {"numa_node": None, "why": repr(e)}
 

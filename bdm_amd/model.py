@@ -73,12 +73,16 @@ class PointCloudModel(_DeviceMixin, nn.Module):
     @torch.no_grad()
     def forward(self, inputs: Tensor, t: Tensor) -> Tensor:
         """(B, N, in_channels) -> (B, N, out_channels)."""
-        x = ops.transpose12(inputs)
         cond = getattr(inputs, "_bdm_cond", None)  # projection conditioning in factored form (ops.Conditioning)
+        if cond is not None and not ops.is_transposed_view_of(inputs, cond.x_cf):
+            # the handle will not travel on (transpose12 is going to COPY): complete the lazily built tensor BEFORE it is copied
+            cond.ensure_features()
+        x = ops.transpose12(inputs)
         if cond is not None and cond.x_cf.data_ptr() == x.data_ptr():
             x._bdm_cond = cond
         elif cond is not None:
-            cond.ensure_features()  # (a lazy handle that does not travel on: complete its tensor first)
+            cond.ensure_features()
+            x = ops.transpose12(inputs)   # (unreachable unless transpose12's view test and the one above disagree: redo the copy)
         return ops.transpose12(self.model(x, t))
 
 

@@ -291,12 +291,22 @@ class PVConv(nn.Module):
             return None
         return cond
 
+    def _need_features(self, features):
+        """A reader that does NOT take the hoisted map is about to read rows 3.. of the conditioned input: if this step's input was
+        built lazily (coordinate rows only, ops.Conditioning), complete it now, on the CURRENT stream (callers call this before they
+        fork a branch stream).  PVCNN2Base._hoist_complete is only the fast path that spares the launch; the readers protect themselves."""
+        cond = self._cond
+        if cond is not None and not cond.features_ready and features.data_ptr() == cond.x_cf.data_ptr():
+            cond.ensure_features()
+
     def _point_branch(self, features, fold=False):
         """-> (activations, event | None, pending): with fold the LAST GroupNorm + Swish of the branch is left to the caller
         (pending = (stats, gn), activations = raw convolution output; None when the layer cannot be folded)."""
         cond = self._hoisted(features)
         if cond is not None and len(self.point_features.layers) != 3:
             cond = None
+        if cond is None:
+            self._need_features(features)   # (on the caller's stream, before the branch stream forks from it)
 
         def run():
             x, first_weight, first_add = features, None, None
@@ -362,6 +372,8 @@ class PVConv(nn.Module):
                 want_stats = (self.fold_gn1 and self.conv_impl == "fp16x3" and not getattr(self, "h2_saturated", False)
                               and impl != "sparse_fused")
                 cond = self._hoisted(features)
+                if not (cond is not None and 27 * conv1.out_channels <= 1024):
+                    self._need_features(features)
                 if cond is not None and 27 * conv1.out_channels <= 1024:  # hoisted map instead of feature gather + K = 390 GEMM
                     v = ops.sparse_first_conv_from_map(cond, plan, conv1, conv1.out_channels, gn_groups=gn1.num_groups if want_stats else None)
                 elif self.wants_dilated_plan(features.shape[0], plan.n):
@@ -377,6 +389,7 @@ class PVConv(nn.Module):
                 if want_stats:
                     v, gn1_stats = v
             else:
+                self._need_features(features)
                 norm_coords, vox_coords = ops.voxel_coords(coords, r, self.voxelization.eps)
                 x3 = ops.avg_voxelize_s3(features, vox_coords, r)
                 v = ops.conv3d_s3(x3, self._packed_weight(conv1, "bf16x6"), conv1.bias, conv1.in_channels,
@@ -443,6 +456,7 @@ class PVConv(nn.Module):
         # the first conv's input is the freshly voxelised cloud: on the 32^3 grids (<= 12.5 % occupied cells) the
         # occupancy-skipping variant wins (measured 1.3-1.4x); on 16^3 / 8^3 the dense kernel is as fast or faster
         sparse = r >= 32
+        self._need_features(features)
         vox, norm_coords = self.voxelization(features, coords, with_row_occupancy=sparse)
         rowocc = None
         if sparse:
@@ -584,6 +598,21 @@ class PointNetFPModule(nn.Module):
             self._wt = hit
         return hit[1]
 
+    def _need_skip(self, points_features):
+        """The skip rows are about to be READ (no hoisted map took their place): complete a lazily conditioned input first."""
+        cond = self._cond
+        if (cond is not None and not cond.features_ready and points_features is not None
+                and points_features.data_ptr() == cond.x_cf[:, 3:].data_ptr()):
+            cond.ensure_features()
+
+    def can_split(self, centers_features, points_features, temb):
+        """May this module take the time embedding as a per-shape bias (centers_features arriving WITHOUT the embedding)?  The ONE
+        predicate of pvcnn.decode (which then does not concatenate) and of forward (which then does not expect the concatenation)."""
+        conv0 = self.mlp.layers[0]
+        c_skip = 0 if points_features is None else points_features.shape[1]
+        return (centers_features.is_cuda and ops.is_point_invariant(temb) and not ops.is_point_invariant(centers_features)
+                and centers_features.shape[1] + temb.shape[1] + c_skip == conv0.in_channels)
+
     def _forward_split(self, pc, cc, idx, w, features, points_features, temb, points_coords):
         from . import _lib as L
         B, _, n = pc.shape
@@ -600,6 +629,7 @@ class PointNetFPModule(nn.Module):
         _, _, _, _, bs_0, ld_0 = ops._bcl(buf)
         L.check(L.lib().bdm_fp_assemble(B, m, n, L.ptr(idx), L.ptr(w), c_feat, L.ptr(fa), L.c_ll(bs_a), ld_a, 0, None, L.c_ll(0), 0,
                                         0, None, L.c_ll(0), 0, L.ptr(buf), L.c_ll(bs_0), ld_0, None, L.c_ll(0), 0, L.stream()), "fp_assemble")
+        temb = temb[:, :, :1].expand(-1, -1, n)   # the reference's interpolated_temb: (B, c_t, n) (pointnet.py:108)
         if c_skip == 0:
             return self.mlp.run(buf, first_weight=hoisted_first_weight(self.mlp, conv0, c_feat), first_bias=bb), points_coords, temb
         cond = self._cond
@@ -610,6 +640,7 @@ class PointNetFPModule(nn.Module):
             g = cond.gather(fmap)
             return (self.mlp.run(buf, first_weight=hoisted_first_weight(self.mlp, conv0, c_feat), first_add=g[:, 3:], first_bias=bb),
                     points_coords, temb)
+        self._need_skip(points_features)
         keep = ((0, c_feat), (c_feat + c_t, c_feat + c_t + c_skip))
         return self.mlp.run(buf, x2=points_features, first_weight=hoisted_first_weight(self.mlp, conv0, keep), first_bias=bb), points_coords, temb
 
@@ -643,10 +674,7 @@ class PointNetFPModule(nn.Module):
         # per-shape bias W[:, t columns] . t -- no concatenation, 64 channels less to interpolate (twice: the reference interpolates
         # cat([features, t_emb]) AND t_emb) and 64 columns less in the first GEMM
         c_t = temb.shape[1]
-        conv0 = self.mlp.layers[0]
-        split = (dev.type == "cuda" and ops.is_point_invariant(temb) and not ops.is_point_invariant(centers_features)
-                 and centers_features.shape[1] + c_t + (0 if points_features is None else points_features.shape[1]) == conv0.in_channels)
-        if split:
+        if self.can_split(centers_features, points_features, temb):
             return self._forward_split(pc, cc, idx, w, centers_features, points_features, temb, points_coords)
         cf = ops.materialize(centers_features)
         c_int = cf.shape[1]
@@ -661,6 +689,7 @@ class PointNetFPModule(nn.Module):
         fa, _, _, _, bs_a, ld_a = ops._bcl(cf)
         ft, _, c_t, _, bs_t, ld_t = ops._bcl(t_src)
         if c_skip:
+            self._need_skip(points_features)
             fs, _, _, _, bs_s, ld_s = ops._bcl(points_features)
         else:
             fs, bs_s, ld_s = None, 0, 0
@@ -678,5 +707,6 @@ class PointNetFPModule(nn.Module):
                                 lambda conv=conv, lo=c_int, C=cond.C: conv.weight.detach().reshape(conv.out_channels, -1)[:, lo:lo + C])
                 g = cond.gather(fmap)
                 return self.mlp.run(buf, first_weight=hoisted_first_weight(self.mlp, conv, c_int), first_add=g[:, 3:]), points_coords, interpolated_temb
+            self._need_skip(skip_src)
             return self.mlp.run(buf, x2=skip_src), points_coords, interpolated_temb
         return self.mlp.run(buf), points_coords, interpolated_temb

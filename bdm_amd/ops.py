@@ -339,6 +339,13 @@ def transpose12(x):
     return out
 
 
+def is_transposed_view_of(x, x_cf):
+    """Is the (B, R, C) tensor `x` the no-copy transposed view of the channel-first (B, C, R) tensor `x_cf` (the case transpose12
+    answers without a copy)?"""
+    return (x.dim() == 3 and not x.is_contiguous() and x.transpose(1, 2).is_contiguous() and x.data_ptr() == x_cf.data_ptr()
+            and tuple(x.transpose(1, 2).shape) == tuple(x_cf.shape))
+
+
 def time_embedding(t, w0, b0, w2, b2):
     B, dim = t.shape[0], w0.shape[0]
     tf = t.to(torch.float32).contiguous()

@@ -299,8 +299,13 @@ def decode(fp_layers, classifier, features, coords, t_emb, coords_list, in_featu
     if split:
         _fp_temb_biases(fp_layers, in_features_list, features.shape[1], t_emb)
     for fp_idx, fp_blocks in enumerate(fp_layers):
-        # (split: the module takes the embedding's share of its first layer as a per-shape bias and hands the embedding on unchanged)
-        cf = features if (split and ops.is_point_invariant(t_emb)) else ops.cat_channels([features, t_emb])
+        # (split: the module takes the embedding's share of its first layer as a per-shape bias and hands the embedding on unchanged;
+        # the module's OWN predicate decides, so decode and forward cannot disagree about whether the concatenation happened)
+        fp = fp_blocks[0] if isinstance(fp_blocks, nn.Sequential) else fp_blocks
+        can = split and hasattr(fp, "can_split") and fp.can_split(features, in_features_list[-1 - fp_idx], t_emb)
+        if not can:
+            fp._temb_bias = None
+        cf = features if can else ops.cat_channels([features, t_emb])
         features, coords, t_emb = run_blocks(fp_blocks, (coords_list[-1 - fp_idx], coords, cf, in_features_list[-1 - fp_idx], t_emb))
     return run_classifier(classifier, features)
 

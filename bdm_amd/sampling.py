@@ -21,6 +21,10 @@ from .pvd import generate_pvd_xyz
 
 DEFAULT_MILESTONES = [1000, 968, 936, 872, 128, 64, 32, 0]
 
+# optional callable(segment index, cloud (B, N, 3) on the device) invoked at the end of every schedule segment of bdm_blending /
+# bdm_merging (diagnosis: where along a trajectory two implementations part; the parity tests set it, nothing else does)
+SEGMENT_HOOK = None
+
 
 @torch.no_grad()
 def pvd_prior(pvd_model, points, start_time, end_time):
@@ -149,6 +153,8 @@ def _bdm_blending(batch, cfg, model, pvd_model, generator, init_noise, blend_mas
                 indices = torch.randint(0, 2, (B, num_points), generator=generator).long()
             blends += 1
             pred_pc = blend_select(out_recon, out_prior, indices)
+        if SEGMENT_HOOK is not None:
+            SEGMENT_HOOK(i, pred_pc)
     return Pointclouds(pred_pc)
 
 
@@ -190,6 +196,8 @@ def _bdm_merging(batch, cfg, prior_model, recon_model, fusion_model, init_noise,
                                               scheduler=cfg.run.diffusion_scheduler,
                                               num_inference_steps=cfg.run.num_inference_steps,
                                               timestep=milestones[i + 1] - roll_step)
+        if SEGMENT_HOOK is not None:
+            SEGMENT_HOOK(i, pred_pc)
     return Pointclouds(pred_pc)
 
 

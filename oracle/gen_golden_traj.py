@@ -5,7 +5,8 @@ so that the `-m gpu` parity tests do not spend minutes of host time per run re-d
 
 writes tests/golden/traj_<name>.npz = the case description (seeds, sizes, schedule, head scale: everything
 `tests/trajectory_case.build` needs to rebuild the identical weights / inputs / random draws procedurally), the oracle's final
-(1, N, 3) cloud and its clouds at every milestone boundary (for diagnosis when a test fails).  Nothing of /root/reference is read:
+(1, N, 3) cloud and its cloud at the end of every schedule segment (`segment_0` .. `segment_6` for the seven windows of the real
+milestones, the last one = `final`): a failing test reports the first segment past the bound.  Nothing of /root/reference is read:
 the oracle is this repository's own restatement (oracle/ref_sampler.py, ref_net.py, pvcnn_ops_ref.c), pinned by the network
 and module goldens.  A fixture is host-independent enough for the 1e-3 bound it is used with: the oracle's own 1-ulp
 self-sensitivity over the full schedule at head scale 0.1 is 3.5e-5, and the live-oracle forms of the
@@ -55,8 +56,9 @@ def generate(name):
 
     def trace(kind, t, x):
         n[0] += 1
-        if kind == "recon" and t in c.milestones[1:]:
-            snaps[f"recon_after_t{t}"] = x.detach().clone().numpy()
+        if kind == "segment":   # t = index of the schedule segment that just ended (ref_sampler.bdm_blending / bdm_merging)
+            snaps[f"segment_{t}"] = x.detach().clone().numpy()
+            return
         if n[0] % 100 == 0:
             print(f"  [{name}] {n[0]:5d} / {len(order)} steps, {time.time() - t0:6.0f} s", flush=True)
     R.TRACE = trace
@@ -64,7 +66,8 @@ def generate(name):
         final = case.run_oracle(oc)
     finally:
         R.TRACE = None
-    out = os.path.join(ROOT, "tests", "golden", f"traj_{name}.npz")
+    assert len(snaps) == len(c.milestones) - 1 and np.array_equal(snaps[f"segment_{len(snaps) - 1}"], final.numpy())
+    out = os.path.join(os.environ.get("BDM_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")), f"traj_{name}.npz")
     np.savez_compressed(out, final=final.numpy().astype(np.float32), N=d["N"], B=d["B"], merging=d["merging"],
                         philox_seed=-1 if d["philox_seed"] is None else d["philox_seed"], row=d["row"],
                         head_scale=HEAD_SCALE, milestones=np.asarray(c.milestones), roll_step=c.roll_step,

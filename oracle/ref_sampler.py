@@ -286,6 +286,7 @@ def bdm_blending(sd_pc2, sd_pvd, x_init, cams, local_features, milestones, roll_
             m = masks[k].bool()[:, :, None]
             k += 1
             x = torch.where(m, pri, rec)
+        _trace("segment", i, x)   # the cloud the next segment starts from (the last one = the result)
     return x
 
 
@@ -317,4 +318,5 @@ def bdm_merging(sd_pc2, sd_pvd, sd_fuse, x_init, cams, local_features, fuse_loca
             pri = pvd_prior(sd_pvd, x.clone(), milestones[i + 1], milestones[i + 1] - roll_step + 1, prior_noise)
             t = milestones[i + 1] - roll_step
             x = nstep_fuse(sd_fuse, pri, rec, cams, fuse_local_features, t, fuse_noise.get(t))
+        _trace("segment", i, x)
     return x

@@ -103,3 +103,29 @@ def pytest_sessionfinish(session, exitstatus):
         meta = {"host_cpus": _usable_cpus(), "host": platform.processor() or platform.machine(), "exitstatus": int(exitstatus),
                 "total_s": round(sum(_durations.values()), 1)}
         json.dump({"meta": meta, "tests": {k: round(v, 2) for k, v in sorted(_durations.items())}}, open(path, "w"), indent=0)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """One line per parity figure the session measured (helpers.parity): `name  value / bound  (fraction of the bound)`, worst
+    fraction first, so that the tail of a `-q` run shows the MARGIN of every parity claim, not only that it held."""
+    try:
+        import helpers
+    except ImportError:
+        return
+    rows = list(helpers.PARITY)
+    if not rows:
+        return
+    tr = terminalreporter
+    tr.write_sep("=", f"parity figures ({len(rows)}): measured / asserted bound")
+    worst = {}
+    for name, value, bound, note in rows:   # a name reported several times (parametrised steps): keep its worst
+        if name not in worst or value / max(bound, 1e-300) > worst[name][0] / max(worst[name][1], 1e-300):
+            worst[name] = (value, bound, note)
+    ordered = sorted(worst.items(), key=lambda kv: -(kv[1][0] / max(kv[1][1], 1e-300)))
+    headline = [kv for kv in ordered if kv[0].startswith("traj_")]
+    others = [kv for kv in ordered if not kv[0].startswith("traj_")]
+    for name, (value, bound, note) in others[:60][::-1] + headline[::-1]:   # headline trajectories last = nearest the tail
+        frac = value / max(bound, 1e-300)
+        tr.write_line(f"PARITY {name:<58s} {value:9.3e} / {bound:7.1e}  ({frac:5.1%} of bound){'  ' + note if note else ''}")
+    if len(others) > 60:
+        tr.write_line(f"PARITY ... {len(others) - 60} more figures below {others[60][1][0] / max(others[60][1][1], 1e-300):.1%} of their bounds")

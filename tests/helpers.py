@@ -26,6 +26,45 @@ def rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
+# ---- parity figures for the terminal summary (tests/conftest.py::pytest_terminal_summary) -------------------------------------
+# `-q` swallows the tests' prints, so a passing run would only prove "<= bound", not how far from it.  Parity tests report their
+# measured figure here; the summary prints one line per figure (`name  value / bound`) at the end of the session, where the
+# driver's record of the run keeps it.
+PARITY = []
+
+
+def parity(name, value, bound, note=""):
+    """Record `value` (measured) against `bound` (asserted by the caller) under `name`; returns the value."""
+    PARITY.append((str(name), float(value), float(bound), str(note)))
+    return float(value)
+
+
+def current_test():
+    """`file::test[param]` of the running test (pytest sets PYTEST_CURRENT_TEST), without the directory and the phase."""
+    import os
+    return os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].replace("tests/", "")
+
+
+def check_rel_l2(got, ref, tol, what=""):
+    """assert rel_l2(got, ref) < tol, and put the figure on the session's parity record under the test's own name."""
+    v = parity(current_test() + (" " + what if what else ""), rel_l2(got, ref), tol)
+    assert v < tol, f"rel-L2 {v:.3e} >= {tol:.1e} {what}"
+    return v
+
+
+def first_segment_past(bound, got_segments, golden, key="segment_{}"):
+    """Index and error of the first schedule segment whose end-of-segment cloud is further than `bound` from the oracle fixture's
+    (tests/golden/traj_*.npz hold `segment_0` .. `segment_6`), plus the whole curve; (None, curve) when none is."""
+    curve = []
+    for i, x in enumerate(got_segments):
+        k = key.format(i)
+        if k not in golden:
+            break
+        curve.append(rel_l2(x, torch.from_numpy(golden[k])))
+    first = next((i for i, e in enumerate(curve) if e > bound), None)
+    return first, curve
+
+
 def golden_trajectory(name):
     """tests/golden/traj_<name>.npz (oracle/gen_golden_traj.py): case description + the oracle's final cloud."""
     import os

@@ -18,13 +18,17 @@
 import pytest
 import torch
 
-from helpers import golden_trajectory, point_cloud_inputs, rel_l2
+from helpers import first_segment_past, golden_trajectory, parity, point_cloud_inputs, rel_l2
 import trajectory_case as case
 
 HEAD_SCALE = 0.1
 NORTH_STAR = 1e-3
 TOL_FORWARD = 1e-4
 TOL_BATCH = 1e-6   # the same shape at B = 1 and inside its per-GPU batch
+# early warning on the headline trajectory: measured 4.8e-4 - 4.9e-4 (rounds 3 - 4) against the 1e-3 bound; every kernel change moves
+# rounding, and one that doubles the figure would otherwise fail the north-star test with no warning.  Past this line the test
+# fails with "margin gone" although the bound itself still holds.
+C2_MARGIN_LINE = 7e-4
 
 
 @pytest.mark.gpu
@@ -37,11 +41,18 @@ def test_full_c2_trajectory_batch16_vs_oracle_fixture(hip):
     assert (B, N) == (16, 4096)
     c = case.build(N, head_scale=float(g["head_scale"]), merging=False, B=B)
     assert list(g["milestones"]) == list(c.milestones) and len(case.program_order(c.milestones, c.roll_step)) == int(g["forwards"])
-    got = case.run_hip_streams(c, seed, list(range(B)))
+    with case.segments() as seg:
+        got = case.run_hip_streams(c, seed, list(range(B)))
     assert got.shape == (B, N, 3) and bool(torch.isfinite(got).all())
-    err = rel_l2(got[row:row + 1], torch.from_numpy(g["final"]))
-    print(f"full C2 trajectory at B=16, N=4096 (per-shape Philox streams), shape {row} vs the oracle fixture: final rel-L2 {err:.3e}")
-    assert err <= NORTH_STAR
+    err = parity(f"traj_c2_b16_shape{row} final cloud (bench size, Philox mode)", rel_l2(got[row:row + 1], torch.from_numpy(g["final"])),
+                 NORTH_STAR, note=f"margin line {C2_MARGIN_LINE:.0e}")
+    first, curve = first_segment_past(NORTH_STAR, [x[row:row + 1] for x in seg.clouds], g)
+    print(f"full C2 trajectory at B=16, N=4096 (per-shape Philox streams), shape {row} vs the oracle fixture: final rel-L2 {err:.3e}; "
+          "per segment " + " ".join(f"{e:.1e}" for e in curve))
+    assert err <= NORTH_STAR, (f"final rel-L2 {err:.3e} > {NORTH_STAR}; first schedule segment past the bound: {first} "
+                               f"(segment curve {['%.2e' % e for e in curve]})")
+    assert err <= C2_MARGIN_LINE, (f"margin gone: final rel-L2 {err:.3e} is inside the 1e-3 bound but past the {C2_MARGIN_LINE:.0e} early-warning "
+                                   f"line (rounds 3 - 4 measured 4.8e-4 - 4.9e-4); segment curve {['%.2e' % e for e in curve]}")
     assert rel_l2(got[0:1], got[row:row + 1]) > 0.1
 
 
@@ -53,7 +64,7 @@ def test_full_c2_trajectory_batch16_sampled_shape_vs_oracle(hip, oracle_ops):
     got = case.run_hip_streams(c, seed, list(range(B)))
     assert got.shape == (B, N, 3) and bool(torch.isfinite(got).all())
     ref = case.run_oracle(case.philox_shape_case(c, seed, row, row))
-    err = rel_l2(got[row:row + 1], ref)
+    err = parity(f"traj_live_c2_b16_shape{row} final cloud", rel_l2(got[row:row + 1], ref), NORTH_STAR)
     print(f"full C2 trajectory at B=16, N=4096 (per-shape Philox streams), shape {row} vs oracle: final rel-L2 {err:.3e}")
     assert err <= NORTH_STAR
     # the batch-mates are different samples (different streams, images, cameras): not one cloud repeated 16 times
@@ -68,9 +79,9 @@ def test_c3_mini_merging_batch16(hip, oracle_ops):
     got = case.run_hip_streams(c, seed, list(range(B)))
     assert bool(torch.isfinite(got).all())
     ref = case.run_oracle(case.philox_shape_case(c, seed, row, row))
-    err = rel_l2(got[row:row + 1], ref)
+    err = parity("c3 mini-Merging B=16 N=4096: sampled shape vs oracle", rel_l2(got[row:row + 1], ref), NORTH_STAR)
     alone = case.run_hip_streams(case.subset(c, [row]), seed, [row])
-    inv = rel_l2(alone, got[row:row + 1])
+    inv = parity("c3 mini-Merging B=16: shape vs itself at B=1", rel_l2(alone, got[row:row + 1]), 1e-4)
     print(f"mini BDM-Merging at B=16, N=4096: shape {row} vs oracle {err:.3e}; vs itself at B=1 {inv:.3e}")
     assert err <= NORTH_STAR
     assert inv <= 1e-4, f"batch-dependent result: rel-L2 {inv:.3e}"   # ten free-running steps at head scale 1 amplify the 1e-6 of a forward
@@ -111,6 +122,9 @@ def test_per_gpu_batch_forward(hip, oracle_ops, monkeypatch, name, B, N, extra, 
     got, ref, alone, alone_default = _forward_case(PVCNN2_PC2 if extra else PVCNN2_PVD, B, N, extra, 31 + B, row, monkeypatch)
     assert got.shape == (B, 3, N) and bool(torch.isfinite(got).all())
     err, inv, inv_d = rel_l2(got[row:row + 1], ref), rel_l2(alone, got[row:row + 1]), rel_l2(alone_default, got[row:row + 1])
+    parity(f"forward {name} B={B} N={N}: sampled shape vs oracle", err, TOL_FORWARD)
+    parity(f"forward {name}: shape vs itself at B=1 (same kernel forms)", inv, TOL_BATCH)
+    parity(f"forward {name}: shape vs itself at B=1 (default forms)", inv_d, 10 * TOL_BATCH)
     print(f"{name}: B={B}, N={N}: shape {row} vs oracle {err:.3e}; vs itself at B=1 {inv:.3e} (same kernel forms), {inv_d:.3e} (default forms at B=1)")
     assert err < TOL_FORWARD
     assert inv <= TOL_BATCH, f"batch-dependent result: rel-L2 {inv:.3e}"

@@ -16,7 +16,7 @@ the per-step teacher-forced tests (tests/test_hip_teacher_forced.py) cover the h
 import pytest
 import torch
 
-from helpers import golden_trajectory, rel_l2
+from helpers import first_segment_past, golden_trajectory, parity, rel_l2
 import trajectory_case as case
 
 HEAD_SCALE = 0.1
@@ -33,10 +33,14 @@ def test_full_trajectory_vs_oracle_fixture(hip, name):
     c = case.build(int(g["N"]), head_scale=float(g["head_scale"]), merging=bool(g["merging"]), B=int(g["B"]))
     assert list(g["milestones"]) == list(c.milestones) and int(g["roll_step"]) == c.roll_step
     assert len(case.program_order(c.milestones, c.roll_step, c.merging)) == int(g["forwards"])
-    got = case.run_hip(c)
-    err = rel_l2(got, torch.from_numpy(g["final"]))
-    print(f"full trajectory {name} ({int(g['forwards'])} forwards, N={int(g['N'])}) vs the oracle fixture: final rel-L2 {err:.3e}")
-    assert err <= NORTH_STAR
+    with case.segments() as seg:
+        got = case.run_hip(c)
+    err = parity(f"traj_{name} final cloud, {int(g['forwards'])} forwards", rel_l2(got, torch.from_numpy(g["final"])), NORTH_STAR)
+    first, curve = first_segment_past(NORTH_STAR, seg.clouds, g)
+    print(f"full trajectory {name} ({int(g['forwards'])} forwards, N={int(g['N'])}) vs the oracle fixture: final rel-L2 {err:.3e}; "
+          "per segment " + " ".join(f"{e:.1e}" for e in curve))
+    assert err <= NORTH_STAR, (f"final rel-L2 {err:.3e} > {NORTH_STAR}; first schedule segment past the bound: {first} "
+                               f"(segment curve {['%.2e' % e for e in curve]})")
 
 
 @pytest.mark.gpu_slow
@@ -45,7 +49,7 @@ def test_full_blending_trajectory_literal_bound(hip, oracle_ops):
     assert len(case.program_order(c.milestones, c.roll_step)) == 1080
     ref = case.run_oracle(c)
     got = case.run_hip(c)
-    err = rel_l2(got, ref)
+    err = parity("traj_live_blending_n1024 final cloud", rel_l2(got, ref), NORTH_STAR)
     print(f"full BDM-Blending trajectory (1000 PC^2 + 80 PVD + 5 blends, N=1024): final rel-L2 {err:.3e}")
     assert err <= NORTH_STAR
 
@@ -58,6 +62,6 @@ def test_full_merging_trajectory_literal_bound(hip, oracle_ops):
     assert sum(k == "fuse" for k, _ in order) == 5
     ref = case.run_oracle(c)
     got = case.run_hip(c)
-    err = rel_l2(got, ref)
+    err = parity("traj_live_merging_n1024 final cloud", rel_l2(got, ref), NORTH_STAR)
     print(f"full BDM-Merging trajectory (995 PC^2 + 75 PVD + 5 fused, N=1024): final rel-L2 {err:.3e}")
     assert err <= NORTH_STAR

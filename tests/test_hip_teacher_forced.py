@@ -13,7 +13,7 @@ Asserted per step:
 import pytest
 import torch
 
-from helpers import rel_l2, seeded
+from helpers import current_test, parity, rel_l2, seeded
 
 X_TOL, EPS_TOL = 1e-5, 1e-4
 
@@ -82,6 +82,8 @@ def _check_pc2(model, batch, rec, num_inference_steps):
             assert ee <= EPS_TOL, f"t={t}: eps rel-L2 {ee:.3e}"
     finally:
         sched.noise_source = None
+    parity(current_test() + f" worst x_prev of {len(rec)} teacher-forced steps", worst_x, X_TOL)
+    parity(current_test() + f" worst eps of {len(rec)} teacher-forced steps (head scale 1)", worst_eps, EPS_TOL)
     print(f"teacher-forced over {len(rec)} timesteps: worst x_prev rel-L2 {worst_x:.2e}, worst eps rel-L2 {worst_eps:.2e}, "
           f"{flips} steps with eps > 1e-4")
 
@@ -152,4 +154,6 @@ def test_pvd_chain_strided(hip, oracle_ops):
             assert ex <= X_TOL and ee <= EPS_TOL, (t, ex, ee)
     finally:
         pvd.diffusion.noise_source = None
+    parity(current_test() + f" worst x of {len(rec)} PVD steps", worst_x, X_TOL)
+    parity(current_test() + f" worst eps of {len(rec)} PVD steps", worst_eps, EPS_TOL)
     print(f"PVD teacher-forced over {len(rec)} timesteps: worst x rel-L2 {worst_x:.2e}, worst eps {worst_eps:.2e}")

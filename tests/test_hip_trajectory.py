@@ -65,6 +65,9 @@ def test_c1_chaos_monitor_divergence_no_faster_than_the_oracles_own(hip, oracle_
     final = rel_l2(y.cpu(), curve_ref[-1])
     print("oracle self-sensitivity (1 ulp)     :", " ".join(f"{c:.1e}" for c in self_sens[::10]))
     print(f"C1 trajectory: final rel-L2 {final:.3e} (oracle self-sensitivity {self_sens[-1]:.3e}), worst {worst:.3e}")
+    from helpers import parity
+    parity("c1 trajectory (head scale 1, chaos monitor): first 10 steps", max(curve[:10]), 1e-5)
+    parity("c1 trajectory (head scale 1, chaos monitor): final vs 4x oracle self-sensitivity", final, max(1e-3, 4 * self_sens[-1]))
     assert max(curve[:10]) < 1e-5
     assert final <= max(1e-3, 4 * self_sens[-1])
 

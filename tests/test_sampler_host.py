@@ -166,12 +166,28 @@ for lr in (0, 1, 2):
     out.append((info, sorted(os.sched_getaffinity(0))))
     os.sched_setaffinity(0, {allowed!r})
 out.append((pin_to_gpu_numa_node(0, sysfs="/nonexistent"), None))
+# KFD topology present: HIP order = KFD GPU-node order (here the REVERSE of the PCI order), CPU nodes (simd_count 0) skipped
+for nid, (simd, minor) in enumerate([(0, -1), (256, 129), (256, 128)]):
+    d = os.path.join({str(sysfs)!r}, "class/kfd/kfd/topology/nodes", str(nid))
+    os.makedirs(d)
+    open(os.path.join(d, "properties"), "w").write(f"cpu_cores_count 0\\nsimd_count {{simd}}\\ndrm_render_minor {{minor}}\\n")
+out.append((pin_to_gpu_numa_node(0, sysfs={str(sysfs)!r}), None))
+os.sched_setaffinity(0, {allowed!r})
+os.environ["HIP_VISIBLE_DEVICES"] = "1"      # ordinal into the KFD order -> the 0000:05 device
+out.append((pin_to_gpu_numa_node(0, sysfs={str(sysfs)!r}), None))
+os.sched_setaffinity(0, {allowed!r})
+os.environ["ROCR_VISIBLE_DEVICES"] = "GPU-deadbeef"   # cannot be interpreted: no pinning, no guess
+out.append((pin_to_gpu_numa_node(0, sysfs={str(sysfs)!r}), sorted(os.sched_getaffinity(0))))
 print(json.dumps(out))
 """
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr[-2000:]
     import json
-    r0, r1, r2, r3 = json.loads(res.stdout.strip().splitlines()[-1])
+    r0, r1, r2, r3, k0, k1, k2 = json.loads(res.stdout.strip().splitlines()[-1])
+    assert k0[0]["pci"] == "0000:85:00.0" and k0[0]["order"] == "kfd" and k0[0]["numa_node"] == 1
+    assert k1[0]["pci"] == "0000:05:00.0" and k1[0]["numa_node"] == 0
+    assert k2[0]["numa_node"] is None and "VISIBLE_DEVICES" in k2[0]["why"] and k2[1] == allowed
+    assert r0[0]["order"] == "pci"
     assert r0[0]["numa_node"] == 0 and r0[1] == nodes[0] and r0[0]["pci"] == "0000:05:00.0"
     assert r1[0]["numa_node"] == 1 and r1[1] == nodes[1]
     assert r2[0]["numa_node"] is None and r2[1] == allowed          # only two amdgpu devices: rank 2 is left alone

@@ -159,6 +159,22 @@ def run_oracle(c, progress=False):
         R.TRACE = None
 
 
+class segments:
+    """with segments() as seg: run_hip(...) -> seg.clouds = the HIP path's (B, N, 3) host copies at the end of every schedule
+    segment (bdm_amd.sampling.SEGMENT_HOOK), to be compared with the fixtures' `segment_k`."""
+
+    def __enter__(self):
+        from bdm_amd import sampling
+        self.clouds = []
+        sampling.SEGMENT_HOOK = lambda i, x: self.clouds.append(x.detach().cpu().clone())
+        return self
+
+    def __exit__(self, *exc):
+        from bdm_amd import sampling
+        sampling.SEGMENT_HOOK = None
+        return False
+
+
 def run_hip(c, device="cuda"):
     """Final (B, N, 3) cloud of the HIP path on the same draws, fed through the replay hooks in program order."""
     from bdm_amd.sampling import bdm_blending, bdm_merging
