@@ -248,7 +248,7 @@ class PVConv(nn.Module):
     fold_gn1 = True  # GroupNorm-1 statistics from the sparse gather's epilogue
     fold_pf = True  # point branch's GroupNorm folded into the devoxelisation kernel
     point_stream = True  # the point branch of a PVConv on its own stream (False: inline; tests and tools/coresidency/two_proc_race.py flip it)
-    point_stream_min = 8192  # B * N below which the branch stays on the main stream
+    point_stream_min = int(os.environ.get("BDM_POINT_STREAM_MIN", "8192"))  # B * N below which the branch stays on the main stream
     _streams = {}
 
     def voxel_plan_args(self):
@@ -283,6 +283,25 @@ class PVConv(nn.Module):
                 and (self.compact_tail == "always" or ops.compact_tail_pays(batch, n_points, self.resolution, c)))
 
     _cond = None  # ops.Conditioning of this forward when the input is the raw conditioned cloud (set by PVCNN2Base.forward)
+    _next_pv = None  # the PVConv that consumes this one's output inside the same nn.Sequential (pvcnn.run_blocks), else None
+
+    def accepts_rows(self, plan, channels, batch):
+        """Will this module's first convolution take the fp16x3 GEMM over the occupied rows of `plan` (so that the previous PVConv's
+        tail may leave it the operand, ops.VoxelRows)?  Mirrors the route choice in forward."""
+        conv1 = self.voxel_layers[0]
+        return (ops.SMALL_GLUE and self.conv_impl == "fp16x3" and self.sparse_first_conv and self.resolution == plan.r
+                and self.resolution in self.sparse_resolutions and self.sparse_gemm == "sparse_h2" and plan.n_max <= 256
+                and conv1.in_channels == channels and channels % 8 == 0 and not getattr(self, "h2_saturated", False)
+                and not self.wants_dilated_plan(batch, plan.n))
+
+    def _head_for_next(self, plan, gn2, batch, device):
+        """(plan, power-of-two scale, saturation word) for bdm_pvconv_tail_small's head, or None: the next PVConv of the Sequential runs on
+        the same voxel plan (same coordinates, same resolution) and takes the operand."""
+        nxt = self._next_pv
+        if nxt is None or plan is None or not nxt.accepts_rows(plan, self.out_channels, batch):
+            return None
+        pf_gn = self.point_features.layers[-2]
+        return plan, ops.h2_sum_scale([gn2, pf_gn]), ops.saturation_slot(nxt, device)
 
     def _hoisted(self, features):
         """The handle, if `features` IS the conditioned input it describes (first PVConv of the PC^2 denoiser)."""
@@ -348,8 +367,9 @@ class PVConv(nn.Module):
         att = next((m for m in rest if isinstance(m, Attention)), None)
         se = next((m for m in rest if isinstance(m, SE3d)), None)
 
+        rows_in = getattr(features, "_bdm_rows", None)   # first-convolution operand left by the previous PVConv's tail (ops.VoxelRows)
         features = ops.materialize(features)
-        gn1_stats = None
+        gn1_stats, plan, xh_ready = None, None, None
         cg2_, tile_ = conv2.out_channels // gn2.num_groups, (64 if (conv2.out_channels > 32 and r != 8) else 32)
         folded_tail = (self.conv_impl == "fp16x3" and not getattr(self, "h2_saturated", False) and self.fold_gn2 and att is None
                        and se is not None and cg2_ in (4, 8, 16, 32) and tile_ % cg2_ == 0)
@@ -384,8 +404,19 @@ class PVConv(nn.Module):
                     v = ops.sparse_first_conv_os(features, plan, self._packed_weight(conv1, "fp16x3"), conv1.bias, conv1.out_channels,
                                                  gn_groups=gn1.num_groups if want_stats else None, compact=want_stats)
                 else:
-                    v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, impl), conv1.bias, conv1.out_channels,
-                                                      gn_groups=gn1.num_groups if want_stats else None)
+                    if rows_in is not None and not (impl == "sparse_h2" and rows_in.plan is plan and rows_in.channels == conv1.in_channels):
+                        rows_in = None
+                    if (impl == "sparse_h2" and want_stats and folded_tail and plan.n_max <= 256
+                            and ops.small_grid_gather_ok(r, conv1.out_channels, gn1.num_groups)):
+                        # small grid: GroupNorm-1 + Swish + the second convolution's operand split in the gather's epilogue (one
+                        # workgroup per (shape, group)): no dense fp32 grid, no statistics hand-off, no to_h2 launch (pvconv_small.hip)
+                        xh_ready = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, impl), conv1.bias, conv1.out_channels,
+                                                                 rows=rows_in, h2_out=(gn1, ops.h2_activation_scale(gn1),
+                                                                                       ops.saturation_slot(self, features.device)))
+                        v, want_stats = None, False
+                    else:
+                        v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, impl), conv1.bias, conv1.out_channels,
+                                                          gn_groups=gn1.num_groups if want_stats else None, rows=rows_in)
                 if want_stats:
                     v, gn1_stats = v
             else:
@@ -416,8 +447,11 @@ class PVConv(nn.Module):
             if self.conv_impl == "fp16x3" and not getattr(self, "h2_saturated", False):
                 # saturation guard: to_h2 raises this layer's sticky device word when a scaled activation leaves fp16's
                 # range; ops.poll_h2_saturation() (once per trajectory) then routes the layer to bf16x6 and warns
-                sat = ops.saturation_slot(self, v.device) if v.is_cuda else None
-                xh = ops.to_h2(v, gn1, swish=True, saturated=sat, stats=gn1_stats)
+                if xh_ready is not None:
+                    xh = xh_ready
+                else:
+                    sat = ops.saturation_slot(self, v.device) if v.is_cuda else None
+                    xh = ops.to_h2(v, gn1, swish=True, saturated=sat, stats=gn1_stats)
                 cg2, tile = conv2.out_channels // gn2.num_groups, (64 if (conv2.out_channels > 32 and r != 8) else 32)
                 if self.fold_gn2 and att is None and se is not None and cg2 in (4, 8, 16, 32) and tile % cg2 == 0:
                     # GroupNorm-folded tail: the convolution leaves the statistics of its output, SE and the devoxelisation
@@ -425,6 +459,21 @@ class PVConv(nn.Module):
                     v, stats = ops.conv3d_h2_gn(xh, self._packed_weight(conv2, "fp16x3"), conv2.bias, conv2.in_channels,
                                                 conv2.out_channels, r, gn2.num_groups)
                     w1, w2 = se.fc[0].weight, se.fc[2].weight
+                    if ops.small_grid_tail_ok(r, conv2.out_channels, features.shape[2]) and w1.shape[0] <= 256:
+                        # small grid: SE's FC layers + GroupNorm-2 + Swish + gate + devoxelisation + point branch in one launch of
+                        # per-shape workgroups, which also leave the NEXT PVConv's first-convolution operand when it shares the plan
+                        if pf_ready is not None:
+                            tape.wait_event(pf_ready)
+                        pf_coef = None
+                        if pf_pending is not None:
+                            mean, coef, pf_coef = ops.se_means_gn(v, stats, gn2, pf=pf_pending, n_points=pf.shape[2])
+                        else:
+                            mean, coef = ops.se_means_gn(v, stats, gn2)
+                        out, rows = ops.pvconv_tail_small(norm_coords, v, coef, mean, w1, w2, r, add=pf, add_coef=pf_coef,
+                                                          head=self._head_for_next(plan, gn2, features.shape[0], features.device))
+                        if rows is not None:
+                            out._bdm_rows = rows
+                        return out, coords, temb
                     if self.se_in_devox and w1.shape[0] <= 64:
                         # SE block's FC layers inside the devoxelisation kernel: one launch less, but every workgroup re-reads
                         # w1 / w2 (measured at B=16: devoxelisation 325 -> 650 us per forward for 100 us of se_fc saved), so

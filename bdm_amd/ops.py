@@ -715,14 +715,23 @@ def se_gate_gn(x, stats, gn, w1, w2, pf=None, n_points=0):
     return gate, coef
 
 
-def se_means_gn(x, stats, gn):
+def se_means_gn(x, stats, gn, pf=None, n_points=0):
     """Per-channel means of swish(group_norm(x)) + the rows' affine forms, from the raw grid and the producer's statistics:
-    (mean (B,C), coef (B,C,2)).  The SE block's FC layers are then evaluated inside the devoxelisation kernel."""
+    (mean (B,C), coef (B,C,2)).  The SE block's FC layers are then evaluated inside the devoxelisation kernel.
+    pf = ((partial, slices, groups), gn) of the PVConv's point branch: also returns that GroupNorm's affine forms (B,C,2)."""
     ws, slices = stats
     B, C = x.shape[:2]
     l = x.numel() // (B * C)
     mean = torch.empty(B, C, dtype=torch.float32, device=x.device)
     coef = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+    if pf is not None:
+        (pp, ps, pg), pgn = pf
+        pf_coef = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+        L.check(L.lib().bdm_se_gate_gn_pf(B, C, 1, l, gn.num_groups, L.ptr(x), L.ptr(ws), slices, L.ptr(gn.weight), L.ptr(gn.bias),
+                                          L.c_float(gn.eps), L.ptr(None), L.ptr(None), L.ptr(mean), L.ptr(coef), L.ptr(None),
+                                          L.ptr(pp), ps, pg, int(n_points), L.ptr(pgn.weight), L.ptr(pgn.bias), L.c_float(pgn.eps),
+                                          L.ptr(pf_coef), L.stream()), "se_means_gn_pf")
+        return mean, coef, pf_coef
     L.check(L.lib().bdm_se_gate_gn(B, C, 1, l, gn.num_groups, L.ptr(x), L.ptr(ws), slices, L.ptr(gn.weight), L.ptr(gn.bias),
                                    L.c_float(gn.eps), L.ptr(None), L.ptr(None), L.ptr(mean), L.ptr(coef), L.ptr(None), L.stream()),
             "se_means_gn")
@@ -763,6 +772,73 @@ def devoxelize_gn_gate_add(norm_coords, grid, coef, r, gate=None, add=None, add_
     L.check(L.lib().bdm_devoxelize_gn_gate_add(B, C, n, int(r), L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(gate), L.ptr(add),
                                                bs_a, ld_a, L.ptr(out), bs_o, ld_o, L.stream()), "devoxelize_gn_gate_add")
     return out
+
+
+# ---- PVConv glue on the small voxel grids (csrc/pvconv_small.hip) ------------------------------------------------------------------
+SMALL_GLUE = os.environ.get("BDM_SMALL_GLUE", "1") == "1"   # fused tail / head / gather of the 8^3 PVConvs (0: the operator chain)
+
+
+def small_grid_tail_ok(r, c, n):
+    """bdm_pvconv_tail_small covers it: a slab's cells (8 channels x r^3) + its features (8 x n) fit LDS comfortably"""
+    return SMALL_GLUE and c % 8 == 0 and (r ** 3) % 4 == 0 and (8 * r ** 3 + 8 * n + c + 64) * 4 <= 64 * 1024
+
+
+def small_grid_gather_ok(r, cout, groups):
+    cg = cout // groups if groups and cout % groups == 0 else 0
+    return SMALL_GLUE and cg >= 8 and cg % 8 == 0 and cg <= 64 and 256 % (cg // 4) == 0 and (cg * (r ** 3 + 1) + r ** 3) * 4 <= 150 * 1024
+
+
+def h2_sum_scale(gns, sigmas=64.0):
+    """Power-of-two scale for a SUM of GroupNorm(+Swish) outputs (|Swish(y)| <= |y|; convex combinations and gates in [0, 1] do not
+    raise the bound): the fused features of a PVConv = devoxelised Swish(GroupNorm-2) * gate + Swish(GroupNorm(point branch)), and every
+    mean of them over the points of a cell.  From the parameters only (cached per parameter version), as h2_activation_scale."""
+    sig = tuple((g.weight._version, g.bias._version, g.weight.data_ptr()) for g in gns) + (sigmas,)
+    owner = gns[0]
+    hit = getattr(owner, "_bdm_h2_sum_scale", None)
+    if hit is None or hit[0] != sig:
+        bound = sum(float((g.weight.detach().abs() * sigmas + g.bias.detach().abs()).max()) for g in gns)
+        hit = (sig, _pow2_below(32768.0 / max(bound, 1e-30)))
+        owner._bdm_h2_sum_scale = hit
+    return hit[1]
+
+
+class VoxelRows:
+    """First-convolution operand of a PVConv, formed by the PREVIOUS PVConv's tail on the same voxel plan (bdm_pvconv_tail_small):
+    xh (B, C/8, 2, n_max, 8) fp16 records + amax (B) for bdm_sparse_conv_gemm_h2; valid for `plan` and `features` only."""
+    __slots__ = ("plan", "xh", "amax", "channels")
+
+    def __init__(self, plan, xh, amax, channels):
+        self.plan, self.xh, self.amax, self.channels = plan, xh, amax, channels
+
+
+def pvconv_tail_small(norm_coords, grid, coef, mean, w1, w2, r, add=None, add_coef=None, head=None):
+    """SE gate + Swish(GroupNorm-2) + devoxelisation + point branch in one launch (-> out (B, C, n)); head = (plan, x_scale, saturated):
+    also the next PVConv's operand on `plan` -> (out, VoxelRows)."""
+    B, C = grid.shape[:2]
+    n = norm_coords.shape[2]
+    out = torch.empty(B, C, n, dtype=torch.float32, device=grid.device)
+    _, _, _, _, bs_o, ld_o = _bcl(out)
+    if add is not None:
+        aa, _, _, _, bs_a, ld_a = _bcl(add)
+        assert aa.data_ptr() == add.data_ptr()
+    else:
+        bs_a, ld_a = 0, 0
+    rows = None
+    if head is not None:
+        plan, x_scale, saturated = head
+        xh = torch.empty(B, C // 8, 2, plan.n_max, 8, dtype=torch.float16, device=grid.device)
+        amax = torch.empty(B, dtype=torch.float32, device=grid.device)
+        rows = VoxelRows(plan, xh, amax, C)
+        L.check(L.lib().bdm_pvconv_tail_small(B, C, n, int(r), w1.shape[0], L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(mean),
+                                              L.ptr(w1), L.ptr(w2), L.ptr(add), bs_a, ld_a, L.ptr(add_coef), L.ptr(out), bs_o, ld_o,
+                                              L.ptr(plan.cnt), L.ptr(plan.ws), L.ptr(plan.occ_list), L.ptr(plan.n_occ), plan.n_max,
+                                              L.c_float(x_scale), L.ptr(xh), L.ptr(amax), L.ptr(saturated), L.stream()), "pvconv_tail_small")
+        return out, rows
+    L.check(L.lib().bdm_pvconv_tail_small(B, C, n, int(r), w1.shape[0], L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(mean),
+                                          L.ptr(w1), L.ptr(w2), L.ptr(add), bs_a, ld_a, L.ptr(add_coef), L.ptr(out), bs_o, ld_o,
+                                          L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None), 0, L.c_float(0.0), L.ptr(None), L.ptr(None),
+                                          L.ptr(None), L.stream()), "pvconv_tail_small")
+    return out, None
 
 
 # ---- sparse first convolution of a PVConv (csrc/sparse_conv.hip) ----------------------------------------------------
@@ -1078,24 +1154,43 @@ def _gather(lib, nb, cout, r, plan, b0, y, bias, out, gn):
                 "sparse_conv_gather_gn")
 
 
-def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None):
+def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None, rows=None, h2_out=None):
     """Conv3d(k3, p1)(avg_voxelize(features)) on the occupied voxels of `plan`: (B, cout, r^3) fp32.
-    gn_groups: also return the GroupNorm(gn_groups) statistics of the output as (partial, slices = r*r, groups) -> (out, stats)."""
+    gn_groups: also return the GroupNorm(gn_groups) statistics of the output as (partial, slices = r*r, groups) -> (out, stats).
+    rows (fp16x3 GEMM only): a VoxelRows the previous PVConv's tail left for this very plan -- the feature pass and the split are skipped.
+    h2_out = (gn, act_scale, saturated) (fp16x3 GEMM on a small grid, small_grid_gather_ok): GroupNorm + Swish + the second convolution's
+    operand split in the gather's epilogue -> ((B, cout/8, 2, r^3, 8) fp16, 1 / act_scale); the dense fp32 grid is not written."""
     f, B, C, n, bs_f, ld_f = _bcl(features)
     dev, lib, r = f.device, L.lib(), plan.r
     if isinstance(wt, tuple) and wt[0] == "h2":  # fp16x3 GEMM (sparse_conv_pack_h2) + gather: the default
         _, packed, inv_scale = wt
-        xr = torch.empty(B, (C + 7) // 8, plan.n_max, 8, dtype=torch.float32, device=dev)
-        amax = amax_slots(dev, B)  # one activation scale per shape: a shape's result does not depend on its batch-mates
-        L.check(lib.bdm_sparse_voxel_features_f32(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),
-                                                  L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()),
-                "sparse_voxel_features_f32")
-        xh = torch.empty(B, (C + 7) // 8, 2, plan.n_max, 8, dtype=torch.float16, device=dev)
-        L.check(lib.bdm_sparse_split_h2(B, C, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(xh), L.stream()), "sparse_split_h2")
-        out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
+        if rows is not None:
+            assert rows.plan is plan and rows.channels == C
+            xh, amax = rows.xh, rows.amax
+        else:
+            xr = torch.empty(B, (C + 7) // 8, plan.n_max, 8, dtype=torch.float32, device=dev)
+            amax = amax_slots(dev, B)  # one activation scale per shape: a shape's result does not depend on its batch-mates
+            L.check(lib.bdm_sparse_voxel_features_f32(B, C, n, r, plan.n_max, L.ptr(f), bs_f, ld_f, L.ptr(plan.cnt), L.ptr(plan.ws),
+                                                      L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()),
+                    "sparse_voxel_features_f32")
+            xh = torch.empty(B, (C + 7) // 8, 2, plan.n_max, 8, dtype=torch.float16, device=dev)
+            L.check(lib.bdm_sparse_split_h2(B, C, plan.n_max, L.ptr(xr), L.ptr(amax), L.ptr(xh), L.stream()), "sparse_split_h2")
         per_shape = plan.n_max * 27 * cout * 4
         gb = max(1, min(B, SPARSE_Y_BYTES // max(per_shape, 1)))
         y = torch.empty(gb, plan.n_max, 27 * cout, dtype=torch.float32, device=dev)
+        if h2_out is not None:
+            gn1, act_scale, saturated = h2_out
+            x2 = torch.empty(B, cout // 8, 2, r ** 3, 8, dtype=torch.float16, device=dev)
+            for b0 in range(0, B, gb):
+                nb = min(gb, B - b0)
+                L.check(lib.bdm_sparse_conv_gemm_h2(nb, plan.n_max, C, cout, L.ptr(xh[b0:]), L.ptr(amax[b0:]), L.ptr(packed), L.ptr(inv_scale),
+                                                    L.ptr(plan.n_occ[b0:]), L.ptr(y), L.stream()), "sparse_conv_gemm_h2")
+                L.check(lib.bdm_sparse_conv_gather_h2_small(nb, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index[b0:]), L.ptr(bias),
+                                                            gn1.num_groups, L.ptr(gn1.weight), L.ptr(gn1.bias), L.c_float(gn1.eps),
+                                                            L.c_float(act_scale), L.ptr(x2[b0:]), L.ptr(saturated), L.stream()),
+                        "sparse_conv_gather_h2_small")
+            return x2, 1.0 / act_scale
+        out = torch.empty(B, cout, r ** 3, dtype=torch.float32, device=dev)
         gn, stats = None, None
         if gn_groups and gather_gn_ok(cout, gn_groups):
             partial = torch.empty(B, gn_groups, r * r, 2, dtype=torch.float64, device=dev)

@@ -98,7 +98,11 @@ def create_classifier(in_channels, dropout, num_classes, width_multiplier=1):
 def run_blocks(blocks, inputs):
     """nn.Sequential protocol of the reference: every block maps a tuple to a tuple."""
     if isinstance(blocks, nn.Sequential):
-        for blk in blocks:
+        mods = list(blocks)
+        for i, blk in enumerate(mods):
+            if isinstance(blk, PVConv):
+                # (not a submodule registration: the successor is only looked at, PVConv._head_for_next)
+                blk.__dict__["_next_pv"] = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], PVConv) else None
             inputs = blk(inputs)
         return inputs
     return blocks(inputs)

@@ -40,6 +40,12 @@ def _host_only(name):
             or name.startswith("bdm_tape_") or name in ("bdm_last_error", "bdm_abi_version"))
 
 
+# BDM_TAPE_SKIP=bdm_x,bdm_y: TIMING EXPERIMENTS ONLY -- these C-ABI functions run while the step is recorded but are not put on the tape,
+# so the replayed step shows what the loop would cost WITHOUT their launches (results are garbage: their outputs go stale).  The way a
+# fusion is priced before it is built (tools/replay_host_time.py).
+_PRICE_SKIP = frozenset(v for v in os.environ.get("BDM_TAPE_SKIP", "").split(",") if v)
+
+
 class _RecordingLib:
     """Stands in for the ctypes handle while a step is recorded: calls go through AND onto the tape."""
 
@@ -51,6 +57,9 @@ class _RecordingLib:
         if _host_only(name):
             return fn
         calls = self._tape.calls
+        if name in _PRICE_SKIP:   # pricing experiment (BDM_TAPE_SKIP): executed while recording, LEFT OUT of the replayed step
+            self.__dict__[name] = fn
+            return fn
 
         def call(*args):
             calls.append((fn, args))

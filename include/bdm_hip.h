@@ -386,6 +386,28 @@ int bdm_devoxelize_gn_se_add(int b, int c, int n, int r, const float *coords, co
                              const float *se_mean, int hidden, const float *w1, const float *w2, const float *add,
                              long long bs_a, int ld_a, float *out, long long bs_o, int ld_o, void *stream);
 
+/* ---- PVConv glue on the SMALL voxel grids (8^3 levels; csrc/pvconv_small.hip) -- per-shape workgroups, no hand-off between them ----
+ * bdm_pvconv_tail_small: SE gate (both FC layers of se.py:8-19, from se_mean (b, c) = bdm_se_gate_gn(w1 = NULL)'s channel means)
+ * + Swish(GroupNorm-2(grid)) * gate + trilinear devoxelisation at the n points + Swish(GroupNorm(point branch)) (add_coef; NULL: `add`
+ * is added as it is) -> out (pvconv.py:91-97), one workgroup per (shape, 8 channels); bit-identical to bdm_se_gate_gn_pf +
+ * bdm_devoxelize_gn_gate_add_pf.  With xh != NULL the same workgroups also form the NEXT PVConv's first-convolution operand on the same
+ * voxel plan (cnt / plan_workspace / occ_list / n_occ / n_max of bdm_voxelize_plan_full): per occupied cell the mean of `out` over its
+ * points (vox.cu:18-72 on the plan's ordered lists: the values of bdm_sparse_voxel_features_f32), times the power of two x_scale,
+ * split into (hi, lo) fp16 records xh (b, c/8, 2, n_max) -- what bdm_sparse_split_h2 writes -- and amax_out (b) such that
+ * bdm_sparse_conv_gemm_h2 derives x_scale from it; *saturated |= 1 when a scaled value leaves fp16's range. */
+int bdm_pvconv_tail_small(int b, int c, int n, int r, int hidden, const float *coords, const float *grid, const float *coef,
+                          const float *se_mean, const float *w1, const float *w2, const float *add, long long bs_a, int ld_a,
+                          const float *add_coef, float *out, long long bs_o, int ld_o, const int *cnt, const void *plan_workspace,
+                          const int *occ_list, const int *n_occ, int n_max, float x_scale, void *xh, float *amax_out, int *saturated,
+                          void *stream);
+/* bdm_sparse_conv_gather_h2_small: bdm_sparse_conv_gather_gn + bdm_group_norm_to_h2_stats in one launch, one workgroup per (shape,
+ * GroupNorm group): y (b, n_max, 27, cout) = the GEMM's output, out_h2 (b, cout/8, 2, r^3) records = act_scale *
+ * Swish(GroupNorm(groups)(conv1 output)) as two fp16 terms (the second convolution's operand); the dense fp32 output of the first
+ * convolution is not written.  Needs 8 | cout / groups <= 64. */
+int bdm_sparse_conv_gather_h2_small(int b, int cout, int r, int n_max, const float *y, const int *occ_index, const float *bias,
+                                    int groups, const float *gamma, const float *beta, float eps, float act_scale, void *out_h2,
+                                    unsigned int *saturated, void *stream);
+
 /* bf16x6 form of the two steps above (default): operands pre-split into exact bf16 triples ("S3" records of 8
  * channels x 16 bytes), GEMM on v_mfma_f32_32x32x16_bf16 with six partial products per fp32 product.
  *   xs (b, ceil(c/8), 3, n_max) records; ws (ceil(cin/8), 3, 27*cout) records = bdm_sparse_conv_s3_weight_elems bf16. */
