@@ -15,6 +15,7 @@
 
 #include "../../include/bdm_hip.h"
 #include "common.h"
+#include "se_fc.h"
 
 using namespace bdm;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -1344,17 +1345,9 @@ __global__ void se_fc_kernel(int c, int h, const float *__restrict__ mean, const
   const int bi = blockIdx.x;
   for (int i = threadIdx.x; i < c; i += blockDim.x) s[i] = mean[(size_t)bi * c + i];
   __syncthreads();
-  for (int j = threadIdx.x; j < h; j += blockDim.x) {
-    float a = 0.f;
-    for (int k = 0; k < c; ++k) a += w1[(size_t)j * c + k] * s[k];
-    hid[j] = fmaxf(a, 0.f);
-  }
+  se_hidden_layer(c, h, w1, s, hid);
   __syncthreads();
-  for (int i = threadIdx.x; i < c; i += blockDim.x) {
-    float a = 0.f;
-    for (int k = 0; k < h; ++k) a += w2[(size_t)i * h + k] * hid[k];
-    gate[(size_t)bi * c + i] = 1.0f / (1.0f + expf(-a));
-  }
+  for (int i = threadIdx.x; i < c; i += blockDim.x) gate[(size_t)bi * c + i] = se_gate_of(i, h, w2, hid);
 }
 // One launch: every workgroup reduces one (shape, channel) row; the LAST workgroup of a shape to finish (device-scope
 // counter behind a release fence, acquire fence before reading the means) evaluates the two small FC layers.  The sums
@@ -1388,17 +1381,9 @@ __global__ __launch_bounds__(256) void se_gate_fused_kernel(int c, int h, int l,
   const volatile float *mv = mean + (size_t)bi * c;
   for (int i = threadIdx.x; i < c; i += blockDim.x) sv[i] = mv[i];
   __syncthreads();
-  for (int j = threadIdx.x; j < h; j += blockDim.x) {
-    float a = 0.f;
-    for (int k = 0; k < c; ++k) a += w1[(size_t)j * c + k] * sv[k];
-    hid[j] = fmaxf(a, 0.f);
-  }
+  se_hidden_layer(c, h, w1, sv, hid);
   __syncthreads();
-  for (int i = threadIdx.x; i < c; i += blockDim.x) {
-    float a = 0.f;
-    for (int k = 0; k < h; ++k) a += w2[(size_t)i * h + k] * hid[k];
-    gate[(size_t)bi * c + i] = 1.0f / (1.0f + expf(-a));
-  }
+  for (int i = threadIdx.x; i < c; i += blockDim.x) gate[(size_t)bi * c + i] = se_gate_of(i, h, w2, hid);
   if (threadIdx.x == 0) counters[bi] = 0;  // ready for the next call (ordered by the kernel boundary)
 }
 
@@ -1527,9 +1512,7 @@ extern "C" int bdm_se_gate_gn_pf(int b, int c, int hidden, int l, int groups, co
 }
 
 __device__ __forceinline__ float se_gate_from_hidden(int ci, int hidden, const float *__restrict__ w2, const float *s_hid) {
-  float a = 0.f;  // same expression (and contraction mode) as se_fc_kernel
-  for (int k = 0; k < hidden; ++k) a += w2[(size_t)ci * hidden + k] * s_hid[k];
-  return 1.0f / (1.0f + expf(-a));
+  return se_gate_of(ci, hidden, w2, s_hid);  // (se_fc.h: the one definition of the gate)
 }
 
 // se_mean != NULL: the SE block's two small FC layers (se.py:8-19) are evaluated HERE from the per-channel means -- every
@@ -1542,17 +1525,15 @@ __global__ void devox_gn_fused_kernel(int b, int cslots, int pblocks, int c, int
                                       const float *__restrict__ add, long long bs_a, int ld_a,
                                       const float2 *__restrict__ add_coef, float *__restrict__ out, long long bs_o, int ld_o) {
   __shared__ float s_hid[64];
+  __shared__ float s_mv[1024];
   const int span = 8 * pblocks, wg = blockIdx.x;
   const int unit = (wg / span) * 8 + (wg % span) % 8, pb = (wg % span) / 8;
   if (unit >= b * cslots) return;
   const int bi = unit / cslots, c_first = unit % cslots;
   if (se_mean != nullptr) {  // block-uniform
-    const float *mv = se_mean + (size_t)bi * c;
-    for (int j = threadIdx.x; j < hidden; j += blockDim.x) {
-      float a = 0.f;
-      for (int k = 0; k < c; ++k) a += w1[(size_t)j * c + k] * mv[k];
-      s_hid[j] = fmaxf(a, 0.f);
-    }
+    for (int k = threadIdx.x; k < c; k += blockDim.x) s_mv[k] = se_mean[(size_t)bi * c + k];
+    __syncthreads();
+    se_hidden_layer(c, hidden, w1, s_mv, s_hid);
     __syncthreads();
   }
   {
@@ -1674,7 +1655,7 @@ static int devox_gn_launch(int b, int c, int n, int r, const float *coords, cons
                            const float *add, long long bs_a, int ld_a, const float *add_coef, float *out, long long bs_o, int ld_o,
                            void *stream) {
   BDM_REQUIRE(b >= 0 && c >= 1 && n >= 1 && r >= 1 && coef != nullptr, "devoxelize_gn_gate_add: bad arguments");
-  BDM_REQUIRE(se_mean == nullptr || (hidden >= 1 && hidden <= 64 && w1 != nullptr && w2 != nullptr), "devoxelize_gn_se_add: bad SE arguments");
+  BDM_REQUIRE(se_mean == nullptr || (hidden >= 1 && hidden <= 64 && c <= 1024 && w1 != nullptr && w2 != nullptr), "devoxelize_gn_se_add: bad SE arguments");
   if (b == 0) return BDM_OK;
   const int lsel = bdm_staging_choice();  // BDM_STAGING=0 keeps the global-memory gather, =1 forces the LDS form (common.h)
   const int r3 = r * r * r;

@@ -1,3 +1,7 @@
+// EXPERIMENTAL family (`make EXPERIMENTAL=1`): built, parity-tested, measured and NOT faster than the operator chain --
+// FP0 PVConv 167 -> 180 us, FP1 218 -> 220 us per module at B = 16 with both kernels; the step 5.40 ms either way.  Kept as the
+// record of VERDICT r4 next-1 (a) + (c); the default library does not contain it.
+//
 // pvconv_small.hip -- the glue of a PVConv on the SMALL voxel grids (8^3: 64 - 256 points, 128 - 256 channels per shape), where a
 // module is a chain of ~10 dependent launches of 5 - 20 us each and the dense second convolution is the only kernel that fills the
 // chip.  Everything here is PER SHAPE: a workgroup owns (shape, channel slab) and never
@@ -10,7 +14,10 @@
 //                           [+ optionally the HEAD of the next PVConv on the same voxel plan: mean of the fused features per
 //                           occupied cell (vox.cu:18-72 on the plan's ordered lists) and their two-term fp16 split, i.e. the A
 //                           operand of that PVConv's sparse GEMM -- the feature tensor is voxelised by the workgroup that just
-//                           produced it].  Replaces se_fc + devox_gn_fused (+ sparse_vox_features + sparse_split_h2).
+//                           produced it].  Replaces se_fc + devox_gn_fused (+ sparse_vox_features + sparse_split_h2).  (A one-workgroup-
+//                           per-shape form that also computed the channel means -- no row-mean launch -- was built and measured at
+//                           57 - 126 us per launch against 9 + 25 for row means + this kernel: one CU streaming a shape's 512 KB grid
+//                           twice through eight slab barriers is slower than 512 workgroups; removed)
 //   bdm_sparse_conv_gather_h2_small
 //                           the sparse first convolution's gather (sparse_conv.hip) with GroupNorm-1 + Swish + the fp16 operand
 //                           split of the second convolution in its epilogue: a workgroup owns (shape, GroupNorm group) over the
@@ -19,12 +26,13 @@
 //
 // Arithmetic: the same expressions, in the same order, as the kernels they replace wherever a value is shared with them (gate,
 // devoxelised sums, per-cell means), so the two-launch forms stay usable as bit-exact references in the tests.
-#include "../../include/bdm_hip.h"
-#include "common.h"
+#include "../../../include/bdm_hip.h"
+#include "../common.h"
+#include "../se_fc.h"
 
 using namespace bdm;
 
-#include "sparse_h2_common.h"
+#include "../sparse_h2_common.h"
 
 namespace {
 
@@ -54,20 +62,12 @@ __global__ __launch_bounds__(TAIL_T) void pv_tail_small_kernel(int c, int n, int
   float *s_mean = fs + (hd.xh ? TAIL_CS * n : 0);   // [c]
   float *s_hid = s_mean + c;                // [hidden]
   float *s_gate = s_hid + hidden;           // [CS]
-  // ---- SE gate of the slab's channels: the two FC layers in the summation order of se_fc_kernel (dense_ops.hip) ----------------
+  // ---- SE gate of the slab's channels: the two FC layers as every other kernel evaluates them (se_fc.h) -------------------------------
   for (int i = tid; i < c; i += TAIL_T) s_mean[i] = se_mean[(size_t)bi * c + i];
   __syncthreads();
-  for (int j = tid; j < hidden; j += TAIL_T) {
-    float a = 0.f;
-    for (int k = 0; k < c; ++k) a += w1[(size_t)j * c + k] * s_mean[k];
-    s_hid[j] = fmaxf(a, 0.f);
-  }
+  se_hidden_layer(c, hidden, w1, s_mean, s_hid);
   __syncthreads();
-  if (tid < TAIL_CS) {
-    float a = 0.f;
-    for (int k = 0; k < hidden; ++k) a += w2[(size_t)(c0 + tid) * hidden + k] * s_hid[k];
-    s_gate[tid] = 1.0f / (1.0f + expf(-a));
-  }
+  if (tid < TAIL_CS) s_gate[tid] = se_gate_of(c0 + tid, hidden, w2, s_hid);
   __syncthreads();
   {
 #pragma clang fp contract(off)
@@ -164,6 +164,186 @@ __global__ __launch_bounds__(TAIL_T) void pv_tail_small_kernel(int c, int n, int
   }
 }
 
+
+// The same kernel for the sizes of the 8^3 levels (c <= 256, hidden <= 32, n <= 256 points, n_max <= 256 rows) with EVERY global load that
+// does not depend on the gate issued up front: the means, W1's slices (a wave owns hidden units w, w + 4, ..: 32 registers), W2's 8 rows,
+// the slab's cells, the point's coordinates, the point branch's values and, for the head, the cell's point list.  The generic kernel
+// above walks ~17 dependent global round trips (means -> W1 -> W2 -> cells -> per item: coordinates + point branch -> per row: cell ->
+// count / start -> list), ~25 us for 4096 cells; here it is one trip plus LDS work.  Same expressions in the same order: same bits.
+__global__ __launch_bounds__(TAIL_T) void pv_tail_small_fast_kernel(int c, int n, int r, int hidden, const float *__restrict__ coords,
+                                                                    const float *__restrict__ grid, const float2 *__restrict__ coef,
+                                                                    const float *__restrict__ se_mean, const float *__restrict__ w1,
+                                                                    const float *__restrict__ w2, const float *__restrict__ add,
+                                                                    long long bs_a, int ld_a, const float2 *__restrict__ add_coef,
+                                                                    float *__restrict__ out, long long bs_o, int ld_o, TailHead hd) {
+  extern __shared__ __align__(16) float smem[];
+  const int r2 = r * r, r3 = r2 * r, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slabs = c / TAIL_CS, bi = blockIdx.x / slabs, c0 = (blockIdx.x % slabs) * TAIL_CS;
+  float *vals = smem;                       // [CS][r3]
+  float *fs = vals + TAIL_CS * r3;          // [CS][n] (head only)
+  float *s_mean = fs + (hd.xh ? TAIL_CS * n : 0);
+  float *s_hid = s_mean + c;                // [32]
+  float *s_gate = s_hid + 32;               // [CS]
+  float *s_w2 = s_gate + TAIL_CS;           // [CS][32]
+  // ---- every load that does not wait for the gate -----------------------------------------------------------------------------------
+  const float m_reg = tid < c ? se_mean[(size_t)bi * c + tid] : 0.f;
+  float w1r[8][4];                          // W1[j][k]: j = wave + 4 u, k = lane + 64 v (clamped addresses, zeroed beyond the matrix)
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int j = wave + 4 * u, k = lane + 64 * v;
+      const float w = w1[(size_t)min(j, hidden - 1) * c + min(k, c - 1)];
+      w1r[u][v] = (j < hidden && k < c) ? w : 0.f;
+    }
+  const int g_ch = tid >> 5, g_k = tid & 31;  // gate: 32 lanes per channel of the slab
+  const float w2r = g_k < hidden ? w2[(size_t)(c0 + g_ch) * hidden + g_k] : 0.f;
+  const int q4 = r3 >> 2;
+  float4 cell[4];
+  float2 cab[4];
+  int ccl[4], ce[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {          // cells: e = tid + 256 it over CS * q4 (4096 cells at 8^3: four float4 per thread)
+    const int e = tid + TAIL_T * it, cl = min(e / q4, TAIL_CS - 1);
+    ccl[it] = cl; ce[it] = e - cl * q4;
+    const bool ok = e < TAIL_CS * q4;
+    cell[it] = reinterpret_cast<const float4 *>(grid + ((size_t)bi * c + c0 + cl) * r3)[ok ? ce[it] : 0];
+    cab[it] = coef[(size_t)bi * c + c0 + cl];
+  }
+  // points: slot pi of PS (a power of two >= n), channel lane cln of CL = 256 / PS; the thread's channels: cln, cln + CL, ...
+  const int PS = n > 128 ? 256 : (n > 64 ? 128 : 64), CL = TAIL_T / PS, pi = tid & (PS - 1), cln = tid / PS;
+  const bool pok = pi < n;
+  const float *pc = coords + (size_t)bi * 3 * n;
+  const float px = pc[pok ? pi : 0], py = pc[n + (pok ? pi : 0)], pz = pc[2 * n + (pok ? pi : 0)];
+  float av[8];
+  float2 apf[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int cl = cln + u * CL;
+    av[u] = 0.f; apf[u] = make_float2(0.f, 0.f);
+    if (cl < TAIL_CS) {
+      if (add) av[u] = add[(size_t)bi * bs_a + (size_t)(c0 + cl) * ld_a + (pok ? pi : 0)];
+      if (add_coef) apf[u] = add_coef[(size_t)bi * c + c0 + cl];
+    }
+  }
+  // head: the cell of row k = tid and the head of its point list (three dependent loads, in flight behind everything above)
+  int h_cv = 0;
+  const int *h_so = nullptr;
+  int h_p[4] = {0, 0, 0, 0};
+  if (hd.xh) {
+    const int nocc = min(hd.n_occ[bi], hd.n_max);
+    if (tid < nocc) {
+      const int v = hd.occ_list[(size_t)bi * hd.n_max + tid];
+      h_cv = hd.cnt[(size_t)bi * r3 + v];
+      h_so = hd.sorted + (size_t)bi * n + hd.start[(size_t)bi * r3 + v];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) h_p[qq] = h_so[min(qq, h_cv - 1)];
+    }
+  }
+  // ---- SE gate (se_fc.h's sums: lanes k = lane + 64 v ascending, se_wave_sum; gate: k ascending) ---------------------------------------
+  if (tid < c) s_mean[tid] = m_reg;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int j = wave + 4 * u;
+    if (j < hidden) {                       // wave-uniform
+      float a = 0.f;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (lane + 64 * v < c) a += w1r[u][v] * s_mean[lane + 64 * v];
+      a = se_wave_sum(a);
+      if (lane == 0) s_hid[j] = fmaxf(a, 0.f);
+    }
+  }
+  s_w2[tid] = w2r;                          // [channel of the slab][k]: the eight rows of W2, read back below by one thread per channel
+  __syncthreads();
+  if (tid < TAIL_CS) {                      // se_gate_of's sum (k ascending) from LDS
+    float a = 0.f;
+    for (int k = 0; k < hidden; ++k) a += s_w2[tid * 32 + k] * s_hid[k];
+    s_gate[tid] = 1.0f / (1.0f + expf(-a));
+  }
+  __syncthreads();
+  {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if (tid + TAIL_T * it < TAIL_CS * q4) {
+        const float s = s_gate[ccl[it]];
+        const float4 g = cell[it];
+        const float2 ab = cab[it];
+        reinterpret_cast<float4 *>(vals + (size_t)ccl[it] * r3)[ce[it]] =
+            make_float4(swishf(g.x * ab.x + ab.y) * s, swishf(g.y * ab.x + ab.y) * s, swishf(g.z * ab.x + ab.y) * s, swishf(g.w * ab.x + ab.y) * s);
+      }
+    }
+  }
+  __syncthreads();
+  {
+#pragma clang fp contract(off)
+    const float x = px, y = py, z = pz;
+    const float xl = floorf(x), yl = floorf(y), zl = floorf(z);
+    const float x1 = x - xl, y1 = y - yl, z1 = z - zl;
+    const float x0 = 1.0f - x1, y0 = 1.0f - y1, z0 = 1.0f - z1;
+    const float w000 = x0 * y0 * z0, w001 = x0 * y0 * z1, w010 = x0 * y1 * z0, w011 = x0 * y1 * z1,
+                w100 = x1 * y0 * z0, w101 = x1 * y0 * z1, w110 = x1 * y1 * z0, w111 = x1 * y1 * z1;
+    const int sx = x1 > 0 ? r2 : 0, sy = y1 > 0 ? r : 0, sz = z1 > 0 ? 1 : 0;
+    const int i000 = (int)xl * r2 + (int)yl * r + (int)zl;
+    const int i001 = i000 + sz, i010 = i000 + sy, i011 = i010 + sz;
+    const int i100 = i000 + sx, i101 = i100 + sz, i110 = i100 + sy, i111 = i110 + sz;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int cl = cln + u * CL;
+      if (cl < TAIL_CS && pok) {
+        const float *v = vals + (size_t)cl * r3;
+        float cv[8] = {v[i000], v[i001], v[i010], v[i011], v[i100], v[i101], v[i110], v[i111]};
+        lds_settle8(cv);
+        float acc = w000 * cv[0];
+        acc += w001 * cv[1];
+        acc += w010 * cv[2];
+        acc += w011 * cv[3];
+        acc += w100 * cv[4];
+        acc += w101 * cv[5];
+        acc += w110 * cv[6];
+        acc += w111 * cv[7];
+        if (add) {
+          float a2 = av[u];
+          if (add_coef) a2 = swishf(a2 * apf[u].x + apf[u].y);
+          acc += a2;
+        }
+        out[(size_t)bi * bs_o + (size_t)(c0 + cl) * ld_o + pi] = acc;
+        if (hd.xh) fs[cl * n + pi] = acc;
+      }
+    }
+  }
+  if (!hd.xh) return;
+  __syncthreads();
+  {
+#pragma clang fp contract(off)
+    const int g = c0 / 8, G = c / 8;
+    int sat = 0;
+    if (tid < hd.n_max) {
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      const float inv = h_cv > 0 ? (float)(1.0 / (double)(float)h_cv) : 0.f;
+      for (int qq = 0; qq < h_cv; ++qq) {
+        const int p = qq < 4 ? h_p[qq < 4 ? qq : 0] : h_so[qq];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = acc[j] + fs[j * n + p] * inv;
+      }
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(acc[j] * hd.x_scale));
+      sat |= m > 65504.f;
+      f16x8 hi, lo;
+      split_record(make_float4(acc[0], acc[1], acc[2], acc[3]), make_float4(acc[4], acc[5], acc[6], acc[7]), hd.x_scale, hi, lo);
+      hd.xh[(((size_t)bi * G + g) * 2 + 0) * hd.n_max + tid] = *reinterpret_cast<const uint4 *>(&hi);
+      hd.xh[(((size_t)bi * G + g) * 2 + 1) * hd.n_max + tid] = *reinterpret_cast<const uint4 *>(&lo);
+    }
+    if (sat && hd.saturated) atomicOr(hd.saturated, 1);
+    if (c0 == 0 && tid == 0) hd.amax_out[bi] = 24576.0f / hd.x_scale;
+  }
+}
+
 }  // namespace
 
 extern "C" int bdm_pvconv_tail_small(int b, int c, int n, int r, int hidden, const float *coords, const float *grid,
@@ -183,8 +363,15 @@ extern "C" int bdm_pvconv_tail_small(int b, int c, int n, int r, int hidden, con
     VoxWs w = vox_ws(const_cast<void *>(plan_workspace), b, n, r3);
     hd = TailHead{cnt, w.start, w.sorted, occ_list, n_occ, n_max, x_scale, (uint4 *)xh, amax_out, saturated};
   }
-  const size_t smem = sizeof(float) * ((size_t)TAIL_CS * r3 + (xh ? (size_t)TAIL_CS * n : 0) + c + hidden + TAIL_CS);
+  const size_t smem = sizeof(float) * ((size_t)TAIL_CS * r3 + (xh ? (size_t)TAIL_CS * n : 0) + c + (hidden > 32 ? hidden : 32) + TAIL_CS + TAIL_CS * 32);
   BDM_REQUIRE(smem <= 160 * 1024, "pvconv_tail_small: %zu bytes of LDS (r=%d, n=%d): not a small grid", smem, r, n);
+  static const bool generic_only = getenv("BDM_TAIL_SMALL_GENERIC") != nullptr;   // (tests: the generic kernel on the fast kernel's sizes)
+  if (!generic_only && c <= 256 && hidden <= 32 && n <= 256 && (xh == nullptr || n_max <= 256) && TAIL_CS * (r3 >> 2) <= 4 * TAIL_T) {
+    BDM_ALLOW_LDS(pv_tail_small_fast_kernel, smem);
+    hipLaunchKernelGGL(pv_tail_small_fast_kernel, dim3(b * (c / TAIL_CS)), dim3(TAIL_T), smem, (hipStream_t)stream, c, n, r, hidden, coords,
+                       grid, (const float2 *)coef, se_mean, w1, w2, add, bs_a, ld_a, (const float2 *)add_coef, out, bs_o, ld_o, hd);
+    return launch_status("pvconv_tail_small");
+  }
   BDM_ALLOW_LDS(pv_tail_small_kernel, smem);
   hipLaunchKernelGGL(pv_tail_small_kernel, dim3(b * (c / TAIL_CS)), dim3(TAIL_T), smem, (hipStream_t)stream, c, n, r, hidden, coords,
                      grid, (const float2 *)coef, se_mean, w1, w2, add, bs_a, ld_a, (const float2 *)add_coef, out, bs_o, ld_o, hd);
@@ -202,6 +389,9 @@ extern "C" int bdm_pvconv_tail_small(int b, int c, int n, int r, int hidden, con
 // =====================================================================================================================================
 namespace {
 
+constexpr int GATHER_T = 1024;   // 16 waves: a (shape, group) tile is 4096 (cell, channel quad) items -- four per thread, i.e. four
+                                 // dependent trips to the GEMM's output instead of sixteen (256 threads: 64 us per launch, latency-bound)
+
 __device__ __forceinline__ void split2h(float v, unsigned short &h, unsigned short &l) {   // conv3d_h2.hip's split2
   v = fminf(fmaxf(v, -65504.f), 65504.f);
   const _Float16 hi = (_Float16)v;
@@ -210,7 +400,7 @@ __device__ __forceinline__ void split2h(float v, unsigned short &h, unsigned sho
   l = __builtin_bit_cast(unsigned short, lo);
 }
 
-__global__ __launch_bounds__(256) void gather_h2_small_kernel(int cout, int r, int n_max, int cg, const float *__restrict__ y,
+__global__ __launch_bounds__(GATHER_T) void gather_h2_small_kernel(int cout, int r, int n_max, int cg, const float *__restrict__ y,
                                                               const int *__restrict__ occ_index, const float *__restrict__ bias,
                                                               const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                                               float act_scale, uint4 *__restrict__ out, unsigned *__restrict__ saturated) {
@@ -219,39 +409,42 @@ __global__ __launch_bounds__(256) void gather_h2_small_kernel(int cout, int r, i
   const int G = cout / cg, bi = blockIdx.x / G, g = blockIdx.x % G, Q = cg >> 2, ldt = r3 + 1;
   float *tile = smem;                                        // [cg][r3 + 1]
   int *oi = reinterpret_cast<int *>(tile + (size_t)cg * ldt);  // [r3]
-  __shared__ double s_red[4][2];
+  __shared__ double s_red[GATHER_T / 64][2];
   __shared__ float s_ab[64][2];
-  for (int e = tid; e < r3; e += 256) oi[e] = occ_index[(size_t)bi * r3 + e];
+  for (int e = tid; e < r3; e += GATHER_T) oi[e] = occ_index[(size_t)bi * r3 + e];
   __syncthreads();
   const float *yb = y + (size_t)bi * n_max * 27 * cout + g * cg;
-  const int q = tid % Q;                                     // the thread's channel quad (256 % Q == 0: the same for all its items)
+  const int q = tid % Q;                                     // the thread's channel quad (GATHER_T % Q == 0: the same for all its items)
   const float4 b4 = bias ? *reinterpret_cast<const float4 *>(bias + g * cg + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   double ds = 0.0, dq = 0.0;
-  for (int item = tid; item < r3 * Q; item += 256) {
+  for (int item = tid; item < r3 * Q; item += GATHER_T) {
     const int v = item / Q;
     const int x = v / r2, yy = (v / r) % r, z = v % r;
-    // rows of the occupied neighbours, tap order; absent -> -1
-    int kk[27];
+    // which taps have an occupied input cell (bit t), then ONLY those row pieces, up to 14 in flight, added in ascending tap order
+    // (a trip to the GEMM's output per batch: one for almost every cell -- a cell has 3 - 11 occupied neighbours on these levels)
     unsigned mask = 0u;
 #pragma unroll
     for (int t = 0; t < 27; ++t) {
       const int gx = x + t / 9 - 1, gy = yy + (t / 3) % 3 - 1, gz = z + t % 3 - 1;
-      int k = -1;
-      if (gx >= 0 && gx < r && gy >= 0 && gy < r && gz >= 0 && gz < r) k = oi[(gx * r + gy) * r + gz];
-      kk[t] = k;
-      mask |= (k >= 0 ? 1u : 0u) << t;
+      const bool in = gx >= 0 && gx < r && gy >= 0 && gy < r && gz >= 0 && gz < r;
+      mask |= ((in && oi[in ? (gx * r + gy) * r + gz : 0] >= 0) ? 1u : 0u) << t;
     }
     float4 acc = b4;
-    // all present taps' row pieces in flight, then added in ascending tap order
-    float4 vv[27];
+    while (mask) {
+      float4 vv[14];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) {
-      vv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (mask & (1u << t)) vv[t] = *reinterpret_cast<const float4 *>(yb + ((size_t)kk[t] * 27 + t) * cout + q * 4);
+      for (int u = 0; u < 14; ++u) {
+        vv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mask) {
+          const int t = __ffs((int)mask) - 1;
+          mask &= mask - 1;
+          const int k = oi[((x + t / 9 - 1) * r + (yy + (t / 3) % 3 - 1)) * r + (z + t % 3 - 1)];
+          vv[u] = *reinterpret_cast<const float4 *>(yb + ((size_t)k * 27 + t) * cout + q * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 14; ++u) { acc.x += vv[u].x; acc.y += vv[u].y; acc.z += vv[u].z; acc.w += vv[u].w; }
     }
-#pragma unroll
-    for (int t = 0; t < 27; ++t)
-      if (mask & (1u << t)) { acc.x += vv[t].x; acc.y += vv[t].y; acc.z += vv[t].z; acc.w += vv[t].w; }
     float *tp = tile + (size_t)(q * 4) * ldt + v;
     tp[0] = acc.x; tp[ldt] = acc.y; tp[2 * ldt] = acc.z; tp[3 * ldt] = acc.w;
     ds += (double)((acc.x + acc.y) + (acc.z + acc.w));
@@ -262,8 +455,8 @@ __global__ __launch_bounds__(256) void gather_h2_small_kernel(int cout, int r, i
   if (lane == 0) { s_red[wave][0] = ds; s_red[wave][1] = dq; }
   __syncthreads();
   if (tid < cg) {
-    const double a = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
-    const double qq = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
+    double a = 0.0, qq = 0.0;
+    for (int w = 0; w < GATHER_T / 64; ++w) { a += s_red[w][0]; qq += s_red[w][1]; }   // waves in order
     const double cnt = (double)cg * r3, mean = a / cnt;
     double var = qq / cnt - mean * mean;
     if (var < 0) var = 0;
@@ -277,7 +470,7 @@ __global__ __launch_bounds__(256) void gather_h2_small_kernel(int cout, int r, i
   // records: (8 channels) x cell, cells on the lanes
   const int C8 = cout / 8, recs = cg / 8;
   bool sat = false;
-  for (int item = tid; item < recs * r3; item += 256) {
+  for (int item = tid; item < recs * r3; item += GATHER_T) {
     const int rl = item / r3, v = item - rl * r3;
     unsigned short h[8], l[8];
 #pragma unroll
@@ -304,7 +497,7 @@ extern "C" int bdm_sparse_conv_gather_h2_small(int b, int cout, int r, int n_max
                                                unsigned int *saturated, void *stream) {
   const int cg = groups >= 1 && cout % groups == 0 ? cout / groups : 0;
   BDM_REQUIRE(b >= 0 && r >= 1 && n_max >= 1 && y && occ_index && gamma && beta && out_h2 && cg >= 8 && cg % 8 == 0 && cg <= 64 &&
-              256 % (cg / 4) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0,
+              GATHER_T % (cg / 4) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0,
               "sparse_conv_gather_h2_small: needs 8 | channels per group <= 64, (cg / 4) | 256 (cout=%d groups=%d)", cout, groups);
   {
     int ex = 0;
@@ -316,7 +509,7 @@ extern "C" int bdm_sparse_conv_gather_h2_small(int b, int cout, int r, int n_max
   const size_t smem = sizeof(float) * (size_t)cg * (r3 + 1) + sizeof(int) * (size_t)r3;
   BDM_REQUIRE(smem <= 150 * 1024, "sparse_conv_gather_h2_small: %zu bytes of LDS (r=%d, %d channels per group): not a small grid", smem, r, cg);
   BDM_ALLOW_LDS(gather_h2_small_kernel, smem);
-  hipLaunchKernelGGL(gather_h2_small_kernel, dim3(b * groups), dim3(256), smem, (hipStream_t)stream, cout, r, n_max, cg, y, occ_index, bias,
+  hipLaunchKernelGGL(gather_h2_small_kernel, dim3(b * groups), dim3(GATHER_T), smem, (hipStream_t)stream, cout, r, n_max, cg, y, occ_index, bias,
                      gamma, beta, eps, act_scale, (uint4 *)out_h2, saturated);
   return launch_status("sparse_conv_gather_h2_small");
 }

@@ -19,6 +19,7 @@
 
 #include "../../include/bdm_hip.h"
 #include "common.h"
+#include "se_fc.h"
 
 using namespace bdm;
 
@@ -354,17 +355,9 @@ __global__ void se_rows_fc_kernel(int c, int h, int V, const float *__restrict__
   }
   __syncthreads();
   if (w1 == nullptr) return;
-  for (int j = threadIdx.x; j < h; j += blockDim.x) {
-    float a = 0.f;
-    for (int k = 0; k < c; ++k) a += w1[(size_t)j * c + k] * s[k];
-    hid[j] = fmaxf(a, 0.f);
-  }
+  se_hidden_layer(c, h, w1, s, hid);
   __syncthreads();
-  for (int i = threadIdx.x; i < c; i += blockDim.x) {
-    float a = 0.f;
-    for (int k = 0; k < h; ++k) a += w2[(size_t)i * h + k] * hid[k];
-    gate[(size_t)bi * c + i] = 1.0f / (1.0f + expf(-a));
-  }
+  for (int i = threadIdx.x; i < c; i += blockDim.x) gate[(size_t)bi * c + i] = se_gate_of(i, h, w2, hid);
 }
 
 static int se_rows_impl(int b, int c, int hidden, int v, int groups, const float *rows, int n_rows_max, const int *tile_start,

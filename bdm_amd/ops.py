@@ -775,7 +775,9 @@ def devoxelize_gn_gate_add(norm_coords, grid, coef, r, gate=None, add=None, add_
 
 
 # ---- PVConv glue on the small voxel grids (csrc/pvconv_small.hip) ------------------------------------------------------------------
-SMALL_GLUE = os.environ.get("BDM_SMALL_GLUE", "1") == "1"   # fused tail / head / gather of the 8^3 PVConvs (0: the operator chain)
+# fused tail / head / gather of the 8^3 PVConvs (csrc/experimental/pvconv_small.hip, `make EXPERIMENTAL=1` builds only): built for VERDICT r4
+# next-1 and measured NOT faster than the operator chain -- off unless asked for
+SMALL_GLUE = os.environ.get("BDM_SMALL_GLUE", "0") == "1"
 
 
 def small_grid_tail_ok(r, c, n):
@@ -829,12 +831,12 @@ def pvconv_tail_small(norm_coords, grid, coef, mean, w1, w2, r, add=None, add_co
         xh = torch.empty(B, C // 8, 2, plan.n_max, 8, dtype=torch.float16, device=grid.device)
         amax = torch.empty(B, dtype=torch.float32, device=grid.device)
         rows = VoxelRows(plan, xh, amax, C)
-        L.check(L.lib().bdm_pvconv_tail_small(B, C, n, int(r), w1.shape[0], L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(mean),
+        L.check(L.experimental("bdm_pvconv_tail_small")(B, C, n, int(r), w1.shape[0], L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(mean),
                                               L.ptr(w1), L.ptr(w2), L.ptr(add), bs_a, ld_a, L.ptr(add_coef), L.ptr(out), bs_o, ld_o,
                                               L.ptr(plan.cnt), L.ptr(plan.ws), L.ptr(plan.occ_list), L.ptr(plan.n_occ), plan.n_max,
                                               L.c_float(x_scale), L.ptr(xh), L.ptr(amax), L.ptr(saturated), L.stream()), "pvconv_tail_small")
         return out, rows
-    L.check(L.lib().bdm_pvconv_tail_small(B, C, n, int(r), w1.shape[0], L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(mean),
+    L.check(L.experimental("bdm_pvconv_tail_small")(B, C, n, int(r), w1.shape[0], L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(mean),
                                           L.ptr(w1), L.ptr(w2), L.ptr(add), bs_a, ld_a, L.ptr(add_coef), L.ptr(out), bs_o, ld_o,
                                           L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None), 0, L.c_float(0.0), L.ptr(None), L.ptr(None),
                                           L.ptr(None), L.stream()), "pvconv_tail_small")
@@ -1185,7 +1187,7 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None, ro
                 nb = min(gb, B - b0)
                 L.check(lib.bdm_sparse_conv_gemm_h2(nb, plan.n_max, C, cout, L.ptr(xh[b0:]), L.ptr(amax[b0:]), L.ptr(packed), L.ptr(inv_scale),
                                                     L.ptr(plan.n_occ[b0:]), L.ptr(y), L.stream()), "sparse_conv_gemm_h2")
-                L.check(lib.bdm_sparse_conv_gather_h2_small(nb, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index[b0:]), L.ptr(bias),
+                L.check(L.experimental("bdm_sparse_conv_gather_h2_small")(nb, cout, r, plan.n_max, L.ptr(y), L.ptr(plan.occ_index[b0:]), L.ptr(bias),
                                                             gn1.num_groups, L.ptr(gn1.weight), L.ptr(gn1.bias), L.c_float(gn1.eps),
                                                             L.c_float(act_scale), L.ptr(x2[b0:]), L.ptr(saturated), L.stream()),
                         "sparse_conv_gather_h2_small")

@@ -325,8 +325,12 @@ def main():
             if pts.shape[2] > n_:
                 pts = BF.furthest_point_sample(pts, n_)
             bops.clear_plan_cache()
-            plan = bops.voxel_plan(pts, r_)
+            plan = bops.voxel_plan(pts, r_, dilate=2 if r_ in (16, 32) else 0)
             profiling.OCCUPANCY[plan.n_max] = float(plan.n_occ.float().mean()) / plan.n_max
+            if getattr(plan, "d2_tiles", None) is not None:   # once- / twice-dilated fraction of the grid: what the list convolutions compute
+                d1 = float(plan.tile_start[:, :, 1].max(dim=1).values.float().mean()) / r_ ** 3
+                d2 = float(plan.d2_tiles[:, :, 1].max(dim=1).values.float().mean()) / r_ ** 3
+                profiling.DILATED[r_] = (d1, d2)
         rows, classes = prof.table()
         if classes:
             # dominant class of the MAIN stream: the furthest-point sampler runs concurrently on its own stream (a chain of M - 1
@@ -336,7 +340,7 @@ def main():
             head = top_rows[0]
             traffic, traffic_commit = None, None
             try:  # HBM bytes per launch of that kernel from the committed PMC pass (separate rocprofv3 --pmc runs)
-                pm_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(p))
+                pm_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(p))
                 pm = json.load(open(pm_path))
                 key = f"{head['function']}{tuple(head['shape'])}"
                 ent = (pm["kernels"].get(key) or pm["kernels"].get(key.replace("_h2_gn(", "_h2("))  # same kernels + GN epilogue
@@ -345,20 +349,26 @@ def main():
                     traffic, traffic_commit = ent["bytes_per_launch"], pm.get("commit")
             except (OSError, KeyError, ValueError, StopIteration):
                 pass
-            line["roofline"] = {"bound": top["bound"], "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
-                                "frac": top["frac"], "traffic": traffic, "traffic_commit": traffic_commit,
-                                "kernel_class": top["class"], "share_of_kernel_time": top["share"],
+            own = profiling.row_fraction(head) or (top["bound"], top["achieved"], top["peak"], top["unit"], top["frac"])
+            line["roofline"] = {"bound": own[0], "achieved": own[1], "peak": own[2], "unit": own[3],
+                                "frac": own[4], "traffic": traffic, "traffic_commit": traffic_commit,
+                                "kernel_class": top["class"], "class_frac": top["frac"], "share_of_kernel_time": top["share"],
                                 "kernel": f"{head['function']}{tuple(head['shape'])}", "avg_launch_us": head["avg_us"],
                                 "launches_timed": sum(r["sampled"] for r in top_rows),
                                 "launches_total": sum(r["calls"] for r in top_rows),
-                                "note": "class with the largest share of kernel time; achieved = ALGORITHMIC work of its launches "
-                                        "/ their summed duration (HIP events on the launching stream around every 4th launch of the eagerly run steps: every "
+                                "note": "`kernel` = the heaviest (function, shape) row of the class with the largest share of kernel time; achieved / "
+                                        "frac are THAT kernel's own (its algorithmic flops per launch / its average launch duration); class_frac = the "
+                                        "whole class (list convolutions priced by the matrix work they issue: listed voxels x 27 taps); durations: (HIP events on the launching stream around every 4th launch of the eagerly run steps: every "
                                         "50th PC2 step of the replayed loop and the PVD / fusion forwards); the sampler stream's class is excluded; for the "
                                         "fp16x3 convolution every fp32 product is 3 fp16 MFMA products: peak = 2500 TFLOP/s / 3"}
             line["roofline"]["sparse_rows_occupied_fraction"] = {str(k): round(v, 4) for k, v in profiling.OCCUPANCY.items()}
+            line["roofline"]["dilated_fraction_of_grid"] = {str(k): [round(v[0], 4), round(v[1], 4)] for k, v in profiling.DILATED.items()}
             line["roofline_table"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in c.items()} for c in classes]
-            line["roofline_rows"] = [{"kernel": f"{r['function']}{tuple(r['shape'])}", "class": r["class"], "share": round(r["share"], 4),
-                                      "avg_us": round(r["avg_us"], 2), "launches": r["calls"]} for r in rows[:12]]
+            def _own(r):
+                f = profiling.row_fraction(r)
+                return {} if f is None else {"bound": f[0], "frac": round(f[4], 4)}
+            line["roofline_rows"] = [dict({"kernel": f"{r['function']}{tuple(r['shape'])}", "class": r["class"], "share": round(r["share"], 4),
+                                           "avg_us": round(r["avg_us"], 2), "launches": r["calls"]}, **_own(r)) for r in rows[:12]]
             # north-star target g1 (">= 40 % of the HBM roofline on the ball-query / gather kernel"): the first set-abstraction level
             # (n points -> 1024 centres x 32 neighbours) from the in-run events of THIS run -- the query priced against the VALU issue rate
             # that bounds it (profiling.VALU_TESTS_PEAK) and against HBM, the grouping gather (point-major repack + gather: one ABI call,

@@ -386,7 +386,8 @@ int bdm_devoxelize_gn_se_add(int b, int c, int n, int r, const float *coords, co
                              const float *se_mean, int hidden, const float *w1, const float *w2, const float *add,
                              long long bs_a, int ld_a, float *out, long long bs_o, int ld_o, void *stream);
 
-/* ---- PVConv glue on the SMALL voxel grids (8^3 levels; csrc/pvconv_small.hip) -- per-shape workgroups, no hand-off between them ----
+#ifdef BDM_EXPERIMENTAL  /* fused PVConv glue of the small voxel grids (csrc/experimental/pvconv_small.hip): measured not faster, DESIGN.md 7.9 */
+/* ---- PVConv glue on the SMALL voxel grids (8^3 levels) -- per-shape workgroups, no hand-off between them ----
  * bdm_pvconv_tail_small: SE gate (both FC layers of se.py:8-19, from se_mean (b, c) = bdm_se_gate_gn(w1 = NULL)'s channel means)
  * + Swish(GroupNorm-2(grid)) * gate + trilinear devoxelisation at the n points + Swish(GroupNorm(point branch)) (add_coef; NULL: `add`
  * is added as it is) -> out (pvconv.py:91-97), one workgroup per (shape, 8 channels); bit-identical to bdm_se_gate_gn_pf +
@@ -407,6 +408,7 @@ int bdm_pvconv_tail_small(int b, int c, int n, int r, int hidden, const float *c
 int bdm_sparse_conv_gather_h2_small(int b, int cout, int r, int n_max, const float *y, const int *occ_index, const float *bias,
                                     int groups, const float *gamma, const float *beta, float eps, float act_scale, void *out_h2,
                                     unsigned int *saturated, void *stream);
+#endif /* BDM_EXPERIMENTAL */
 
 /* bf16x6 form of the two steps above (default): operands pre-split into exact bf16 triples ("S3" records of 8
  * channels x 16 bytes), GEMM on v_mfma_f32_32x32x16_bf16 with six partial products per fp32 product.

@@ -52,7 +52,7 @@ def hip():
 # * tests/durations.json = seconds per test recorded on the builder's GPU box (`tools/record_durations.py`); the driver's host
 #   was measured 1.8x slower on host-bound tests, so the collection FAILS when recorded x 1.8 exceeds the limit.
 GPU_FILE_ORDER = ["test_hip_net.py", "test_module_goldens.py", "test_hip_ops.py", "test_rng.py", "test_abi.py", "test_hip_dense.py",
-                  "test_hip_sampler.py", "test_backward_ops.py", "test_hip_bench_variants.py", "test_hip_uninit.py",
+                  "test_hip_small_glue.py", "test_hip_sampler.py", "test_backward_ops.py", "test_hip_bench_variants.py", "test_hip_uninit.py",
                   "test_hip_trajectory.py", "test_hip_teacher_forced.py", "test_hip_cli.py", "test_hip_full_size.py",
                   "test_hip_full_trajectory.py"]
 GPU_SUITE_LIMIT_S, SLOW_HOST_FACTOR = 600.0, 1.8

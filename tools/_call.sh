@@ -1,5 +1,6 @@
-mkdir -p gpurun_out/r05
-python tools/error_budget.py pc2 4096 1 > gpurun_out/r05/error_budget.txt 2>&1
-python tools/error_budget.py pvd 4096 1 >> gpurun_out/r05/error_budget.txt 2>&1
-python tools/error_budget.py pc2 1024 2 >> gpurun_out/r05/error_budget.txt 2>&1
-cat gpurun_out/r05/error_budget.txt
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_hip_small_glue.py -x -q 2>&1 | tail -3
+BDM_TAIL_SMALL_GENERIC=1 python -m pytest tests/test_hip_small_glue.py -x -q -k "bit_identical" 2>&1 | tail -2
+for n in 64 256; do python tools/tail_bench.py $n 2>&1 | grep -A9 "head=True"; done
+echo "== glue on"; python tools/replay_host_time.py 16 4096 2>&1 | grep replayed
+echo "== BDM_SMALL_GLUE=0"; BDM_SMALL_GLUE=0 python tools/replay_host_time.py 16 4096 2>&1 | grep replayed

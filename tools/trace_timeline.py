@@ -13,6 +13,6 @@ for r in sel:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     gap = (s - last_end[q]) / 1e3 if q in last_end else 0.0
     last_end[q] = e
-    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+    name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "")
     if gap >= min_gap:
         print(f"q{q} t={(s - t0) / 1e3:8.1f}  dur={(e - s) / 1e3:7.1f}  gap={gap:7.1f}  grid=({r['Grid_Size_X']},{r['Grid_Size_Y']},{r['Grid_Size_Z']})  {name[:60]}")
