@@ -42,6 +42,17 @@ using namespace bdm;
 typedef __attribute__((ext_vector_type(4))) float f32x4a;
 typedef float f32x4v_t __attribute__((ext_vector_type(4)));
 
+// sum over the 16 lanes of a DPP row, left in every lane of the row: quad_perm xor 1, xor 2, half-row mirror, row mirror -- four
+// 1-pass DPP moves instead of four dependent ds_bpermute round trips per value (the epilogue of a 64 x 64 wave tile reduces 32 values:
+// 128 bpermutes were a quarter of it).  Fixed order: deterministic.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // plan side: dilated voxel list, ranks, plane prefixes, tile table
 // ---------------------------------------------------------------------------------------------------------------------
@@ -167,7 +178,8 @@ __global__ __launch_bounds__(1024) void vox_dilate_kernel(int r, int n_dil_max, 
   __threadfence();
   __syncthreads();
   // tile_start[t][0..7] = first entry, end entry, first voxel of the linear range the tile owns, its end, first compact row of the
-  // tile's input range, rows in it, -, live tiles of the shape: everything a workgroup needs in ONE 32-byte read
+  // tile's input range, rows in it, (first x-plane << 8) | last x-plane of its voxels, live tiles of the shape: everything a workgroup
+  // needs in ONE 32-byte read
   const int nt = s_tiles, nd = min(tot_d, n_dil_max);
   for (int t = tid; t < tiles_max; t += T) {
     int *e = tile_start + ((size_t)bi * tiles_max + t) * 8;
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(1024) void vox_dilate_kernel(int r, int n_dil_max, 
       klo = ps_o[max(x0 - 1, 0)];
       nr = min(ps_o[min(x1 + 2, r)] - klo, xcap);
     } else if (t == 0) { vf = 0; ve = r3; }                // a grid without an occupied cell: tile 0 owns everything (all bias)
-    e[0] = j0; e[1] = jn; e[2] = vf; e[3] = ve; e[4] = klo; e[5] = nr; e[6] = 0; e[7] = nt;
+    e[0] = j0; e[1] = jn; e[2] = vf; e[3] = ve; e[4] = klo; e[5] = nr; e[6] = t < nt ? tinfo[2 * t + 1] : 0; e[7] = nt;
   }
 }
 
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
   const int4 *te = reinterpret_cast<const int4 *>(tile_start + ((size_t)bi * tiles_max + tile) * 8);
   const int4 ta = te[0], tb = te[1];
   const int j0 = ta.x, jn = ta.y, v_first = ta.z, v_end = ta.w, k_lo = tb.x;   // entries [j0, jn) of the list; linear range owned; input rows
-  const int tiles_live = tb.w;
+  const int tiles_live = tb.w, tile_x0 = tb.z >> 8, tile_x1 = tb.z & 255;
   if (tile >= max(tiles_live, 1)) {   // nothing to compute here: an empty slice of the statistics
     if (gn_partial != nullptr) {
       const int ngt = BM / gn_cg;
@@ -312,7 +324,6 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
   for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int q = 0; q < NT; ++q) acc[a][q] = f32x4a{0.f, 0.f, 0.f, 0.f};
-  if (tid < 128) Xs[(tid >> 6) * XS + xcap + (tid & 63)] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero records of both splits
   f32x4v_t cr = {0.f, 0.f, 0.f, 0.f};                                                            // (H2IN) this thread's copy of the constant record
 
   const float4 *xb = xr + (size_t)bi * C8 * n_max * 2;
@@ -387,7 +398,18 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
   int rec[NT][NQ];                    // LDS record of this lane's (voxel, tap) neighbour; xcap + lane = this lane's zero record
   unsigned amask = 0u;
   {
+    // The index planes the tile's 27-neighbourhoods touch (x0 - 1 .. x1 + 1) are copied into the operand area of LDS first (coalesced,
+    // the area is free until chunk 0 is stored) and the 28 look-ups per lane read LDS: as scattered 4-byte GLOBAL loads -- 64 different
+    // lines per wave instruction -- they were 9 us of an 84 us tile (tools/sparse_dil_timeline.py), bound by the address unit.
+    const int pl0 = max(tile_x0 - 1, 0), pl1 = min(tile_x1 + 1, R - 1), n_oi = (pl1 - pl0 + 1) * R2;
+    const bool staged = !nothing && n_oi * (int)sizeof(int) <= 2 * XS * (int)sizeof(float4);   // (uniform; r = 32 tiles spanning > 25 planes: global)
+    int *s_oi = reinterpret_cast<int *>(Xs);
     const int *oi = occ_index + (size_t)bi * R3;
+    if (staged) {
+      const int4 *src = reinterpret_cast<const int4 *>(oi + pl0 * R2);
+      for (int e = tid; e < n_oi / 4; e += NT_) reinterpret_cast<int4 *>(s_oi)[e] = src[e];
+      __syncthreads();
+    }
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       const int j = j0 + (q * NW + wave) * 16 + l16;
@@ -401,7 +423,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
         if (v >= 0 && t < 27) {
           const int gx = vx + t / 9 - 1, gy = vy + (t / 3) % 3 - 1, gz = vz + t % 3 - 1;
           inside = gx >= 0 && gx < R && gy >= 0 && gy < R && gz >= 0 && gz < R;
-          if (inside) k = oi[(gx * R + gy) * R + gz];
+          if (inside) k = staged ? s_oi[((gx - pl0) * R + gy) * R + gz] : oi[(gx * R + gy) * R + gz];
         }
         const bool here = k >= k_lo && k - k_lo < nrows;       // (always, for a present neighbour: the range covers its plane)
         const bool live = here || (H2IN && inside);            // a constant neighbour contributes too
@@ -416,6 +438,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
     for (int c8 = 0; c8 < C8; ++c8) {
       __syncthreads();
       if (c8 == 0) DIL_STAMP(2);
+      if (c8 == 0 && tid < 128) Xs[(tid >> 6) * XS + xcap + (tid & 63)] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero records of both splits
       store_chunk(c8);
       __syncthreads();
       if (c8 == 0) DIL_STAMP(3);
@@ -491,11 +514,8 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
         }
       }
       if (gn_partial != nullptr) {
-#pragma unroll
-        for (int ofs = 1; ofs < 16; ofs <<= 1) {
-          bs += __shfl_xor(bs, ofs, 64);
-          bq += __shfl_xor(bq, ofs, 64);
-        }
+        bs = row16_sum(bs);
+        bq = row16_sum(bq);
         if (l16 == 0) {
           const int nb = q * NW + wave;
           red[nb * NB + (mt * 4 + kg) * 2 + 0] = bs;

@@ -37,6 +37,12 @@ CASES = {
     # (two fp32 implementations that are each ~8e-7 from exact arithmetic end 5e-4 .. 9e-4 apart whichever way their sums are ordered:
     # DESIGN.md section 5, tools/error_budget.py), so the EARLY-WARNING line of the C2-size test sits on this calmer twin
     "c2_b16_shape11_h003": dict(N=4096, B=16, merging=False, philox_seed=42, row=11, head_scale=0.03),
+    # ... and of the two N = 1024 cases: at head scale 0.1 their figures moved between 2e-6 and 3e-4 from one summation order of a
+    # kernel to the next (rounds 4 - 5); the calm twins carry the early-warning lines
+    "c2_b16_shape3_h003": dict(N=4096, B=16, merging=False, philox_seed=42, row=3, head_scale=0.03),    # two more shapes of the same batch
+    "c2_b16_shape7_h003": dict(N=4096, B=16, merging=False, philox_seed=42, row=7, head_scale=0.03),
+    "blending_n1024_h003": dict(N=1024, B=1, merging=False, philox_seed=None, row=0, head_scale=0.03),
+    "merging_n1024_h003": dict(N=1024, B=1, merging=True, philox_seed=None, row=0, head_scale=0.03),
 }
 
 

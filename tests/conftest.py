@@ -122,8 +122,14 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         if name not in worst or value / max(bound, 1e-300) > worst[name][0] / max(worst[name][1], 1e-300):
             worst[name] = (value, bound, note)
     ordered = sorted(worst.items(), key=lambda kv: -(kv[1][0] / max(kv[1][1], 1e-300)))
-    headline = [kv for kv in ordered if kv[0].startswith("traj_")]
+    headline = [kv for kv in ordered if kv[0].startswith("traj_") and " segment " not in kv[0]]
+    segs = sorted(kv for kv in ordered if kv[0].startswith("traj_") and " segment " in kv[0])
     others = [kv for kv in ordered if not kv[0].startswith("traj_")]
+    by_traj = {}
+    for name, (value, bound, note) in segs:   # one line per trajectory: its error at the end of every schedule segment
+        by_traj.setdefault(name.split(" segment ")[0], []).append(value)
+    for tname, vals in by_traj.items():
+        tr.write_line(f"PARITY {tname} per schedule segment: " + " ".join(f"{v:.1e}" for v in vals))
     for name, (value, bound, note) in others[:60][::-1] + headline[::-1]:   # headline trajectories last = nearest the tail
         frac = value / max(bound, 1e-300)
         tr.write_line(f"PARITY {name:<58s} {value:9.3e} / {bound:7.1e}  ({frac:5.1%} of bound){'  ' + note if note else ''}")

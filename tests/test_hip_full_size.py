@@ -25,18 +25,25 @@ HEAD_SCALE = 0.1
 NORTH_STAR = 1e-3
 TOL_FORWARD = 1e-4
 TOL_BATCH = 1e-6   # the same shape at B = 1 and inside its per-GPU batch
-# early warning on the headline trajectory: measured 4.8e-4 - 4.9e-4 (rounds 3 - 4) against the 1e-3 bound; every kernel change moves
-# rounding, and one that doubles the figure would otherwise fail the north-star test with no warning.  Past this line the test
-# fails with "margin gone" although the bound itself still holds.
-C2_MARGIN_LINE = 7e-4
+# Head scales of the two C2-size fixtures.  tests/test_hip_full_trajectory.py's rule -- the largest head scale of {1, 0.3, 0.1, 0.03, 0.01} at
+# which a 1-ulp change of the initial cloud moves the final cloud by < 1e-4 -- was calibrated at N = 1024 (0.1: 1.9e-5 .. 4.9e-5).  At the
+# bench's own size it gives 0.03: `tools/chaos_probe.py --hip --points 4096` measures 6.6e-4 at head scale 0.1 (a ONE-ulp perturbation ends
+# as far away as the HIP path is from the oracle: 4.9e-4 .. 8.9e-4 depending on the summation order of the round's kernels) and 6.8e-5 at
+# 0.03.  `tools/error_budget.py` (oracle/truth.py: the same network in float64 on fp32 geometry) splits the per-forward distance: HIP vs
+# exact 0.8 - 1.1e-6, fp32 CPU oracle vs exact 0.75 - 0.83e-6 -- the HIP path is as close to exact arithmetic as the reference's own
+# fp32 path, so at 0.1 the figure is the chaos of the procedural network times the fp32 noise floor of BOTH sides, not kernel error.
+#   * head 0.03 (`c2_b16_shape11_h003`): THE bench-size parity test -- literal 1e-3 bound plus the early-warning line below;
+#   * head 0.1  (`c2_b16_shape11`): kept at the literal 1e-3 bound as a chaos monitor (like C1's), its figure printed on the record.
+C2_MARGIN_LINE = {"c2_b16_shape11_h003": 3e-4, "c2_b16_shape11": None}
 
 
 @pytest.mark.gpu
-def test_full_c2_trajectory_batch16_vs_oracle_fixture(hip):
-    """(a) in the default `-m gpu` selection: the oracle's cloud of the sampled shape is tests/golden/traj_c2_b16_shape11.npz
+@pytest.mark.parametrize("name", ["c2_b16_shape11_h003", "c2_b16_shape11"])
+def test_full_c2_trajectory_batch16_vs_oracle_fixture(hip, name):
+    """(a) in the default `-m gpu` selection: the oracle's cloud of the sampled shape is tests/golden/traj_<name>.npz
     (oracle/gen_golden_traj.py: the same case and streams, run once in the build container); the HIP side is the full B = 16,
     N = 4096, 1080-forward trajectory exactly as bench.py runs it."""
-    g = golden_trajectory("c2_b16_shape11")
+    g = golden_trajectory(name)
     B, N, seed, row = int(g["B"]), int(g["N"]), int(g["philox_seed"]), int(g["row"])
     assert (B, N) == (16, 4096)
     c = case.build(N, head_scale=float(g["head_scale"]), merging=False, B=B)
@@ -44,15 +51,19 @@ def test_full_c2_trajectory_batch16_vs_oracle_fixture(hip):
     with case.segments() as seg:
         got = case.run_hip_streams(c, seed, list(range(B)))
     assert got.shape == (B, N, 3) and bool(torch.isfinite(got).all())
-    err = parity(f"traj_c2_b16_shape{row} final cloud (bench size, Philox mode)", rel_l2(got[row:row + 1], torch.from_numpy(g["final"])),
-                 NORTH_STAR, note=f"margin line {C2_MARGIN_LINE:.0e}")
+    line = C2_MARGIN_LINE[name]
+    err = parity(f"traj_{name} final cloud (bench size, Philox mode, head {float(g['head_scale']):g})",
+                 rel_l2(got[row:row + 1], torch.from_numpy(g["final"])), NORTH_STAR, note="" if line is None else f"margin line {line:.0e}")
     first, curve = first_segment_past(NORTH_STAR, [x[row:row + 1] for x in seg.clouds], g)
-    print(f"full C2 trajectory at B=16, N=4096 (per-shape Philox streams), shape {row} vs the oracle fixture: final rel-L2 {err:.3e}; "
-          "per segment " + " ".join(f"{e:.1e}" for e in curve))
+    for i, e in enumerate(curve):
+        parity(f"traj_{name} segment {i}", e, NORTH_STAR)
+    print(f"full C2 trajectory at B=16, N=4096 (per-shape Philox streams), head {float(g['head_scale']):g}, shape {row} vs the oracle fixture: "
+          f"final rel-L2 {err:.3e}; per segment " + " ".join(f"{e:.1e}" for e in curve))
     assert err <= NORTH_STAR, (f"final rel-L2 {err:.3e} > {NORTH_STAR}; first schedule segment past the bound: {first} "
                                f"(segment curve {['%.2e' % e for e in curve]})")
-    assert err <= C2_MARGIN_LINE, (f"margin gone: final rel-L2 {err:.3e} is inside the 1e-3 bound but past the {C2_MARGIN_LINE:.0e} early-warning "
-                                   f"line (rounds 3 - 4 measured 4.8e-4 - 4.9e-4); segment curve {['%.2e' % e for e in curve]}")
+    if line is not None:
+        assert err <= line, (f"margin gone: final rel-L2 {err:.3e} is inside the 1e-3 bound but past the {line:.0e} early-warning line of the calm "
+                             f"(head {float(g['head_scale']):g}) fixture; segment curve {['%.2e' % e for e in curve]}")
     assert rel_l2(got[0:1], got[row:row + 1]) > 0.1
 
 

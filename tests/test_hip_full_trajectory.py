@@ -37,6 +37,8 @@ def test_full_trajectory_vs_oracle_fixture(hip, name):
         got = case.run_hip(c)
     err = parity(f"traj_{name} final cloud, {int(g['forwards'])} forwards", rel_l2(got, torch.from_numpy(g["final"])), NORTH_STAR)
     first, curve = first_segment_past(NORTH_STAR, seg.clouds, g)
+    for i, e in enumerate(curve):
+        parity(f"traj_{name} segment {i}", e, NORTH_STAR)
     print(f"full trajectory {name} ({int(g['forwards'])} forwards, N={int(g['N'])}) vs the oracle fixture: final rel-L2 {err:.3e}; "
           "per segment " + " ".join(f"{e:.1e}" for e in curve))
     assert err <= NORTH_STAR, (f"final rel-L2 {err:.3e} > {NORTH_STAR}; first schedule segment past the bound: {first} "

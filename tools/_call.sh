@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_hip_small_glue.py -x -q 2>&1 | tail -3
-BDM_TAIL_SMALL_GENERIC=1 python -m pytest tests/test_hip_small_glue.py -x -q -k "bit_identical" 2>&1 | tail -2
-for n in 64 256; do python tools/tail_bench.py $n 2>&1 | grep -A9 "head=True"; done
-echo "== glue on"; python tools/replay_host_time.py 16 4096 2>&1 | grep replayed
-echo "== BDM_SMALL_GLUE=0"; BDM_SMALL_GLUE=0 python tools/replay_host_time.py 16 4096 2>&1 | grep replayed
+for i in 1 2; do
+echo "== B=1 default"; python tools/replay_host_time.py 1 1024 2>&1 | grep replayed | tail -2
+echo "== B=1 nowait"; TRACE_NO_WAIT=1 python tools/replay_host_time.py 1 1024 2>&1 | grep replayed | tail -2
+done
+echo "== B=16 nowait"; TRACE_NO_WAIT=1 python tools/replay_host_time.py 16 4096 2>&1 | grep replayed | tail -2
+echo "== B=16 default"; python tools/replay_host_time.py 16 4096 2>&1 | grep replayed | tail -2

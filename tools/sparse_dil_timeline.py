@@ -14,7 +14,7 @@ lib = L.lib()
 lib.bdm_debug_dil_timestamps.argtypes = [ctypes.c_void_p]
 for name, cin, cout, r, n in [("SA0.1", 32, 32, 32, 4096), ("FP2.x", 128, 128, 16, 1024), ("FP3.x", 64, 64, 32, 4096)]:
     ops.clear_plan_cache()
-    plan = ops.voxel_plan(clouds[n], r)
+    plan = ops.voxel_plan(clouds[n], r, dilate=1)
     f = torch.randn(B, cin, n, generator=g).cuda()
     w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).cuda()
     bias = torch.zeros(cout).cuda()
