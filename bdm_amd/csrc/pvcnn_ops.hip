@@ -75,6 +75,14 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 //     degenerate rounds (equal distances), so a readlane replaces the second 64-lane reduction; ties take the reduction;
 //   * <= 4 waves: every thread reads all wave slots and folds them in a pairwise tree of 64-bit keys (no second DPP reduction);
 //   * the centre of round j-1 is written by thread 0 at the top of round j, from the coordinates every thread has just read.
+#ifdef FPS_TIMING   // per-phase shader-clock sums of rounds 64 .. 191, wave 0 (a debug build for tools/fps_phase_probe.py only)
+__device__ unsigned long long *g_fps_ts = nullptr;
+extern "C" int bdm_debug_fps_timestamps(unsigned long long *buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_fps_ts), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; }
+#define FPS_STAMP(i) do { if (timed) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_readcyclecounter(); acc_ts[i] += t_ - last_ts; last_ts = t_; } } while (0)
+#else
+#define FPS_STAMP(i)
+#endif
+
 template <int T, int PPT, bool use_lds>
 __global__ __launch_bounds__(T) void fps_kernel(int n, int m, const float *__restrict__ coords, int *__restrict__ indices,
                                                 float *__restrict__ centers_out) {
@@ -115,12 +123,20 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, const float *__res
   __syncthreads();
 
   int cur = 0;
+#ifdef FPS_TIMING
+  unsigned long long acc_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ts = 0;
+#endif
   for (int j = 1; j <= m; ++j) {
+#ifdef FPS_TIMING
+    const bool timed = j >= 64 && j < 192 && g_fps_ts != nullptr;
+    if (timed) { __builtin_amdgcn_s_waitcnt(0); last_ts = __builtin_readcyclecounter(); }
+#endif
     float x1, y1, z1;
     if (use_lds) { x1 = sx[cur]; y1 = sy[cur]; z1 = sz[cur]; }
     else { x1 = cx[cur]; y1 = cy[cur]; z1 = cz[cur]; }
     if (tid == 0 && cen) { cen[j - 1] = x1; cen[m + j - 1] = y1; cen[2 * m + j - 1] = z1; }
     if (j == m) break;
+    FPS_STAMP(0);   // centre fetched
     const f2 qx = {x1, x1}, qy = {y1, y1}, qz = {z1, z1};
     unsigned bd = 0u;
 #pragma unroll
@@ -133,21 +149,25 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, const float *__res
       const unsigned ab = a > b ? a : b;
       bd = bd > ab ? bd : ab;
     }
+    FPS_STAMP(1);   // distances + per-thread maximum
     int bi = PPT - 1;
 #pragma unroll
     for (int i = PPT - 2; i >= 0; --i) bi = dist[i] == bd ? i : bi;  // first (= best-ranked) point at the maximum
     const unsigned k = (unsigned)point_of(bi);
     const unsigned br = 0xFFFFFFFFu - ((k & 511u) * Q + (k >> 9));
+    FPS_STAMP(2);   // per-thread argmax + rank key
     unsigned wd = wave_max_u32(bd), wr;
     {
       const unsigned long long hit = __ballot(bd == wd);
       if ((hit & (hit - 1ull)) == 0ull) wr = (unsigned)__builtin_amdgcn_readlane((int)br, (int)__builtin_ctzll(hit));
       else wr = wave_max_u32(bd == wd ? br : 0u);
     }
+    FPS_STAMP(3);   // wave maximum + winner's rank
     if (NW > 1) {
       uint2 *slot = slots + (j & 1) * 16;
       if (lane == 0) slot[wave] = make_uint2(wd, wr);
       __syncthreads();
+      FPS_STAMP(4); // slot write + barrier
       if (NW <= 4) {
         // every thread folds all wave slots: (distance bits, ~rank) as one 64-bit key, pairwise tree (independent compares)
         unsigned long long key[NW];
@@ -171,12 +191,18 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, const float *__res
         else wr = wave_max_u32((sv.x == wd && lane < NW) ? sv.y : 0u);
       }
     }
+    FPS_STAMP(5);   // slots read + folded
     const unsigned rank = 0xFFFFFFFFu - wr;
     // rank -> point index; Q is a power of two for the usual sizes: shifts instead of two integer divisions per round
     cur = q_pow2 ? (int)(((rank & (Q - 1u)) << 9) + (rank >> q_shift)) : (int)((rank % Q) * 512u + rank / Q);
     cur = __builtin_amdgcn_readfirstlane(cur);
     if (tid == 0) out[j] = cur;
+    FPS_STAMP(6);   // rank -> index, output
   }
+#ifdef FPS_TIMING
+  if (g_fps_ts != nullptr && lane == 0)
+    for (int i = 0; i < 8; ++i) g_fps_ts[((size_t)blockIdx.x * 16 + wave) * 8 + i] = acc_ts[i];
+#endif
 }
 
 // Threads per shape, measured at B = 16 on MI355X (us per call, round 3): n=4096,m=1024: 128 thr 981 | 256: 711 | 512: 705 | 1024: 780

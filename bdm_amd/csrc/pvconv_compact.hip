@@ -313,8 +313,14 @@ __global__ __launch_bounds__(256) void se_rows_partial_kernel(int c, int V, int 
     if (rl < RL && ch < c) {
       const float ga = s_a[ch], be = s_b[ch];
       const float *col = rows + (size_t)bi * n_rows_max * c + ch;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four rows in flight per thread (one dependent load per step was latency-bound)
-      int j = j_lo + rl;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // rows in flight per thread: eight, then four (one dependent load per step was
+      int j = j_lo + rl;                               // latency-bound; a slab of ~200 rows was still twelve trips with four)
+      for (; j + 7 * RL < j_hi; j += 8 * RL) {
+        const float v0 = col[(size_t)j * c], v1 = col[(size_t)(j + RL) * c], v2 = col[(size_t)(j + 2 * RL) * c], v3 = col[(size_t)(j + 3 * RL) * c];
+        const float v4 = col[(size_t)(j + 4 * RL) * c], v5 = col[(size_t)(j + 5 * RL) * c], v6 = col[(size_t)(j + 6 * RL) * c], v7 = col[(size_t)(j + 7 * RL) * c];
+        a0 += swishf(v0 * ga + be); a1 += swishf(v1 * ga + be); a2 += swishf(v2 * ga + be); a3 += swishf(v3 * ga + be);
+        a0 += swishf(v4 * ga + be); a1 += swishf(v5 * ga + be); a2 += swishf(v6 * ga + be); a3 += swishf(v7 * ga + be);
+      }
       for (; j + 3 * RL < j_hi; j += 4 * RL) {
         const float v0 = col[(size_t)j * c], v1 = col[(size_t)(j + RL) * c], v2 = col[(size_t)(j + 2 * RL) * c], v3 = col[(size_t)(j + 3 * RL) * c];
         a0 += swishf(v0 * ga + be); a1 += swishf(v1 * ga + be); a2 += swishf(v2 * ga + be); a3 += swishf(v3 * ga + be);
@@ -345,10 +351,19 @@ __global__ void se_rows_fc_kernel(int c, int h, int V, const float *__restrict__
     double a = 0.0;
     for (int sl = 0; sl < SE_SLABS; ++sl) a += (double)part[((size_t)bi * SE_SLABS + sl) * c + i];
     const float2 ab = coef[(size_t)bi * c + i];
+    // the 27 class constants are read UNCONDITIONALLY, all in flight at once (a class without voxels has a finite constant and
+    // contributes 0 x value: the sum keeps its bits).  Loading them under `if (count)` made 27 dependent round trips of them: 17 us
+    // for this 16-workgroup kernel (round 5, rocprofv3 trace).
+    float cv[27];
+    int cn[27];
+#pragma unroll
     for (int k = 0; k < 27; ++k) {
-      const int n = class_count[(size_t)bi * 27 + k];
-      if (n) a += (double)n * (double)swishf(class_vals[((size_t)bi * 27 + k) * c + i] * ab.x + ab.y);
+      cn[k] = class_count[(size_t)bi * 27 + k];
+      cv[k] = class_vals[((size_t)bi * 27 + k) * c + i];
     }
+#pragma unroll
+    for (int k = 0; k < 27; ++k)
+      if (cn[k]) a += (double)cn[k] * (double)swishf(cv[k] * ab.x + ab.y);
     const float m = (float)(a / (double)V);
     s[i] = m;
     mean[(size_t)bi * c + i] = m;
