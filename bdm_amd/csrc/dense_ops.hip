@@ -1269,7 +1269,18 @@ __global__ void voxel_coords_kernel(int n, int r, float eps, const float *__rest
   const int bi = blockIdx.x, tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
   const float *p = coords + (size_t)bi * 3 * n;
   double s[3] = {0.0, 0.0, 0.0};
-  for (int i = tid; i < n; i += T) { s[0] += p[i]; s[1] += p[n + i]; s[2] += p[2 * n + i]; }
+  // the thread's first four points stay in registers for all three passes (n <= 4 T: every level of the denoisers), loaded with all
+  // twelve reads in flight; the passes were 3 x (n / T) dependent round trips of one load each
+  float px[4], py[4], pz[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = tid + u * T, ic = i < n ? i : 0;
+    px[u] = p[ic]; py[u] = p[n + ic]; pz[u] = p[2 * n + ic];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (tid + u * T < n) { s[0] += px[u]; s[1] += py[u]; s[2] += pz[u]; }
+  for (int i = tid + 4 * T; i < n; i += T) { s[0] += p[i]; s[1] += p[n + i]; s[2] += p[2 * n + i]; }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     s[d] = wave_sum(s[d]);
@@ -1284,7 +1295,13 @@ __global__ void voxel_coords_kernel(int n, int r, float eps, const float *__rest
   __syncthreads();
   const float mx = s_mean[0], my = s_mean[1], mz = s_mean[2];
   float best = 0.f;
-  for (int i = tid; i < n; i += T) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (tid + u * T < n) {
+      const float x = px[u] - mx, y = py[u] - my, z = pz[u] - mz;
+      best = fmaxf(best, sqrtf(x * x + y * y + z * z));
+    }
+  for (int i = tid + 4 * T; i < n; i += T) {
     const float x = p[i] - mx, y = p[n + i] - my, z = p[2 * n + i] - mz;
     best = fmaxf(best, sqrtf(x * x + y * y + z * z));
   }
@@ -1301,7 +1318,21 @@ __global__ void voxel_coords_kernel(int n, int r, float eps, const float *__rest
   float *nc = norm_coords + (size_t)bi * 3 * n;
   int *vc = vox_coords + (size_t)bi * 3 * n;
   const float hi = (float)(r - 1);
-  for (int i = tid; i < n; i += T) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = tid + u * T;
+    if (i < n) {
+      const float pv[3] = {px[u], py[u], pz[u]};
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float v = (pv[d] - s_mean[d]) / denom + 0.5f;
+        v = fminf(fmaxf(v * (float)r, 0.f), hi);
+        nc[(size_t)d * n + i] = v;
+        vc[(size_t)d * n + i] = (int)rintf(v);
+      }
+    }
+  }
+  for (int i = tid + 4 * T; i < n; i += T) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       float v = (p[(size_t)d * n + i] - s_mean[d]) / denom + 0.5f;

@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256) void to_h2_rows_kernel(int C, int V, int G, in
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ca[j] = s_a[c8 * 8 + j]; cb[j] = s_b[c8 * 8 + j]; }
   if (rl < per_pass) {
-    for (int j = blockIdx.x * RB + rl; j < min(nd, (int)(blockIdx.x + 1) * RB); j += per_pass) {
-      float in[8];
+    auto load_row = [&](int j, float (&in)[8]) {
       if (dense_in) {
         const int v = dil_list[(size_t)bi * n_rows_max + j];
         const float *xb = x + ((size_t)bi * C + c8 * 8) * V + v;
@@ -148,6 +147,8 @@ __global__ __launch_bounds__(256) void to_h2_rows_kernel(int C, int V, int G, in
           for (int u = 0; u < 8; ++u) in[u] = row[min(u, nch - 1)];
         }
       }
+    };
+    auto emit_row = [&](int j, const float (&in)[8]) {
       float val[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -160,6 +161,19 @@ __global__ __launch_bounds__(256) void to_h2_rows_kernel(int C, int V, int G, in
       split_rec(val, ph, pl);
       rows_h2[(((size_t)bi * C8 + c8) * 2 + 0) * n_rows_max + j] = ph;
       rows_h2[(((size_t)bi * C8 + c8) * 2 + 1) * n_rows_max + j] = pl;
+    };
+    // four rows per step, their loads in flight together (one row per step was RB / per_pass = 16+ dependent round trips per workgroup)
+    const int j_end = min(nd, (int)(blockIdx.x + 1) * RB);
+    int j = blockIdx.x * RB + rl;
+    for (; j + 3 * per_pass < j_end; j += 4 * per_pass) {
+      float in0[8], in1[8], in2[8], in3[8];
+      load_row(j, in0); load_row(j + per_pass, in1); load_row(j + 2 * per_pass, in2); load_row(j + 3 * per_pass, in3);
+      emit_row(j, in0); emit_row(j + per_pass, in1); emit_row(j + 2 * per_pass, in2); emit_row(j + 3 * per_pass, in3);
+    }
+    for (; j < j_end; j += per_pass) {
+      float in0[8];
+      load_row(j, in0);
+      emit_row(j, in0);
     }
   }
   if (saturated != nullptr && __ballot(sat) != 0ull && lane == __ffsll((long long)__ballot(sat)) - 1) atomicOr(saturated, 1u);
@@ -484,20 +498,30 @@ __global__ __launch_bounds__(256) void devox_rows_kernel(int c, int n, int r, in
       const int pl = t * 16 + ps;
       tile[4 * l16 + 0][pl] = acc.x; tile[4 * l16 + 1][pl] = acc.y; tile[4 * l16 + 2][pl] = acc.z; tile[4 * l16 + 3][pl] = acc.w;
     }
-    __syncthreads();
-    // 64 channels x 64 points: a wave writes one channel's 64 points (256 bytes) per step
+    // 64 channels x 64 points: a wave writes one channel's 64 points (256 bytes) per step.  The point branch's values of the wave's 16
+    // channels are fetched BEFORE the barrier, all in flight (they do not depend on the tile): read inside the store loop they were 16
+    // dependent round trips per pass
     const int lane = tid & 63, wv = tid >> 6;
-    for (int cl = wv; cl < 64; cl += 4) {
-      const int ci = c0 + cl, i = p0 + lane;
+    float av[16];
+    float2 ac[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int ci = c0 + wv + 4 * u, i = p0 + lane;
+      const bool ok = ci < c && i < n;
+      av[u] = 0.f; ac[u] = make_float2(0.f, 0.f);
+      if (add) av[u] = add[(size_t)bi * bs_a + (size_t)(ok ? ci : 0) * ld_a + (ok ? i : 0)];
+      if (add_coef) ac[u] = add_coef[(size_t)bi * c + (ok ? ci : 0)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int cl = wv + 4 * u, ci = c0 + cl, i = p0 + lane;
       if (ci >= c || i >= n) continue;
       float acc = tile[cl][lane];
       if (add) {
-        float av = add[(size_t)bi * bs_a + (size_t)ci * ld_a + i];
-        if (add_coef) {
-          const float2 pc2 = add_coef[(size_t)bi * c + ci];
-          av = swishf(av * pc2.x + pc2.y);
-        }
-        acc += av;
+        float a2 = av[u];
+        if (add_coef) a2 = swishf(a2 * ac[u].x + ac[u].y);
+        acc += a2;
       }
       out[(size_t)bi * bs_o + (size_t)ci * ld_o + i] = acc;
     }

@@ -79,11 +79,22 @@ __global__ __launch_bounds__(1024) void vox_dilate_kernel(int r, int n_dil_max, 
   int *wtot = reinterpret_cast<int *>(bits + r2);         // [2][16]
   int *ps_o = wtot + 32, *ps_d = ps_o + (r + 2);           // occupied / dilated cells before plane x
   const int *c = cnt + (size_t)bi * r3;
-  // a wave turns 64 consecutive cells into bits with one ballot (coalesced reads): r = 32: two rows, r = 16: four, r = 8: eight
-  for (int v0 = wave * 64; v0 < r3; v0 += T) {
-    const unsigned long long m = __ballot(c[v0 + lane] > thr);   // a cell of the input set (thr = 0: point counts, -1: ranks of a list)
-    const int rows = 64 / r;
-    if (lane < rows) occ[v0 / r + lane] = (unsigned)((m >> (lane * r)) & (r == 32 ? 0xffffffffull : ((1ull << r) - 1ull)));
+  // a wave turns 64 consecutive cells into bits with one ballot (coalesced reads): r = 32: two rows, r = 16: four, r = 8: eight.
+  // Eight loads in flight per lane: one load -> ballot -> next load was 32 dependent round trips at 32^3 (r^3 / 1024 threads), i.e.
+  // most of this single-workgroup-per-shape kernel's 32 - 40 us
+  for (int v0 = wave * 64; v0 < r3; v0 += 8 * T) {
+    int cv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cv[u] = v0 + u * T < r3 ? c[v0 + u * T + lane] : thr;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int vu = v0 + u * T;
+      if (vu < r3) {   // (wave-uniform)
+        const unsigned long long m = __ballot(cv[u] > thr);   // a cell of the input set (thr = 0: point counts, -1: ranks of a list)
+        const int rows = 64 / r;
+        if (lane < rows) occ[vu / r + lane] = (unsigned)((m >> (lane * r)) & (r == 32 ? 0xffffffffull : ((1ull << r) - 1ull)));
+      }
+    }
   }
   __syncthreads();
   const unsigned full = r == 32 ? 0xffffffffu : ((1u << r) - 1u);
