@@ -76,21 +76,63 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
   return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
+// 64-lane reductions on DPP row operations (xor 1, xor 2, half-row mirror, row mirror: four single-pass moves inside a row of 16
+// lanes) + one readlane per row, rows combined in order 0..3: the result is wave-uniform.  The `__shfl_xor` butterflies these replace are
+// six DEPENDENT ds_bpermute round trips through the LDS crossbar per value (twelve for a double) -- measured 5.3 us for the 32 dot products
+// of one SE gate (round 5); every GroupNorm statistic, row mean and amax of the small kernels goes through one of these.  Fixed order:
+// deterministic and independent of the batch.  All 64 lanes must be active.
+#if defined(__HIPCC__)
+#define BDM_DPP_QUAD_XOR1 0xB1
+#define BDM_DPP_QUAD_XOR2 0x4E
+#define BDM_DPP_ROW_HALF_MIRROR 0x141
+#define BDM_DPP_ROW_MIRROR 0x140
+__device__ __forceinline__ float dpp_f32(float v, const int ctrl) {
+  switch (ctrl) {
+    case BDM_DPP_QUAD_XOR1: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), BDM_DPP_QUAD_XOR1, 0xF, 0xF, true));
+    case BDM_DPP_QUAD_XOR2: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), BDM_DPP_QUAD_XOR2, 0xF, 0xF, true));
+    case BDM_DPP_ROW_HALF_MIRROR: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), BDM_DPP_ROW_HALF_MIRROR, 0xF, 0xF, true));
+    default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), BDM_DPP_ROW_MIRROR, 0xF, 0xF, true));
+  }
+}
+__device__ __forceinline__ double dpp_f64(double v, const int ctrl) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  int lo2, hi2;
+  switch (ctrl) {
+    case BDM_DPP_QUAD_XOR1: lo2 = __builtin_amdgcn_update_dpp(0, lo, BDM_DPP_QUAD_XOR1, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, BDM_DPP_QUAD_XOR1, 0xF, 0xF, true); break;
+    case BDM_DPP_QUAD_XOR2: lo2 = __builtin_amdgcn_update_dpp(0, lo, BDM_DPP_QUAD_XOR2, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, BDM_DPP_QUAD_XOR2, 0xF, 0xF, true); break;
+    case BDM_DPP_ROW_HALF_MIRROR: lo2 = __builtin_amdgcn_update_dpp(0, lo, BDM_DPP_ROW_HALF_MIRROR, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, BDM_DPP_ROW_HALF_MIRROR, 0xF, 0xF, true); break;
+    default: lo2 = __builtin_amdgcn_update_dpp(0, lo, BDM_DPP_ROW_MIRROR, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, BDM_DPP_ROW_MIRROR, 0xF, 0xF, true); break;
+  }
+  return __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ float readlane_f32(float v, const int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double readlane_f64(double v, const int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f32(v, BDM_DPP_QUAD_XOR1);
+  v += dpp_f32(v, BDM_DPP_QUAD_XOR2);
+  v += dpp_f32(v, BDM_DPP_ROW_HALF_MIRROR);
+  v += dpp_f32(v, BDM_DPP_ROW_MIRROR);
+  return ((readlane_f32(v, 0) + readlane_f32(v, 16)) + readlane_f32(v, 32)) + readlane_f32(v, 48);
 }
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f64(v, BDM_DPP_QUAD_XOR1);
+  v += dpp_f64(v, BDM_DPP_QUAD_XOR2);
+  v += dpp_f64(v, BDM_DPP_ROW_HALF_MIRROR);
+  v += dpp_f64(v, BDM_DPP_ROW_MIRROR);
+  return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f32(v, BDM_DPP_QUAD_XOR1));
+  v = fmaxf(v, dpp_f32(v, BDM_DPP_QUAD_XOR2));
+  v = fmaxf(v, dpp_f32(v, BDM_DPP_ROW_HALF_MIRROR));
+  v = fmaxf(v, dpp_f32(v, BDM_DPP_ROW_MIRROR));
+  return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
 }
+#endif
 
 // workspace layout of the deterministic voxeliser (pvcnn_ops.hip: vox_plan_kernel)
 struct VoxWs {

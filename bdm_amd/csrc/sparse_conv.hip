@@ -235,6 +235,15 @@ __global__ __launch_bounds__(1024) void sparse_vox_features_lds_kernel(int c, in
       cs[i] = start[(size_t)bi * r3 + v];
     }
   }
+  // ... and so are the first four entries of each cell's point list (cells hold 1 - 3 points on these levels): after the barrier the
+  // common cell needs LDS only (its list read there was one more dependent round trip per cell, two per thread at 32^3)
+  int pre[CPT][4];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int *so = sorted + (size_t)bi * n + cs[i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pre[i][u] = cc[i] > 0 ? so[min(u, cc[i] - 1)] : 0;
+  }
   const float *fb = feat + (size_t)bi * bs_f + (size_t)g * 8 * ld_f;
   if ((n & 3) == 0 && (ld_f & 3) == 0 && ((reinterpret_cast<size_t>(fb) & 15) == 0)) {  // 16-byte row pieces
     const int n4 = n >> 2;
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(1024) void sparse_vox_features_lds_kernel(int c, in
     for (int q0 = 0; q0 < cv; q0 += 4) {
       int p[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) p[u] = so[min(q0 + u, cv - 1)];
+      for (int u = 0; u < 4; ++u) p[u] = q0 == 0 ? pre[i][u] : so[min(q0 + u, cv - 1)];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (q0 + u < cv) {
