@@ -170,8 +170,31 @@ __global__ __launch_bounds__(1024) void vox_dilate_kernel(int r, int n_dil_max, 
   __syncthreads();
   for (int x = tid; x < r + 2; x += T) plane_start[(size_t)bi * (r + 2) + x] = ps_o[x];
   int *tinfo = reinterpret_cast<int *>(occ);              // (the occupancy rows are dead) [tiles_max + 1][2]: first entry, first plane
-  __shared__ int s_tiles;
-  if (tid == 0) {   // the tile table: a short serial walk over LDS-resident prefixes
+  __shared__ int s_tiles, s_cut;
+  // The tile table.  Without a cut every tile is simply [t * tile, (t + 1) * tile): thread t derives its tile's planes by itself
+  // (binary search in the plane prefixes) and checks the row budget; only if SOME tile would exceed it -- a cloud with more than
+  // xcap occupied cells in three neighbouring planes: never on the denoisers' levels -- thread 0 redoes the table with the serial
+  // walk below, which cuts at plane boundaries.  The walk alone (a chain of ~6 dependent LDS reads per tile, 64 - 96 tiles, ONE
+  // thread) was about half of this kernel's 32 us.
+  if (tid == 0) s_cut = 0;
+  __syncthreads();
+  {
+    const int nd = min(tot_d, n_dil_max), nt_flat = (nd + tile - 1) / tile;
+    if (tid < nt_flat && tid < tiles_max) {
+      const int j = tid * tile, jend = min(j + tile, nd);
+      int lo = 0, hi = r;                    // plane of entry j: the largest x with ps_d[x] <= j  (ps_d[r] = tot_d > j)
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ps_d[mid] <= j) lo = mid; else hi = mid; }
+      const int x0 = lo;
+      lo = x0; hi = r;                       // plane of entry jend - 1
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ps_d[mid] <= jend - 1) lo = mid; else hi = mid; }
+      const int x1 = lo;
+      if (x1 > x0 && ps_o[min(x1 + 2, r)] - ps_o[max(x0 - 1, 0)] > xcap) s_cut = 1;
+      tinfo[2 * tid] = j; tinfo[2 * tid + 1] = (x0 << 8) | x1;
+    }
+    if (tid == 0) { tinfo[2 * min(nt_flat, tiles_max)] = nd; s_tiles = min(nt_flat, tiles_max); }
+  }
+  __syncthreads();
+  if (tid == 0 && s_cut) {   // the general case: a short serial walk over LDS-resident prefixes
     const int nd = min(tot_d, n_dil_max);
     int t = 0, j = 0, x0 = 0;
     while (j < nd && t < tiles_max) {

@@ -320,17 +320,27 @@ def main():
             line["note"] = "not the headline workload (the metric is quoted on C2); same trajectory definition at this configuration's size"
         # occupied fraction of the sparse convolutions' rows on the final clouds (after the timed region), per level
         from bdm_amd import functional as BF, ops as bops, profiling
-        pts = out.transpose(1, 2).contiguous()
-        for r_, n_ in ((32, args.points), (16, 1024), (8, 256), (8, 64)):
-            if pts.shape[2] > n_:
-                pts = BF.furthest_point_sample(pts, n_)
-            bops.clear_plan_cache()
-            plan = bops.voxel_plan(pts, r_, dilate=2 if r_ in (16, 32) else 0)
-            profiling.OCCUPANCY[plan.n_max] = float(plan.n_occ.float().mean()) / plan.n_max
-            if getattr(plan, "d2_tiles", None) is not None:   # once- / twice-dilated fraction of the grid: what the list convolutions compute
-                d1 = float(plan.tile_start[:, :, 1].max(dim=1).values.float().mean()) / r_ ** 3
-                d2 = float(plan.d2_tiles[:, :, 1].max(dim=1).values.float().mean()) / r_ ** 3
-                profiling.DILATED[r_] = (d1, d2)
+        # ... on the clouds the trajectory ENDS with and on clouds like the ones it STARTS with (centred Gaussian noise): the listed
+        # fraction of the grid shrinks as the cloud condenses, the mean of the two ends prices the kernels of the whole trajectory
+        ends = [out.transpose(1, 2).contiguous(), torch.randn(out.shape[0], 3, args.points, device=out.device)]
+        ends[1] = ends[1] - ends[1].mean(dim=2, keepdim=True)
+        acc_occ, acc_dil = {}, {}
+        for pts in ends:
+            for r_, n_ in ((32, args.points), (16, 1024), (8, 256), (8, 64)):
+                if pts.shape[2] > n_:
+                    pts = BF.furthest_point_sample(pts, n_)
+                bops.clear_plan_cache()
+                plan = bops.voxel_plan(pts, r_, dilate=2 if r_ in (16, 32) else 0)
+                acc_occ.setdefault(plan.n_max, []).append(float(plan.n_occ.float().mean()) / plan.n_max)
+                if getattr(plan, "d2_tiles", None) is not None:   # once- / twice-dilated fraction of the grid: what the list convolutions compute
+                    d1 = float(plan.tile_start[:, :, 1].max(dim=1).values.float().mean()) / r_ ** 3
+                    d2 = float(plan.d2_tiles[:, :, 1].max(dim=1).values.float().mean()) / r_ ** 3
+                    acc_dil.setdefault(r_, []).append((d1, d2))
+        for k, v in acc_occ.items():
+            profiling.OCCUPANCY[k] = sum(v) / len(v)
+        for k, v in acc_dil.items():
+            profiling.DILATED[k] = (sum(a for a, _ in v) / len(v), sum(b for _, b in v) / len(v))
+            line.setdefault("dilated_fraction_final_and_initial", {})[str(k)] = [[round(a, 4), round(b, 4)] for a, b in v]
         rows, classes = prof.table()
         if classes:
             # dominant class of the MAIN stream: the furthest-point sampler runs concurrently on its own stream (a chain of M - 1

@@ -34,11 +34,12 @@ TOL_BATCH = 1e-6   # the same shape at B = 1 and inside its per-GPU batch
 # fp32 path, so at 0.1 the figure is the chaos of the procedural network times the fp32 noise floor of BOTH sides, not kernel error.
 #   * head 0.03 (`c2_b16_shape11_h003`): THE bench-size parity test -- literal 1e-3 bound plus the early-warning line below;
 #   * head 0.1  (`c2_b16_shape11`): kept at the literal 1e-3 bound as a chaos monitor (like C1's), its figure printed on the record.
-C2_MARGIN_LINE = {"c2_b16_shape11_h003": 3e-4, "c2_b16_shape11": None}
+C2_MARGIN_LINE = {"c2_b16_shape11_h003": 3e-4, "c2_b16_shape3_h003": 3e-4, "c2_b16_shape7_h003": 3e-4, "c2_b16_shape11": None}
+_C2_RUNS = {}   # (head scale) -> (clouds, segment clouds) of the ONE B = 16 trajectory the fixtures of that head scale share
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["c2_b16_shape11_h003", "c2_b16_shape11"])
+@pytest.mark.parametrize("name", ["c2_b16_shape11_h003", "c2_b16_shape3_h003", "c2_b16_shape7_h003", "c2_b16_shape11"])
 def test_full_c2_trajectory_batch16_vs_oracle_fixture(hip, name):
     """(a) in the default `-m gpu` selection: the oracle's cloud of the sampled shape is tests/golden/traj_<name>.npz
     (oracle/gen_golden_traj.py: the same case and streams, run once in the build container); the HIP side is the full B = 16,
@@ -48,13 +49,16 @@ def test_full_c2_trajectory_batch16_vs_oracle_fixture(hip, name):
     assert (B, N) == (16, 4096)
     c = case.build(N, head_scale=float(g["head_scale"]), merging=False, B=B)
     assert list(g["milestones"]) == list(c.milestones) and len(case.program_order(c.milestones, c.roll_step)) == int(g["forwards"])
-    with case.segments() as seg:
-        got = case.run_hip_streams(c, seed, list(range(B)))
+    key = (float(g["head_scale"]), seed)
+    if key not in _C2_RUNS:     # three sampled shapes of the calm batch are checked against ONE run of it
+        with case.segments() as seg:
+            _C2_RUNS[key] = (case.run_hip_streams(c, seed, list(range(B))), seg.clouds)
+    got, seg_clouds = _C2_RUNS[key]
     assert got.shape == (B, N, 3) and bool(torch.isfinite(got).all())
     line = C2_MARGIN_LINE[name]
     err = parity(f"traj_{name} final cloud (bench size, Philox mode, head {float(g['head_scale']):g})",
                  rel_l2(got[row:row + 1], torch.from_numpy(g["final"])), NORTH_STAR, note="" if line is None else f"margin line {line:.0e}")
-    first, curve = first_segment_past(NORTH_STAR, [x[row:row + 1] for x in seg.clouds], g)
+    first, curve = first_segment_past(NORTH_STAR, [x[row:row + 1] for x in seg_clouds], g)
     for i, e in enumerate(curve):
         parity(f"traj_{name} segment {i}", e, NORTH_STAR)
     print(f"full C2 trajectory at B=16, N=4096 (per-shape Philox streams), head {float(g['head_scale']):g}, shape {row} vs the oracle fixture: "
@@ -64,7 +68,7 @@ def test_full_c2_trajectory_batch16_vs_oracle_fixture(hip, name):
     if line is not None:
         assert err <= line, (f"margin gone: final rel-L2 {err:.3e} is inside the 1e-3 bound but past the {line:.0e} early-warning line of the calm "
                              f"(head {float(g['head_scale']):g}) fixture; segment curve {['%.2e' % e for e in curve]}")
-    assert rel_l2(got[0:1], got[row:row + 1]) > 0.1
+    assert rel_l2(got[(row + 1) % B:(row + 1) % B + 1], got[row:row + 1]) > 0.1
 
 
 @pytest.mark.gpu_slow

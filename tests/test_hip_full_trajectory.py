@@ -23,8 +23,13 @@ HEAD_SCALE = 0.1
 NORTH_STAR = 1e-3
 
 
+# Early-warning lines of the CALM twins (head scale 0.03; the 0.1 fixtures keep the literal bound only: their figures moved between 2e-6
+# and 3e-4 from one summation order of a kernel to the next in rounds 4 - 5 -- chaos of the procedural network)
+MARGIN_LINE = {"blending_n1024_h003": 1e-4, "merging_n1024_h003": 1e-4}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["blending_n1024", "merging_n1024"])
+@pytest.mark.parametrize("name", ["blending_n1024_h003", "merging_n1024_h003", "blending_n1024", "merging_n1024"])
 def test_full_trajectory_vs_oracle_fixture(hip, name):
     """The default (`-m gpu`) form: the oracle's final cloud comes from tests/golden/traj_<name>.npz, written by
     oracle/gen_golden_traj.py (the same case, the same oracle, run once in the build container: ~3 min of host time each that the
@@ -43,6 +48,10 @@ def test_full_trajectory_vs_oracle_fixture(hip, name):
           "per segment " + " ".join(f"{e:.1e}" for e in curve))
     assert err <= NORTH_STAR, (f"final rel-L2 {err:.3e} > {NORTH_STAR}; first schedule segment past the bound: {first} "
                                f"(segment curve {['%.2e' % e for e in curve]})")
+    line = MARGIN_LINE.get(name)
+    if line is not None:
+        assert err <= line, (f"margin gone: final rel-L2 {err:.3e} is inside the 1e-3 bound but past the {line:.0e} early-warning line of the calm "
+                             f"(head 0.03) fixture; segment curve {['%.2e' % e for e in curve]}")
 
 
 @pytest.mark.gpu_slow
