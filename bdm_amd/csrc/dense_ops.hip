@@ -1804,9 +1804,18 @@ __global__ __launch_bounds__(1024) void attn_small_kernel(int C, int L, int nsl,
   float *S = sm, *Sp = S + LL, *Qs = Sp + nsl * LL, *Ks = Qs + C * L, *Vs = Ks + C * L;
   const int bi = blockIdx.x;
   const float *qb = q + (size_t)bi * bs, *kb = k + (size_t)bi * bs, *vb = v + (size_t)bi * bs;
-  for (int e = tid; e < C * L; e += T) {
-    const int c = e / L, i = e % L;
-    Qs[e] = qb[(size_t)c * ld + i]; Ks[e] = kb[(size_t)c * ld + i]; Vs[e] = vb[(size_t)c * ld + i];
+  // four elements of each operand per step, their twelve loads in flight together (one element per step was C L / T = 8 dependent
+  // round trips for the global attention's 16 tokens x 512 channels: a third of this single-workgroup-per-shape kernel)
+  for (int e0 = tid; e0 < C * L; e0 += 4 * T) {
+    float qv[4], kv[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = min(e0 + u * T, C * L - 1), c = e / L, i = e - c * L;
+      qv[u] = qb[(size_t)c * ld + i]; kv[u] = kb[(size_t)c * ld + i]; vv[u] = vb[(size_t)c * ld + i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (e0 + u * T < C * L) { Qs[e0 + u * T] = qv[u]; Ks[e0 + u * T] = kv[u]; Vs[e0 + u * T] = vv[u]; }
   }
   __syncthreads();
   if (nsl > 1) {  // L^2 <= T / 2: thread = (slice, pair)

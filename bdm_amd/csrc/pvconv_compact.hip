@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256) void class_constants_kernel(int cin, int cout,
   const double *wk = wsum + (size_t)k * cin * cout;
   for (int co = tid; co < cout; co += blockDim.x) {
     double a = bias ? (double)bias[co] : 0.0;
+#pragma unroll 8   // (eight weight loads in flight; the sum stays in ascending ci)
     for (int ci = 0; ci < cin; ++ci) a += wk[(size_t)ci * cout + co] * (double)s_c[ci];
     const float v = (float)a;
     class_vals[((size_t)bi * 27 + k) * cout + co] = v;

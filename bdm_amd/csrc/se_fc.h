@@ -29,12 +29,31 @@ __device__ __forceinline__ float se_wave_sum(float v) {
 
 __device__ __forceinline__ void se_hidden_layer(int c, int hidden, const float *__restrict__ w1, const float *s_mean, float *s_hid) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int j = wave; j < hidden; j += nw) {
-    const float *wr = w1 + (size_t)j * c;
-    float a = 0.f;
-    for (int k = lane; k < c; k += 64) a += wr[k] * s_mean[k];
-    a = se_wave_sum(a);
-    if (lane == 0) s_hid[j] = fmaxf(a, 0.f);
+  // four units of the wave at a time, and up to four k per lane of each, with all their weight loads in flight (clamped addresses,
+  // zeroed beyond the matrix): one unit after the other, each waiting for its own loads, was hidden / nw dependent round trips --
+  // 11.6 us for a 32 x 256 layer, slower than the scalar loop it replaced.  Per lane k ascending, then se_wave_sum: same sums.
+  for (int j0 = wave; j0 < hidden; j0 += 4 * nw) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = lane; k0 < c; k0 += 4 * 64) {
+      float w[4][4], sk[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int k = k0 + 64 * v;
+        sk[v] = k < c ? s_mean[k] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u][v] = w1[(size_t)min(j0 + u * nw, hidden - 1) * c + min(k, c - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (k0 + 64 * v < c) a[u] += w[u][v] * sk[v];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float r = se_wave_sum(a[u]);
+      if (lane == 0 && j0 + u * nw < hidden) s_hid[j0 + u * nw] = fmaxf(r, 0.f);
+    }
   }
 }
 

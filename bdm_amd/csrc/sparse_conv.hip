@@ -500,40 +500,81 @@ __global__ __launch_bounds__(256) void sparse_rows_from_map_kernel(int n, int r3
                                                                    const int *__restrict__ n_occ, float *__restrict__ y) {
   const int bi = blockIdx.y, k0 = blockIdx.x * 8, nocc = min(n_occ[bi], n_max);
   if (k0 >= nocc) return;
-  const int c4 = threadIdx.x;  // float4 column
-  if (c4 * 4 >= n27) return;
-  const float4 w0 = make_float4(wx[(c4 * 4 + 0) * 3 + 0], wx[(c4 * 4 + 1) * 3 + 0], wx[(c4 * 4 + 2) * 3 + 0], wx[(c4 * 4 + 3) * 3 + 0]);
-  const float4 w1 = make_float4(wx[(c4 * 4 + 0) * 3 + 1], wx[(c4 * 4 + 1) * 3 + 1], wx[(c4 * 4 + 2) * 3 + 1], wx[(c4 * 4 + 3) * 3 + 1]);
-  const float4 w2 = make_float4(wx[(c4 * 4 + 0) * 3 + 2], wx[(c4 * 4 + 1) * 3 + 2], wx[(c4 * 4 + 2) * 3 + 2], wx[(c4 * 4 + 3) * 3 + 2]);
+  const int c4 = threadIdx.x, c4c = min(c4, (n27 >> 2) - 1);  // float4 column (threads beyond the row only help with the index chase)
+  const float4 w0 = make_float4(wx[(c4c * 4 + 0) * 3 + 0], wx[(c4c * 4 + 1) * 3 + 0], wx[(c4c * 4 + 2) * 3 + 0], wx[(c4c * 4 + 3) * 3 + 0]);
+  const float4 w1 = make_float4(wx[(c4c * 4 + 0) * 3 + 1], wx[(c4c * 4 + 1) * 3 + 1], wx[(c4c * 4 + 2) * 3 + 1], wx[(c4c * 4 + 3) * 3 + 1]);
+  const float4 w2 = make_float4(wx[(c4c * 4 + 0) * 3 + 2], wx[(c4c * 4 + 1) * 3 + 2], wx[(c4c * 4 + 2) * 3 + 2], wx[(c4c * 4 + 3) * 3 + 2]);
   const float *px = xyz + (size_t)bi * 3 * n;
   const int *pp = pix + (size_t)bi * n;
   const float4 *hb = reinterpret_cast<const float4 *>(hmap + (size_t)bi * hw * n27);
   const int n27q = n27 >> 2;
-  for (int k = k0; k < min(k0 + 8, nocc); ++k) {
-    const int v = occ_list[(size_t)bi * n_max + k];
-    const int cv = cnt[(size_t)bi * r3 + v];
-    const int *so = sorted + (size_t)bi * n + start[(size_t)bi * r3 + v];
-    const float inv = cv > 0 ? (float)(1.0 / (double)(float)cv) : 0.f;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int q0 = 0; q0 < cv; q0 += 2) {  // two points per round: their row reads are in flight together
-      const int i0 = so[q0], i1 = so[min(q0 + 1, cv - 1)];
-      const int p0 = pp[i0], p1 = pp[i1];
-      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 h0 = p0 >= 0 ? hb[(size_t)p0 * n27q + c4] : zero;
-      const float4 h1 = (p1 >= 0 && q0 + 1 < cv) ? hb[(size_t)p1 * n27q + c4] : zero;
-      const float x0 = px[i0], y0 = px[n + i0], z0 = px[2 * n + i0];
-      const float x1 = px[i1], y1 = px[n + i1], z1 = px[2 * n + i1];
-      float4 t;
-      t.x = h0.x + (w0.x * x0 + w1.x * y0 + w2.x * z0); t.y = h0.y + (w0.y * x0 + w1.y * y0 + w2.y * z0);
-      t.z = h0.z + (w0.z * x0 + w1.z * y0 + w2.z * z0); t.w = h0.w + (w0.w * x0 + w1.w * y0 + w2.w * z0);
-      acc.x += t.x * inv; acc.y += t.y * inv; acc.z += t.z * inv; acc.w += t.w * inv;
-      if (q0 + 1 < cv) {
-        t.x = h1.x + (w0.x * x1 + w1.x * y1 + w2.x * z1); t.y = h1.y + (w0.y * x1 + w1.y * y1 + w2.y * z1);
-        t.z = h1.z + (w0.z * x1 + w1.z * y1 + w2.z * z1); t.w = h1.w + (w0.w * x1 + w1.w * y1 + w2.w * z1);
+  // The index chase of the workgroup's 8 cells (cell -> count / list start -> point -> owning pixel + coordinates) is done ONCE, by 8 and
+  // then 32 threads, into LDS; every thread then has the map rows of four cells' points in flight together.  Chased by every thread for
+  // one cell after the other it was ~5 dependent round trips per cell, 40 per workgroup: 78 us for the level-0 layer (round 5).
+  __shared__ int s_cv[8], s_st[8], s_pt[8][4], s_pix[8][4];
+  __shared__ float s_xyz[8][4][3];
+  if (threadIdx.x < 8) {
+    const int k = k0 + threadIdx.x;
+    int cv = 0, st = 0;
+    if (k < nocc) {
+      const int v = occ_list[(size_t)bi * n_max + k];
+      cv = cnt[(size_t)bi * r3 + v];
+      st = start[(size_t)bi * r3 + v];
+    }
+    s_cv[threadIdx.x] = cv; s_st[threadIdx.x] = st;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int cell = threadIdx.x >> 2, q = threadIdx.x & 3;
+    if (q < s_cv[cell]) {
+      const int i = sorted[(size_t)bi * n + s_st[cell] + q];
+      s_pt[cell][q] = i;
+      s_pix[cell][q] = pp[i];
+      s_xyz[cell][q][0] = px[i]; s_xyz[cell][q][1] = px[n + i]; s_xyz[cell][q][2] = px[2 * n + i];
+    }
+  }
+  __syncthreads();
+  if (c4 * 4 >= n27) return;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int half = 0; half < 2; ++half) {
+    float4 h[4][4];
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cell = half * 4 + cl;
+        const int p = q < s_cv[cell] ? s_pix[cell][q] : -1;
+        h[cl][q] = p >= 0 ? hb[(size_t)p * n27q + c4] : zero;
+      }
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl) {
+      const int cell = half * 4 + cl, k = k0 + cell;
+      if (k >= nocc) continue;
+      const int cv = s_cv[cell];
+      const float inv = cv > 0 ? (float)(1.0 / (double)(float)cv) : 0.f;
+      float4 acc = zero;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < cv) {
+          const float x0 = s_xyz[cell][q][0], y0 = s_xyz[cell][q][1], z0 = s_xyz[cell][q][2];
+          const float4 h0 = h[cl][q];
+          float4 t;
+          t.x = h0.x + (w0.x * x0 + w1.x * y0 + w2.x * z0); t.y = h0.y + (w0.y * x0 + w1.y * y0 + w2.y * z0);
+          t.z = h0.z + (w0.z * x0 + w1.z * y0 + w2.z * z0); t.w = h0.w + (w0.w * x0 + w1.w * y0 + w2.w * z0);
+          acc.x += t.x * inv; acc.y += t.y * inv; acc.z += t.z * inv; acc.w += t.w * inv;
+        }
+      const int *so = sorted + (size_t)bi * n + s_st[cell];
+      for (int q = 4; q < cv; ++q) {   // a cell with more than four points: the rest one by one (rare on the denoisers' levels)
+        const int i0 = so[q], p0 = pp[i0];
+        const float4 h0 = p0 >= 0 ? hb[(size_t)p0 * n27q + c4] : zero;
+        const float x0 = px[i0], y0 = px[n + i0], z0 = px[2 * n + i0];
+        float4 t;
+        t.x = h0.x + (w0.x * x0 + w1.x * y0 + w2.x * z0); t.y = h0.y + (w0.y * x0 + w1.y * y0 + w2.y * z0);
+        t.z = h0.z + (w0.z * x0 + w1.z * y0 + w2.z * z0); t.w = h0.w + (w0.w * x0 + w1.w * y0 + w2.w * z0);
         acc.x += t.x * inv; acc.y += t.y * inv; acc.z += t.z * inv; acc.w += t.w * inv;
       }
+      reinterpret_cast<float4 *>(y + ((size_t)bi * n_max + k) * n27)[c4] = acc;
     }
-    reinterpret_cast<float4 *>(y + ((size_t)bi * n_max + k) * n27)[c4] = acc;
   }
 }
 
