@@ -459,7 +459,8 @@ class PVConv(nn.Module):
                     v, stats = ops.conv3d_h2_gn(xh, self._packed_weight(conv2, "fp16x3"), conv2.bias, conv2.in_channels,
                                                 conv2.out_channels, r, gn2.num_groups)
                     w1, w2 = se.fc[0].weight, se.fc[2].weight
-                    if ops.small_grid_tail_ok(r, conv2.out_channels, features.shape[2]) and w1.shape[0] <= 256:
+                    head = self._head_for_next(plan, gn2, features.shape[0], features.device) if ops.SMALL_GLUE else None
+                    if ops.small_grid_tail_ok(r, conv2.out_channels, features.shape[2]) and w1.shape[0] <= 256 and (head is not None or not ops.SMALL_GLUE_TAIL_ONLY):
                         # small grid: SE's FC layers + GroupNorm-2 + Swish + gate + devoxelisation + point branch in one launch of
                         # per-shape workgroups, which also leave the NEXT PVConv's first-convolution operand when it shares the plan
                         if pf_ready is not None:
@@ -469,8 +470,7 @@ class PVConv(nn.Module):
                             mean, coef, pf_coef = ops.se_means_gn(v, stats, gn2, pf=pf_pending, n_points=pf.shape[2])
                         else:
                             mean, coef = ops.se_means_gn(v, stats, gn2)
-                        out, rows = ops.pvconv_tail_small(norm_coords, v, coef, mean, w1, w2, r, add=pf, add_coef=pf_coef,
-                                                          head=self._head_for_next(plan, gn2, features.shape[0], features.device))
+                        out, rows = ops.pvconv_tail_small(norm_coords, v, coef, mean, w1, w2, r, add=pf, add_coef=pf_coef, head=head)
                         if rows is not None:
                             out._bdm_rows = rows
                         return out, coords, temb

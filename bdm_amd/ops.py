@@ -775,9 +775,14 @@ def devoxelize_gn_gate_add(norm_coords, grid, coef, r, gate=None, add=None, add_
 
 
 # ---- PVConv glue on the small voxel grids (csrc/pvconv_small.hip) ------------------------------------------------------------------
-# fused tail / head / gather of the 8^3 PVConvs (csrc/experimental/pvconv_small.hip, `make EXPERIMENTAL=1` builds only): built for VERDICT r4
-# next-1 and measured NOT faster than the operator chain -- off unless asked for
-SMALL_GLUE = os.environ.get("BDM_SMALL_GLUE", "0") == "1"
+# Small voxel grids (8^3 levels; round 5):
+#   "tail" (default): where the NEXT PVConv of a stage shares the voxel plan, the tail of a PVConv (SE FC layers + GroupNorm-2 + Swish + gate
+#            + devoxelisation + point branch) also leaves that PVConv's first-convolution operand (csrc/pvconv_small.hip): -13 us per module;
+#   "1":     the tail kernel everywhere + the gather + GroupNorm-1 + split kernel (csrc/experimental/, EXPERIMENTAL=1 builds): measured slower;
+#   "0":     the operator chain.
+_SMALL_GLUE_MODE = os.environ.get("BDM_SMALL_GLUE", "tail")
+SMALL_GLUE = _SMALL_GLUE_MODE in ("1", "tail")
+SMALL_GLUE_TAIL_ONLY = _SMALL_GLUE_MODE == "tail"   # only the tail, and only where a next PVConv takes its operand
 
 
 def small_grid_tail_ok(r, c, n):
@@ -787,7 +792,7 @@ def small_grid_tail_ok(r, c, n):
 
 def small_grid_gather_ok(r, cout, groups):
     cg = cout // groups if groups and cout % groups == 0 else 0
-    return SMALL_GLUE and cg >= 8 and cg % 8 == 0 and cg <= 64 and 256 % (cg // 4) == 0 and (cg * (r ** 3 + 1) + r ** 3) * 4 <= 150 * 1024
+    return SMALL_GLUE and not SMALL_GLUE_TAIL_ONLY and cg >= 8 and cg % 8 == 0 and cg <= 64 and 256 % (cg // 4) == 0 and (cg * (r ** 3 + 1) + r ** 3) * 4 <= 150 * 1024
 
 
 def h2_sum_scale(gns, sigmas=64.0):
@@ -831,12 +836,12 @@ def pvconv_tail_small(norm_coords, grid, coef, mean, w1, w2, r, add=None, add_co
         xh = torch.empty(B, C // 8, 2, plan.n_max, 8, dtype=torch.float16, device=grid.device)
         amax = torch.empty(B, dtype=torch.float32, device=grid.device)
         rows = VoxelRows(plan, xh, amax, C)
-        L.check(L.experimental("bdm_pvconv_tail_small")(B, C, n, int(r), w1.shape[0], L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(mean),
+        L.check(L.lib().bdm_pvconv_tail_small(B, C, n, int(r), w1.shape[0], L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(mean),
                                               L.ptr(w1), L.ptr(w2), L.ptr(add), bs_a, ld_a, L.ptr(add_coef), L.ptr(out), bs_o, ld_o,
                                               L.ptr(plan.cnt), L.ptr(plan.ws), L.ptr(plan.occ_list), L.ptr(plan.n_occ), plan.n_max,
                                               L.c_float(x_scale), L.ptr(xh), L.ptr(amax), L.ptr(saturated), L.stream()), "pvconv_tail_small")
         return out, rows
-    L.check(L.experimental("bdm_pvconv_tail_small")(B, C, n, int(r), w1.shape[0], L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(mean),
+    L.check(L.lib().bdm_pvconv_tail_small(B, C, n, int(r), w1.shape[0], L.ptr(norm_coords), L.ptr(grid), L.ptr(coef), L.ptr(mean),
                                           L.ptr(w1), L.ptr(w2), L.ptr(add), bs_a, ld_a, L.ptr(add_coef), L.ptr(out), bs_o, ld_o,
                                           L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None), 0, L.c_float(0.0), L.ptr(None), L.ptr(None),
                                           L.ptr(None), L.stream()), "pvconv_tail_small")

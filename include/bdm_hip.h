@@ -386,8 +386,7 @@ int bdm_devoxelize_gn_se_add(int b, int c, int n, int r, const float *coords, co
                              const float *se_mean, int hidden, const float *w1, const float *w2, const float *add,
                              long long bs_a, int ld_a, float *out, long long bs_o, int ld_o, void *stream);
 
-#ifdef BDM_EXPERIMENTAL  /* fused PVConv glue of the small voxel grids (csrc/experimental/pvconv_small.hip): measured not faster, DESIGN.md 7.9 */
-/* ---- PVConv glue on the SMALL voxel grids (8^3 levels) -- per-shape workgroups, no hand-off between them ----
+/* ---- PVConv tail on the SMALL voxel grids (8^3 levels; csrc/pvconv_small.hip) -- per-shape workgroups, no hand-off between them ----
  * bdm_pvconv_tail_small: SE gate (both FC layers of se.py:8-19, from se_mean (b, c) = bdm_se_gate_gn(w1 = NULL)'s channel means)
  * + Swish(GroupNorm-2(grid)) * gate + trilinear devoxelisation at the n points + Swish(GroupNorm(point branch)) (add_coef; NULL: `add`
  * is added as it is) -> out (pvconv.py:91-97), one workgroup per (shape, 8 channels); bit-identical to bdm_se_gate_gn_pf +
@@ -401,6 +400,7 @@ int bdm_pvconv_tail_small(int b, int c, int n, int r, int hidden, const float *c
                           const float *add_coef, float *out, long long bs_o, int ld_o, const int *cnt, const void *plan_workspace,
                           const int *occ_list, const int *n_occ, int n_max, float x_scale, void *xh, float *amax_out, int *saturated,
                           void *stream);
+#ifdef BDM_EXPERIMENTAL  /* csrc/experimental/sparse_gather_h2_small.hip: measured not faster */
 /* bdm_sparse_conv_gather_h2_small: bdm_sparse_conv_gather_gn + bdm_group_norm_to_h2_stats in one launch, one workgroup per (shape,
  * GroupNorm group): y (b, n_max, 27, cout) = the GEMM's output, out_h2 (b, cout/8, 2, r^3) records = act_scale *
  * Swish(GroupNorm(groups)(conv1 output)) as two fp16 terms (the second convolution's operand); the dense fp32 output of the first
