@@ -1221,7 +1221,7 @@ extern "C" int bdm_transpose(int b, int rows, int cols, const float *x, float *y
 // =====================================================================================
 // Timestep embedding + embedf   (pvcnn_utils.py:171-185, pvcnn.py:72-76,87-88)
 // =====================================================================================
-__global__ void time_embed_kernel(int dim, const float *__restrict__ t, const float *__restrict__ w0,
+__global__ void time_embed_kernel(int dim, const float *__restrict__ t, const long long *__restrict__ t64, const float *__restrict__ w0,
                                   const float *__restrict__ b0, const float *__restrict__ w2,
                                   const float *__restrict__ b2, float *__restrict__ out) {
   extern __shared__ float sh[];  // emb[dim], hid[dim]
@@ -1231,7 +1231,7 @@ __global__ void time_embed_kernel(int dim, const float *__restrict__ t, const fl
     const int fi = i < half ? i : i - half;
     // numpy float64 exp, then .float()
     const float freq = (float)exp(-(double)fi * (log(10000.0) / (double)(half - 1)));
-    const float arg = t[bi] * freq;
+    const float arg = (t64 ? (float)t64[bi] : t[bi]) * freq;   // (t.float(): pvcnn_utils.py:178)
     emb[i] = i < half ? sinf(arg) : cosf(arg);
   }
   __syncthreads();
@@ -1252,8 +1252,18 @@ extern "C" int bdm_time_embedding(int b, int dim, const float *t, const float *w
   BDM_REQUIRE(b >= 0 && dim >= 4 && dim % 2 == 0 && dim <= 1024, "time_embedding: bad dim %d", dim);
   if (b == 0) return BDM_OK;
   hipLaunchKernelGGL(time_embed_kernel, dim3(b), dim3((dim + 63) / 64 * 64), 2 * dim * sizeof(float),
-                     (hipStream_t)stream, dim, t, w0, b0, w2, b2, out);
+                     (hipStream_t)stream, dim, t, (const long long *)nullptr, w0, b0, w2, b2, out);
   return launch_status("time_embedding");
+}
+// The same from the int64 timesteps the schedulers hand over (the `.float()` of pvcnn_utils.py:178 happens in the kernel: no cast
+// launch inside a recorded reverse step).
+extern "C" int bdm_time_embedding_i64(int b, int dim, const long long *t, const float *w0, const float *b0,
+                                      const float *w2, const float *b2, float *out, void *stream) {
+  BDM_REQUIRE(b >= 0 && dim >= 4 && dim % 2 == 0 && dim <= 1024 && t != nullptr, "time_embedding_i64: bad arguments (dim %d)", dim);
+  if (b == 0) return BDM_OK;
+  hipLaunchKernelGGL(time_embed_kernel, dim3(b), dim3((dim + 63) / 64 * 64), 2 * dim * sizeof(float),
+                     (hipStream_t)stream, dim, (const float *)nullptr, t, w0, b0, w2, b2, out);
+  return launch_status("time_embedding_i64");
 }
 
 // =====================================================================================

@@ -37,7 +37,9 @@ class _Backend:
     def furthest_point_sampling(coords, num_samples):
         _chk_f(coords, "coords")
         b, _, n = coords.shape
-        idx = torch.zeros(b, int(num_samples), dtype=torch.int32, device=coords.device)
+        idx = torch.empty(b, int(num_samples), dtype=torch.int32, device=coords.device)   # (every entry is written by the kernel)
+        if int(num_samples) <= 0:
+            return idx
         L.check(L.lib().bdm_furthest_point_sampling(b, n, int(num_samples), L.ptr(coords), L.ptr(idx),
                                                     L.ptr(None), L.stream()), "furthest_point_sampling")
         return idx

@@ -278,6 +278,16 @@ def broadcast_rows(v, l, out=None):
     return out
 
 
+def xyz_rows(inputs):
+    """inputs[:, :3, :] of a channel-first (B, C, N) tensor as a contiguous (B, 3, N) tensor: one library launch (a torch
+    `.contiguous()` of the strided view is an elementwise kernel + a copy and a Python entry on a recorded step)."""
+    v = inputs[:, :3, :]
+    if v.is_contiguous() or not inputs.is_cuda:
+        return v.contiguous()
+    out = torch.empty(inputs.shape[0], 3, inputs.shape[2], dtype=torch.float32, device=inputs.device)
+    return copy_rows(v, out)
+
+
 def copy_rows(x, out):
     xx, B, C, l, bs_x, ld_x = _bcl(x)
     _, _, _, _, bs_y, ld_y = _bcl(out)
@@ -348,8 +358,12 @@ def is_transposed_view_of(x, x_cf):
 
 def time_embedding(t, w0, b0, w2, b2):
     B, dim = t.shape[0], w0.shape[0]
-    tf = t.to(torch.float32).contiguous()
     out = torch.empty(B, dim, dtype=torch.float32, device=t.device)
+    if t.dtype == torch.int64 and t.is_contiguous():   # the schedulers' timesteps: cast inside the kernel (no torch operator in a recorded step)
+        L.check(L.lib().bdm_time_embedding_i64(B, dim, L.ptr(t), L.ptr(w0), L.ptr(b0), L.ptr(w2), L.ptr(b2), L.ptr(out), L.stream()),
+                "time_embedding_i64")
+        return out
+    tf = t.to(torch.float32).contiguous()
     L.check(L.lib().bdm_time_embedding(B, dim, L.ptr(tf), L.ptr(w0), L.ptr(b0), L.ptr(w2), L.ptr(b2), L.ptr(out),
                                        L.stream()), "time_embedding")
     return out
@@ -932,7 +946,7 @@ def _amax_slot(device):
 class VoxelPlan:
     """Everything that depends on (coords, r) only: normalised / integer voxel coordinates, per-voxel point lists,
     occupied-cell compaction and row occupancy.  PVConvs of one level share it (exactly the same values)."""
-    __slots__ = ("r", "n", "n_max", "norm_coords", "vox_coords", "ind", "cnt", "ws", "occ_index", "occ_list", "n_occ", "rowocc",
+    __slots__ = ("r", "n", "n_max", "coords", "norm_coords", "vox_coords", "ind", "cnt", "ws", "occ_index", "occ_list", "n_occ", "rowocc",
                  "ready", "stream", "dil_list", "dil_index", "plane_start", "tile_start", "n_dil_max",
                  "d2_list", "d2_index", "d2_tiles", "d2_class_count")
 
@@ -963,6 +977,7 @@ def voxel_plan(coords, r, eps=0.0, dilate=False):
     p = VoxelPlan()
     p.ready = None
     p.r, p.n, p.n_max = int(r), n, min(n, r3)
+    p.coords = coords   # (the contiguous (B, 3, n) tensor the plan describes: consumers that need the xyz rows again take them from here)
     p.norm_coords, p.vox_coords = voxel_coords(coords, r, eps)
     p.ind = torch.empty(B, n, dtype=torch.int32, device=dev)
     p.cnt = torch.empty(B, r3, dtype=torch.int32, device=dev)
@@ -1130,7 +1145,10 @@ def sparse_first_conv_from_map(cond, plan, conv, cout, gn_groups=None):
     B, _, n = cond.x_cf.shape
     dev, lib, r = cond.x_cf.device, L.lib(), plan.r
     xyz = cond.x_cf[:, :3]
-    xyz = xyz if xyz.is_contiguous() else xyz.contiguous()
+    if not xyz.is_contiguous():
+        # the plan was built from a contiguous copy of exactly these rows (pvcnn.encode): no second copy inside the step
+        pc = getattr(plan, "coords", None)
+        xyz = pc if (pc is not None and pc.is_contiguous() and tuple(pc.shape) == tuple(xyz.shape)) else xyz_rows(cond.x_cf)
     y = torch.empty(B, plan.n_max, n27, dtype=torch.float32, device=dev)
     L.check(lib.bdm_sparse_conv_rows_from_map(B, n, r, plan.n_max, n27, hmap.shape[1], L.ptr(hmap), L.ptr(cond.pix), L.ptr(xyz), L.ptr(wx),
                                               L.ptr(plan.cnt), L.ptr(plan.ws), L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(y), L.stream()),

@@ -162,7 +162,7 @@ def early_first_sampler(net, x_t):
     cur, side = _side_stream(x_t.device)
     tape.wait_stream(side, cur)
     with torch.cuda.stream(side):
-        c0 = x_t.transpose(1, 2).contiguous()   # the values of the denoiser's coordinate rows (model.get_input_with_conditioning)
+        c0 = ops.transpose12(x_t) if x_t.is_contiguous() else x_t.transpose(1, 2).contiguous()   # the values of the denoiser's coordinate rows (model.get_input_with_conditioning); one library launch
         centers0 = first.sample(c0)
     return (c0, centers0, side)
 
@@ -241,7 +241,7 @@ def plan_sampling_chain(sa_layers, coords, early=None):
 
 def encode(sa_layers, global_att, inputs, t_emb, early=None):
     """Down path (pvcnn.py:90-110)."""
-    coords = inputs[:, :3, :].contiguous()
+    coords = ops.xyz_rows(inputs)
     ops.clear_plan_cache()  # voxel plans are valid within one encoder/decoder pass
     NN_PLANS.clear()
     for blocks in sa_layers:  # sampler plans too: never inherit one from an aborted or foreign forward

@@ -250,6 +250,9 @@ int bdm_transpose(int b, int rows, int cols, const float *x, float *y, void *str
  * t (b,) float -> out (b, dim) = Linear(LeakyReLU_0.1(Linear([sin, cos](t * freq)))). */
 int bdm_time_embedding(int b, int dim, const float *t, const float *w0, const float *b0,
                        const float *w2, const float *b2, float *out, void *stream);
+/* the same from int64 timesteps (what the schedulers hand over): t.float() inside the kernel */
+int bdm_time_embedding_i64(int b, int dim, const long long *t, const float *w0, const float *b0,
+                           const float *w2, const float *b2, float *out, void *stream);
 
 /* Voxelization.forward's coordinate maths (modules/voxelization.py:16-25, normalize=True):
  * coords (b,3,n) -> norm_coords (b,3,n) float in [0, r-1], vox_coords (b,3,n) int32 (round half even). */

@@ -1,7 +1,11 @@
 cd $GRAFT_REPO_ROOT
-BDM_LIB_PATH=bdm_amd/libbdm_hip_diltiming.so python tools/vox_dilate_probe.py 2>&1 | grep -v amdgpu.ids
-python -m pytest tests/test_hip_dense.py tests/test_hip_compact_tail.py tests/test_hip_net.py -x -q 2>&1 | tail -2
+python tools/tape_torch_ops.py 16 4096 2>&1 | grep -v amdgpu.ids | tail -8
+python -m pytest tests/test_hip_net.py tests/test_hip_trajectory.py tests/test_hip_uninit.py tests/test_hip_sampler.py tests/test_hip_ops.py -x -q 2>&1 | tail -3
 for i in 1 2 3; do
-echo "== step base"; BDM_LIB_PATH=bdm_amd/libbdm_hip_base.so python tools/replay_host_time.py 16 4096 2>&1 | grep replayed | tail -2
+echo "== step legacy copies"; BDM_LEGACY_COPIES=1 python tools/replay_host_time.py 16 4096 2>&1 | grep replayed | tail -2
 echo "== step new"; python tools/replay_host_time.py 16 4096 2>&1 | grep replayed | tail -2
+done
+for i in 1 2; do
+echo "== B=1 legacy"; BDM_LEGACY_COPIES=1 python tools/replay_host_time.py 1 1024 2>&1 | grep replayed | tail -2
+echo "== B=1 new"; python tools/replay_host_time.py 1 1024 2>&1 | grep replayed | tail -2
 done
