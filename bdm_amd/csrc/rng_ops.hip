@@ -84,9 +84,10 @@ __global__ void philox_bits_kernel(long long per_shape, const unsigned long long
 // mode 0: DDPM (diffusers) step, coefficients (sqrt_beta_prod, sqrt_alpha_prod, c_x0, c_x, sigma); sigma == 0 -> no draw used
 // mode 1: PVD step, coefficients (a, b, c1, c2, sigma)
 template <int MODE>
-__global__ void step_philox_kernel(long long per_shape, const float *__restrict__ x, const float *__restrict__ eps,
+// (x and out may be the SAME buffer: the reverse loops step in place; hence no __restrict__ on the two)
+__global__ void step_philox_kernel(long long per_shape, const float *x, const float *__restrict__ eps,
                                    const unsigned long long *__restrict__ keys, uint32_t draw, uint32_t purpose, float k0,
-                                   float k1, float k2, float k3, float sigma, float *__restrict__ out) {
+                                   float k1, float k2, float k3, float sigma, float *out) {
   const int bi = blockIdx.y;
   const unsigned long long key = keys[bi];
   const long long blocks = (per_shape + 3) / 4;

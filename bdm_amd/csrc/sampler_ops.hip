@@ -14,9 +14,10 @@
 using namespace bdm;
 
 // x_{t-1} = c_x0 * ((x - sqrt(1-abar_t) * eps) / sqrt(abar_t)) + c_x * x  [+ sigma * z]
-__global__ void ddpm_step_kernel(long long n, const float *__restrict__ x, const float *__restrict__ eps,
+// (x and out may be the SAME buffer -- the reverse loops step in place -- hence no __restrict__ on them)
+__global__ void ddpm_step_kernel(long long n, const float *x, const float *__restrict__ eps,
                                  const float *__restrict__ z, float sqrt_beta_prod, float sqrt_alpha_prod,
-                                 float c_x0, float c_x, float sigma, float *__restrict__ out) {
+                                 float c_x0, float c_x, float sigma, float *out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float xi = x[i];
     const float x0 = (xi - sqrt_beta_prod * eps[i]) / sqrt_alpha_prod;

@@ -425,7 +425,10 @@ class ConditionalPointCloudDiffusionModel(PointCloudProjectionModel):
                 eps = denoise()
                 g["warm"] = True
             # the scheduler step stays eager (one launch): its scalars, its noise draw and the per-shape Philox streams change per step
-            g["x"].copy_(scheduler.step(eps, t, g["x"], generator=generator, **self._step_kwargs).prev_sample)
+            if type(scheduler) is DDPMScheduler and not self._step_kwargs:
+                scheduler.step(eps, t, g["x"], generator=generator, out=g["x"])   # in place: the step is elementwise (no copy launch)
+            else:
+                g["x"].copy_(scheduler.step(eps, t, g["x"], generator=generator, **self._step_kwargs).prev_sample)
         return g["x"].clone()
 
     @torch.no_grad()

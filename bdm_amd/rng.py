@@ -64,11 +64,13 @@ class ShapeStreams:
         return out
 
     # fused scheduler steps: the noise never touches memory -------------------------------------------------------
-    def ddpm_step(self, x, eps, c, purpose=PC2):
-        """DDPMScheduler.step arithmetic (schedulers.py) with this batch's noise generated in the kernel."""
+    def ddpm_step(self, x, eps, c, purpose=PC2, out=None):
+        """DDPMScheduler.step arithmetic (schedulers.py) with this batch's noise generated in the kernel.  out: where the result goes
+        (may be `x` itself: the kernel is elementwise)."""
         x, eps = x.contiguous(), eps.contiguous()
         per = self._check(x.shape)
-        out = torch.empty_like(x)
+        if out is None or not (out.is_contiguous() and out.shape == x.shape and out.dtype == x.dtype):
+            out = torch.empty_like(x)
         sigma = c["sigma"] if c.get("noise", True) else 0.0
         draw = self._next(purpose) if sigma != 0.0 else 0
         L.check(L.lib().bdm_ddpm_step_philox(x.shape[0], per, L.ptr(x), L.ptr(eps), L.ptr(self.keys), draw, purpose,

@@ -93,17 +93,22 @@ class DDPMScheduler:
             return self.streams.normal(tuple(shape), self.stream_purpose)
         return torch.randn(shape, generator=generator, device=device, dtype=torch.float32)
 
-    def step(self, model_output, timestep, sample, generator=None, return_dict=True):
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True, out=None):
+        """out (an extension of the diffusers signature): a contiguous tensor the result is written to -- `sample` itself is allowed (the
+        step is elementwise), which spares the reverse loops a copy launch per step."""
         t = int(timestep)
         c = self.step_coefficients(t)
         x = sample.contiguous()
         eps = model_output.contiguous()
         assert x.shape == eps.shape and x.dtype == torch.float32
+        if out is not None and not (out.is_contiguous() and out.shape == x.shape and out.dtype == x.dtype and out.device == x.device):
+            out = None
         if self.streams is not None and self.noise_source is None:
-            out = self.streams.ddpm_step(x, eps, dict(c, noise=t > 0), purpose=self.stream_purpose)
+            out = self.streams.ddpm_step(x, eps, dict(c, noise=t > 0), purpose=self.stream_purpose, out=out)
             return SimpleNamespace(prev_sample=out) if return_dict else (out,)
         noise = self._noise(x.shape, x.device, generator) if t > 0 else None
-        out = torch.empty_like(x)
+        if out is None:
+            out = torch.empty_like(x)
         L.check(L.lib().bdm_ddpm_step(L.c_ll(x.numel()), L.ptr(x), L.ptr(eps), L.ptr(noise), L.c_float(c["sqrt_beta_prod"]),
                                       L.c_float(c["sqrt_alpha_prod"]), L.c_float(c["coef_x0"]), L.c_float(c["coef_x"]),
                                       L.c_float(c["sigma"]), L.ptr(out), L.stream()), "ddpm_step")

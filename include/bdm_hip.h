@@ -582,7 +582,8 @@ int bdm_devoxelize_gn_gate_add_rows_pf(int b, int c, int n, int r, const float *
  * variance, clip_sample=False), call sites experiments/model/model.py:193,286,563.
  *   x0   = (x - sqrt_beta_prod * eps) / sqrt_alpha_prod
  *   out  = coef_x0 * x0 + coef_x * x  [+ sigma * noise   when noise != NULL, i.e. t > 0]
- * The five scalars are the scheduler's per-timestep float32 coefficients (host side). */
+ * The five scalars are the scheduler's per-timestep float32 coefficients (host side).  `out` may be `x` (elementwise: the reverse
+ * loops step in place); the same holds for bdm_ddpm_step_philox / bdm_pvd_step_philox. */
 int bdm_ddpm_step(long long n, const float *x, const float *eps, const float *noise,
                   float sqrt_beta_prod, float sqrt_alpha_prod, float coef_x0, float coef_x,
                   float sigma, float *out, void *stream);
