@@ -795,8 +795,9 @@ def devoxelize_gn_gate_add(norm_coords, grid, coef, r, gate=None, add=None, add_
 #   "1":     the tail kernel everywhere + the gather + GroupNorm-1 + split kernel (csrc/experimental/, EXPERIMENTAL=1 builds): measured slower;
 #   "0":     the operator chain.
 _SMALL_GLUE_MODE = os.environ.get("BDM_SMALL_GLUE", "tail")
-SMALL_GLUE = _SMALL_GLUE_MODE in ("1", "tail")
+SMALL_GLUE = _SMALL_GLUE_MODE in ("1", "tail", "tail_all")
 SMALL_GLUE_TAIL_ONLY = _SMALL_GLUE_MODE == "tail"   # only the tail, and only where a next PVConv takes its operand
+SMALL_GLUE_NO_GATHER = _SMALL_GLUE_MODE in ("tail", "tail_all")   # ("tail_all": the tail kernel on every small-grid PVConv, A/B only)
 
 
 def small_grid_tail_ok(r, c, n):
@@ -806,7 +807,7 @@ def small_grid_tail_ok(r, c, n):
 
 def small_grid_gather_ok(r, cout, groups):
     cg = cout // groups if groups and cout % groups == 0 else 0
-    return SMALL_GLUE and not SMALL_GLUE_TAIL_ONLY and cg >= 8 and cg % 8 == 0 and cg <= 64 and 256 % (cg // 4) == 0 and (cg * (r ** 3 + 1) + r ** 3) * 4 <= 150 * 1024
+    return SMALL_GLUE and not SMALL_GLUE_NO_GATHER and cg >= 8 and cg % 8 == 0 and cg <= 64 and 256 % (cg // 4) == 0 and (cg * (r ** 3 + 1) + r ** 3) * 4 <= 150 * 1024
 
 
 def h2_sum_scale(gns, sigmas=64.0):

@@ -1,4 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_hip_sampler.py tests/test_hip_trajectory.py tests/test_hip_full_trajectory.py tests/test_hip_full_size.py tests/test_hip_cli.py tests/test_rng.py -x -q 2>&1 | tail -14
-python tools/replay_host_time.py 16 4096 2>&1 | grep replayed | tail -2
-python tools/replay_host_time.py 1 1024 2>&1 | grep replayed | tail -2
+for i in 1 2 3; do
+echo "== step default (tail where a head follows)"; python tools/replay_host_time.py 16 4096 2>&1 | grep replayed | tail -2
+echo "== step tail_all"; BDM_SMALL_GLUE=tail_all python tools/replay_host_time.py 16 4096 2>&1 | grep replayed | tail -2
+done
+echo "== B=1 default"; python tools/replay_host_time.py 1 1024 2>&1 | grep replayed | tail -2
+echo "== B=1 tail_all"; BDM_SMALL_GLUE=tail_all python tools/replay_host_time.py 1 1024 2>&1 | grep replayed | tail -2
