@@ -381,7 +381,7 @@ extern "C" int bdm_sparse_conv_pack_weights_s3(int cout, int cin, const float *w
 // per stage, register-prefetched: the 12 global loads of stage c+1 are in flight during the 48 MFMAs of stage c.
 __global__ __launch_bounds__(256) void sparse_gemm_s3_kernel(int M, int G, int N, const uint4 *__restrict__ A,
                                                              const uint4 *__restrict__ Bw, const int *__restrict__ m_count,
-                                                             float *__restrict__ Y) {
+                                                             const float *__restrict__ col_bias, long long bs_cb, float *__restrict__ Y) {
   constexpr int BM = 128, BN = 128, AI = 12 * BM / 256, BI = 12 * BN / 256;
   __shared__ uint4 As[12 * BM], Bs[12 * BN];  // [group-in-stage][split][row]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -465,21 +465,34 @@ __global__ __launch_bounds__(256) void sparse_gemm_s3_kernel(int M, int G, int N
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
       const int nn = n0 + (wc * 2 + y) * 32 + li;
+      const float cb = (col_bias != nullptr && nn < N) ? col_bias[(size_t)bi * bs_cb + nn] : 0.f;  // (bdm_sparse_conv_gemm_h2_cb's addend)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wr * 2 + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < M && nn < N) Yb[(size_t)m * N + nn] = acc[x][y][r];
+        if (m < M && nn < N) Yb[(size_t)m * N + nn] = acc[x][y][r] + cb;
       }
     }
 }
 
-extern "C" int bdm_sparse_conv_gemm_s3(int b, int n_max, int cin, int n27, const void *xs, const void *ws, const int *n_occ,
-                                       float *y, void *stream) {
+static int sparse_gemm_s3_launch(int b, int n_max, int cin, int n27, const void *xs, const void *ws, const int *n_occ,
+                                 const float *col_bias, long long bs_cb, float *y, void *stream) {
   BDM_REQUIRE(b >= 0 && n_max >= 1 && cin >= 1 && n27 >= 1, "sparse_conv_gemm_s3: bad sizes");
   if (b == 0) return BDM_OK;
   hipLaunchKernelGGL(sparse_gemm_s3_kernel, dim3(cdiv(n27, 128), cdiv(n_max, 128), b), dim3(256), 0, (hipStream_t)stream,
-                     n_max, (cin + 7) / 8, n27, (const uint4 *)xs, (const uint4 *)ws, n_occ, y);
+                     n_max, (cin + 7) / 8, n27, (const uint4 *)xs, (const uint4 *)ws, n_occ, col_bias, bs_cb, y);
   return launch_status("sparse_conv_gemm_s3");
+}
+
+extern "C" int bdm_sparse_conv_gemm_s3(int b, int n_max, int cin, int n27, const void *xs, const void *ws, const int *n_occ,
+                                       float *y, void *stream) {
+  return sparse_gemm_s3_launch(b, n_max, cin, n27, xs, ws, n_occ, nullptr, 0, y, stream);
+}
+
+// + a per-shape column addend col_bias (b, n27): see bdm_sparse_conv_gemm_h2_cb
+extern "C" int bdm_sparse_conv_gemm_s3_cb(int b, int n_max, int cin, int n27, const void *xs, const void *ws, const int *n_occ,
+                                          const float *col_bias, long long bs_cb, float *y, void *stream) {
+  BDM_REQUIRE(col_bias != nullptr && bs_cb >= n27, "sparse_conv_gemm_s3_cb: col_bias is null or its batch stride < n27");
+  return sparse_gemm_s3_launch(b, n_max, cin, n27, xs, ws, n_occ, col_bias, bs_cb, y, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -146,7 +146,7 @@ template <int BM>
 __global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N, int Cout, const uint4 *__restrict__ A,
                                                              const float *__restrict__ amax, const uint4 *__restrict__ Bw,
                                                              const float *__restrict__ inv_sw, const int *__restrict__ m_count,
-                                                             float *__restrict__ Y) {
+                                                             const float *__restrict__ col_bias, long long bs_cb, float *__restrict__ Y) {
   constexpr int BN = 128, MX = BM / 64, BI = 8 * BN / 256;  // 4 groups x 2 splits per stage
   __shared__ uint4 As[8 * BM], Bs[8 * BN];  // [group-in-stage][split][row]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -226,10 +226,11 @@ __global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N
     for (int y = 0; y < 2; ++y) {
       const int nn = n0 + (wc * 2 + y) * 32 + li;
       const float post = nn < N ? inv_sw[nn % Cout] * inv_sx : 0.f;
+      const float cb = (col_bias != nullptr && nn < N) ? col_bias[(size_t)bi * bs_cb + nn] : 0.f;  // per-shape column addend (see the _cb entry point)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wr * MX + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < M && nn < N) Yb[(size_t)m * N + nn] = acc[x][y][r] * post;
+        if (m < M && nn < N) Yb[(size_t)m * N + nn] = acc[x][y][r] * post + cb;
       }
     }
 }
@@ -246,18 +247,32 @@ extern "C" int bdm_sparse_split_h2(int b, int cin, int n_max, const void *xr, co
   return launch_status("sparse_split_h2");
 }
 
-extern "C" int bdm_sparse_conv_gemm_h2(int b, int n_max, int cin, int cout, const void *xh, const float *amax, const void *packed_w,
-                                       const float *inv_scale, const int *n_occ, float *y, void *stream) {
+// col_bias (b, 27 * cout) or null: a per-shape addend of every row's column (tap, co) -- the share of input channels that are CONSTANT over
+// a shape's occupied cells (the time embedding concatenated to the features, pvcnn.py:103: avg_voxelize of a constant is the constant on
+// every occupied cell), u[b][tap][co] = sum_c W[co][c][tap] t[b][c]; the gather then adds it once per OCCUPIED neighbour, which is what
+// the zero-padded convolution of the concatenated grid does.
+static int sparse_gemm_h2_launch(int b, int n_max, int cin, int cout, const void *xh, const float *amax, const void *packed_w,
+                                 const float *inv_scale, const int *n_occ, const float *col_bias, long long bs_cb, float *y, void *stream) {
   BDM_REQUIRE(b >= 0 && n_max >= 1 && cin >= 1 && cout >= 1 && amax != nullptr && inv_scale != nullptr, "sparse_conv_gemm_h2: bad arguments");
   if (b == 0) return BDM_OK;
   const int n27 = 27 * cout, G = (cin + 7) / 8;
   hipStream_t s = (hipStream_t)stream;
   if (n_max <= 256)
     hipLaunchKernelGGL(sparse_gemm_h2_kernel<64>, dim3(cdiv(n27, 128), cdiv(n_max, 64), b), dim3(256), 0, s, n_max, G, n27, cout,
-                       (const uint4 *)xh, amax, (const uint4 *)packed_w, inv_scale, n_occ, y);
+                       (const uint4 *)xh, amax, (const uint4 *)packed_w, inv_scale, n_occ, col_bias, bs_cb, y);
   else
     hipLaunchKernelGGL(sparse_gemm_h2_kernel<128>, dim3(cdiv(n27, 128), cdiv(n_max, 128), b), dim3(256), 0, s, n_max, G, n27, cout,
-                       (const uint4 *)xh, amax, (const uint4 *)packed_w, inv_scale, n_occ, y);
+                       (const uint4 *)xh, amax, (const uint4 *)packed_w, inv_scale, n_occ, col_bias, bs_cb, y);
   return launch_status("sparse_conv_gemm_h2");
 }
 
+extern "C" int bdm_sparse_conv_gemm_h2(int b, int n_max, int cin, int cout, const void *xh, const float *amax, const void *packed_w,
+                                       const float *inv_scale, const int *n_occ, float *y, void *stream) {
+  return sparse_gemm_h2_launch(b, n_max, cin, cout, xh, amax, packed_w, inv_scale, n_occ, nullptr, 0, y, stream);
+}
+
+extern "C" int bdm_sparse_conv_gemm_h2_cb(int b, int n_max, int cin, int cout, const void *xh, const float *amax, const void *packed_w,
+                                          const float *inv_scale, const int *n_occ, const float *col_bias, long long bs_cb, float *y, void *stream) {
+  BDM_REQUIRE(col_bias != nullptr && bs_cb >= 27LL * cout, "sparse_conv_gemm_h2_cb: col_bias is null or its batch stride < 27 * cout");
+  return sparse_gemm_h2_launch(b, n_max, cin, cout, xh, amax, packed_w, inv_scale, n_occ, col_bias, bs_cb, y, stream);
+}

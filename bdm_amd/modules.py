@@ -229,17 +229,58 @@ class PVConv(nn.Module):
     sparse_dil_resolutions = {int(v) for v in os.environ.get("BDM_SPARSE_DIL_R", "32,16").split(",") if v}
     sparse_dil_always = os.environ.get("BDM_SPARSE_DIL_ALWAYS", "0") == "1"   # ignore ops.sparse_dil_pays (tests, A/B timing)
 
-    def _packed_weight(self, conv, impl):
-        key = (id(conv), impl)
+    def _packed_weight(self, conv, impl, cin=None):
+        """cin: pack the first `cin` input channels only (the others enter as a per-shape addend: forward's time-embedding split)"""
+        key = (id(conv), impl, cin)
         sig = (conv.weight._version, conv.weight.data_ptr())
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
             pack = {"bf16x6": ops.conv3d_s3_pack, "fp16x3": ops.conv3d_h2_pack, "sparse": ops.sparse_conv_pack, "class": ops.conv_class_pack,
                     "sparse_s3": ops.sparse_conv_pack_s3, "sparse_fused": ops.sparse_conv_pack_fused, "sparse_h2": ops.sparse_conv_pack_h2,
                     "fp32": ops.conv3d_pack}[impl]
-            hit = (sig, pack(conv.weight.detach()))
+            w = conv.weight.detach()
+            hit = (sig, pack(w if cin is None else w[:, :cin].contiguous()))
             self._packed[key] = hit
         return hit[1]
+
+    # The time embedding as a per-shape term (VERDICT r3 / r4): the reference concatenates the point-invariant embedding to the features before
+    # the first PVConv of set-abstraction levels 1.. (pvcnn.py:103).  Its voxel mean is the same constant on every occupied cell, so its share of
+    # the first convolution is u[b][tap][co] = W[co][c_feat:, tap] . t[b], added once per occupied neighbour: a column addend of the occupied-row
+    # GEMM (bdm_sparse_conv_gemm_*_cb); its share of the point branch is a per-shape bias.  No concatenation, K = the real feature channels.
+    temb_split = os.environ.get("BDM_ENC_TEMB_SPLIT", "1") == "1"
+    _temb_terms = None   # (B, 28 * cout) = [u | point-branch bias] of this forward when pvcnn.encode computed all levels' in one launch
+
+    def temb_rows(self, c_t):
+        """(27 * cout + cout, c_t): the embedding's columns of the first voxel convolution (row tap * cout + co) and of the point branch"""
+        conv1, pconv = self.voxel_layers[0], self.point_features.layers[0]
+        key = (conv1.weight._version, conv1.weight.data_ptr(), pconv.weight._version, pconv.weight.data_ptr(), c_t)
+        hit = getattr(self, "_temb_rows", None)
+        if hit is None or hit[0] != key:
+            cout, c_feat = conv1.out_channels, self.in_channels - c_t
+            wv = conv1.weight.detach()[:, c_feat:].reshape(cout, c_t, 27).permute(2, 0, 1).reshape(27 * cout, c_t)
+            wp = pconv.weight.detach().reshape(pconv.out_channels, -1)[:, c_feat:]
+            hit = (key, torch.cat([wv, wp], dim=0).contiguous())
+            self._temb_rows = hit
+        return hit[1]
+
+    def can_split_temb(self, features, temb):
+        """May this module take `features` WITHOUT the concatenated embedding?  The one predicate of pvcnn.encode and of forward."""
+        c_feat = features.shape[1]
+        return (self.temb_split and features.is_cuda and ops.is_point_invariant(temb) and not ops.is_point_invariant(features)
+                and c_feat + temb.shape[1] == self.in_channels and c_feat % 8 == 0
+                and self.conv_impl in ("bf16x6", "fp16x3") and self.sparse_first_conv and self.resolution in self.sparse_resolutions
+                and self.sparse_gemm in ("sparse_h2", "sparse_s3") and len(self.point_features.layers) == 3
+                and self.point_features.layers[0].out_channels == self.voxel_layers[0].out_channels
+                and not self.wants_dilated_plan(features.shape[0], features.shape[2]))
+
+    def _temb_split_terms(self, features, temb):
+        """-> (col_bias (B, 27 * cout), point-branch bias (B, cout)) views"""
+        cout, B = self.voxel_layers[0].out_channels, features.shape[0]
+        terms, self._temb_terms = self._temb_terms, None
+        if terms is None or tuple(terms.shape) != (B, 28 * cout):
+            tvec = temb[:, :, 0].contiguous()
+            terms = ops.pointwise_conv(tvec[:, :, None], self.temb_rows(temb.shape[1]))[:, :, 0]
+        return terms[:, :27 * cout], terms[:, 27 * cout:]
 
     # The point branch (1x1 conv + GroupNorm + Swish on the N points) does not depend on the voxel branch: it is enqueued on
     # a second stream and joined before the devoxelisation adds it, so its small, latency-bound kernels run beside the
@@ -318,10 +359,11 @@ class PVConv(nn.Module):
         if cond is not None and not cond.features_ready and features.data_ptr() == cond.x_cf.data_ptr():
             cond.ensure_features()
 
-    def _point_branch(self, features, fold=False):
+    def _point_branch(self, features, fold=False, temb_bias=None):
         """-> (activations, event | None, pending): with fold the LAST GroupNorm + Swish of the branch is left to the caller
-        (pending = (stats, gn), activations = raw convolution output; None when the layer cannot be folded)."""
-        cond = self._hoisted(features)
+        (pending = (stats, gn), activations = raw convolution output; None when the layer cannot be folded).
+        temb_bias (B, cout): `features` arrive without the concatenated time embedding, whose share is this per-shape bias."""
+        cond = self._hoisted(features) if temb_bias is None else None
         if cond is not None and len(self.point_features.layers) != 3:
             cond = None
         if cond is None:
@@ -329,6 +371,11 @@ class PVConv(nn.Module):
 
         def run():
             x, first_weight, first_add = features, None, None
+            if temb_bias is not None:
+                first_weight = hoisted_first_weight(self.point_features, self.point_features.layers[0], features.shape[1])
+                if fold:
+                    return self.point_features.run(x, fold_last=True, first_weight=first_weight, first_bias=temb_bias)
+                return self.point_features.run(x, first_weight=first_weight, first_bias=temb_bias), None
             if cond is not None:
                 # W . [xyz, F[pix]] = Wx . xyz + (F . Wf^T)[pix]: gather 32 map channels instead of convolving 390 (ops.Conditioning).
                 # The gather runs HERE, on the branch's stream: its output is allocated on the stream that consumes it (a block of
@@ -369,12 +416,19 @@ class PVConv(nn.Module):
 
         rows_in = getattr(features, "_bdm_rows", None)   # first-convolution operand left by the previous PVConv's tail (ops.VoxelRows)
         features = ops.materialize(features)
+        col_bias, pb_bias, cin1 = None, None, None
+        if features.shape[1] != self.in_channels:   # the caller (pvcnn.encode) left the time embedding out: it enters as per-shape terms
+            if not self.can_split_temb(features, temb):
+                raise ValueError(f"PVConv expects {self.in_channels} input channels, got {features.shape[1]} "
+                                 f"(and the time embedding cannot enter as a per-shape term here)")
+            col_bias, pb_bias = self._temb_split_terms(features, temb)
+            cin1 = features.shape[1]
         gn1_stats, plan, xh_ready = None, None, None
         cg2_, tile_ = conv2.out_channels // gn2.num_groups, (64 if (conv2.out_channels > 32 and r != 8) else 32)
         folded_tail = (self.conv_impl == "fp16x3" and not getattr(self, "h2_saturated", False) and self.fold_gn2 and att is None
                        and se is not None and cg2_ in (4, 8, 16, 32) and tile_ % cg2_ == 0)
         # with the folded tail the branch's GroupNorm + Swish is applied by the devoxelisation kernel (one launch less)
-        pf, pf_ready, pf_pending = self._point_branch(features, fold=folded_tail and self.fold_pf and not self.se_in_devox)
+        pf, pf_ready, pf_pending = self._point_branch(features, fold=folded_tail and self.fold_pf and not self.se_in_devox, temb_bias=pb_bias)
         if self.conv_impl in ("bf16x6", "fp16x3"):
             if self.sparse_first_conv and r in self.sparse_resolutions:
                 # conv1 sees the freshly voxelised cloud: evaluate it on the occupied cells only (sparse_conv.hip);
@@ -385,18 +439,18 @@ class PVConv(nn.Module):
                 # 64-row tiles cut the padding; on the 16^3 / 32^3 levels the batched GEMM is bound by its 27x-expanded
                 # output and the extra operand split costs more than it saves (measured: tools/sparse_bench.py)
                 impl = self.sparse_gemm
-                wide16 = plan.n_max <= 1024 and conv1.in_channels >= 128 and conv1.out_channels >= 128  # 108 vs 121 us at 16^3
+                wide16 = plan.n_max <= 1024 and (cin1 or conv1.in_channels) >= 128 and conv1.out_channels >= 128  # 108 vs 121 us at 16^3
                 if impl == "sparse_h2" and plan.n_max > 256 and not wide16:
                     impl = "sparse_s3"
                 # with the fp16x3 second convolution the gather also leaves GroupNorm-1's statistics (no pass over the grid for them)
                 want_stats = (self.fold_gn1 and self.conv_impl == "fp16x3" and not getattr(self, "h2_saturated", False)
                               and impl != "sparse_fused")
-                cond = self._hoisted(features)
+                cond = self._hoisted(features) if col_bias is None else None
                 if not (cond is not None and 27 * conv1.out_channels <= 1024):
                     self._need_features(features)
                 if cond is not None and 27 * conv1.out_channels <= 1024:  # hoisted map instead of feature gather + K = 390 GEMM
                     v = ops.sparse_first_conv_from_map(cond, plan, conv1, conv1.out_channels, gn_groups=gn1.num_groups if want_stats else None)
-                elif self.wants_dilated_plan(features.shape[0], plan.n):
+                elif col_bias is None and self.wants_dilated_plan(features.shape[0], plan.n):
                     # one output-stationary implicit GEMM with tap skipping over the dilated voxel list: no 27x intermediate; with the
                     # statistics in its epilogue the output stays COMPACT (rows of the dilated voxels) and the operand split of the
                     # second convolution reads it through the plan's index -- the dense fp32 grid is never written (sparse_conv_os.hip)
@@ -404,9 +458,10 @@ class PVConv(nn.Module):
                     v = ops.sparse_first_conv_os(features, plan, self._packed_weight(conv1, "fp16x3"), conv1.bias, conv1.out_channels,
                                                  gn_groups=gn1.num_groups if want_stats else None, compact=want_stats)
                 else:
-                    if rows_in is not None and not (impl == "sparse_h2" and rows_in.plan is plan and rows_in.channels == conv1.in_channels):
+                    if rows_in is not None and not (impl == "sparse_h2" and rows_in.plan is plan and rows_in.channels == conv1.in_channels
+                                                    and col_bias is None):
                         rows_in = None
-                    if (impl == "sparse_h2" and want_stats and folded_tail and plan.n_max <= 256
+                    if (impl == "sparse_h2" and want_stats and folded_tail and plan.n_max <= 256 and col_bias is None
                             and ops.small_grid_gather_ok(r, conv1.out_channels, gn1.num_groups)):
                         # small grid: GroupNorm-1 + Swish + the second convolution's operand split in the gather's epilogue (one
                         # workgroup per (shape, group)): no dense fp32 grid, no statistics hand-off, no to_h2 launch (pvconv_small.hip)
@@ -415,11 +470,12 @@ class PVConv(nn.Module):
                                                                                        ops.saturation_slot(self, features.device)))
                         v, want_stats = None, False
                     else:
-                        v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, impl), conv1.bias, conv1.out_channels,
-                                                          gn_groups=gn1.num_groups if want_stats else None, rows=rows_in)
+                        v = ops.sparse_first_conv_planned(features, plan, self._packed_weight(conv1, impl, cin=cin1), conv1.bias, conv1.out_channels,
+                                                          gn_groups=gn1.num_groups if want_stats else None, rows=rows_in, col_bias=col_bias)
                 if want_stats:
                     v, gn1_stats = v
             else:
+                assert col_bias is None
                 self._need_features(features)
                 norm_coords, vox_coords = ops.voxel_coords(coords, r, self.voxelization.eps)
                 x3 = ops.avg_voxelize_s3(features, vox_coords, r)
@@ -581,6 +637,27 @@ class PointNetSAModule(nn.Module):
     # grouped MLP by recomputation where bdm_sa_mlp2_fused covers it (the first level); the equality tests flip it
     fuse_mlp = os.environ.get("BDM_SA_FUSED", "1") != "0"
 
+    _temb_terms = None   # (B, M) = W[:, t columns] . t of this forward, when pvcnn.encode computed all levels' in one launch
+
+    def temb_rows(self, c_t):
+        """(M, c_t): the time embedding's columns (the LAST c_t: [xyz diff, features, t], ball_query.py:31-33 after pvcnn.py:103) of the
+        grouped MLP's first layer"""
+        w = self.mlps[0].layers[0].weight
+        hit = getattr(self, "_temb_rows", None)
+        if hit is None or hit[0] != (w._version, w.data_ptr(), c_t):
+            w2 = w.detach().reshape(w.shape[0], -1)
+            hit = ((w._version, w.data_ptr(), c_t), w2[:, w2.shape[1] - c_t:].contiguous())
+            self._temb_rows = hit
+        return hit[1]
+
+    def can_split_temb(self, features, temb):
+        """May this module take `features` WITHOUT the concatenated time embedding (it then enters the grouped MLP's first layer as a
+        per-shape bias: grouping a point-invariant channel is the identity)?  The one predicate of pvcnn.encode and of forward."""
+        conv0 = self.mlps[0].layers[0]
+        return (PVConv.temb_split and features is not None and features.is_cuda and len(self.groupers) == 1
+                and self.groupers[0].include_coordinates and ops.is_point_invariant(temb) and not ops.is_point_invariant(features)
+                and 3 + features.shape[1] + temb.shape[1] == conv0.in_channels)
+
     def plan(self, coords):
         """Geometry-only part of the module (furthest point sampling + ball query): depends on the coordinates
         alone, so the denoiser's encoder runs it for all levels on a side stream while the first PVConvs compute."""
@@ -623,7 +700,18 @@ class PointNetSAModule(nn.Module):
             out = ops.sa_mlp2_fused(coords, centers_coords.contiguous(), features, idx, self.mlps[0])
             return out, centers_coords, temb[:, :, :1].expand(-1, -1, self.num_centers)
         grouped, g_t = self.groupers[0](coords, centers_coords, temb, features, neighbor_indices=idx)
-        h, pending = self.mlps[0].run(grouped, fold_last=True)
+        conv0 = self.mlps[0].layers[0]
+        if grouped.shape[1] != conv0.in_channels:   # the caller (pvcnn.encode) left the time embedding out
+            if not self.can_split_temb(features, temb):
+                raise ValueError(f"PointNetSAModule's MLP expects {conv0.in_channels} grouped channels, got {grouped.shape[1]}")
+            bb, self._temb_terms = self._temb_terms, None
+            if bb is None or tuple(bb.shape) != (grouped.shape[0], conv0.out_channels):
+                tvec = temb[:, :, 0].contiguous()
+                bb = ops.pointwise_conv(tvec[:, :, None], self.temb_rows(temb.shape[1]))[:, :, 0]
+            h, pending = self.mlps[0].run(grouped, fold_last=True, first_bias=bb,
+                                          first_weight=hoisted_first_weight(self.mlps[0], conv0, grouped.shape[1]))
+        else:
+            h, pending = self.mlps[0].run(grouped, fold_last=True)
         out = ops.max_over_neighbors(h, fold=pending)
         if g_t.stride(2) == 0 and g_t.stride(3) == 0:
             temb_out = g_t[:, :, 0, 0][:, :, None].expand(-1, -1, self.num_centers)

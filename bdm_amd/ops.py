@@ -1180,14 +1180,26 @@ def _gather(lib, nb, cout, r, plan, b0, y, bias, out, gn):
                 "sparse_conv_gather_gn")
 
 
-def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None, rows=None, h2_out=None):
+def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None, rows=None, h2_out=None, col_bias=None):
     """Conv3d(k3, p1)(avg_voxelize(features)) on the occupied voxels of `plan`: (B, cout, r^3) fp32.
     gn_groups: also return the GroupNorm(gn_groups) statistics of the output as (partial, slices = r*r, groups) -> (out, stats).
     rows (fp16x3 GEMM only): a VoxelRows the previous PVConv's tail left for this very plan -- the feature pass and the split are skipped.
     h2_out = (gn, act_scale, saturated) (fp16x3 GEMM on a small grid, small_grid_gather_ok): GroupNorm + Swish + the second convolution's
-    operand split in the gather's epilogue -> ((B, cout/8, 2, r^3, 8) fp16, 1 / act_scale); the dense fp32 grid is not written."""
+    operand split in the gather's epilogue -> ((B, cout/8, 2, r^3, 8) fp16, 1 / act_scale); the dense fp32 grid is not written.
+    col_bias (B, 27 * cout) (fp16x3 / bf16x6 GEMM): per-shape addend of every occupied row's columns -- the share of input channels that are
+    constant over a shape (the time embedding; `features` and `wt` then hold the other channels only: bdm_sparse_conv_gemm_s3_cb)."""
     f, B, C, n, bs_f, ld_f = _bcl(features)
     dev, lib, r = f.device, L.lib(), plan.r
+    if col_bias is not None:
+        assert tuple(col_bias.shape) == (B, 27 * cout) and col_bias.stride(1) == 1 and h2_out is None
+
+    def gemm_h2(nb, b0, xh, amax, packed, inv_scale, y):
+        if col_bias is None:
+            L.check(lib.bdm_sparse_conv_gemm_h2(nb, plan.n_max, C, cout, L.ptr(xh[b0:]), L.ptr(amax[b0:]), L.ptr(packed), L.ptr(inv_scale),
+                                                L.ptr(plan.n_occ[b0:]), L.ptr(y), L.stream()), "sparse_conv_gemm_h2")
+        else:
+            L.check(lib.bdm_sparse_conv_gemm_h2_cb(nb, plan.n_max, C, cout, L.ptr(xh[b0:]), L.ptr(amax[b0:]), L.ptr(packed), L.ptr(inv_scale),
+                                                   L.ptr(plan.n_occ[b0:]), L.ptr(col_bias[b0:]), L.c_ll(col_bias.stride(0)), L.ptr(y), L.stream()), "sparse_conv_gemm_h2_cb")
     if isinstance(wt, tuple) and wt[0] == "h2":  # fp16x3 GEMM (sparse_conv_pack_h2) + gather: the default
         _, packed, inv_scale = wt
         if rows is not None:
@@ -1223,11 +1235,11 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None, ro
             gn, stats = (partial, int(gn_groups)), (partial, r * r, int(gn_groups))
         for b0 in range(0, B, gb):
             nb = min(gb, B - b0)
-            L.check(lib.bdm_sparse_conv_gemm_h2(nb, plan.n_max, C, cout, L.ptr(xh[b0:]), L.ptr(amax[b0:]), L.ptr(packed), L.ptr(inv_scale),
-                                                L.ptr(plan.n_occ[b0:]), L.ptr(y), L.stream()), "sparse_conv_gemm_h2")
+            gemm_h2(nb, b0, xh, amax, packed, inv_scale, y)
             _gather(lib, nb, cout, r, plan, b0, y, bias, out, gn)
         return (out, stats) if gn_groups else out
     if isinstance(wt, tuple):  # fused kernel (sparse_conv_pack_fused): GEMM + scatter in one launch, no intermediate
+        assert col_bias is None
         _, packed, inv_scale = wt
         xr = torch.empty(B, (C + 7) // 8, plan.n_max, 8, dtype=torch.float32, device=dev)
         amax = amax_slots(dev, B)  # one activation scale per shape: a shape's result does not depend on its batch-mates
@@ -1265,10 +1277,14 @@ def sparse_first_conv_planned(features, plan, wt, bias, cout, gn_groups=None, ro
         gn, stats = (partial, int(gn_groups)), (partial, r * r, int(gn_groups))
     for b0 in range(0, B, gb):
         nb = min(gb, B - b0)
-        if s3:
+        if s3 and col_bias is not None:
+            L.check(lib.bdm_sparse_conv_gemm_s3_cb(nb, plan.n_max, C, 27 * cout, L.ptr(xs[b0:]), L.ptr(wt), L.ptr(plan.n_occ[b0:]),
+                                                   L.ptr(col_bias[b0:]), L.c_ll(col_bias.stride(0)), L.ptr(y), L.stream()), "sparse_conv_gemm_s3_cb")
+        elif s3:
             L.check(lib.bdm_sparse_conv_gemm_s3(nb, plan.n_max, C, 27 * cout, L.ptr(xs[b0:]), L.ptr(wt), L.ptr(plan.n_occ[b0:]),
                                                 L.ptr(y), L.stream()), "sparse_conv_gemm_s3")
         else:
+            assert col_bias is None
             L.check(lib.bdm_sparse_conv_gemm(nb, plan.n_max, C, 27 * cout, L.ptr(xs[b0:]), L.ptr(wt), L.ptr(plan.n_occ[b0:]),
                                              L.ptr(y), L.stream()), "sparse_conv_gemm")
         _gather(lib, nb, cout, r, plan, b0, y, bias, out, gn)

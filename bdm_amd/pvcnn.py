@@ -259,10 +259,41 @@ def encode(sa_layers, global_att, inputs, t_emb, early=None):
         if i == 0:
             features, coords, t_emb = run_blocks(sa_blocks, (features, coords, t_emb))
         else:
-            features, coords, t_emb = run_blocks(sa_blocks, (ops.cat_channels([features, t_emb]), coords, t_emb))
+            # (split: the level's first module takes the embedding's share of its first layers as per-shape terms; the module's OWN
+            # predicate decides, so encode and forward cannot disagree about whether the concatenation happened)
+            first = sa_blocks[0] if isinstance(sa_blocks, nn.Sequential) else sa_blocks
+            can = hasattr(first, "can_split_temb") and first.can_split_temb(features, t_emb)
+            if can and i == 1:
+                _enc_temb_terms(sa_layers, t_emb)
+            if not can and hasattr(first, "_temb_terms"):
+                first._temb_terms = None
+            features, coords, t_emb = run_blocks(sa_blocks, (features if can else ops.cat_channels([features, t_emb]), coords, t_emb))
     if global_att is not None:
         features = global_att(features)
     return features, coords, t_emb, coords_list, in_features_list
+
+
+def _enc_temb_terms(sa_layers, t_emb):
+    """The per-shape time-embedding terms of every encoder level's first module (PVConv.temb_rows / PointNetSAModule.temb_rows) in ONE
+    launch: module i gets its (B, rows_i) view as _temb_terms (a module without one computes its own)."""
+    mods = [(b[0] if isinstance(b, nn.Sequential) else b) for b in list(sa_layers)[1:]]
+    mods = [m for m in mods if hasattr(m, "temb_rows")]
+    if not mods:
+        return
+    c_t = t_emb.shape[1]
+    parts = [m.temb_rows(c_t) for m in mods]
+    key = tuple((p.data_ptr(), p._version) for p in parts)
+    owner = mods[0]
+    hit = getattr(owner, "_temb_rows_all", None)
+    if hit is None or hit[0] != key:
+        hit = (key, torch.cat(parts, dim=0).contiguous())
+        owner._temb_rows_all = hit
+    tvec = t_emb[:, :, 0].contiguous()
+    bb = ops.pointwise_conv(tvec[:, :, None], hit[1])[:, :, 0]   # (B, sum rows_i)
+    lo = 0
+    for m, p in zip(mods, parts):
+        m._temb_terms = bb[:, lo:lo + p.shape[0]]
+        lo += p.shape[0]
 
 
 FP_TEMB_SPLIT = os.environ.get("BDM_FP_TEMB_SPLIT", "1") == "1"  # FP modules take the point-invariant time embedding as a per-shape bias

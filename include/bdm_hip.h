@@ -423,6 +423,13 @@ size_t bdm_sparse_conv_s3_weight_elems(int cout, int cin);
 int bdm_sparse_conv_pack_weights_s3(int cout, int cin, const float *w, void *ws, void *stream);
 int bdm_sparse_conv_gemm_s3(int b, int n_max, int cin, int n27, const void *xs, const void *ws, const int *n_occ,
                             float *y, void *stream);
+/* + col_bias (b, n27; batch stride bs_cb floats): y[b][k][tap * cout + co] += col_bias[b][tap * cout + co] on every row -- the share of input channels that are
+ * CONSTANT over a shape's occupied cells: the time embedding the reference concatenates to the features before the first PVConv of
+ * set-abstraction levels 1.. (pvcnn.py:103; avg_voxelize of a per-shape constant is that constant on every occupied cell, vox.cu:18-72),
+ * col_bias[b][tap][co] = sum_c W[co][cin + c][tap] t[b][c].  The gather adds a row once per OCCUPIED neighbour: exactly the
+ * zero-padded convolution of the concatenated grid, with the GEMM's K and the feature pass reduced to the real feature channels. */
+int bdm_sparse_conv_gemm_s3_cb(int b, int n_max, int cin, int n27, const void *xs, const void *ws, const int *n_occ,
+                               const float *col_bias, long long bs_cb, float *y, void *stream);
 
 /* Hoisted form of bdm_sparse_voxel_features* + bdm_sparse_conv_gemm* for an input whose feature channels are a gather of a per-image
  * map (the projection conditioning x_in[i] = [xyz_i, F[pix_i]], projection_model.py:179-231): with hmap (b, hw, n27) = F . Wf^T
@@ -490,6 +497,9 @@ int bdm_sparse_conv_pack_weights_h2(int cout, int cin, const float *w, void *pac
 int bdm_sparse_split_h2(int b, int cin, int n_max, const void *xr, const float *amax, void *xh, void *stream);
 int bdm_sparse_conv_gemm_h2(int b, int n_max, int cin, int cout, const void *xh, const float *amax, const void *packed_w,
                             const float *inv_scale, const int *n_occ, float *y, void *stream);
+/* + the per-shape column addend of bdm_sparse_conv_gemm_s3_cb (col_bias (b, 27 * cout)) */
+int bdm_sparse_conv_gemm_h2_cb(int b, int n_max, int cin, int cout, const void *xh, const float *amax, const void *packed_w,
+                               const float *inv_scale, const int *n_occ, const float *col_bias, long long bs_cb, float *y, void *stream);
 
 /* The same first convolution as ONE output-stationary implicit GEMM with tap skipping (sparse_conv_os.hip, round 4; the default
  * wherever the input is not the hoisted conditioning map): no (n_occ x 27*cout) intermediate, no gather, no operand-split pass.  Only

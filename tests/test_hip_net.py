@@ -259,3 +259,66 @@ def test_time_embedding_as_a_per_shape_bias_of_the_fp_modules(hip, monkeypatch, 
     assert torch.equal(net(x, t), got)                     # deterministic
     alone = net(x[1:2].contiguous(), t[1:2])
     assert torch.equal(alone[0], got[1])                   # and batch-invariant
+
+
+@pytest.mark.parametrize("which", ["pc2", "pvd"])
+def test_time_embedding_as_per_shape_terms_of_the_encoder(hip, monkeypatch, which):
+    """pvcnn.encode in split form: the point-invariant time embedding is not concatenated before the first PVConv of levels 1, 2 and before
+    the last set-abstraction module (pvcnn.py:103).  Its voxel mean is the same constant on every occupied cell (vox.cu:18-72), so its share of
+    the first voxel convolution is a per-shape column addend of the occupied-row GEMM, added by the gather once per occupied neighbour
+    (bdm_sparse_conv_gemm_*_cb) = the zero-padded convolution of the concatenated grid; its share of the point branch and of the grouped
+    MLP is a per-shape bias.  Same forward up to the reassociation of those shares (and the activation scale of a narrower operand)."""
+    import bdm_amd.pvcnn as PV
+    from bdm_amd.modules import PVConv, PointNetSAModule
+    from bdm_amd.utils.procedural import fill_module_
+    B, N = 3, 2048
+    net = fill_module_((PV.PVCNN2_PC2(3, 64, extra_feature_channels=32) if which == "pc2" else PV.PVCNN2_PVD(3, 64, extra_feature_channels=0)).eval(),
+                       seed=9).cuda()
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.randn(B, 3, N, generator=g) * 0.4, torch.randn(B, 32 if which == "pc2" else 0, N, generator=g)], dim=1).cuda()
+    t = torch.tensor([900, 400, 3]).cuda()
+    took = []
+    for cls in (PVConv, PointNetSAModule):
+        orig = cls.can_split_temb
+        monkeypatch.setattr(cls, "can_split_temb", lambda self, f, te, orig=orig: (took.append(type(self).__name__ if orig(self, f, te) else None) or took[-1] is not None))
+    monkeypatch.setattr(PVConv, "temb_split", False)
+    ref = net(x, t).clone()
+    assert not any(took)
+    monkeypatch.setattr(PVConv, "temb_split", True)
+    del took[:]
+    got = net(x, t)
+    assert [k for k in took if k] .count("PVConv") >= 2 and "PointNetSAModule" in took, took    # levels 1, 2 and the last module
+    check_rel_l2(got.cpu(), ref.cpu(), 5e-6)
+    assert not torch.equal(got, ref)                       # really another route
+    assert torch.equal(net(x, t), got)                     # deterministic
+    alone = net(x[1:2].contiguous(), t[1:2])
+    assert torch.equal(alone[0], got[1])                   # and batch-invariant
+
+
+def test_pvconv_takes_the_time_embedding_as_column_addend_and_bias(hip, monkeypatch):
+    """One PVConv of each encoder kind (16^3: bf16x6 GEMM; 8^3: fp16x3 GEMM) against itself on the concatenated input, plus the refusal of
+    an input of the wrong width."""
+    from bdm_amd import ops
+    from bdm_amd.modules import PVConv
+    from bdm_amd.utils.procedural import fill_module_
+    g = torch.Generator().manual_seed(5)
+    for (cf, cout, r, n) in ((64, 64, 16, 1024), (128, 128, 8, 256)):
+        B, ct = 3, 64
+        m = fill_module_(PVConv(cf + ct, cout, 3, r, with_se=True, with_se_relu=True).eval(), seed=4).cuda()
+        f = torch.randn(B, cf, n, generator=g).cuda()
+        coords = (torch.randn(B, 3, n, generator=g) * 0.4).cuda()
+        te = torch.randn(B, ct, generator=g).cuda()[:, :, None].expand(-1, -1, n)
+        ref = m((torch.cat([f, te], dim=1).contiguous(), coords, te))[0].clone()
+        ops.clear_plan_cache()
+        got = m((f, coords, te))[0]
+        check_rel_l2(got.cpu(), ref.cpu(), 3e-6, f"PVConv {cf}+{ct} -> {cout} at {r}^3")
+        assert not torch.equal(got, ref)
+        ops.clear_plan_cache()
+        with pytest.raises(ValueError):
+            m((f[:, :cf - 8].contiguous(), coords, te))
+        monkeypatch.setattr(PVConv, "temb_split", False)
+        ops.clear_plan_cache()
+        with pytest.raises(ValueError):
+            m((f, coords, te))
+        monkeypatch.setattr(PVConv, "temb_split", True)
+        ops.clear_plan_cache()
