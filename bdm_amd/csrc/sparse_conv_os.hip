@@ -312,7 +312,9 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
   // B = 16 batch had to land on 256 CUs in ONE round; workgroups go round-robin over the 8 XCDs by index, a few XCDs got 33 of them
   // for their 32 CUs, and those stragglers started when the first round ended: the kernel took two workgroup lifetimes (measured
   // with wall-clock stamps, tools/sparse_dil_timeline.py: 159 us for an 84 us workgroup).  The counter is zero on entry
-  // (caller) and is not reset: which workgroup computes a tile does not change any result.
+  // (caller) and is not reset: which workgroup computes a tile does not change any result.  (Round 5, measured and NOT done: a fixed
+  // first item per workgroup, or fetching the next item while the matrix phase runs, hands LIVE tiles to workgroups that cannot start
+  // them yet -- a late starter then holds one, or an early one reserves one behind its own: 96 -> 121 .. 154 us.)
   for (;;) {
     // the thread index is laundered once per item: everything derived from it (staging offsets, fragment addresses, ...) would
     // otherwise be hoisted out of the item loop and held in registers across it (+50 VGPRs: the 64 x 64 wave tile spilled)
@@ -439,6 +441,12 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
     const bool staged = !nothing && n_oi * (int)sizeof(int) <= 2 * XS * (int)sizeof(float4);   // (uniform; r = 32 tiles spanning > 25 planes: global)
     int *s_oi = reinterpret_cast<int *>(Xs);
     const int *oi = occ_index + (size_t)bi * R3;
+    int vq[NT];                       // this lane's voxels: read BEFORE the planes are staged (one round trip for both, not two)
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int j = j0 + (q * NW + wave) * 16 + l16;
+      vq[q] = j < jn ? dl[j] : -1;
+    }
     if (staged) {
       const int4 *src = reinterpret_cast<const int4 *>(oi + pl0 * R2);
       for (int e = tid; e < n_oi / 4; e += NT_) reinterpret_cast<int4 *>(s_oi)[e] = src[e];
@@ -446,8 +454,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
     }
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
-      const int j = j0 + (q * NW + wave) * 16 + l16;
-      const int v = j < jn ? dl[j] : -1;
+      const int v = vq[q];
       const int vx = v / R2, vy = (v / R) % R, vz = v % R;
 #pragma unroll
       for (int Q = 0; Q < NQ; ++Q) {

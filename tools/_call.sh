@@ -1,2 +1,13 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_hip_net.py tests/test_hip_dense.py tests/test_hip_full_size.py -q -x 2>&1 | tail -30
+R=$GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05
+cd /tmp && export TMPDIR=/tmp
+for rep in 1 2; do
+for v in base new; do
+  if [ $v = base ]; then export BDM_LIB_PATH=$R/bdm_amd/libbdm_hip_base.so; else unset BDM_LIB_PATH; fi
+  rm -rf /tmp/trf_$v
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/trf_$v -o fwd -- python3 $R/tools/trace_forward.py pc2 > /dev/null 2>&1
+  echo "== $v $rep"
+  python3 $R/tools/trace_summary.py $(find /tmp/trf_$v -name "*kernel_trace.csv" | head -1) 80 | grep "sconv_dil\|^[0-9]* launches"
+done
+done
