@@ -91,6 +91,11 @@ SPEC = {
                                 lambda a: ("mfma_aux", 2.0 * a[0] * a[1] * OCCUPANCY.get(a[1], 1.0) * a[2] * a[3], MFMA16_PEAK_TFLOPS / 6)),
     "bdm_sparse_conv_gemm_h2": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]),
                                 lambda a: ("mfma_aux", 2.0 * a[0] * a[1] * OCCUPANCY.get(a[1], 1.0) * a[2] * 27 * a[3], MFMA16_PEAK_TFLOPS / 3)),
+    # (+ the per-shape column addend: the time embedding's share, modules.PVConv.can_split_temb)
+    "bdm_sparse_conv_gemm_s3_cb": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]),
+                                   lambda a: ("mfma_aux", 2.0 * a[0] * a[1] * OCCUPANCY.get(a[1], 1.0) * a[2] * a[3], MFMA16_PEAK_TFLOPS / 6)),
+    "bdm_sparse_conv_gemm_h2_cb": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]),
+                                   lambda a: ("mfma_aux", 2.0 * a[0] * a[1] * OCCUPANCY.get(a[1], 1.0) * a[2] * 27 * a[3], MFMA16_PEAK_TFLOPS / 3)),
     "bdm_sparse_split_h2": ("sparse first conv", lambda a: (a[0], a[1], a[2]), lambda a: ("hbm", 0.0)),
     "bdm_sparse_conv_gemm": ("sparse first conv", lambda a: (a[0], a[1], a[2], a[3]),
                              lambda a: ("mfma_aux", 2.0 * a[0] * a[1] * OCCUPANCY.get(a[1], 1.0) * a[2] * a[3], MFMA32_PEAK_TFLOPS)),

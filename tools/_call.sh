@@ -1,13 +1,12 @@
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r05
-cd /tmp && export TMPDIR=/tmp
-for rep in 1 2; do
-for v in base new; do
-  if [ $v = base ]; then export BDM_LIB_PATH=$R/bdm_amd/libbdm_hip_base.so; else unset BDM_LIB_PATH; fi
-  rm -rf /tmp/trf_$v
-  timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/trf_$v -o fwd -- python3 $R/tools/trace_forward.py pc2 > /dev/null 2>&1
-  echo "== $v $rep"
-  python3 $R/tools/trace_summary.py $(find /tmp/trf_$v -name "*kernel_trace.csv" | head -1) 80 | grep "sconv_dil\|^[0-9]* launches"
+for i in 1 2 3; do
+  for v in r4 r5; do
+    if [ $v = r4 ]; then cd $R/gpurun_tmp/r4; else cd $R; fi
+    echo "== $v B=16 N=4096"; python tools/replay_host_time.py 16 4096 2>&1 | grep replayed | tail -1
+  done
 done
+for v in r4 r5 r4 r5; do
+    if [ $v = r4 ]; then cd $R/gpurun_tmp/r4; else cd $R; fi
+    echo "== $v B=1 N=1024"; python tools/replay_host_time.py 1 1024 2>&1 | grep replayed | tail -1
 done

@@ -13,7 +13,7 @@ def rows_of(path, counter):
 
 
 def short(name):
-    return re.sub(r"\(.*", "", name).replace("void ", "")
+    return re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "")).replace("void ", "")
 
 
 def load(rows):

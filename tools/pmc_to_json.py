@@ -17,8 +17,8 @@ FAMILIES = [
     (("conv3d_h2q_kernel",), 1, {"bdm_conv3d_3x3x3_h2_gn": _conv, "bdm_conv3d_3x3x3_h2": _conv}),
     # compact first / second convolution over the dilated voxel lists: rows in, compact rows out -- the list lengths are data (None)
     (("sconv_dil_kernel",), 1, {"bdm_sparse_conv_dil_gn": None, "bdm_sparse_conv_dil": None, "bdm_sparse_conv_dil_h2_gn": None}),
-    (("sparse_gemm_s3_kernel",), 1, {"bdm_sparse_conv_gemm_s3": None}),
-    (("sparse_gemm_h2_kernel",), 1, {"bdm_sparse_conv_gemm_h2": None}),
+    (("sparse_gemm_s3_kernel",), 1, {"bdm_sparse_conv_gemm_s3": None, "bdm_sparse_conv_gemm_s3_cb": None}),
+    (("sparse_gemm_h2_kernel",), 1, {"bdm_sparse_conv_gemm_h2": None, "bdm_sparse_conv_gemm_h2_cb": None}),
     (("sparse_gather_v4_kernel",), 1, {"bdm_sparse_conv_gather_gn": lambda a: 4 * a[0] * a[1] * a[2] ** 3,
                                        "bdm_sparse_conv_gather": lambda a: 4 * a[0] * a[1] * a[2] ** 3}),
     (("sparse_rows_from_map_kernel",), 1, {"bdm_sparse_conv_rows_from_map": None}),
@@ -31,6 +31,8 @@ FAMILIES = [
     (("se_rows_partial_kernel", "se_rows_fc_kernel"), 2, {"bdm_se_gate_gn_rows_pf": None, "bdm_se_gate_gn_rows": None}),
     (("devox_rows_kernel",), 1, {"bdm_devoxelize_gn_gate_add_rows_pf": None, "bdm_devoxelize_gn_gate_add_rows": None}),
     (("vox_dilate_kernel",), 1, {"bdm_voxel_dilate": None, "bdm_voxel_dilate_again": None}),
+    # small-grid PVConv tail (+ the next PVConv's operand): grid in, points out
+    (("pv_tail_small",), 1, {"bdm_pvconv_tail_small": lambda a: 4 * a[0] * a[1] * (a[3] ** 3 + 2 * a[2])}),
 ]
 disp = list(csv.DictReader(open(sys.argv[1])))
 log = json.load(open(sys.argv[2]))   # [[function, [int args...]], ...] in call order

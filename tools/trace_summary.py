@@ -21,7 +21,7 @@ for q, iv in sorted(byq.items(), key=lambda kv: -len(kv[1])):
               f"p90 {gs[int(len(gs) * 0.9)] / 1e3:.2f} us, span {(iv[-1][1] - iv[0][0]) / 1e3:.1f} us")
 agg = collections.OrderedDict()
 for r in sel:
-    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+    name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "")
     key = (name, r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     a = agg.setdefault(key, [0, 0.0]); a[0] += 1; a[1] += d
