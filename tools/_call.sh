@@ -1,12 +1,6 @@
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
-for i in 1 2 3; do
-  for v in r4 r5; do
-    if [ $v = r4 ]; then cd $R/gpurun_tmp/r4; else cd $R; fi
-    echo "== $v B=16 N=4096"; python tools/replay_host_time.py 16 4096 2>&1 | grep replayed | tail -1
-  done
-done
-for v in r4 r5 r4 r5; do
-    if [ $v = r4 ]; then cd $R/gpurun_tmp/r4; else cd $R; fi
-    echo "== $v B=1 N=1024"; python tools/replay_host_time.py 1 1024 2>&1 | grep replayed | tail -1
-done
+mkdir -p gpurun_out/r05
+for c in c3 c4 c5; do python bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r05/bench_$c.json; python3 -c "
+import json; d=json.loads(open('gpurun_out/r05/bench_$c.json').read()); print('$c', round(d['value'],3), d['unit'], round(d['ms_per_step'],1), d['config'].get('workload','')[:80])"; done
+bash tools/pmc_mfma.sh > gpurun_out/r05/mfma_busy.txt 2>&1; head -30 gpurun_out/r05/mfma_busy.txt

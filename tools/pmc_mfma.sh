@@ -8,7 +8,7 @@ python3 - <<PY
 import csv, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); dur = collections.defaultdict(float); cnt = collections.Counter(); seen=set()
 for r in csv.DictReader(open("$R/gpurun_out/mfma_1.csv")):
-    key = (re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", ""), r["Grid_Size"])
+    key = (re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", ""), r["Grid_Size"])
     agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
     if (key, r["Dispatch_Id"]) not in seen:
         seen.add((key, r["Dispatch_Id"])); cnt[key]+=1; dur[key] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
