@@ -7,6 +7,8 @@ denoiser in nn.DataParallel, :480-484); here `_ModuleHolder` provides the `.modu
 any DataParallel scatter/gather -- one process drives one GPU.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -91,9 +93,14 @@ class GaussianDiffusion:
         # device->host synchronisation at every step
         tt = int(t_int) if t_int is not None else (int(t[0]) if torch.is_tensor(t) else int(t))
         eps = denoise_fn(data, t)
+        return self.p_step(data, eps, tt, noise_fn=noise_fn, use_var=use_var)
+
+    def p_step(self, data, eps, tt, noise_fn=torch.randn, use_var=True, out=None):
+        """The arithmetic of p_sample after the denoiser (:206-224) for the predicted noise `eps` at timestep `tt` (a Python int).
+        out: may be `data` itself (contiguous; the step is elementwise)."""
         c = self.step_coefficients(tt)
         if self.streams is not None and self.noise_source is None and use_var:
-            return self.streams.pvd_step(data, eps, c)
+            return self.streams.pvd_step(data, eps, c, out=out)
         if self.noise_source is not None:
             noise = self.noise_source(tuple(data.shape), data.device)
         else:
@@ -101,7 +108,9 @@ class GaussianDiffusion:
         x = data.contiguous()
         eps = eps.contiguous()
         noise = noise.contiguous()
-        out = torch.empty_like(x)
+        if out is None:
+            out = torch.empty_like(x)
+        assert out.is_contiguous() and out.shape == x.shape
         L.check(L.lib().bdm_pvd_step(L.c_ll(x.numel()), L.ptr(x), L.ptr(eps), L.ptr(noise), L.c_float(c["a"]),
                                      L.c_float(c["b"]), L.c_float(c["c1"]), L.c_float(c["c2"]),
                                      L.c_float(c["sigma"] if use_var else 0.0), L.ptr(out), L.stream()), "pvd_step")
@@ -121,6 +130,11 @@ class GaussianDiffusion:
                                   clip_denoised=clip_denoised, return_pred_xstart=False, t_int=t)
         assert img_t.shape == tuple(shape) or img_t.shape == shape
         return img_t
+
+
+def _no_constraint(x, t):
+    """the reference's default constrain_fn (pvd/__init__.py:226: lambda x, t: x)"""
+    return x
 
 
 class _ModuleHolder(nn.Module):
@@ -153,8 +167,70 @@ class Model(nn.Module):
         assert out.shape == torch.Size([B, D, N])
         return out
 
-    def gen_samples(self, data, shape, device, noise_fn=torch.randn, constrain_fn=lambda x, t: x, clip_denoised=False,
+    # ---- launch-tape form of the sampling loop (tape.py; the PC^2 loop's form: model._denoise_loop_tape) ----------------------
+    # The denoiser forward on static buffers is recorded while it runs eagerly (second step: the first leaves every lazy cache behind it)
+    # and later steps -- of this call, of later prior segments, of later trajectories -- replay the flat list of C-ABI calls; the
+    # p_sample arithmetic stays eager (one launch, in place): its scalars and its noise draw change per step.  The BDM recipes run the
+    # prior in segments of `roll_step` (16) steps, 80 per shape: eager, those steps are host-bound at B = 16 (~190 launches each).
+    tape_steps = os.environ.get("BDM_TAPE", "auto")
+    tape_max_points = 1 << 20
+    tape_min_steps = 4
+    tape_pvd = os.environ.get("BDM_PVD_TAPE", "1") == "1"   # (A/B switch: 0 keeps the prior's loop eager while the PC^2 loop replays)
+
+    def _weights_signature(self):
+        return hash(tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
+
+    def _tape_ok(self, data, constrain_fn, clip_denoised, keep_running, n_steps):
+        return (data.is_cuda and not clip_denoised and not keep_running and n_steps >= self.tape_min_steps
+                and self.tape_pvd and constrain_fn is _no_constraint and data.dim() == 3 and data.dtype == torch.float32
+                and (self.tape_steps == "1" or (self.tape_steps == "auto" and data.shape[0] * data.shape[2] <= self.tape_max_points)))
+
+    def _gen_samples_tape(self, data, noise_fn, start_time, final_time):
+        from . import ops, profiling, tape as T
+        dev, B = data.device, data.shape[0]
+        key = (tuple(data.shape), str(dev), torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()), self._weights_signature(),
+               ops.saturation_epoch())
+        g = getattr(self, "_tape_cache", None)
+        if g is None or g["key"] != key:
+            g = {"key": key, "tape": None, "warm": False, "off": None, "eps": None,
+                 "x": torch.empty_like(data, memory_format=torch.contiguous_format),
+                 "t": torch.zeros(B, dtype=torch.int64, device=dev)}
+            self._tape_cache = g
+        g["x"].copy_(data)
+        probe = int(getattr(self, "eager_probe_every", 0))  # bench.py: every k-th step runs eagerly through the kernel-class profiler
+        for t in reversed(range(final_time, start_time)):
+            g["t"].fill_(t)
+            g["steps"] = i = g.get("steps", -1) + 1
+            if g["tape"] is not None and probe and i % probe == probe - 1:
+                profiling.PROBE_WEIGHT[0] = probe
+                try:
+                    eps = self._denoise(g["x"], g["t"])
+                finally:
+                    profiling.PROBE_WEIGHT[0] = 1
+            elif g["tape"] is not None:
+                g["tape"].replay()
+                eps = g["eps"]
+            elif g["warm"] and g["off"] is None:
+                with ops.static_step(), T.record() as tp:
+                    eps = self._denoise(g["x"], g["t"])
+                if tp.broken:
+                    g["off"] = tp.broken   # stay eager (on the static buffers) and say why: Model._tape_cache["off"]
+                else:
+                    g["tape"], g["eps"] = tp, eps
+            else:
+                eps = self._denoise(g["x"], g["t"])
+                g["warm"] = True
+            self.diffusion.p_step(g["x"], eps, t, noise_fn=noise_fn, out=g["x"])   # in place: elementwise
+        return g["x"].clone()
+
+    def gen_samples(self, data, shape, device, noise_fn=torch.randn, constrain_fn=None, clip_denoised=False,
                     start_time=None, final_time=None, keep_running=False):
+        constrain_fn = _no_constraint if constrain_fn is None else constrain_fn
+        st = self.diffusion.num_timesteps if start_time is None else start_time
+        ft = 0 if final_time is None else final_time
+        if self._tape_ok(data, constrain_fn, clip_denoised, keep_running, st - ft):
+            assert tuple(shape) == tuple(data.shape)
+            return self._gen_samples_tape(data, noise_fn, st, ft)
         return self.diffusion.p_sample_loop(data=data, denoise_fn=self._denoise, shape=shape, device=device,
                                             noise_fn=noise_fn, constrain_fn=constrain_fn, clip_denoised=clip_denoised,
                                             start_time=start_time, final_time=final_time, keep_running=keep_running)

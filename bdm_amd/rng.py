@@ -78,10 +78,13 @@ class ShapeStreams:
                                              L.ptr(out), L.stream()), "ddpm_step_philox")
         return out
 
-    def pvd_step(self, x, eps, c, purpose=PVD):
+    def pvd_step(self, x, eps, c, purpose=PVD, out=None):
+        """out: may be `x` itself (contiguous): the step is elementwise (pvd.Model's replayed loop steps in place)"""
         x, eps = x.contiguous(), eps.contiguous()
         per = self._check(x.shape)
-        out = torch.empty_like(x)
+        if out is None:
+            out = torch.empty_like(x)
+        assert out.is_contiguous() and out.shape == x.shape
         draw = self._next(purpose)  # the reference draws at t == 0 too (pvd/__init__.py:213): the index advances
         L.check(L.lib().bdm_pvd_step_philox(x.shape[0], per, L.ptr(x), L.ptr(eps), L.ptr(self.keys), draw, purpose,
                                             c["a"], c["b"], c["c1"], c["c2"], c["sigma"], L.ptr(out), L.stream()),

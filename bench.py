@@ -275,6 +275,7 @@ def main():
 
     model.eager_probe_every = 50  # replayed loops (launch tape, BDM_GRAPH=1): every 50th step runs eagerly so that single launches
                                   # can be timed; the profiler counts each of its launches 50 times (profiling.PROBE_WEIGHT)
+    pvd_model.eager_probe_every = model.eager_probe_every   # (the prior's replayed loop likewise: pvd.Model._gen_samples_tape)
     from bdm_amd.profiling import KernelClassProfiler
     prof = KernelClassProfiler(every=4).install()
     barrier()

@@ -149,6 +149,48 @@ def test_launch_tape_replay_equals_eager_loop(hip, monkeypatch):
     assert torch.equal(changed_tape, changed_eager) and not torch.equal(changed_tape, eager)
 
 
+def test_prior_loop_replayed_from_a_tape_equals_the_eager_loop(hip, monkeypatch):
+    """pvd.Model.gen_samples in launch-tape form (the prior's 16-step segments of the BDM recipes, pvd/__init__.py:226-270 through
+    generate_pvd_xyz :450-473): the bits of the eager loop, with the reference's global-generator noise and with the per-shape Philox
+    streams; the recording is re-used by the next segment and dropped when a weight changes."""
+    from bdm_amd import rng
+    from bdm_amd.pvd import Model, generate_pvd_xyz, prepare_pvd_model
+    B, N, steps = 2, 1024, 8
+    pvd = prepare_pvd_model({"model": None, "nc": 3, "embed_dim": 64, "attention": True, "dropout": 0.1}, torch.device("cuda"))
+    x0 = (torch.randn(B, 3, N, generator=torch.Generator().manual_seed(5)) * 0.5).cuda()
+
+    def run(taped, philox):
+        monkeypatch.setattr(Model, "tape_pvd", taped)
+        pvd.diffusion.streams = rng.ShapeStreams(7, range(B), torch.device("cuda")) if philox else None
+        if not philox:
+            torch.manual_seed(11)
+            torch.cuda.manual_seed_all(11)
+        try:
+            first = generate_pvd_xyz(pvd, x0.clone(), 400, 400 - steps)
+            return generate_pvd_xyz(pvd, first, 300, 300 - steps).cpu()      # a second segment
+        finally:
+            pvd.diffusion.streams = None
+
+    for philox in (False, True):
+        pvd._tape_cache = None
+        eager = run(False, philox)
+        assert getattr(pvd, "_tape_cache", None) is None
+        taped = run(True, philox)
+        g = pvd._tape_cache
+        assert g["off"] is None, g["off"]
+        assert g["tape"] is not None and len(g["tape"]) > 120 and g["steps"] == 2 * steps - 1
+        assert torch.equal(eager, taped), philox
+    tape_before = pvd._tape_cache["tape"]
+    again = run(True, True)
+    assert pvd._tape_cache["tape"] is tape_before and torch.equal(again, taped)
+    with torch.no_grad():
+        conv = next(m for m in pvd.model.modules() if isinstance(m, torch.nn.Conv3d))
+        conv.weight.mul_(1.25)
+    changed_tape, changed_eager = run(True, True), run(False, True)
+    assert pvd._tape_cache["tape"] is not tape_before
+    assert torch.equal(changed_tape, changed_eager) and not torch.equal(changed_tape, taped)
+
+
 def test_saturation_reroute_reaches_a_recorded_step(hip, monkeypatch):
     """a recorded reverse step has a layer's fp16x3 kernels baked in.  When poll_h2_saturation() switches
     that layer to bf16x6, the recording must not be replayed: the cache key carries ops.saturation_epoch(), the next loop

@@ -1,6 +1,11 @@
 cd $GRAFT_REPO_ROOT
-R=$GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r05
-for c in c3 c4 c5; do python bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r05/bench_$c.json; python3 -c "
-import json; d=json.loads(open('gpurun_out/r05/bench_$c.json').read()); print('$c', round(d['value'],3), d['unit'], round(d['ms_per_step'],1), d['config'].get('workload','')[:80])"; done
-bash tools/pmc_mfma.sh > gpurun_out/r05/mfma_busy.txt 2>&1; head -30 gpurun_out/r05/mfma_busy.txt
+python -m pytest tests/test_hip_trajectory.py -q -x -k "prior_loop or launch_tape" 2>&1 | tail -15
+for i in 1 2; do
+  for e in 0 1; do
+    BDM_PVD_TAPE=$e python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('PVD tape $e', 'run $i', 'shapes/s', round(d['value'], 4), 'ms_per_trajectory', round(d['ms_per_step'], 1), 'timed', d['roofline'].get('launches_timed'), 'total', d['roofline'].get('launches_total'))"
+  done
+done
+python -m pytest tests/test_hip_full_trajectory.py tests/test_hip_sampler.py tests/test_hip_cli.py tests/test_hip_full_size.py -q -x 2>&1 | tail -12
