@@ -1000,6 +1000,11 @@ def voxel_plan(coords, r, eps=0.0, dilate=False):
     return p
 
 
+def has_voxel_plan(coords, r):
+    """Is the plan of (this very coordinate tensor, r) in the pass's cache?"""
+    return (coords.data_ptr(), coords._version, tuple(coords.shape), int(r)) in _plan_cache
+
+
 DILATED_PLAN = True   # voxel plans carry the once-dilated voxel list + tile table of the compact first convolution (sparse_conv_os.hip)
 
 

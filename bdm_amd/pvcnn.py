@@ -126,6 +126,7 @@ _side_streams = {}
 SIDE_STREAM = os.environ.get("BDM_SIDE_STREAM", "1") == "1"  # sampler chain on its own stream (0: inline, for experiments)
 # voxel plans of levels 1.. on the sampler's side stream (tools/coresidency/two_proc_race.py flips it)
 SIDE_PLAN = os.environ.get("BDM_SIDE_PLAN", "1") == "1"
+DECODER_PLAN = os.environ.get("BDM_DECODER_PLAN", "1") == "1"   # ... and those of the decoder's PVConvs no encoder level has made (FP0)
 # B * N below which the sampler chain stays on the main stream.  0: always on its own stream -- since the launch count and the
 # per-launch host cost came down it pays even for one small shape (B=1, N=1024: 3.48 -> 3.30 ms; B=4: 3.86 -> 3.42 ms), where
 # furthest point sampling is a fifth of the forward.  (The PVConv point branch keeps its 8192-point threshold: measured slower below.)
@@ -167,7 +168,7 @@ def early_first_sampler(net, x_t):
     return (c0, centers0, side)
 
 
-def plan_sampling_chain(sa_layers, coords, early=None):
+def plan_sampling_chain(sa_layers, coords, early=None, fp_layers=None):
     """Furthest point sampling + ball query of ALL set-abstraction levels depend on the input coordinates only
     (1 356 strictly sequential sampler rounds on 16 CUs).  They are enqueued on a side stream so that they overlap
     the level-0 PVConvs; each SA module waits on its own event.
@@ -206,12 +207,33 @@ def plan_sampling_chain(sa_layers, coords, early=None):
             tape.record_event(plan.ready, side)
         return centers
 
+    # voxel plans of the DECODER's PVConvs: an FP stage's points are an encoder level's points (coords_list), so its plan is usually the
+    # one an encoder PVConv of the same resolution already made; where there is none (FP0: the 64 points SA3 reads, which has no PVConv)
+    # the two launches (voxel coordinates + plan) would sit on the main stream's critical path: they are geometry, planned here
+    wanted = {}
+    for i, blk in enumerate(fp_layers if fp_layers is not None else ()):
+        pv = next((m for m in blk if hasattr(m, "voxel_plan_args")), None) if isinstance(blk, nn.Sequential) else None
+        args = pv.voxel_plan_args() if (pv is not None and SIDE_PLAN and DECODER_PLAN) else None
+        if args is not None:
+            wanted[i] = (pv, args)
+
+    def decoder_plan(points, fp_index):
+        """(side stream) the plan of FP stage fp_index, whose points these are, unless the cache holds it already"""
+        pv, args = wanted.get(fp_index, (None, None))
+        if pv is not None and not ops.has_voxel_plan(points, args[0]):
+            plan = ops.voxel_plan(points, *args, dilate=2 if pv.wants_compact_tail(points.shape[0], points.shape[2]) else
+                                  (1 if pv.wants_dilated_plan(points.shape[0], points.shape[2]) else 0))
+            plan.ready = torch.cuda.Event()
+            tape.record_event(plan.ready, side)
+
     def remaining(c):
         with torch.cuda.stream(side):
             cents = [c]
             for li in range(1, len(sa_layers)):
                 c = level(li, c, None)
                 cents.append(c)
+                if li + 1 < len(sa_layers):   # these centres are level li + 1's points = FP stage (L - 2 - li)'s points (decode: coords_list[-1 - i])
+                    decoder_plan(c, len(sa_layers) - 2 - li)
             # the 3-NN searches of the feature-propagation modules are geometry too (level i's points against level i + 1's
             # centres): four launches that leave the main stream's critical path; an FP module finds its pair in NN_PLANS
             if SIDE_NN:
@@ -239,7 +261,7 @@ def plan_sampling_chain(sa_layers, coords, early=None):
         more()
 
 
-def encode(sa_layers, global_att, inputs, t_emb, early=None):
+def encode(sa_layers, global_att, inputs, t_emb, early=None, fp_layers=None):
     """Down path (pvcnn.py:90-110)."""
     coords = ops.xyz_rows(inputs)
     ops.clear_plan_cache()  # voxel plans are valid within one encoder/decoder pass
@@ -250,7 +272,7 @@ def encode(sa_layers, global_att, inputs, t_emb, early=None):
     # also inside a hipGraph capture: the side stream forks from and joins the capturing stream.  Small problems (one
     # small shape) are bound by kernel-to-kernel dispatch latency, where the extra events cost more than the overlap gains
     if coords.is_cuda and SIDE_STREAM and coords.shape[0] * coords.shape[2] >= SIDE_STREAM_MIN_POINTS:
-        plan_sampling_chain(sa_layers, coords, early)
+        plan_sampling_chain(sa_layers, coords, early, fp_layers)
     features = inputs
     coords_list, in_features_list = [], []
     for i, sa_blocks in enumerate(sa_layers):
@@ -392,7 +414,7 @@ class PVCNN2Base(nn.Module):
                 m._cond = cond
             # (the first level's centres, sampled ahead of the conditioning from this very cloud: the handle vouches for the tensor)
             early = cond.early if (cond is not None and cond.x_cf.data_ptr() == inputs.data_ptr()) else None
-            features, coords, t_emb, coords_list, in_features_list = encode(self.sa_layers, self.global_att, inputs, t_emb, early)
+            features, coords, t_emb, coords_list, in_features_list = encode(self.sa_layers, self.global_att, inputs, t_emb, early, self.fp_layers)
             in_features_list[0] = inputs[:, 3:, :]
             return decode(self.fp_layers, self.classifier, features, coords, t_emb, coords_list, in_features_list)
         finally:
