@@ -9,6 +9,7 @@
 // v and probability scales at the final normalisation).  Probabilities (in [0, 1]) are scaled by 2^14 before their split.
 #include "../../include/bdm_hip.h"
 #include "common.h"
+#include <type_traits>
 
 using namespace bdm;
 
@@ -73,18 +74,23 @@ __global__ void attn_split_v_h2_kernel(int C, int CP, int L, int Lp, const float
 
 #define VROW_H2 36  // fp16 per V row in LDS: 32 keys + 4 pad
 
+// Software-pipelined over the key tiles (round 5).  Iteration t of a wave runs two INDEPENDENT instruction streams:
+//   matrix pipe:  O += P(t-1) V(t-1)   and   S(t+1) = K(t+1)^T Q          (24 MFMAs, 768 cycles)
+//   vector ALU :  online softmax of S(t) -> P(t), running maximum / sum     (~190 instructions, ~900 cycles)
+// In the straight-line form (S, softmax, PV per tile) a wave's matrix phases waited for its own softmax and the matrix pipe was 38 % busy
+// (r05_mfma_busy.txt): the waves of a SIMD run the same phases at the same time (two workgroup barriers per tile keep them aligned), so
+// other waves did not fill the gaps.  K tiles are double-buffered in LDS, V tiles triple-buffered (V(t-1) is read while tile t + 1 is stored).
 template <int CB>  // channel blocks of 32 (C <= 32 * CB)
-// amdgpu_waves_per_eu(3): 196 -> 142 VGPRs without spilling (a target of 4 spills 18): three waves per SIMD instead of two,
-// 334 -> 289 us at B = 16, L = 4096
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_flash_h2_kernel(int C, int L, int Lp, int nb, const uint4 *__restrict__ qs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_flash_h2_kernel(int C, int L, int Lp, int nb, const uint4 *__restrict__ qs,
                                                             const uint4 *__restrict__ ks,
                                                             const unsigned short *__restrict__ vt,
                                                             const float *__restrict__ amax, float *__restrict__ out,
                                                             long long bs_o, int ld_o) {
   constexpr int C8 = 4 * CB, CP = 32 * CB, KT = C8 * 2 * 32, VT = 2 * CP * 4;  // uint4 items per K / V tile
   constexpr int KI = (KT + 255) / 256, VI = (VT + 255) / 256;
-  __shared__ uint4 Ksh[KT];                                       // [c8][split][key]
-  __shared__ __align__(16) unsigned short Vsh[2 * CP * VROW_H2];  // [split][c][VROW_H2]
+  constexpr int VSZ = 2 * CP * VROW_H2;
+  __shared__ uint4 Ksh[2][KT];                                 // [buffer][c8][split][key]
+  __shared__ __align__(16) unsigned short Vsh[3][VSZ];         // [buffer][split][c][VROW_H2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   // XCD-aware item order: workgroup ids are dealt round-robin to the 8 XCDs; XCD x takes the contiguous (shape, query tile) items
   // [x * per, (x + 1) * per), so a shape's K / V stay in ONE XCD's L2 (they were fetched by all eight: 272 MB per launch at B = 16, PMC)
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
   for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
-  float run_max = -INFINITY, run_sum = 0.f;
+  float run_max = -INFINITY, run_sum = 0.f, run_mneg = INFINITY;
 
   typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
   u32x4v kr[KI], vr[VI];
@@ -125,100 +131,160 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
       vr[i] = *reinterpret_cast<const u32x4v *>(vb + ((size_t)rowi * Lp + min(j0 + piece * 8, Lp - 8)));
     }
   };
-  load_tile(0);
-  for (int j0 = 0; j0 < L; j0 += 32) {
-    __syncthreads();
+  auto store_tile = [&](uint4 *kdst, unsigned short *vdst) {
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
       const int e = tid + i * 256;
-      if (e < KT) *reinterpret_cast<u32x4v *>(&Ksh[e]) = kr[i];
+      if (e < KT) *reinterpret_cast<u32x4v *>(&kdst[e]) = kr[i];
     }
 #pragma unroll
     for (int i = 0; i < VI; ++i) {
       const int e = tid + i * 256, piece = e & 3, rowi = e >> 2;
       if (e < VT) {
-        uint2 *d = reinterpret_cast<uint2 *>(Vsh + rowi * VROW_H2 + piece * 8);
+        uint2 *d = reinterpret_cast<uint2 *>(vdst + rowi * VROW_H2 + piece * 8);
         d[0] = make_uint2(vr[i].x, vr[i].y);
         d[1] = make_uint2(vr[i].z, vr[i].w);
       }
     }
-    __syncthreads();
-    if (j0 + 32 < L) load_tile(j0 + 32);
-
-    // S^T[j][i] = sum_c k[c][j] q[c][i]  (scaled by sq * sk); two accumulators: even / odd 16-channel steps
-    f32x16 st, st2;
+  };
+  // S^T[j][i] = sum_c k[c][j] q[c][i]  (scaled by sq * sk); two accumulators: even / odd 16-channel steps
+  // (ONE accumulator chain: the MFMAs are spaced by the softmax's vector instructions, so a dependent successor finds its predecessor done;
+  // the two-chain form cost 16 registers and 8 packed adds per tile)
+  auto scores = [&](const uint4 *kt, f32x16 &st) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { st[r] = 0.f; st2[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 2 * CB; ++s) {
-      const f16x8 ah = as_f16x8(Ksh[((2 * s + lh) * 2 + 0) * 32 + li]), al = as_f16x8(Ksh[((2 * s + lh) * 2 + 1) * 32 + li]);
-      if (s & 1) {
-        st2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qreg[s][0], st2, 0, 0, 0);
-        st2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qreg[s][1], st2, 0, 0, 0);
-        st2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qreg[s][0], st2, 0, 0, 0);
-      } else {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qreg[s][0], st, 0, 0, 0);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qreg[s][1], st, 0, 0, 0);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qreg[s][0], st, 0, 0, 0);
-      }
+      const f16x8 ah = as_f16x8(kt[((2 * s + lh) * 2 + 0) * 32 + li]), al = as_f16x8(kt[((2 * s + lh) * 2 + 1) * 32 + li]);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qreg[s][0], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qreg[s][1], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qreg[s][0], st, 0, 0, 0);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] += st2[r];
-    if (j0 + 32 > L) {  // only the last tile can hold keys beyond L (uniform branch)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (j0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= L) st[r] = -INFINITY;
-    }
-    float tile_max = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tile_max = fmaxf(tile_max, st[r]);
-    tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 32, 64));
-    const float new_max = fmaxf(run_max, tile_max);
-    const float corr = __builtin_amdgcn_exp2f((run_max - new_max) * ec);  // exp(-inf) = 0 on the first tile
-    float psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      st[r] = __builtin_amdgcn_exp2f((st[r] - new_max) * ec);
-      psum += st[r];
-    }
-    psum += __shfl_xor(psum, 32, 64);
-    run_sum = run_sum * corr + psum;
-    run_max = new_max;
+  };
 
-    // P (x 2^14) as B operand: registers 8jj .. 8jj+7 -> the 8 k-slots of MFMA jj, split into fp16 pairs
-    f16x8 pb[2][2];
+  const int T = (L + 31) / 32;
+  load_tile(0);
+  store_tile(Ksh[0], Vsh[0]);
+  __syncthreads();
+  if (T > 1) load_tile(32);
+  f32x16 s_cur;
+  scores(Ksh[0], s_cur);
+  f16x8 p_prev[2][2];     // P(t-1) x 2^14 as B operand (hi, lo), registers 8jj .. 8jj+7 -> the 8 k-slots of MFMA jj
+  float corr_prev = 1.0f; // rescale of O that P(t-1)'s tile asked for
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      unsigned short h[8], lo[8];
+  for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) split2h(st[8 * jj + i] * 16384.f, h[i], lo[i]);
-      pb[jj][0] = as_f16x8(pack8(h));
-      pb[jj][1] = as_f16x8(pack8(lo));
-    }
-    const bool rescale = __any(corr != 1.0f);  // the running maximum moves in the first few tiles only
+    for (int sp = 0; sp < 2; ++sp) p_prev[jj][sp] = as_f16x8(make_uint4(0u, 0u, 0u, 0u));
+
+  // One iteration; the flags are compile-time so that the steady state (all true, no tail mask) is ONE basic block in which the
+  // scheduler interleaves the two streams (sched_group_barrier: one MFMA, then a few vector instructions, ...): a wave issues in order, so
+  // 24 MFMAs in a row would hold its softmax back for the 768 cycles they take to issue.
+  auto iteration = [&](int t, auto has_prev, auto has_next, auto has_cur, auto tail) {
+    constexpr bool HP = decltype(has_prev)::value, HN = decltype(has_next)::value, HC = decltype(has_cur)::value, TAIL = decltype(tail)::value;
+    __syncthreads();                                   // every wave has finished iteration t - 1 (its reads of K(t), V(t-2))
+    if (HN) store_tile(Ksh[(t + 1) & 1], Vsh[(t + 1) % 3]);
+    __syncthreads();
+    if (HN) load_tile((t + 2) * 32);                   // (clamped addresses: a tile beyond the last one re-reads valid memory, never stored)
+    if (HP) {
+      if (__any(corr_prev != 1.0f)) {                  // the running maximum moves in the first few tiles only
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      f32x16 acc = o[cb];
-      if (rescale) {
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] *= corr;
+          for (int r = 0; r < 16; ++r) o[cb][r] *= corr_prev;
       }
+    }
+    // ---- matrix stream: O += P(t-1) V(t-1);  S(t+1) ----------------------------------------------------------------------------
+    f32x16 s_next;
+    if (HP) {
+      const unsigned short *vtile = Vsh[(t - 1) % 3];
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        f32x16 acc = o[cb];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          f16x8 a[2];
+#pragma unroll
+          for (int sp = 0; sp < 2; ++sp) {
+            const unsigned short *rowp = vtile + (sp * CP + cb * 32 + li) * VROW_H2 + 16 * jj + 4 * lh;
+            const uint2 p0 = *reinterpret_cast<const uint2 *>(rowp), p1 = *reinterpret_cast<const uint2 *>(rowp + 8);
+            a[sp] = as_f16x8(make_uint4(p0.x, p0.y, p1.x, p1.y));
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], p_prev[jj][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], p_prev[jj][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], p_prev[jj][0], acc, 0, 0, 0);
+        }
+        o[cb] = acc;
+      }
+    }
+    if (HN) scores(Ksh[(t + 1) & 1], s_next);
+    // ---- vector stream: online softmax of S(t) ------------------------------------------------------------------------------------
+    if (HC) {
+      const int j0 = t * 32;
+      f32x16 st = s_cur;
+      if (TAIL) {         // only the last tile can hold keys beyond L
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (j0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= L) st[r] = -INFINITY;
+      }
+      float tile_max = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tile_max = fmaxf(tile_max, st[r]);
+      tile_max = fmaxf(tile_max, __shfl_xor(tile_max, 32, 64));
+      const float new_max = fmaxf(run_max, tile_max);
+      // exponent offset of this tile, ROUNDED once; the rescale of what was accumulated under the previous offset uses the difference of
+      // the two rounded offsets, so every probability of a query carries the same factor 2^(rounding error) and it cancels in the
+      // normalisation (an offset recomputed per tile from the running maximum would not: measured 7.1e-7 -> 8.3e-7 vs float64)
+      float mneg = -new_max * ec;
+      asm("" : "+v"(mneg));   // opaque: contracted into the subtraction below, the product would not be the ROUNDED value the exponentials use
+      const float corr = __builtin_amdgcn_exp2f(mneg - run_mneg);  // exp2(-inf) = 0 on the first tile (run_mneg = +inf)
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], ec, mneg));   // one rounding of the argument (was subtract, then multiply)
+        psum += st[r];
+      }
+      psum += __shfl_xor(psum, 32, 64);
+      run_sum = run_sum * corr + psum;
+      run_max = new_max;
+      run_mneg = mneg;
+      corr_prev = corr;
+      // P x 2^14 split into fp16 pairs, written as ELEMENTS of the operand vectors: the compiler converts with v_fma_mixlo / mixhi_f16
+      // straight into the two halves of a register (the unsigned-short form packed every pair with a shift and an or: 32 instructions a tile)
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        f16x8 a[2];
+        f16x8 hv, lv;
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          const unsigned short *rowp = Vsh + (sp * CP + cb * 32 + li) * VROW_H2 + 16 * jj + 4 * lh;
-          const uint2 p0 = *reinterpret_cast<const uint2 *>(rowp), p1 = *reinterpret_cast<const uint2 *>(rowp + 8);
-          a[sp] = as_f16x8(make_uint4(p0.x, p0.y, p1.x, p1.y));
+        for (int i = 0; i < 8; ++i) {
+          const float v = st[8 * jj + i] * 16384.f;
+          const _Float16 hi = (_Float16)v;
+          hv[i] = hi;
+          lv[i] = (_Float16)(v - (float)hi);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], pb[jj][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], pb[jj][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], pb[jj][0], acc, 0, 0, 0);
+        p_prev[jj][0] = hv;
+        p_prev[jj][1] = lv;
       }
-      o[cb] = acc;
     }
+    if (HP && HN && HC && !TAIL) {
+      // steady state: 24 MFMAs against ~200 vector instructions
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // eight vector-ALU instructions
+      }
+    }
+    if (HN) s_cur = s_next;
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+  const bool tail = (L & 31) != 0;
+  if (T == 1) {
+    if (tail) iteration(0, no{}, no{}, yes{}, yes{}); else iteration(0, no{}, no{}, yes{}, no{});
+  } else {
+    iteration(0, no{}, yes{}, yes{}, no{});
+    for (int t = 1; t + 1 < T; ++t) iteration(t, yes{}, yes{}, yes{}, no{});
+    if (tail) iteration(T - 1, yes{}, no{}, yes{}, yes{}); else iteration(T - 1, yes{}, no{}, yes{}, no{});
   }
+  iteration(T, yes{}, no{}, no{}, no{});
   const float inv = 1.0f / (run_sum * 16384.f * sv);  // sv and 2^14 are powers of two
   float *ob = out + (size_t)bi * bs_o;
   if (i0 + li < L) {
