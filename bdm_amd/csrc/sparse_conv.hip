@@ -223,7 +223,19 @@ __global__ __launch_bounds__(1024) void sparse_vox_features_lds_kernel(int c, in
   const int lim = min(OUT == 0 ? min((nocc + 127) & ~127, n_max) : n_max, k0 + cells_per);
   if (k0 >= lim) return;  // nothing to write in this slice
   const int nch = min(8, c - g * 8);
-  // the cells' point lists (two dependent index loads) are fetched while the rows stream into LDS
+  // The group's rows go to registers FIRST (independent loads, 16 bytes each): a wave issues in order, so behind the index chain below
+  // (cell -> count / start -> first list entries: three dependent round trips, each ending in a wait) they would not even be requested
+  // before the chain is through -- four serial trips instead of three overlapped with one.
+  const float *fb = feat + (size_t)bi * bs_f + (size_t)g * 8 * ld_f;
+  const bool vec = (n & 3) == 0 && (ld_f & 3) == 0 && ((reinterpret_cast<size_t>(fb) & 15) == 0) && (n >> 2) <= T;   // 16-byte row pieces, one per thread and row
+  const int n4 = n >> 2;
+  float4 rowv[8];
+  if (vec) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      rowv[j] = reinterpret_cast<const float4 *>(fb + (size_t)min(j, nch - 1) * ld_f)[min(tid, n4 - 1)];
+  }
+  // the cells' point lists (two dependent index loads) are fetched while the rows stream in
   int cs[CPT], cc[CPT];
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
@@ -244,9 +256,13 @@ __global__ __launch_bounds__(1024) void sparse_vox_features_lds_kernel(int c, in
 #pragma unroll
     for (int u = 0; u < 4; ++u) pre[i][u] = cc[i] > 0 ? so[min(u, cc[i] - 1)] : 0;
   }
-  const float *fb = feat + (size_t)bi * bs_f + (size_t)g * 8 * ld_f;
-  if ((n & 3) == 0 && (ld_f & 3) == 0 && ((reinterpret_cast<size_t>(fb) & 15) == 0)) {  // 16-byte row pieces
-    const int n4 = n >> 2;
+  if (vec) {
+    if (tid < n4) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        reinterpret_cast<float4 *>(frows + j * n)[tid] = j < nch ? rowv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else if ((n & 3) == 0 && (ld_f & 3) == 0 && ((reinterpret_cast<size_t>(fb) & 15) == 0)) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float4 *src = reinterpret_cast<const float4 *>(fb + (size_t)min(j, nch - 1) * ld_f);

@@ -1,5 +1,11 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do
-echo "base: $(BDM_LIB_PATH=bdm_amd/libbdm_hip_base.so python tools/attn_bench.py 2>&1 | tail -1)"
-echo "new : $(python tools/attn_bench.py 2>&1 | tail -1)"
+R=$GRAFT_REPO_ROOT
+python -m pytest tests/test_hip_dense.py -x -q 2>&1 | tail -2
+cd /tmp && export TMPDIR=/tmp
+for v in base new base new; do
+  if [ $v = base ]; then export BDM_LIB_PATH=$R/bdm_amd/libbdm_hip_base.so; else unset BDM_LIB_PATH; fi
+  rm -rf /tmp/trf_$v
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/trf_$v -o fwd -- python3 $R/tools/trace_forward.py pc2 > /dev/null 2>&1
+  echo "== $v"
+  python3 $R/tools/trace_summary.py $(find /tmp/trf_$v -name "*kernel_trace.csv" | head -1) 80 | grep "sparse_vox_features\|^[0-9]* launches"
 done
