@@ -337,8 +337,11 @@ static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, f
   // 8^3 grids: 128-voxel tiles with 4 waves double the workgroup count; they win when the 256-voxel tiling cannot fill the chip
   // (128 -> 128 at B = 16: 40.6 -> 30.4 us) and lose when it can (256 -> 256: 96 -> 114 us).
   const bool r8_small = r == 8 && (long long)b * 2 * cdiv(cout, 32) < 256;
-  // one or two shapes (config C1): 64-voxel tiles, one 16 x 16 block per wave -- twice the workgroups, half the chain per wave
-  const bool r8_tiny = r == 8 && (long long)b * 4 * cdiv(cout, 32) <= 64;
+  // ... and 64-voxel tiles (one 16 x 16 block per wave: twice the workgroups again, half the chain per wave) when the 128-voxel tiling
+  // cannot either: the LARGEST tile that still gives a workgroup per CU wins at every (batch, width) measured (round 5, us per launch,
+  // 64 / 128 / 256-voxel tiles: B = 8, 128 channels 20.1 / 27.9 / 37.5; B = 4, 256 channels 36.4 / 50.3 / 69.1; B = 8, 256 channels
+  // 71.2 / 54.8 / 73.3; B = 16, 128 channels 38.0 / 30.6 / 39.7; B = 16, 256 channels 144.7 / 109.6 / 83.4).  Same K order, same bits.
+  const bool r8_tiny = r == 8 && (long long)b * 4 * cdiv(cout, 32) < 256;
   // 16^3 / 32^3 grids of a few shapes (config C1 is ONE shape): 64-row x 512-voxel tiles give 16 / 64 workgroups, each walking
   // the whole K loop with 48 MFMAs per step; 32-row (and at 16^3 256-voxel) tiles put 4x / 2x as many CUs on the problem with a
   // 4x / 2x shorter chain per wave (B = 1: 114 -> 4x us at 16^3).  Same K order, same bits.
