@@ -346,7 +346,10 @@ static int conv3d_h2_launch(int b, int cin, int cout, int r, const void *x_h2, f
   // the whole K loop with 48 MFMAs per step; 32-row (and at 16^3 256-voxel) tiles put 4x / 2x as many CUs on the problem with a
   // 4x / 2x shorter chain per wave (B = 1: 114 -> 4x us at 16^3).  Same K order, same bits.
   const long long big_wgs = (long long)b * (r == 32 ? 64 : 8) * cdiv(cout, 64);
-  const bool small = r != 8 && cout > 32 && big_wgs < 128;
+  // Threshold = a workgroup per CU (round 5, us per launch, big / small tiling: 16^3 128 channels B = 8 126.6 / 89.0, B = 16 149.1 / 190.5;
+  // 16^3 64 channels B = 8 66.7 / 26.6, B = 16 71.7 / 50.2; 32^3 64 channels B = 2 75.4 / 46.2, B = 4 84.2 / 89.2).  It was 128: the
+  // half-filled chip of 128 big workgroups lost 30 - 60 % (C4's 16^3 levels, C2's 64-channel 16^3 layer).
+  const bool small = r != 8 && cout > 32 && big_wgs < 256;
   if (r == 32) { tx = 2; ty = 8; }
   else if (r == 16) { tx = small ? 1 : 2; ty = 16; }
   else { tx = r8_tiny ? 1 : (r8_small ? 2 : 4); ty = 8; }
