@@ -1471,6 +1471,7 @@ def densify_rows(rows, class_vals, plan):
     return out
 
 
+COMPACT_16_MIN_ITEMS = 336    # the same for the whole voxel branch on lists at 16^3 (12 tiles per 1024-point shape: 28 shapes)
 SPARSE_DIL_MIN_ITEMS = 160   # tiles x channel blocks x shapes below which the compact convolution cannot fill the chip
 
 
@@ -1498,7 +1499,10 @@ def compact_tail_pays(batch, n_points, r, cout):
     if r == 32:
         tiles = min(64, max(1, (3 * n_points) // 512))
     elif r == 16 and cout <= 64:
+        # (round 5: the dense 16^3 convolution in its small tiling runs 50 us at B = 16, not 72: the lists win from ~28 shapes on --
+        # replayed step with / without them at 16^3: B = 16 4.925 / 4.885 ms, B = 24 7.336 / 7.301, B = 32 (N = 16384) 11.90 / 11.98)
         tiles = min(16, max(1, (3 * n_points) // 256))
+        return batch * tiles >= COMPACT_16_MIN_ITEMS
     else:
         return False
     return batch * tiles * (2 if cout > 64 else 1) >= SPARSE_DIL_MIN_ITEMS
