@@ -412,6 +412,11 @@ __global__ __launch_bounds__(256) void sparse_gemm_s3_kernel(int M, int G, int N
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  float cbv[2] = {0.f, 0.f};   // (bdm_sparse_conv_gemm_s3_cb's addend of this lane's two columns, requested before the K loop)
+  if (col_bias != nullptr) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) cbv[y] = col_bias[(size_t)bi * bs_cb + min(n0 + (wc * 2 + y) * 32 + li, N - 1)];
+  }
   // Staging registers are native vectors and the loads carry neither a branch nor a select on the loaded value (either
   // makes the wave wait for memory inside the load phase, i.e. no prefetch): rows >= M / columns >= N read a clamped
   // address and only feed outputs that are never stored; the channel groups >= G of the last stage are zeroed when the
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(256) void sparse_gemm_s3_kernel(int M, int G, int N
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
       const int nn = n0 + (wc * 2 + y) * 32 + li;
-      const float cb = (col_bias != nullptr && nn < N) ? col_bias[(size_t)bi * bs_cb + nn] : 0.f;  // (bdm_sparse_conv_gemm_h2_cb's addend)
+      const float cb = cbv[y];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wr * 2 + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;

@@ -162,6 +162,13 @@ __global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  // the per-shape column addend of this lane's two columns, requested BEFORE the K loop (read in the epilogue it was one more dependent
+  // round trip between the last MFMA and the stores of a workgroup that lives for two K stages)
+  float cbv[2] = {0.f, 0.f};
+  if (col_bias != nullptr) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) cbv[y] = col_bias[(size_t)bi * bs_cb + min(n0 + (wc * 2 + y) * 32 + li, N - 1)];
+  }
   constexpr int AI = 8 * BM / 256;
   // native-vector staging registers, loads without branch or select (see sparse_gemm_s3_kernel): rows / columns beyond the
   // matrix read a clamped address, channel groups >= G are zeroed on the way to LDS
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N
     for (int y = 0; y < 2; ++y) {
       const int nn = n0 + (wc * 2 + y) * 32 + li;
       const float post = nn < N ? inv_sw[nn % Cout] * inv_sx : 0.f;
-      const float cb = (col_bias != nullptr && nn < N) ? col_bias[(size_t)bi * bs_cb + nn] : 0.f;  // per-shape column addend (see the _cb entry point)
+      const float cb = cbv[y];  // per-shape column addend (see the _cb entry point)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wr * MX + x) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
