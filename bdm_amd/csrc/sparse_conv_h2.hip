@@ -164,10 +164,12 @@ __global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
   // the per-shape column addend of this lane's two columns, requested BEFORE the K loop (read in the epilogue it was one more dependent
   // round trip between the last MFMA and the stores of a workgroup that lives for two K stages)
-  float cbv[2] = {0.f, 0.f};
-  if (col_bias != nullptr) {
+  float cbv[2] = {0.f, 0.f}, postv[2];   // (likewise the per-column weight scales)
 #pragma unroll
-    for (int y = 0; y < 2; ++y) cbv[y] = col_bias[(size_t)bi * bs_cb + min(n0 + (wc * 2 + y) * 32 + li, N - 1)];
+  for (int y = 0; y < 2; ++y) {
+    const int nn = min(n0 + (wc * 2 + y) * 32 + li, N - 1);
+    postv[y] = inv_sw[nn % Cout];
+    if (col_bias != nullptr) cbv[y] = col_bias[(size_t)bi * bs_cb + nn];
   }
   constexpr int AI = 8 * BM / 256;
   // native-vector staging registers, loads without branch or select (see sparse_gemm_s3_kernel): rows / columns beyond the
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void sparse_gemm_h2_kernel(int M, int G, int N
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
       const int nn = n0 + (wc * 2 + y) * 32 + li;
-      const float post = nn < N ? inv_sw[nn % Cout] * inv_sx : 0.f;
+      const float post = postv[y] * inv_sx;
       const float cb = cbv[y];  // per-shape column addend (see the _cb entry point)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
