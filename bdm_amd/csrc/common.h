@@ -125,6 +125,33 @@ __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_f64(v, BDM_DPP_ROW_MIRROR);
   return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
 }
+// Sum over the 16 lanes of a DPP row, left in every lane of the row; over the 32 lanes of a half wave, left in every lane of the half.
+// BIT-IDENTICAL to the `__shfl_xor` butterflies (1, 2, 4, 8[, 16]) they replace: after each step all lanes of a group hold the group's sum and
+// the next step adds the same two partial sums (in the other order: floating-point addition is commutative).
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32(v, BDM_DPP_QUAD_XOR1);
+  v += dpp_f32(v, BDM_DPP_QUAD_XOR2);
+  v += dpp_f32(v, BDM_DPP_ROW_HALF_MIRROR);
+  v += dpp_f32(v, BDM_DPP_ROW_MIRROR);
+  return v;
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_f64(v, BDM_DPP_QUAD_XOR1);
+  v += dpp_f64(v, BDM_DPP_QUAD_XOR2);
+  v += dpp_f64(v, BDM_DPP_ROW_HALF_MIRROR);
+  v += dpp_f64(v, BDM_DPP_ROW_MIRROR);
+  return v;
+}
+__device__ __forceinline__ float half32_sum(float v) {   // all 64 lanes active
+  v = row16_sum(v);
+  const float lo = readlane_f32(v, 0) + readlane_f32(v, 16), hi = readlane_f32(v, 32) + readlane_f32(v, 48);
+  return (threadIdx.x & 32) ? hi : lo;
+}
+__device__ __forceinline__ double half32_sum(double v) {
+  v = row16_sum(v);
+  const double lo = readlane_f64(v, 0) + readlane_f64(v, 16), hi = readlane_f64(v, 32) + readlane_f64(v, 48);
+  return (threadIdx.x & 32) ? hi : lo;
+}
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_f32(v, BDM_DPP_QUAD_XOR1));
   v = fmaxf(v, dpp_f32(v, BDM_DPP_QUAD_XOR2));

@@ -279,11 +279,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
         }
       }
       if (gn_partial != nullptr) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          bs += __shfl_xor(bs, o, 64);
-          bq += __shfl_xor(bq, o, 64);
-        }
+        bs = row16_sum(bs);   // (DPP: bit-identical to the xor butterfly over the 16 voxels of the block)
+        bq = row16_sum(bq);
         if (l16 == 0) {
           const int nb = q * NW + wave;
           red[nb * NB + (mt * 4 + kg) * 2 + 0] = bs;

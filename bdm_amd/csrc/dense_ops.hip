@@ -65,8 +65,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
       const double *pp = gn.in_partial + ((size_t)bi * gn.in_G + g) * gn.in_S * 2;
       for (int sl = l; sl < gn.in_S; sl += 32) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
     }
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    a = half32_sum(a); q = half32_sum(q);   // (the 32 lanes of this group: DPP, bit-identical to the xor butterfly)
     if (l == 0 && g < gn.in_G) {
       const double cnt = (double)cgi * N, mean = a / cnt;
       double var = q / cnt - mean * mean;
@@ -253,11 +252,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
       if (gn.out_partial != nullptr) {  // this 32 x 32 sub-tile's sums: butterfly over its 32 columns, parked in LDS
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#pragma unroll
-          for (int o = 1; o < 32; o <<= 1) {
-            bs[x][j] += __shfl_xor(bs[x][j], o, 64);
-            bq[x][j] += __shfl_xor(bq[x][j], o, 64);
-          }
+          bs[x][j] = half32_sum(bs[x][j]);   // DPP row sums + one readlane per row: bit-identical to the xor butterfly over the 32 columns,
+          bq[x][j] = half32_sum(bq[x][j]);   // without its five dependent LDS-crossbar round trips per value (160 per wave in a 2 x 2 tile)
           if (li == 0) {
             red[wave * NBW + (((x * NI + y) * 2 + lh) * 4 + j) * 2 + 0] = bs[x][j];
             red[wave * NBW + (((x * NI + y) * 2 + lh) * 4 + j) * 2 + 1] = bq[x][j];
@@ -351,8 +347,7 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(int M, int K, int N, con
       const double *pp = gn.in_partial + ((size_t)bi * gn.in_G + g) * gn.in_S * 2;
       for (int sl = l; sl < gn.in_S; sl += 32) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
     }
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    a = half32_sum(a); q = half32_sum(q);   // (the 32 lanes of this group: DPP, bit-identical to the xor butterfly)
     if (l == 0 && g < gn.in_G) {
       const double cnt = (double)cgi * N, mean = a / cnt;
       double var = q / cnt - mean * mean;

@@ -42,16 +42,7 @@ using namespace bdm;
 typedef __attribute__((ext_vector_type(4))) float f32x4a;
 typedef float f32x4v_t __attribute__((ext_vector_type(4)));
 
-// sum over the 16 lanes of a DPP row, left in every lane of the row: quad_perm xor 1, xor 2, half-row mirror, row mirror -- four
-// 1-pass DPP moves instead of four dependent ds_bpermute round trips per value (the epilogue of a 64 x 64 wave tile reduces 32 values:
-// 128 bpermutes were a quarter of it).  Fixed order: deterministic.
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
-  return v;
-}
+// (row16_sum: common.h)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // plan side: dilated voxel list, ranks, plane prefixes, tile table
