@@ -152,6 +152,11 @@ __device__ __forceinline__ double half32_sum(double v) {
   const double lo = readlane_f64(v, 0) + readlane_f64(v, 16), hi = readlane_f64(v, 32) + readlane_f64(v, 48);
   return (threadIdx.x & 32) ? hi : lo;
 }
+// ... and over all 64 lanes in the butterfly's association ((row 0 + row 1) + (row 2 + row 3)): bit-identical to xor 1 .. 32; wave-uniform
+__device__ __forceinline__ double wave_sum_bfly(double v) {
+  v = row16_sum(v);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_f32(v, BDM_DPP_QUAD_XOR1));
   v = fmaxf(v, dpp_f32(v, BDM_DPP_QUAD_XOR2));

@@ -462,8 +462,7 @@ __global__ __launch_bounds__(256) void to_h2_stats_kernel(int C, int V, int G, i
     const double *pp = partial + ((size_t)bi * G + gi) * S * 2;
     double a = 0.0, q = 0.0;
     for (int sl = tid; sl < S; sl += 256) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    a = wave_sum_bfly(a); q = wave_sum_bfly(q);   // (DPP + readlanes, bit-identical to the 64-lane xor butterfly)
     if (lane == 0) { s_red[gi - g_lo][wave][0] = a; s_red[gi - g_lo][wave][1] = q; }
   }
   __syncthreads();
@@ -552,8 +551,7 @@ __global__ __launch_bounds__(256) void to_h2_stats_compact_kernel(int C, int V, 
     const double *pp = partial + ((size_t)bi * G + gi) * S * 2;
     double a = 0.0, q = 0.0;
     for (int sl = tid; sl < S; sl += 256) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    a = wave_sum_bfly(a); q = wave_sum_bfly(q);   // (DPP + readlanes, bit-identical to the 64-lane xor butterfly)
     if (lane == 0) { s_red[gi - g_lo][wave][0] = a; s_red[gi - g_lo][wave][1] = q; }
   }
   __syncthreads();

@@ -469,8 +469,7 @@ __global__ __launch_bounds__(256) void pw_skinny_kernel(int M, int K, int N, con
   if (gn.out_partial != nullptr) {
     // GroupNorm statistics of the tile (layout of pw_gemm_kernel's partials: slices = column tiles x row tiles per group):
     // butterfly over the 32 columns, then the eight (wave, half) row blocks of 4 are added per group in fp64 in a fixed order
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) { gs += __shfl_xor(gs, o, 64); gq += __shfl_xor(gq, o, 64); }
+    gs = half32_sum(gs); gq = half32_sum(gq);   // (bit-identical to the xor butterfly)
     __syncthreads();  // red is dead
     float *blk = &red[0][0][0];  // [8 row blocks][2]
     if (li == 0) { blk[(2 * wave + lh) * 2] = gs; blk[(2 * wave + lh) * 2 + 1] = gq; }
@@ -980,8 +979,7 @@ __global__ void max_u_gn_kernel(int c, int m, int u, int lpr, int G, int S, cons
     const double *pp = partial + ((size_t)bi * G + g) * S * 2;
     double a = 0.0, q = 0.0;
     for (int sl = lane; sl < S; sl += 64) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    a = wave_sum_bfly(a); q = wave_sum_bfly(q);   // (DPP + readlanes, bit-identical to the 64-lane xor butterfly)
     const double cnt = (double)cg * m * u, mean = a / cnt;
     double var = q / cnt - mean * mean;
     if (var < 0) var = 0;

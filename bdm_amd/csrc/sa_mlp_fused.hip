@@ -48,8 +48,7 @@ __device__ __forceinline__ void group_stats8(const double *__restrict__ partial,
 #pragma unroll
     for (int i = 0; i + span < 8; i += 2 * span) { va[i] += va[i + span]; vq[i] += vq[i + span]; }
   double a = va[0], q = vq[0];
-#pragma unroll
-  for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+  a = half32_sum(a); q = half32_sum(q);   // (bit-identical to the xor butterfly over the group's 32 lanes)
   if (l == 0 && g < G) {
     const double mu = a / count;
     double var = q / count - mu * mu;
