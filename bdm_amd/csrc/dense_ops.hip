@@ -81,6 +81,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     }
     // (visible to every wave after the first barrier of the K loop)
   }
+  // the tile's per-row terms (bias, per-shape bias) go to LDS now: fetched in the epilogue they were one more dependent global round trip
+  // between a workgroup's last MFMA and its stores (visible to every wave after the first barrier of the K loop)
+  __shared__ float s_rowterm[2][BM];
+  if (tid < BM) {
+    const int mm = min(m0 + tid, M - 1);
+    s_rowterm[0][tid] = bias ? bias[mm] : 0.f;
+    s_rowterm[1][tid] = bbias ? bbias[(size_t)bi * ldbb + mm] : 0.f;
+  }
   W += (size_t)bi * bsw;
   const float *Xb = X + (size_t)bi * bsx;
   const float *X2b = gn.x2 ? gn.x2 + (size_t)bi * gn.bsx2 : nullptr;
@@ -216,14 +224,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
   for (int x = 0; x < MI; ++x) {
     float badd[16], bb[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) badd[r] = bb[r] = 0.f;
-    if (bias) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) badd[r] = bias[min(m0 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1)];
-    }
-    if (bbias) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bb[r] = bbias[(size_t)bi * ldbb + min(m0 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1)];
+    for (int r = 0; r < 16; ++r) {
+      badd[r] = s_rowterm[0][x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+      bb[r] = s_rowterm[1][x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
     }
 #pragma unroll
     for (int y = 0; y < NI; ++y) {
