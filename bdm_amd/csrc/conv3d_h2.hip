@@ -171,6 +171,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
     for (int q = 0; q < NT; ++q) acc[a][q] = f32x4a{0.f, 0.f, 0.f, 0.f};
 
+  // the tile's output scales and biases go to LDS now (visible after the K loop's first barrier): read from global memory in the epilogue they
+  // were one more dependent round trip between the last MFMA and the stores (as in sconv_dil_kernel)
+  __shared__ float s_osc[BM], s_obi[BM];
+  if (tid < BM) {
+    const int m = min(m0 + tid, Cout - 1);
+    s_osc[tid] = inv_scale[m] * x_inv_scale;
+    s_obi[tid] = bias ? bias[m] : 0.f;
+  }
   for (int e = tid; e < 2 * HALO; e += NT_) Xs[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4,
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + mt * 16 + 4 * kg + i;
         if (m < Cout) {
-          const float v = acc[mt][q][i] * (inv_scale[m] * x_inv_scale) + (bias ? bias[m] : 0.f);
+          const float v = acc[mt][q][i] * s_osc[mt * 16 + 4 * kg + i] + s_obi[mt * 16 + 4 * kg + i];
           yb[(size_t)m * R3 + gvox] = v;
           bs += v;
           bq = __builtin_fmaf(v, v, bq);  // explicitly fused: the same rounding in every tile variant

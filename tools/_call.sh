@@ -1,12 +1,10 @@
 cd $GRAFT_REPO_ROOT
-echo "base:"; BDM_LIB_PATH=bdm_amd/libbdm_hip_base.so python tools/forward_hash.py 2>&1 | tail -2
-echo "new:"; python tools/forward_hash.py 2>&1 | tail -2
-echo "base B=16:"; TB=16 TN=4096 BDM_LIB_PATH=bdm_amd/libbdm_hip_base.so python tools/forward_hash.py 2>&1 | tail -2
-echo "new B=16:"; TB=16 TN=4096 python tools/forward_hash.py 2>&1 | tail -2
-for i in 1 2 3; do
-echo "== step base"; BDM_LIB_PATH=bdm_amd/libbdm_hip_base.so python tools/replay_host_time.py 16 4096 2>&1 | grep replayed | tail -1
-echo "== step new"; python tools/replay_host_time.py 16 4096 2>&1 | grep replayed | tail -1
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+for v in base new base new; do
+  if [ $v = base ]; then export BDM_LIB_PATH=$R/bdm_amd/libbdm_hip_base.so; else unset BDM_LIB_PATH; fi
+  rm -rf /tmp/trf_$v
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/trf_$v -o fwd -- python3 $R/tools/trace_forward.py pc2 > /dev/null 2>&1
+  echo "== $v"
+  python3 $R/tools/trace_summary.py $(find /tmp/trf_$v -name "*kernel_trace.csv" | head -1) 80 | grep "conv3d_h2q\|^[0-9]* launches"
 done
-echo "== B=1 base"; BDM_LIB_PATH=bdm_amd/libbdm_hip_base.so python tools/replay_host_time.py 1 1024 2>&1 | grep replayed | tail -1
-echo "== B=1 new"; python tools/replay_host_time.py 1 1024 2>&1 | grep replayed | tail -1
-python -m pytest tests/test_hip_dense.py tests/test_hip_net.py tests/test_hip_sa_fused.py -x -q 2>&1 | grep -v "^PARITY" | tail -3
