@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                                                             const uint4 *__restrict__ ks,
                                                             const unsigned short *__restrict__ vt,
                                                             const float *__restrict__ amax, float *__restrict__ out,
-                                                            long long bs_o, int ld_o) {
+                                                            long long bs_o, int ld_o, int ksplit, float *__restrict__ part_o,
+                                                            float *__restrict__ part_ml) {
   constexpr int C8 = 4 * CB, CP = 32 * CB, KT = C8 * 2 * 32, VT = 2 * CP * 4;  // uint4 items per K / V tile
   constexpr int KI = (KT + 255) / 256, VI = (VT + 255) / 256;
   constexpr int VSZ = 2 * CP * VROW_H2;
@@ -94,9 +95,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   // XCD-aware item order: workgroup ids are dealt round-robin to the 8 XCDs; XCD x takes the contiguous (shape, query tile) items
   // [x * per, (x + 1) * per), so a shape's K / V stay in ONE XCD's L2 (they were fetched by all eight: 272 MB per launch at B = 16, PMC)
-  const int qtiles = (L + 127) / 128, total = qtiles * nb, per = (total + 7) >> 3;
-  const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (item >= total) return;
+  // ksplit > 1 (few shapes: the (shape, query tile) items alone cannot fill the chip, and an item is a chain of L / 32 dependent key tiles):
+  // an item is (shape, query tile, KEY RANGE); it leaves its unnormalised accumulator, exponent offset and row sum, and
+  // attn_combine_kernel merges the ranges (the order of the sum over keys changes: a different, equally valid rounding)
+  const int qtiles = (L + 127) / 128, total = qtiles * nb * ksplit, per = (total + 7) >> 3;
+  const int item0 = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (item0 >= total) return;
+  const int split = item0 % ksplit, item = item0 / ksplit;
   const int bi = item / qtiles;
   const int i0 = ((item - bi * qtiles) * 4 + wave) * 32;  // this wave's first query
   const uint4 *qb = qs + (size_t)bi * C8 * 2 * L, *kb = ks + (size_t)bi * C8 * 2 * L;
@@ -162,13 +167,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     }
   };
 
-  const int T = (L + 31) / 32;
-  load_tile(0);
-  store_tile(Ksh[0], Vsh[0]);
+  const int T_all = (L + 31) / 32, t_per = (T_all + ksplit - 1) / ksplit;
+  const int tb = min(split * t_per, T_all), T = min(tb + t_per, T_all);   // this item's key tiles [tb, T); buffers are indexed by the absolute tile
+  if (tb >= T) {   // (an empty range: only when ksplit does not divide the tile count) -- contributes nothing
+    if (ksplit > 1 && i0 + li < L && lh == 0) {
+      float *ml = part_ml + (((size_t)split * nb + bi) * L + i0 + li) * 2;
+      ml[0] = INFINITY; ml[1] = 0.f;
+    }
+    return;
+  }
+  load_tile(tb * 32);
+  store_tile(Ksh[tb & 1], Vsh[tb % 3]);
   __syncthreads();
-  if (T > 1) load_tile(32);
+  if (T - tb > 1) load_tile((tb + 1) * 32);
   f32x16 s_cur;
-  scores(Ksh[0], s_cur);
+  scores(Ksh[tb & 1], s_cur);
   f16x8 p_prev[2][2];     // P(t-1) x 2^14 as B operand (hi, lo), registers 8jj .. 8jj+7 -> the 8 k-slots of MFMA jj
   float corr_prev = 1.0f; // rescale of O that P(t-1)'s tile asked for
 #pragma unroll
@@ -276,15 +289,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
-  const bool tail = (L & 31) != 0;
-  if (T == 1) {
-    if (tail) iteration(0, no{}, no{}, yes{}, yes{}); else iteration(0, no{}, no{}, yes{}, no{});
+  const bool tail = (L & 31) != 0 && T == T_all;   // (keys beyond L live in the last tile of the whole range only)
+  if (T - tb == 1) {
+    if (tail) iteration(tb, no{}, no{}, yes{}, yes{}); else iteration(tb, no{}, no{}, yes{}, no{});
   } else {
-    iteration(0, no{}, yes{}, yes{}, no{});
-    for (int t = 1; t + 1 < T; ++t) iteration(t, yes{}, yes{}, yes{}, no{});
+    iteration(tb, no{}, yes{}, yes{}, no{});
+    for (int t = tb + 1; t + 1 < T; ++t) iteration(t, yes{}, yes{}, yes{}, no{});
     if (tail) iteration(T - 1, yes{}, no{}, yes{}, yes{}); else iteration(T - 1, yes{}, no{}, yes{}, no{});
   }
   iteration(T, yes{}, no{}, no{}, no{});
+  if (ksplit > 1) {   // partial result of this key range: O (unnormalised, under the offset run_mneg), the offset and the row sum
+    if (i0 + li < L) {
+      float *po = part_o + ((size_t)split * nb + bi) * CP * (size_t)L;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) po[(size_t)(cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * L + i0 + li] = o[cb][r];
+      if (lh == 0) {
+        float *ml = part_ml + (((size_t)split * nb + bi) * L + i0 + li) * 2;
+        ml[0] = run_mneg; ml[1] = run_sum;
+      }
+    }
+    return;
+  }
   const float inv = 1.0f / (run_sum * 16384.f * sv);  // sv and 2^14 are powers of two
   float *ob = out + (size_t)bi * bs_o;
   if (i0 + li < L) {
@@ -298,13 +325,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   }
 }
 
+// out[c][l] = sum_s O_s[c][l] 2^(m - m_s) / (sum_s l_s 2^(m - m_s)) / (2^14 sv),  m = min_s m_s (the offset of the largest running maximum):
+// the key ranges of a query in ascending order -- a fixed order, deterministic
+__global__ void attn_combine_kernel(int C, int CP, int L, int nb, int ksplit, const float *__restrict__ part_o,
+                                    const float *__restrict__ part_ml, const float *__restrict__ amax, float *__restrict__ out,
+                                    long long bs_o, int ld_o) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.z;
+  if (l >= L) return;
+  float m = INFINITY;
+  for (int s = 0; s < ksplit; ++s) m = fminf(m, part_ml[(((size_t)s * nb + bi) * L + l) * 2]);
+  float f[8], den = 0.f;   // ksplit <= 8
+  for (int s = 0; s < ksplit; ++s) {
+    const float *ml = part_ml + (((size_t)s * nb + bi) * L + l) * 2;
+    f[s] = ml[1] > 0.f ? __builtin_amdgcn_exp2f(m - ml[0]) : 0.f;
+    den += ml[1] * f[s];
+  }
+  const float sv = h2_scale_from_max(amax[bi * 3 + 2]);
+  const float inv = 1.0f / (den * 16384.f * sv);
+  for (int c = blockIdx.y; c < C; c += gridDim.y) {
+    float acc = 0.f;
+    for (int s = 0; s < ksplit; ++s)
+      if (f[s] != 0.f) acc += part_o[(((size_t)s * nb + bi) * CP + c) * (size_t)L + l] * f[s];
+    out[(size_t)bi * bs_o + (size_t)c * ld_o + l] = acc * inv;
+  }
+}
+
+// key ranges per (shape, query tile): 1 when those items fill the chip; the choice depends on the sizes only (and is the same for 1 .. 3 shapes
+// of 4096 positions, so the small-batch equality tests compare like with like)
+static inline int attn_ksplit(int b, int l) {
+  const char *e = getenv("BDM_ATTN_KSPLIT");
+  if (e != nullptr && e[0] >= '1' && e[0] <= '8') return e[0] - '0';
+  const long long items = (long long)b * ((l + 127) / 128);
+  // measured at l = 4096, 64 channels (us per call, 1 / 2 / 4 / 8 ranges): 1 shape 131 / 82 / 60 / 59, 3 shapes 140 / 96 / 87 / 90, 8 shapes 165 / 149 / 158 / 174
+  return l < 1024 ? 1 : (items < 128 ? 4 : (items < 512 ? 2 : 1));
+}
+extern "C" int bdm_attention_h2_key_slices(int b, int l) { return attn_ksplit(b, l); }
 static inline int attn_cp(int c) { return c <= 32 ? 32 : 64; }
 static inline int attn_lp(int l) { return (l + 7) / 8 * 8; }
 
 extern "C" size_t bdm_attention_h2_workspace_bytes(int b, int c, int l) {
   if (l <= 64 || c > 64) return 0;
   const size_t cp = attn_cp(c), qk = (size_t)(cp / 8) * 2 * l * 16, v = 2 * cp * (size_t)attn_lp(l) * 2;
-  return (size_t)b * (2 * qk + v) + 64;
+  return (size_t)b * (2 * qk + v) + 64 + (size_t)8 * b * (cp + 2) * l * sizeof(float) + 64;   // + partial results of up to 8 key ranges
 }
 
 // out (b, c, l) = softmax_keys(q^T k) applied to v, for q, k, v (b, c, l) rows of stride ld_qkv; amax[3 s + 0..2] = max |q|, |k|, |v| of
@@ -322,14 +384,19 @@ extern "C" int bdm_attention_core_h2(int b, int c, int l, const float *q, const 
   unsigned short *vt = reinterpret_cast<unsigned short *>(ks + qk_rec);
   hipLaunchKernelGGL(attn_split_qk_h2_kernel, dim3(cdiv(l, 128), c8, 2 * b), dim3(128), 0, s, c, l, q, k, bs_qkv, ld_qkv, amax, qs, ks);
   hipLaunchKernelGGL(attn_split_v_h2_kernel, dim3(cdiv(lp / 8, 64), cp, b), dim3(64), 0, s, c, cp, l, lp, v, bs_qkv, ld_qkv, amax, vt);
-  const long long total = (long long)cdiv(l, 128) * b;
+  const int ksplit = attn_ksplit(b, l);
+  const long long total = (long long)cdiv(l, 128) * b * ksplit;
   BDM_REQUIRE(total < (1ll << 28), "attention_core_h2: too many workgroups");
+  float *part_o = reinterpret_cast<float *>((reinterpret_cast<size_t>(vt + (size_t)b * 2 * cp * lp) + 63) & ~(size_t)63);
+  float *part_ml = part_o + (size_t)ksplit * b * cp * l;
   dim3 grid((unsigned)(8 * ((total + 7) / 8)));
   if (cp == 32)
     hipLaunchKernelGGL(attn_flash_h2_kernel<1>, grid, dim3(256), 0, s, c, l, lp, b, (const uint4 *)qs, (const uint4 *)ks, vt, amax, out,
-                       bs_o, ld_o);
+                       bs_o, ld_o, ksplit, part_o, part_ml);
   else
     hipLaunchKernelGGL(attn_flash_h2_kernel<2>, grid, dim3(256), 0, s, c, l, lp, b, (const uint4 *)qs, (const uint4 *)ks, vt, amax, out,
-                       bs_o, ld_o);
+                       bs_o, ld_o, ksplit, part_o, part_ml);
+  if (ksplit > 1)
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(cdiv(l, 256), 8, b), dim3(256), 0, s, c, cp, l, b, ksplit, part_o, part_ml, amax, out, bs_o, ld_o);
   return launch_status("attention_core_h2");
 }

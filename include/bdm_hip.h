@@ -284,6 +284,10 @@ int bdm_attention_core(int b, int c, int l, const float *q, const float *k, cons
  * shape s (the projection GEMM leaves them: bdm_pointwise_conv_gn amax with amax_rows = c) and a workspace of bdm_attention_h2_workspace_bytes;
  * 64 < l, c <= 64 */
 size_t bdm_attention_h2_workspace_bytes(int b, int c, int l);
+/* Key ranges per (shape, query tile) of bdm_attention_core_h2 for b shapes of l positions: 1 when the (shape, query tile) items fill the chip;
+ * 2 or 4 for few shapes (each range leaves an unnormalised partial result, merged in ascending key order: deterministic, and a function of
+ * (b, l) only -- but a shape's bits then depend on how many shapes share its launch; BDM_ATTN_KSPLIT=1..8 fixes the count). */
+int bdm_attention_h2_key_slices(int b, int l);
 int bdm_attention_core_h2(int b, int c, int l, const float *q, const float *k, const float *v, long long bs_qkv, int ld_qkv,
                           const float *amax, float *out, long long bs_o, int ld_o, void *workspace, void *stream);
 

@@ -136,6 +136,9 @@ def _forward_case(cls, B, N, extra, seed, row, monkeypatch):
     pays, tail = ops.sparse_dil_pays, ops.compact_tail_pays
     monkeypatch.setattr(ops, "sparse_dil_pays", lambda b, n, r, c: pays(B, n, r, c))   # the batch's choices, whatever the batch
     monkeypatch.setattr(ops, "compact_tail_pays", lambda b, n, r, c: tail(B, n, r, c))
+    # (the voxel attention splits a query's keys into ranges when few shapes share a launch: bdm_attention_h2_key_slices -- the batch's count)
+    from bdm_amd import _lib as L
+    monkeypatch.setenv("BDM_ATTN_KSPLIT", str(L.lib().bdm_attention_h2_key_slices(B, 4096)))
     alone = net(x[row:row + 1].contiguous().cuda(), t[row:row + 1].cuda()).cpu()
     monkeypatch.undo()
     return got, ref, alone, alone_default
