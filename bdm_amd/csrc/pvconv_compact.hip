@@ -55,8 +55,7 @@ __device__ __forceinline__ void all_group_stats(const double *__restrict__ parti
       const double *pp = partial + ((size_t)bi * G + g) * S * 2;
       for (int sl = l; sl < S; sl += 32) { a += pp[2 * sl]; q += pp[2 * sl + 1]; }
     }
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    a = half32_sum(a); q = half32_sum(q);   // (DPP row sums + readlanes: bit-identical to the xor butterfly over the group's 32 lanes)
     if (l == 0 && g < G) {
       const double mu = a / count;
       double var = q / count - mu * mu;
@@ -93,13 +92,42 @@ __global__ __launch_bounds__(256) void to_h2_rows_kernel(int C, int V, int G, in
   constexpr int RB = 512;
   if ((int)blockIdx.x * RB >= nd && blockIdx.x != 0) return;
   const int cg = C / G;
+  // Requested BEFORE the statistics, which they do not depend on (a wave issues in order: behind all_group_stats -- a global round trip, a
+  // reduction and a barrier -- the affine parameters and the first rows were two more dependent round trips): this thread's channel
+  // parameters (C <= 256 = one channel per thread) and its first four rows.
+  const float g_pre = tid < C ? gamma[tid] : 0.f, b_pre = tid < C ? beta[tid] : 0.f;
+  const int per_pass = blockDim.x / C8;                       // rows per pass (C8 <= 32)
+  const int c8 = tid % C8, rl = tid / C8;
+  const int nch = min(8, C - c8 * 8);
+  const bool vec = (C & 3) == 0 && nch == 8;
+  auto load_row = [&](int j, float (&in)[8]) {
+    if (dense_in) {
+      const int v = dil_list[(size_t)bi * n_rows_max + j];
+      const float *xb = x + ((size_t)bi * C + c8 * 8) * V + v;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) in[u] = xb[(size_t)min(u, nch - 1) * V];
+    } else {
+      const float *row = x + ((size_t)bi * n_rows_max + j) * C + c8 * 8;
+      if (vec) {
+        const float4 p = *reinterpret_cast<const float4 *>(row), q = *reinterpret_cast<const float4 *>(row + 4);
+        in[0] = p.x; in[1] = p.y; in[2] = p.z; in[3] = p.w; in[4] = q.x; in[5] = q.y; in[6] = q.z; in[7] = q.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) in[u] = row[min(u, nch - 1)];
+      }
+    }
+  };
+  const int j_end = min(nd, (int)(blockIdx.x + 1) * RB), j_first = blockIdx.x * RB + rl;
+  const bool pre4 = rl < per_pass && j_first + 3 * per_pass < j_end;
+  float pin0[8], pin1[8], pin2[8], pin3[8];
+  if (pre4) { load_row(j_first, pin0); load_row(j_first + per_pass, pin1); load_row(j_first + 2 * per_pass, pin2); load_row(j_first + 3 * per_pass, pin3); }
   all_group_stats(partial, bi, G, S, (double)cg * V, eps, s_mean, s_rstd);
-  for (int ch = tid; ch < C8 * 8; ch += blockDim.x) {
+  for (int ch = tid; ch < C8 * 8; ch += blockDim.x) {   // (one pass: C8 * 8 <= 256)
     float a = 0.f, bsh = 0.f;
     if (ch < C) {
       const int g = ch / cg;
-      a = gamma[ch] * s_rstd[g];
-      bsh = beta[ch] - s_mean[g] * a;
+      a = g_pre * s_rstd[g];
+      bsh = b_pre - s_mean[g] * a;
     }
     s_a[ch] = a; s_b[ch] = bsh;
   }
@@ -123,31 +151,10 @@ __global__ __launch_bounds__(256) void to_h2_rows_kernel(int C, int V, int G, in
     const f16x8 hh = *reinterpret_cast<const f16x8 *>(&ph), ll = *reinterpret_cast<const f16x8 *>(&pl);
     for (int j = 0; j < nch; ++j) const_f32[(size_t)bi * C + c8 * 8 + j] = ((float)hh[j] + (float)ll[j]) * (1.0f / act_scale);
   }
-  const int per_pass = blockDim.x / C8;                       // rows per pass (C8 <= 32)
-  const int c8 = tid % C8, rl = tid / C8;
-  const int nch = min(8, C - c8 * 8);
-  const bool vec = (C & 3) == 0 && nch == 8;
   float ca[8], cb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ca[j] = s_a[c8 * 8 + j]; cb[j] = s_b[c8 * 8 + j]; }
   if (rl < per_pass) {
-    auto load_row = [&](int j, float (&in)[8]) {
-      if (dense_in) {
-        const int v = dil_list[(size_t)bi * n_rows_max + j];
-        const float *xb = x + ((size_t)bi * C + c8 * 8) * V + v;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) in[u] = xb[(size_t)min(u, nch - 1) * V];
-      } else {
-        const float *row = x + ((size_t)bi * n_rows_max + j) * C + c8 * 8;
-        if (vec) {
-          const float4 p = *reinterpret_cast<const float4 *>(row), q = *reinterpret_cast<const float4 *>(row + 4);
-          in[0] = p.x; in[1] = p.y; in[2] = p.z; in[3] = p.w; in[4] = q.x; in[5] = q.y; in[6] = q.z; in[7] = q.w;
-        } else {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) in[u] = row[min(u, nch - 1)];
-        }
-      }
-    };
     auto emit_row = [&](int j, const float (&in)[8]) {
       float val[8];
 #pragma unroll
@@ -163,8 +170,11 @@ __global__ __launch_bounds__(256) void to_h2_rows_kernel(int C, int V, int G, in
       rows_h2[(((size_t)bi * C8 + c8) * 2 + 1) * n_rows_max + j] = pl;
     };
     // four rows per step, their loads in flight together (one row per step was RB / per_pass = 16+ dependent round trips per workgroup)
-    const int j_end = min(nd, (int)(blockIdx.x + 1) * RB);
-    int j = blockIdx.x * RB + rl;
+    int j = j_first;
+    if (pre4) {
+      emit_row(j, pin0); emit_row(j + per_pass, pin1); emit_row(j + 2 * per_pass, pin2); emit_row(j + 3 * per_pass, pin3);
+      j += 4 * per_pass;
+    }
     for (; j + 3 * per_pass < j_end; j += 4 * per_pass) {
       float in0[8], in1[8], in2[8], in3[8];
       load_row(j, in0); load_row(j + per_pass, in1); load_row(j + 2 * per_pass, in2); load_row(j + 3 * per_pass, in3);

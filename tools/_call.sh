@@ -1,13 +1,13 @@
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r05
-bash tools/run_round_profile.sh r05 803b624
-BDM_RECORD_DURATIONS=gpurun_out/r05/durations.json python -m pytest tests -m gpu -q 2>&1 | tail -150 > gpurun_out/r05/gpu_suite.txt
-BDM_LIB_PATH=bdm_amd/libbdm_hip_experimental.so python -m pytest tests/test_hip_small_glue.py -q 2>&1 | tail -3 > gpurun_out/r05/gpu_suite_experimental.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r05/smoke.txt 2>&1
-for v in r4 r5 r4 r5; do
-    if [ $v = r4 ]; then cd $R/gpurun_tmp/r4; else cd $R; fi
-    echo "== $v B=1 N=1024"; python tools/replay_host_time.py 1 1024 2>&1 | grep replayed | tail -1
-done > $R/gpurun_out/r05/c1_step.txt
-cd $R
-tail -3 gpurun_out/r05/gpu_suite.txt; tail -2 gpurun_out/r05/smoke.txt; cat gpurun_out/r05/c1_step.txt
+echo "base B=16:"; TB=16 TN=4096 BDM_LIB_PATH=bdm_amd/libbdm_hip_base.so python tools/forward_hash.py 2>&1 | tail -2
+echo "new B=16:"; TB=16 TN=4096 python tools/forward_hash.py 2>&1 | tail -2
+python -m pytest tests/test_hip_compact_tail.py tests/test_hip_net.py -x -q 2>&1 | grep -v "^PARITY" | tail -2
+cd /tmp && export TMPDIR=/tmp
+for v in base new base new; do
+  if [ $v = base ]; then export BDM_LIB_PATH=$R/bdm_amd/libbdm_hip_base.so; else unset BDM_LIB_PATH; fi
+  rm -rf /tmp/trf_$v
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/trf_$v -o fwd -- python3 $R/tools/trace_forward.py pc2 > /dev/null 2>&1
+  echo "== $v"
+  python3 $R/tools/trace_summary.py $(find /tmp/trf_$v -name "*kernel_trace.csv" | head -1) 120 | grep "to_h2_rows\|se_rows_partial\|devox_rows\|class_constants"
+done
