@@ -175,6 +175,31 @@ def test_attention_core(ops, B, C, L):
             assert rel(got, refs) < 5e-6, ("fp16x3", scale)
 
 
+@pytest.mark.parametrize("B,C,L", [(1, 64, 4096), (2, 32, 4100), (5, 64, 1500)])
+def test_attention_key_ranges_equal_the_single_range_form(ops, monkeypatch, B, C, L):
+    """bdm_attention_core_h2 splits a query's keys into 1 / 2 / 4 ranges by (shapes, positions) (bdm_attention_h2_key_slices) and merges the
+    partial results (attn_combine_kernel): every count against the float64 softmax, against the single-range form, deterministic, and
+    the default equal to the count the library reports."""
+    from bdm_amd import _lib as L_
+    g = torch.Generator().manual_seed(B * L)
+    qkv = torch.randn(B, 3 * C, L, generator=g) * 0.6
+    q, k, v = qkv[:, :C].double(), qkv[:, C:2 * C].double(), qkv[:, 2 * C:].double()
+    ref = torch.matmul(v, torch.softmax(torch.matmul(q.permute(0, 2, 1), k), -1).permute(0, 2, 1)).float()
+    amax = torch.stack([qkv[:, i * C:(i + 1) * C].abs().amax(dim=(1, 2)) for i in range(3)], 1).float().contiguous().cuda()
+    x = qkv.cuda()
+    outs = {}
+    for ks in (1, 2, 3, 4, 8):
+        monkeypatch.setenv("BDM_ATTN_KSPLIT", str(ks))
+        outs[ks] = ops.attention_core(x, C, amax=amax).cpu()
+        assert rel(outs[ks], ref) < 5e-6, ks
+        assert torch.equal(outs[ks], ops.attention_core(x, C, amax=amax).cpu()), ks   # deterministic
+        if ks > 1:
+            assert rel(outs[ks], outs[1]) < 2e-6 and not torch.equal(outs[ks], outs[1]), ks
+    monkeypatch.delenv("BDM_ATTN_KSPLIT")
+    auto = L_.lib().bdm_attention_h2_key_slices(B, L)
+    assert auto in (1, 2, 4) and torch.equal(ops.attention_core(x, C, amax=amax).cpu(), outs[auto])
+
+
 def test_projection_gemm_leaves_operand_maxima_for_the_fp16x3_attention(ops):
     """bdm_pointwise_conv_gn amax output: max |y| per (shape, block of amax_rows rows), and the Attention module on the fp16x3
     path vs the bf16x6 path."""
