@@ -366,7 +366,8 @@ static inline int attn_lp(int l) { return (l + 7) / 8 * 8; }
 extern "C" size_t bdm_attention_h2_workspace_bytes(int b, int c, int l) {
   if (l <= 64 || c > 64) return 0;
   const size_t cp = attn_cp(c), qk = (size_t)(cp / 8) * 2 * l * 16, v = 2 * cp * (size_t)attn_lp(l) * 2;
-  return (size_t)b * (2 * qk + v) + 64 + (size_t)8 * b * (cp + 2) * l * sizeof(float) + 64;   // + partial results of up to 8 key ranges
+  const int ks = attn_ksplit(b, l);   // + the partial results of the key ranges (none for one range)
+  return (size_t)b * (2 * qk + v) + 64 + (ks > 1 ? (size_t)ks * b * (cp + 2) * l * sizeof(float) + 64 : 0);
 }
 
 // out (b, c, l) = softmax_keys(q^T k) applied to v, for q, k, v (b, c, l) rows of stride ld_qkv; amax[3 s + 0..2] = max |q|, |k|, |v| of
