@@ -269,6 +269,9 @@ def encode(sa_layers, global_att, inputs, t_emb, early=None, fp_layers=None):
     for blocks in sa_layers:  # sampler plans too: never inherit one from an aborted or foreign forward
         (blocks[-1] if isinstance(blocks, nn.Sequential) else blocks)._planned = None
         (blocks[-1] if isinstance(blocks, nn.Sequential) else blocks)._more = None
+        first = blocks[0] if isinstance(blocks, nn.Sequential) else blocks
+        if getattr(first, "_temb_terms", None) is not None:   # ... nor the time-embedding terms of another timestep
+            first._temb_terms = None
     # also inside a hipGraph capture: the side stream forks from and joins the capturing stream.  Small problems (one
     # small shape) are bound by kernel-to-kernel dispatch latency, where the extra events cost more than the overlap gains
     if coords.is_cuda and SIDE_STREAM and coords.shape[0] * coords.shape[2] >= SIDE_STREAM_MIN_POINTS:

@@ -295,6 +295,30 @@ def test_time_embedding_as_per_shape_terms_of_the_encoder(hip, monkeypatch, whic
     assert torch.equal(alone[0], got[1])                   # and batch-invariant
 
 
+def test_decoder_voxel_plan_on_the_sampler_stream_same_bits(hip, monkeypatch):
+    """pvcnn.plan_sampling_chain also builds the voxel plan of the FP stage no encoder level shares (FP0's 64 points) on the sampler's
+    stream: the forward's bits do not change, and neither do they when a forward that aborted midway left per-shape time-embedding terms behind."""
+    import bdm_amd.pvcnn as PV
+    from bdm_amd.utils.procedural import fill_module_
+    B, N = 2, 4096
+    net = fill_module_(PV.PVCNN2_PC2(3, 64, extra_feature_channels=32).eval(), seed=9).cuda()
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.randn(B, 3, N, generator=g) * 0.4, torch.randn(B, 32, N, generator=g)], dim=1).cuda()
+    t = torch.tensor([900, 3]).cuda()
+    monkeypatch.setattr(PV, "DECODER_PLAN", False)
+    ref = net(x, t).clone()
+    monkeypatch.setattr(PV, "DECODER_PLAN", True)
+    assert torch.equal(net(x, t), ref)
+    # stale terms of ANOTHER timestep on every encoder module that takes them: encode must not use them
+    net(x, torch.tensor([17, 512]).cuda())
+    for blk in list(net.sa_layers)[1:]:
+        first = blk[0] if isinstance(blk, torch.nn.Sequential) else blk
+        if hasattr(first, "temb_rows"):
+            rows = first.temb_rows(64).shape[0]
+            first._temb_terms = torch.full((B, rows), 7.0, device="cuda")
+    assert torch.equal(net(x, t), ref)
+
+
 def test_pvconv_takes_the_time_embedding_as_column_addend_and_bias(hip, monkeypatch):
     """One PVConv of each encoder kind (16^3: bf16x6 GEMM; 8^3: fp16x3 GEMM) against itself on the concatenated input, plus the refusal of
     an input of the wrong width."""
