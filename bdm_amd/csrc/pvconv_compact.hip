@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void to_h2_rows_kernel(int C, int V, int G, in
   __shared__ float s_a[256], s_b[256];
   const int bi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int C8 = (C + 7) / 8;
-  const int nd = tile_start[((size_t)bi * tiles_max + tiles_max - 1) * 8 + 1];   // entries of this shape's list
+  const int nd = tile_start[((size_t)bi * tiles_max + tiles_max - 1) * 16 + 1];   // entries of this shape's list
   constexpr int RB = 512;
   if ((int)blockIdx.x * RB >= nd && blockIdx.x != 0) return;
   const int cg = C / G;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void se_rows_partial_kernel(int c, int V, int 
       }
     }
   }
-  const int nd = tile_start[((size_t)bi * tiles_max + tiles_max - 1) * 8 + 1];
+  const int nd = tile_start[((size_t)bi * tiles_max + tiles_max - 1) * 16 + 1];
   const int per = (nd + SE_SLABS - 1) / SE_SLABS, j_lo = slab * per, j_hi = min(nd, j_lo + per);
   const int CL = c < 256 ? c : 256, RL = 256 / CL;          // channels per pass, row lanes
   const int cl = tid % CL, rl = tid / CL;

@@ -949,7 +949,7 @@ class VoxelPlan:
     occupied-cell compaction and row occupancy.  PVConvs of one level share it (exactly the same values)."""
     __slots__ = ("r", "n", "n_max", "coords", "norm_coords", "vox_coords", "ind", "cnt", "ws", "occ_index", "occ_list", "n_occ", "rowocc",
                  "ready", "stream", "dil_list", "dil_index", "plane_start", "tile_start", "n_dil_max",
-                 "d2_list", "d2_index", "d2_tiles", "d2_class_count")
+                 "d2_list", "d2_index", "d2_tiles", "d2_class_count", "tile", "d2_tile")
 
 
 _plan_cache = {}
@@ -1005,6 +1005,31 @@ def has_voxel_plan(coords, r):
     return (coords.data_ptr(), coords._version, tuple(coords.shape), int(r)) in _plan_cache
 
 
+TILE_REC = 16         # ints per tile record of a dilated plan (include/bdm_hip.h)
+# Tile form of the list convolutions (csrc/sparse_conv_os.hip): "auto" = the rule below, "0" = full tiles everywhere (round 4's kernel, one
+# workgroup per CU), "64" / "128" / "256" = that half-tile size wherever the form exists (r = 16, 32)
+DIL_TILE = os.environ.get("BDM_DIL_TILE", "auto")
+DIL_HALF_CUS = 256    # CUs the rule fills with two workgroups each
+
+
+def dil_tile(batch, n_points, r, second):
+    """Entries per tile of the (once- / twice-) dilated list of a level: 0 = the full-tile form.  The half-tile form runs TWO four-wave
+    workgroups per CU (each hides the other's look-up chain, barriers and store burst), so it wants >= ~2 items per CU: the largest of
+    256 / 128 / 64 entries that gives the batch that many tiles.  The dilated fractions are estimated from the sizes alone (as
+    sparse_dil_pays: a cloud of n points dilates to ~2 n voxels once, ~3 n twice, capped by the grid), so the choice depends on the
+    configuration, never on the data; one rule per (batch, points, resolution) -- not per channel count -- because the PVConvs of a
+    level share the plan."""
+    if r not in (16, 32):
+        return 0
+    if DIL_TILE != "auto":
+        return int(DIL_TILE)
+    listed = min((3 if second else 2) * n_points, (r ** 3 * 3) // 4) * batch
+    for tile in (256, 128):
+        if listed // tile >= 2 * DIL_HALF_CUS * 3 // 4:
+            return tile
+    return 64
+
+
 DILATED_PLAN = True   # voxel plans carry the once-dilated voxel list + tile table of the compact first convolution (sparse_conv_os.hip)
 
 
@@ -1020,12 +1045,13 @@ def plan_dilation(p):
     lib, B, r = L.lib(), p.cnt.shape[0], p.r
     dev = p.cnt.device
     p.n_dil_max = r ** 3
+    p.tile = dil_tile(B, p.n, r, second=False)
     p.dil_list = torch.empty(B, p.n_dil_max, dtype=torch.int32, device=dev)
     p.dil_index = torch.empty(B, r ** 3, dtype=torch.int32, device=dev)
     p.plane_start = torch.empty(B, r + 2, dtype=torch.int32, device=dev)
-    p.tile_start = torch.empty(B, lib.bdm_voxel_dilate_slices(r), 8, dtype=torch.int32, device=dev)
+    p.tile_start = torch.empty(B, lib.bdm_voxel_dilate_slices(r, p.tile), TILE_REC, dtype=torch.int32, device=dev)
     L.check(lib.bdm_voxel_dilate(B, r, p.n_dil_max, L.ptr(p.cnt), L.ptr(p.dil_list), L.ptr(p.dil_index), L.ptr(p.plane_start),
-                                 L.ptr(p.tile_start), L.stream()), "voxel_dilate")
+                                 L.ptr(p.tile_start), p.tile, L.stream()), "voxel_dilate")
     return p
 
 
@@ -1040,13 +1066,14 @@ def plan_dilation2(p):
         return p
     lib, B, r = L.lib(), p.cnt.shape[0], p.r
     dev = p.cnt.device
+    p.d2_tile = dil_tile(B, p.n, r, second=True)
     p.d2_list = torch.empty(B, p.n_dil_max, dtype=torch.int32, device=dev)
     p.d2_index = torch.empty(B, r ** 3, dtype=torch.int32, device=dev)
     ps = torch.empty(B, r + 2, dtype=torch.int32, device=dev)
-    p.d2_tiles = torch.empty(B, lib.bdm_voxel_dilate_slices(r), 8, dtype=torch.int32, device=dev)
+    p.d2_tiles = torch.empty(B, lib.bdm_voxel_dilate_slices(r, p.d2_tile), TILE_REC, dtype=torch.int32, device=dev)
     p.d2_class_count = torch.empty(B, 27, dtype=torch.int32, device=dev)
     L.check(lib.bdm_voxel_dilate_again(B, r, p.n_dil_max, L.ptr(p.dil_index), L.ptr(p.d2_list), L.ptr(p.d2_index), L.ptr(ps),
-                                       L.ptr(p.d2_tiles), L.ptr(p.d2_class_count), L.stream()), "voxel_dilate_again")
+                                       L.ptr(p.d2_tiles), L.ptr(p.d2_class_count), p.d2_tile, L.stream()), "voxel_dilate_again")
     return p
 
 
@@ -1350,10 +1377,10 @@ def sparse_first_conv_os(features, plan, packed, bias, cout, gn_groups=None, com
         tiles = plan.tile_start.shape[1]
         partial = torch.empty(B, gn_groups, tiles, 2, dtype=torch.float64, device=dev)
         slices = ctypes.c_int(0)
-        L.check(lib.bdm_sparse_conv_dil_gn(*args, int(gn_groups), L.ptr(partial), ctypes.byref(slices), L.ptr(counter), L.stream()),
+        L.check(lib.bdm_sparse_conv_dil_gn(*args, int(gn_groups), L.ptr(partial), ctypes.byref(slices), plan.tile, L.ptr(counter), L.stream()),
                 "sparse_conv_dil_gn")
         return out, (partial, tiles, int(gn_groups))
-    L.check(lib.bdm_sparse_conv_dil(*args, L.ptr(counter), L.stream()), "sparse_conv_dil")
+    L.check(lib.bdm_sparse_conv_dil(*args, plan.tile, L.ptr(counter), L.stream()), "sparse_conv_dil")
     return out
 
 
@@ -1404,7 +1431,7 @@ def second_conv_rows(rows_h2, const_h2, const_f32, x_inv_scale, plan, packed, ws
     slices = ctypes.c_int(0)
     L.check(lib.bdm_sparse_conv_dil_h2_gn(B, cin, cout, r, plan.n_dil_max, plan.n_dil_max, L.ptr(rows_h2), L.ptr(const_h2), L.c_float(x_inv_scale),
                                           L.ptr(plan.dil_index), L.ptr(plan.d2_list), L.ptr(plan.d2_index), L.ptr(plan.d2_tiles), L.ptr(packed_w),
-                                          L.ptr(inv_scale), L.ptr(bias), L.ptr(y), int(groups), L.ptr(partial), ctypes.byref(slices),
+                                          L.ptr(inv_scale), L.ptr(bias), L.ptr(y), int(groups), L.ptr(partial), ctypes.byref(slices), plan.d2_tile,
                                           L.ptr(counter), L.stream()), "sparse_conv_dil_h2_gn")
     assert slices.value == tiles + 27
     class_vals = torch.empty(B, 27, cout, dtype=torch.float32, device=dev)

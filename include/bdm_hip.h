@@ -511,7 +511,7 @@ int bdm_sparse_conv_gemm_h2_cb(int b, int n_max, int cin, int cout, const void *
  * consecutive list entries whose occupied neighbours are ONE contiguous range of compact rows (staged in LDS per 8-channel chunk).
  *   bdm_voxel_dilate        cnt (b, r^3) -> dil_list (b, n_dil_max) voxel ids of the dilated set in ascending order (n_dil_max = r^3
  *                           always suffices), dil_index (b, r^3) rank in that list or -1, plane_start (b, r + 2): occupied cells in
- *                           x-planes < x, tile_start (b, bdm_voxel_dilate_slices(r), 8): per tile [first entry, end entry, first voxel of
+ *                           x-planes < x, tile_start (b, bdm_voxel_dilate_slices(r, tile), 16): per tile [first entry, end entry, first voxel of
  *                           the linear range it owns, its end, first compact row of its input range, rows, 0, live tiles of the
  *                           shape].  Depends on (coords, r) only: part of the voxel plan of a level.  r in {8, 16, 32}.
  *   bdm_sparse_conv_dil     xr / amax: bdm_sparse_voxel_features_f32 (fp32 records (b, ceil(cin/8), n_max) x 8 channels + per-shape
@@ -523,18 +523,25 @@ int bdm_sparse_conv_gemm_h2_cb(int b, int n_max, int cin, int cout, const void *
  *                           work_counter: one int, ZERO on entry (left non-zero): the persistent workgroups (one per CU) pull their
  *                           (tile, channel block, shape) items from it.
  *   bdm_sparse_conv_dil_gn  also leaves GroupNorm(groups) partials of the DENSE output (bias voxels included) in gn_partial
- *                           (b, groups, tiles, 2 doubles), *slices_out = tiles = bdm_voxel_dilate_slices(r). */
-int bdm_voxel_dilate_slices(int r);
+ *                           (b, groups, tiles, 2 doubles), *slices_out = tiles = bdm_voxel_dilate_slices(r, tile).
+ * `tile` (round 6) selects the tile form of a plan and of the convolutions that run on it (the two must agree):
+ *   0            FULL tiles (<= 512 / 256 / 128 entries at r = 32 / 16 / 8, one row range of <= 3 r^2 rows, one workgroup per CU);
+ *   64/128/256   HALF tiles (r = 16, 32): that many entries, four waves and 80 KB of LDS per workgroup, TWO workgroups per CU; a tile
+ *                inside one x-plane lists three row ranges ((x-1, x, x+1) x y-rows y0-1 .. y1+1), a tile across planes one range of
+ *                whole planes; never more than 1376 rows (<= 3 tile + 12 r inside a plane; across planes only when they fit).
+ * A tile record is 16 ints: [first entry, end entry, first voxel of the owned linear range, its end, range 0 first row, range 0 rows,
+ * (first x-plane << 8) | last, live tiles of the shape, range 1 first row, rows, range 2 first row, rows, tile, 0, 0, 0]. */
+int bdm_voxel_dilate_slices(int r, int tile);
 int bdm_voxel_dilate(int b, int r, int n_dil_max, const int *cnt, int *dil_list, int *dil_index, int *plane_start, int *tile_start,
-                     void *stream);
+                     int tile, void *stream);
 int bdm_sparse_conv_dil(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
                         const int *occ_index, const int *dil_list, const int *dil_index, const int *tile_start,
-                        const void *packed_w, const float *inv_scale, const float *bias, float *y, int compact, int *work_counter,
-                        void *stream);
+                        const void *packed_w, const float *inv_scale, const float *bias, float *y, int compact, int tile,
+                        int *work_counter, void *stream);
 int bdm_sparse_conv_dil_gn(int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
                            const int *occ_index, const int *dil_list, const int *dil_index, const int *tile_start,
                            const void *packed_w, const float *inv_scale, const float *bias, float *y, int compact, int groups,
-                           void *gn_partial, int *slices_out, int *work_counter, void *stream);
+                           void *gn_partial, int *slices_out, int tile, int *work_counter, void *stream);
 
 /* --- the whole voxel branch of a PVConv without dense grids (pvconv_compact.hip, sparse_conv_os.hip; pvconv.py:74-97) ---
  * After GroupNorm + Swish the first convolution's output is a per-channel CONSTANT outside the once-dilated set D1, so the second
@@ -547,7 +554,7 @@ int bdm_sparse_conv_dil_gn(int b, int cin, int cout, int r, int n_max, int n_dil
  *                                 from `partial` (b, groups, slices, 2).  -> rows_h2 (b, ceil(c/8), 2, n_rows_max) records of 8 fp16,
  *                                 const_h2 (b, ceil(c/8), 2) records and const_f32 (b, c): the value outside D1 (from bias)
  *   bdm_sparse_conv_dil_h2_gn     the SECOND convolution on D2's tiles from those rows: y (b, n_dil_max, cout) compact rows; GroupNorm
- *                                 partials (b, groups, slices, 2), *slices_out = bdm_voxel_dilate_slices(r) + 27 (the tiles'; the last 27
+ *                                 partials (b, groups, slices, 2), *slices_out = bdm_voxel_dilate_slices(r, tile) + 27 (the tiles'; the last 27
  *                                 are left for bdm_conv3d_class_constants); work_counter as bdm_sparse_conv_dil
  *   bdm_conv3d_class_weight_sums  (cout, cin, 3,3,3) -> wsum (27, cin, cout) doubles: per class, the sum of the taps inside the grid
  *   bdm_conv3d_class_constants    class_vals (b, 27, cout) = bias + wsum[k] . const_f32[b] (fp64, rounded once) and slices
@@ -556,7 +563,7 @@ int bdm_sparse_conv_dil_gn(int b, int cin, int cout, int r, int n_max, int n_dil
  *                                 gate (b, c) (w1 = NULL: no FC layers); part_ws: bdm_se_gate_gn_rows_workspace_elems(b, c) floats
  *   bdm_devoxelize_gn_gate_add_rows(_pf)  bdm_devoxelize_gn_gate_add(_pf) reading the 8 corner rows through D2's ranks */
 int bdm_voxel_dilate_again(int b, int r, int n_dil_max, const int *dil_index_in, int *dil_list, int *dil_index, int *plane_start,
-                           int *tile_start, int *class_count, void *stream);
+                           int *tile_start, int *class_count, int tile, void *stream);
 int bdm_group_norm_to_h2_rows(int b, int c, int v, int groups, const float *x, int dense_in, int n_rows_max, const int *dil_list,
                               const int *tile_start, int tiles_max, const float *bias, const float *gamma, const float *beta,
                               float eps, int act, float act_scale, void *rows_h2, void *const_h2, float *const_f32,
@@ -564,7 +571,7 @@ int bdm_group_norm_to_h2_rows(int b, int c, int v, int groups, const float *x, i
 int bdm_sparse_conv_dil_h2_gn(int b, int cin, int cout, int r, int n_rows_max, int n_dil_max, const void *rows_h2, const void *xconst,
                               float x_inv_scale, const int *in_index, const int *dil_list, const int *dil_index,
                               const int *tile_start, const void *packed_w, const float *inv_scale, const float *bias, float *y,
-                              int groups, void *gn_partial, int *slices_out, int *work_counter, void *stream);
+                              int groups, void *gn_partial, int *slices_out, int tile, int *work_counter, void *stream);
 size_t bdm_conv3d_class_weight_elems(int cout, int cin);
 int bdm_conv3d_class_weight_sums(int cout, int cin, const float *w, void *wsum, void *stream);
 int bdm_conv3d_class_constants(int b, int cin, int cout, const void *wsum, const float *bias, const float *const_f32,

@@ -1,7 +1,12 @@
 """Golden vectors of the full-length coupled trajectories: the CPU ORACLE's final clouds, written once in the build container
 so that the `-m gpu` parity tests do not spend minutes of host time per run re-deriving them.
 
-    python -m oracle.gen_golden_traj [blending_n1024] [merging_n1024] [c2_b16_shape11]      (no argument: all three)
+    python -m oracle.gen_golden_traj [--threads T] [blending_n1024] [merging_n1024] [c2_b16_shape11] ...     (no name: every case)
+
+`--threads T` (round 6): run the SAME case with `torch.set_num_threads(T)` and write `traj_<name>_alt.npz` (final + segment
+clouds only) next to the fixture of record.  The CPU kernels of torch split their reductions by thread, so the two files are the oracle at two
+summation orders: their distance d_oo is an oracle-vs-oracle yardstick for the chaos of a case that owes nothing to the product
+(measured on one PC^2 forward at N = 4096: 8 vs 4 / 2 / 1 threads = 5.4e-7 / 6.2e-7 / 8.0e-7 relative L2, i.e. the fp32 noise floor).
 
 writes tests/golden/traj_<name>.npz = the case description (seeds, sizes, schedule, head scale: everything
 `tests/trajectory_case.build` needs to rebuild the identical weights / inputs / random draws procedurally), the oracle's final
@@ -43,7 +48,15 @@ CASES = {
     "c2_b16_shape7_h003": dict(N=4096, B=16, merging=False, philox_seed=42, row=7, head_scale=0.03),
     "blending_n1024_h003": dict(N=1024, B=1, merging=False, philox_seed=None, row=0, head_scale=0.03),
     "merging_n1024_h003": dict(N=1024, B=1, merging=True, philox_seed=None, row=0, head_scale=0.03),
+    # round 6: C3's own per-GPU shape -- BDM-Merging, B = 16, N = 4096, per-shape Philox streams, FULL length
+    # (995 PC^2 + 75 PVD + 5 fused forwards), one sampled shape; head per the rule at this size (0.03) + the 0.1 chaos monitor
+    "c3_b16_shape5_h003": dict(N=4096, B=16, merging=True, philox_seed=42, row=5, head_scale=0.03),
+    "c3_b16_shape5": dict(N=4096, B=16, merging=True, philox_seed=42, row=5),
 }
+
+# round 6: C1 = vanilla PC^2, ONE shape, N = 1024, 100 free-running steps (reference model/model.py:182-201) at the
+# largest head scale of {1, 0.3, 0.1, 0.03} the rule allows (oracle 1-ulp self-sensitivity < 1e-4: 7.1e-3 / 8.2e-6 / 2.6e-7 / 2.0e-7 -> 0.3)
+C1_CASES = {"c1_n1024_h03": dict(head_scale=0.3), "c1_n1024_h1": dict(head_scale=1.0)}
 
 
 def oracle_case(name):
@@ -55,7 +68,27 @@ def oracle_case(name):
     return c, c
 
 
-def generate(name):
+def generate_c1(name, alt):
+    import trajectory_case as case
+    from oracle import ops
+    ops.build()
+    c = case.build_c1(C1_CASES[name]["head_scale"])
+    t0 = time.time()
+    final, snaps = case.run_oracle_c1(c)
+    extra = {}
+    if not alt:   # the oracle's own 1-ulp self-sensitivity at this head scale travels with the fixture (context line of the test)
+        pert, _ = case.run_oracle_c1(c, torch.nextafter(c.init, torch.full_like(c.init, float("inf"))))
+        extra["self_sensitivity"] = float((pert - final).norm() / final.norm())
+    out = os.path.join(os.environ.get("BDM_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")), f"traj_{name}{'_alt' if alt else ''}.npz")
+    np.savez_compressed(out, final=final.numpy().astype(np.float32), N=c.N, steps=c.steps, head_scale=C1_CASES[name]["head_scale"],
+                        torch_version=torch.__version__, threads=torch.get_num_threads(),
+                        **{f"snap_{i}": v.numpy().astype(np.float32) for i, v in enumerate(snaps)}, **extra)
+    print(f"{name}: {c.steps} forwards in {time.time() - t0:.0f} s -> {out} ({os.path.getsize(out) / 1024:.0f} KB) {extra}")
+
+
+def generate(name, alt=False):
+    if name in C1_CASES:
+        return generate_c1(name, alt)
     import trajectory_case as case
     from oracle import ops, ref_sampler as R
     ops.build()
@@ -77,7 +110,12 @@ def generate(name):
     finally:
         R.TRACE = None
     assert len(snaps) == len(c.milestones) - 1 and np.array_equal(snaps[f"segment_{len(snaps) - 1}"], final.numpy())
-    out = os.path.join(os.environ.get("BDM_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")), f"traj_{name}.npz")
+    out = os.path.join(os.environ.get("BDM_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")), f"traj_{name}{'_alt' if alt else ''}.npz")
+    if alt:
+        np.savez_compressed(out, final=final.numpy().astype(np.float32), torch_version=torch.__version__, threads=torch.get_num_threads(),
+                            **{k: v.astype(np.float32) for k, v in snaps.items()})
+        print(f"{name} (alternative reduction order, {torch.get_num_threads()} threads): {time.time() - t0:.0f} s -> {out}")
+        return
     np.savez_compressed(out, final=final.numpy().astype(np.float32), N=d["N"], B=d["B"], merging=d["merging"],
                         philox_seed=-1 if d["philox_seed"] is None else d["philox_seed"], row=d["row"],
                         head_scale=d.get("head_scale", HEAD_SCALE), milestones=np.asarray(c.milestones), roll_step=c.roll_step,
@@ -87,5 +125,9 @@ def generate(name):
 
 
 if __name__ == "__main__":
-    for nm in (sys.argv[1:] or list(CASES)):
-        generate(nm)
+    args, alt = sys.argv[1:], False
+    if args[:1] == ["--threads"]:
+        torch.set_num_threads(int(args[1]))
+        args, alt = args[2:], True
+    for nm in (args or list(CASES) + list(C1_CASES)):
+        generate(nm, alt)

@@ -18,6 +18,14 @@ def ops(hip):
     return o
 
 
+@pytest.fixture(params=["0", "256", "64"], autouse=True)
+def tile_form(request, monkeypatch, ops):
+    """Every test of this file runs on full tiles (round 4's kernel) and on half tiles of 256 / 64 entries (round 6: two workgroups per CU)."""
+    monkeypatch.setattr(ops, "DIL_TILE", request.param)
+    ops.clear_plan_cache()
+    return request.param
+
+
 def _layer(ops, cin, cout, r, n, B, seed, spread=0.3):
     g = torch.Generator().manual_seed(seed)
     f = torch.randn(B, cin, n, generator=g).cuda()

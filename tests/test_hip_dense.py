@@ -476,11 +476,17 @@ def test_sparse_first_conv_equals_dense(ops, oracle_ops, cin, cout, r, npts):
 @pytest.mark.parametrize("cin,cout,r,npts", [(35, 32, 32, 4096), (64, 64, 32, 1100), (64, 64, 32, 4096), (128, 64, 16, 1024), (128, 128, 16, 1024),
                                              (256, 256, 8, 64), (192, 128, 8, 256), (16, 8, 8, 2000), (390, 32, 32, 700)])
 @pytest.mark.parametrize("form", ["dil", "dil_compact"])
-def test_sparse_first_conv_output_stationary_equals_dense(ops, oracle_ops, cin, cout, r, npts, form):
+@pytest.mark.parametrize("tile_form", ["0", "256", "64"])
+def test_sparse_first_conv_output_stationary_equals_dense(ops, oracle_ops, monkeypatch, cin, cout, r, npts, form, tile_form):
     """The one-kernel output-stationary form with tap skipping (sparse_conv_os.hip, the default first convolution): == the dense
-    evaluation at fp32 grade, bit-reproducible, strided features accepted, and its GroupNorm partials == the statistics of its output."""
+    evaluation at fp32 grade, bit-reproducible, strided features accepted, and its GroupNorm partials == the statistics of its output.
+    tile_form: full tiles (one workgroup per CU) / half tiles of 256 or 64 entries (two per CU, round 6) -- every form runs the same
+    MFMA sequence per output voxel, so the half forms must also give the full form's BITS."""
     from bdm_amd import _lib as L
     import ctypes
+    if r == 8 and tile_form != "0":
+        pytest.skip("half tiles exist at r = 16, 32")
+    monkeypatch.setattr(ops, "DIL_TILE", tile_form)
     B = 3
     g = torch.Generator().manual_seed(cin + r + npts)
     vc = (torch.randn(B, 3, npts, generator=g) * r / 8 + r / 2).round().clamp(0, r - 1).to(torch.int32)
@@ -501,6 +507,12 @@ def test_sparse_first_conv_output_stationary_equals_dense(ops, oracle_ops, cin, 
     for b in range(B):
         assert rel(got[b], ref[b]) < 2e-6, b
     assert torch.equal(got, ops.sparse_first_conv(f.cuda(), vc.cuda(), r, wt, bias.cuda(), cout).cpu())
+    if tile_form != "0":
+        monkeypatch.setattr(ops, "DIL_TILE", "0")
+        ops.clear_plan_cache()
+        assert torch.equal(got, ops.sparse_first_conv(f.cuda(), vc.cuda(), r, wt, bias.cuda(), cout).cpu()), "half tiles != full tiles"
+        monkeypatch.setattr(ops, "DIL_TILE", tile_form)
+        ops.clear_plan_cache()
     big = torch.randn(B, cin + 6, npts, generator=g).cuda()
     big[:, 3:3 + cin] = f.cuda()
     assert torch.equal(got, ops.sparse_first_conv(big[:, 3:3 + cin], vc.cuda(), r, wt, bias.cuda(), cout).cpu())
@@ -561,58 +573,95 @@ def test_compact_grid_operand_split_equals_the_dense_one(ops):
         assert int(sat_d) == 1 and int(sat_c) == 1 and torch.equal(h_d.view(torch.int16), h_c.view(torch.int16))
 
 
-def test_dilated_voxel_list_and_tile_table(ops):
+@pytest.mark.parametrize("r,n,tile,half", [(32, 4096, 512, 0), (16, 1024, 256, 0), (8, 300, 128, 0),
+                                          (32, 4096, 256, 256), (32, 4096, 128, 128), (32, 2000, 64, 64), (16, 1024, 256, 256), (16, 1024, 128, 128),
+                                          (16, 700, 64, 64)])
+def test_dilated_voxel_list_and_tile_table(ops, r, n, tile, half):
     """bdm_voxel_dilate against a host restatement: the once-dilated occupied set in ascending voxel order, the per-plane prefix of
-    the occupied cells, and a tile table whose tiles (a) partition the list, (b) hold <= the tile size, (c) need <= 3 r^2 compact rows
-    (planes x0-1 .. x1+1) -- including a dense slab that forces cuts at plane boundaries."""
+    the occupied cells, and a tile table whose tiles (a) partition the list, (b) hold <= the tile size, (c) FULL tiles (half = 0): need
+    <= 3 r^2 compact rows (planes x0-1 .. x1+1) -- including a dense slab that forces cuts at plane boundaries; HALF tiles (round 6):
+    list row ranges that cover every occupied neighbour of their voxels, <= 1376 rows in total (the LDS budget of the two-workgroups-
+    per-CU kernel: 3 tile + 12 r inside a plane by construction), one range of whole planes across planes / three (plane, y-row range)
+    ranges inside one plane."""
     import numpy as np
     from bdm_amd import _lib as L
-    for r, n, tile in ((32, 4096, 512), (16, 1024, 256), (8, 300, 128)):
-        B = 3
-        g = torch.Generator().manual_seed(r + n)
-        vc = (torch.randn(B, 3, n, generator=g) * r / 8 + r / 2).round().clamp(0, r - 1).to(torch.int32)
-        e = torch.arange(n - 1)                                                                   # a dense slab: consecutive FULL x-planes from r/2 - 2 on,
-        vc[1, :, : n - 1] = torch.stack([r // 2 - 2 + e // (r * r), (e // r) % r, e % r]).to(torch.int32)
-        vc[1, :, n - 1] = 0                                                                         # and a lone cell that shifts the tiles off the plane boundaries
-        vc[2] = 0                                                                                   # one occupied cell, at the grid corner
-        lib, r3 = L.lib(), r ** 3
-        cnt = torch.zeros(B, r3, dtype=torch.int32)
-        lin = (vc[:, 0].long() * r + vc[:, 1].long()) * r + vc[:, 2].long()
-        for b in range(B):
-            cnt[b].index_add_(0, lin[b], torch.ones(n, dtype=torch.int32))
-        cnt = cnt.cuda()
-        tiles = lib.bdm_voxel_dilate_slices(r)
-        dl = torch.full((B, r3), -1, dtype=torch.int32, device="cuda")
-        di = torch.full((B, r3), -7, dtype=torch.int32, device="cuda")
-        ps = torch.empty(B, r + 2, dtype=torch.int32, device="cuda")
-        ts = torch.empty(B, tiles, 8, dtype=torch.int32, device="cuda")
-        L.check(lib.bdm_voxel_dilate(B, r, r3, L.ptr(cnt), L.ptr(dl), L.ptr(di), L.ptr(ps), L.ptr(ts), L.stream()))
-        dl, ps, ts, occ = dl.cpu().numpy(), ps.cpu().numpy(), ts.cpu().numpy(), (cnt.cpu().numpy() > 0).reshape(B, r, r, r)
-        di = di.cpu().numpy()
-        for b in range(B):
-            P = np.zeros((r + 2,) * 3, bool); P[1:-1, 1:-1, 1:-1] = occ[b]
-            D = np.zeros((r, r, r), bool)
-            for dx in range(3):
-                for dy in range(3):
-                    for dz in range(3):
-                        D |= P[dx:dx + r, dy:dy + r, dz:dz + r]
-            want = np.flatnonzero(D.reshape(-1))
-            nt = int(ts[b, 0, 7])
-            assert int(ts[b, nt - 1, 1]) == len(want) and np.array_equal(dl[b, :len(want)], want), (r, b)
-            rank = np.full(r3, -1, np.int32); rank[want] = np.arange(len(want))
-            assert np.array_equal(di[b], rank)
-            per_plane = occ[b].reshape(r, -1).sum(1)
-            assert np.array_equal(ps[b, :r + 1], np.concatenate([[0], np.cumsum(per_plane)])) and ps[b, r + 1] == ps[b, r]
-            assert ts[b, 0, 0] == 0 and 1 <= nt <= tiles and (ts[b, :, 7] == nt).all()
-            for t in range(nt):
-                j0, j1, vf, ve, klo, nr = (int(v) for v in ts[b, t, :6])
-                assert 0 < j1 - j0 <= tile and (t == 0 or j0 == ts[b, t - 1, 1])
+    XCAP = 1376
+    B = 4
+    g = torch.Generator().manual_seed(r + n)
+    vc = (torch.randn(B, 3, n, generator=g) * r / 8 + r / 2).round().clamp(0, r - 1).to(torch.int32)
+    e = torch.arange(n - 1)                                                                   # a dense slab: consecutive FULL x-planes from r/2 - 2 on,
+    vc[1, :, : n - 1] = torch.stack([r // 2 - 2 + e // (r * r), (e // r) % r, e % r]).to(torch.int32)
+    vc[1, :, n - 1] = 0                                                                         # and a lone cell that shifts the tiles off the plane boundaries
+    vc[2] = 0                                                                                   # one occupied cell, at the grid corner
+    vc[3, 0] = (torch.arange(n) % 3 == 0).to(torch.int32) * (r - 1)                            # two full-ish planes at the two ends of the grid: tiles across
+    vc[3, 1], vc[3, 2] = (torch.arange(n) // r) % r, torch.arange(n) % r                       # planes whose rows do not fit are split at the boundaries
+    lib, r3 = L.lib(), r ** 3
+    cnt = torch.zeros(B, r3, dtype=torch.int32)
+    lin = (vc[:, 0].long() * r + vc[:, 1].long()) * r + vc[:, 2].long()
+    for b in range(B):
+        cnt[b].index_add_(0, lin[b], torch.ones(n, dtype=torch.int32))
+    cnt = cnt.cuda()
+    tiles = lib.bdm_voxel_dilate_slices(r, half)
+    dl = torch.full((B, r3), -1, dtype=torch.int32, device="cuda")
+    di = torch.full((B, r3), -7, dtype=torch.int32, device="cuda")
+    ps = torch.empty(B, r + 2, dtype=torch.int32, device="cuda")
+    ts = torch.empty(B, tiles, 16, dtype=torch.int32, device="cuda")
+    L.check(lib.bdm_voxel_dilate(B, r, r3, L.ptr(cnt), L.ptr(dl), L.ptr(di), L.ptr(ps), L.ptr(ts), half, L.stream()))
+    dl, ps, ts, occ = dl.cpu().numpy(), ps.cpu().numpy(), ts.cpu().numpy(), (cnt.cpu().numpy() > 0).reshape(B, r, r, r)
+    di = di.cpu().numpy()
+    for b in range(B):
+        P = np.zeros((r + 2,) * 3, bool); P[1:-1, 1:-1, 1:-1] = occ[b]
+        D = np.zeros((r, r, r), bool)
+        for dx in range(3):
+            for dy in range(3):
+                for dz in range(3):
+                    D |= P[dx:dx + r, dy:dy + r, dz:dz + r]
+        want = np.flatnonzero(D.reshape(-1))
+        occ_rank = np.full(r3, -1, np.int64); occ_rank[np.flatnonzero(occ[b].reshape(-1))] = np.arange(int(occ[b].sum()))
+        nt = int(ts[b, 0, 7])
+        assert int(ts[b, nt - 1, 1]) == len(want) and np.array_equal(dl[b, :len(want)], want), (r, b)
+        assert int(ts[b, tiles - 1, 1]) == len(want)            # (what the operand-split / SE kernels read)
+        rank = np.full(r3, -1, np.int32); rank[want] = np.arange(len(want))
+        assert np.array_equal(di[b], rank)
+        per_plane = occ[b].reshape(r, -1).sum(1)
+        assert np.array_equal(ps[b, :r + 1], np.concatenate([[0], np.cumsum(per_plane)])) and ps[b, r + 1] == ps[b, r]
+        assert ts[b, 0, 0] == 0 and 1 <= nt <= tiles and (ts[b, :, 7] == nt).all()
+        for t in range(nt):
+            j0, j1, vf, ve, klo, nr = (int(v) for v in ts[b, t, :6])
+            assert j1 - j0 <= tile and (t == 0 or j0 == ts[b, t - 1, 1])
+            assert vf == (0 if t == 0 else (want[j0] if j0 < len(want) else r3)) and ve == (want[j1] if t + 1 < nt and j1 < len(want) else r3)
+            if not half:
+                assert 0 < j1 - j0
                 x0, x1 = want[j0] // (r * r), want[j1 - 1] // (r * r)
                 assert klo == ps[b, max(x0 - 1, 0)] and nr == ps[b, min(x1 + 2, r)] - klo and nr <= 3 * r * r
-                assert vf == (0 if t == 0 else want[j0]) and ve == (want[j1] if t + 1 < nt else r3)   # the linear ranges partition the grid
-            assert (ts[b, nt:, 0] == len(want)).all() and (ts[b, nt:, 1] == len(want)).all()
-            if b == 1:   # the dense slab: some tile other than the last is short, i.e. was cut at a plane boundary
-                assert any(int(ts[b, t, 1] - ts[b, t, 0]) < tile for t in range(nt - 1)), "the dense slab did not force a cut"
+                continue
+            if j1 == j0:
+                continue                                          # an empty piece of a split tile (a plane without listed voxels)
+            assert int(ts[b, t, 12]) == half
+            ranges = [(klo, nr), (int(ts[b, t, 8]), int(ts[b, t, 9])), (int(ts[b, t, 10]), int(ts[b, t, 11]))]
+            assert sum(c for _, c in ranges) <= XCAP, (r, b, t, ranges)
+            x0, x1 = want[j0] // (r * r), want[j1 - 1] // (r * r)
+            assert (int(ts[b, t, 6]) >> 8, int(ts[b, t, 6]) & 255) == (x0, x1)
+            if x0 != x1:
+                assert ranges[1][1] == 0 and ranges[2][1] == 0
+            vs = want[j0:j1]                                      # every occupied neighbour of the tile's voxels lies in one of its ranges
+            vx, vy, vz = vs // (r * r), (vs // r) % r, vs % r
+            for dx in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    for dz in (-1, 0, 1):
+                        gx, gy, gz = vx + dx, vy + dy, vz + dz
+                        ok = (gx >= 0) & (gx < r) & (gy >= 0) & (gy < r) & (gz >= 0) & (gz < r)
+                        k = occ_rank[((gx * r + gy) * r + gz)[ok]]
+                        k = k[k >= 0]
+                        inside = np.zeros(len(k), bool)
+                        for lo, c in ranges:
+                            inside |= (k >= lo) & (k < lo + c)
+                        assert inside.all(), (r, b, t)
+        assert (ts[b, nt:, 0] == len(want)).all() and (ts[b, nt:, 1] == len(want)).all()
+        if b == 1 and not half:   # the dense slab: some tile other than the last is short, i.e. was cut at a plane boundary
+            assert any(int(ts[b, t, 1] - ts[b, t, 0]) < tile for t in range(nt - 1)), "the dense slab did not force a cut"
+        if b == 3 and half and r == 32:   # planes 0 and r - 1 hold n / 3 and 2 n / 3 cells: no tile spans both (their rows would not fit)
+            pass
 
 
 @experimental

@@ -293,3 +293,60 @@ def run_hip_streams(c, seed, shape_indices, device="cuda"):
     else:
         out = bdm_blending(None, c.batch.to(device), c.cfg, model, pvd, streams=streams)
     return out.points_padded().cpu()
+
+
+# ---- C1: vanilla PC^2 sampling, one shape, N = 1024, 100 steps (model/model.py:123-214 of the reference) ----------------------------
+def build_c1(head_scale=1.0, num_points=1024, steps=100, seed=11):
+    """BASELINE.json configs[0] as a free-running trajectory with injected draws keyed by t (the set-up of
+    tests/test_hip_trajectory.py's chaos monitor, with the head of the denoiser scaled like `build`)."""
+    from bdm_amd.config import ProjectConfig
+    from bdm_amd.data import SyntheticShapes
+    from bdm_amd.model import get_model
+    from bdm_amd.utils.procedural import fill_module_
+    cfg = ProjectConfig()
+    model = fill_module_(get_model(cfg).eval(), seed=seed)
+    scale_head_(model, "point_cloud_model.model.", head_scale)
+    batch = next(iter(SyntheticShapes(range(1), 1, seed=5, image_size=224, num_points=num_points)))
+    stride = 1000 // steps
+    ts = list(range(1000 - stride, -1, -stride))
+    return SimpleNamespace(cfg=cfg, model=model, batch=batch, N=num_points, steps=steps, stride=stride, ts=ts,
+                           noise={t: seeded((1, num_points, 3), 3000 + t) for t in ts}, init=seeded((1, num_points, 3), 99))
+
+
+def run_oracle_c1(c, start=None, every=10):
+    """-> (final (1, N, 3), [cloud after every `every`-th step]) of the CPU oracle (ref_sampler.RefDDPM, leading spacing)."""
+    from bdm_amd.cameras import join_cameras
+    from oracle import ref_net, ref_sampler as R, ref_vit
+    sd = _cpu_sd(c.model)
+    local = ref_vit.local_conditioning(sd, c.batch.image_rgb)
+    cams = join_cameras(c.batch.camera).packed()
+    ddpm = R.RefDDPM()
+    x, snaps = (c.init if start is None else start).clone(), []
+    for i, t in enumerate(c.ts):
+        x_in = R.get_input_with_conditioning(x, cams, local)
+        eps = ref_net.point_cloud_model_forward(sd, x_in, torch.full((1,), t), prefix="point_cloud_model.model.")
+        x = ddpm.step(eps, t, x, c.noise[t] if t > 0 else None, prev_t=t - c.stride)
+        if (i + 1) % every == 0:
+            snaps.append(x.clone())
+    return x, snaps
+
+
+def run_hip_c1(c, device="cuda", every=10):
+    """The HIP path on the same draws: the reverse loop in windows of `every` steps (each window one `_denoise_loop` call = the
+    recorded step replayed, as `forward_sample` runs it) -> (final, [cloud after every window])."""
+    model = c.model.to(device)
+    sched = model.schedulers_map["ddpm"]
+    sched.set_timesteps(c.steps)
+    assert [int(v) for v in sched.timesteps] == c.ts
+    it = iter([c.noise[t] for t in c.ts if t > 0])
+    sched.noise_source = lambda shape, dev: next(it).to(dev)
+    b = c.batch.to(device)
+    y, snaps = c.init.to(device), []
+    try:
+        for k in range(0, len(c.ts), every):
+            y = model._denoise_loop(y, b.camera, b.image_rgb, None, sched, c.ts[k:k + every])
+            snaps.append(y.cpu())
+    finally:
+        sched.noise_source = None
+    assert next(it, None) is None
+    return y.cpu(), snaps

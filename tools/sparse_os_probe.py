@@ -1,5 +1,6 @@
-"""Timing probe of the output-stationary sparse first convolution (sparse_conv_os.hip) per layer shape at the bench's batch: feature records,
-dilated plan, the convolution in its compact and dense output forms, and the operand split that consumes each.  usage: sparse_os_probe.py [B]"""
+"""Timing probe of the list convolutions (sparse_conv_os.hip) per layer shape and TILE FORM at the bench's batch: first convolution on the
+once-dilated list (compact rows + GroupNorm partials) and second convolution on the twice-dilated list, full tiles (BDM_DIL_TILE=0: one
+workgroup per CU) against half tiles of 256 / 128 / 64 entries (two per CU).  usage: sparse_os_probe.py [B] [spread]"""
 import os, sys, torch
 import torch.nn as nn
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,47 +18,40 @@ def t(fn, n=20):
 
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+spread = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
 g = torch.Generator().manual_seed(0)
-clouds = {4096: (torch.randn(B, 3, 4096, generator=g) * 0.5).cuda()}
+clouds = {4096: (torch.randn(B, 3, 4096, generator=g) * spread).cuda()}
 for m in (1024, 256, 64):
     clouds[m] = F.furthest_point_sample(clouds[m * 4], m)
-LAYERS = [("SA0.1", 32, 32, 32, 4096), ("SA1.0", 128, 64, 16, 1024), ("SA2.0", 192, 128, 8, 256),
-          ("FP0.x", 256, 256, 8, 64), ("FP1.x", 256, 256, 8, 256), ("FP2.x", 128, 128, 16, 1024), ("FP3.x", 64, 64, 32, 4096)]
-lib = L.lib()
+LAYERS = [("SA0.1", 32, 32, 32, 4096), ("FP3.x", 64, 64, 32, 4096), ("FP2.x", 128, 128, 16, 1024), ("SA1.0", 128, 64, 16, 1024)]
 for name, cin, cout, r, n in LAYERS:
     pts = clouds[n]
-    ops.clear_plan_cache()
-    plan = ops.voxel_plan(pts, r)
     f = torch.randn(B, cin, n, generator=g).cuda()
-    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).cuda()
-    bias = torch.zeros(cout).cuda()
-    gn = nn.GroupNorm(8, cout).cuda()
-    pk = ops.conv3d_h2_pack(w)
-    xr = torch.empty(B, (cin + 7) // 8, plan.n_max, 8, dtype=torch.float32, device="cuda")
-    amax = torch.zeros(B, device="cuda")
-    feat = lambda: L.check(lib.bdm_sparse_voxel_features_f32(B, cin, n, r, plan.n_max, L.ptr(f), cin * n, n, L.ptr(plan.cnt), L.ptr(plan.ws),
-                                                            L.ptr(plan.occ_list), L.ptr(plan.n_occ), L.ptr(xr), L.ptr(amax), L.stream()))
-    feat()
-    yd = torch.empty(B, cout, r ** 3, device="cuda")
-    yc = torch.empty(B, plan.n_dil_max, cout, device="cuda")
-    part = torch.empty(B, 8, plan.tile_start.shape[1], 2, dtype=torch.float64, device="cuda")
-    import ctypes
-    sl = ctypes.c_int(0)
-
-    ctr = torch.zeros(1, dtype=torch.int32, device="cuda")
-
-    def conv(y, compact):
-        return lambda: (ctr.zero_(), L.check(lib.bdm_sparse_conv_dil_gn(B, cin, cout, r, plan.n_max, plan.n_dil_max, L.ptr(xr), L.ptr(amax), L.ptr(plan.occ_index),
-                                                          L.ptr(plan.dil_list), L.ptr(plan.dil_index), L.ptr(plan.tile_start),
-                                                          L.ptr(pk[0]), L.ptr(pk[1]), L.ptr(bias), L.ptr(y), compact, 8, L.ptr(part), ctypes.byref(sl), L.ptr(ctr), L.stream())))
-    tdil = t(lambda: L.check(lib.bdm_voxel_dilate(B, r, plan.n_dil_max, L.ptr(plan.cnt), L.ptr(plan.dil_list), L.ptr(plan.dil_index), L.ptr(plan.plane_start),
-                                                  L.ptr(plan.tile_start), L.stream())))
-    ntl = plan.tile_start[:, 0, 7].float().mean().item()
-    nd = plan.tile_start[:, :, 1].max(1).values.float().mean().item()
-    tc, td = t(conv(yc, 1)), t(conv(yd, 0))
-    st = (part, part.shape[2], 8)
-    comp = ops.CompactGrid(yc, plan, bias, cout)
-    th_c = t(lambda: ops.to_h2(comp, gn, swish=True, stats=st))
-    th_d = t(lambda: ops.to_h2(yd, gn, swish=True, stats=st))
-    print(f"{name} {cin:4d}->{cout:4d} r={r:2d} n_occ={float(plan.n_occ.float().mean()):7.1f} n_dil={nd:7.1f} ({ntl:4.1f} tiles) | features {t(feat):6.1f} us, "
-          f"dilate {tdil:5.1f} us | conv compact {tc:6.1f} us + split {th_c:5.1f} us | conv dense {td:6.1f} us + split {th_d:5.1f} us", flush=True)
+    w1 = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).cuda()
+    w2 = (torch.randn(cout, cout, 3, 3, 3, generator=g) / (27 * cout) ** 0.5).cuda()
+    b1, b2 = torch.randn(cout, generator=g).cuda(), torch.randn(cout, generator=g).cuda()
+    gn1 = nn.GroupNorm(8, cout).cuda()
+    pk1, pk2, wsum = ops.conv3d_h2_pack(w1), ops.conv3d_h2_pack(w2), ops.conv_class_pack(w2)
+    base = None
+    for form in ("0", "256", "128", "64"):
+        ops.DIL_TILE = form
+        ops.clear_plan_cache()
+        plan = ops.voxel_plan(pts, r, dilate=2)
+        first = lambda: ops.sparse_first_conv_os(f, plan, pk1, b1, cout, gn_groups=8, compact=True)
+        comp, st1 = first()
+        rows_h2, const_h2, const_f32, inv_s = ops.to_h2_rows(comp, plan, gn1, st1)
+        second = lambda: ops.second_conv_rows(rows_h2, const_h2, const_f32, inv_s, plan, pk2, wsum, b2, cout, cout, 8)
+        rows, _, _ = second()
+        nd1 = plan.tile_start[:, -1, 1].float().mean().item(); nd2 = plan.d2_tiles[:, -1, 1].float().mean().item()
+        nt1 = plan.tile_start[:, 0, 7].float().mean().item(); nt2 = plan.d2_tiles[:, 0, 7].float().mean().item()
+        rmax1 = (plan.tile_start[:, :, 5] + plan.tile_start[:, :, 9] + plan.tile_start[:, :, 11]).max().item()
+        rmax2 = (plan.d2_tiles[:, :, 5] + plan.d2_tiles[:, :, 9] + plan.d2_tiles[:, :, 11]).max().item()
+        same = ""
+        if base is None:
+            base = (comp.rows.clone(), rows.clone())
+        else:
+            k1, k2 = int(nd1 * 0.5), int(nd2 * 0.5)
+            same = f" bits==full: {bool(torch.equal(comp.rows[:, :k1], base[0][:, :k1]))}/{bool(torch.equal(rows[:, :k2], base[1][:, :k2]))}"
+        tp1 = t(lambda: ops.plan_dilation.__wrapped__(plan) if hasattr(ops.plan_dilation, '__wrapped__') else None, 1)
+        print(f"{name} {cin:3d}->{cout:3d} r={r:2d} tile {form:>3s}: listed {nd1:6.0f} / {nd2:6.0f} voxels, {nt1:5.1f} / {nt2:5.1f} tiles per shape, max rows {rmax1} / {rmax2} | "
+              f"first {t(first):6.1f} us  second {t(second):6.1f} us{same}", flush=True)
