@@ -350,11 +350,11 @@ __global__ void attn_combine_kernel(int C, int CP, int L, int nb, int ksplit, co
   }
 }
 
-// key ranges per (shape, query tile): 1 when those items fill the chip; the choice depends on the sizes only (and is the same for 1 .. 3 shapes
-// of 4096 positions, so the small-batch equality tests compare like with like)
+// key ranges per (shape, query tile) the library RECOMMENDS: 1 when those items fill the chip; a function of the sizes only (the same for 1 .. 3
+// shapes of 4096 positions, so the small-batch equality tests compare like with like).  The count a launch USES is the caller's argument
+// (no environment look-up here -- the workspace size and the launch can no longer disagree, and a caller that wants a shape's bits
+// independent of its launch's batch passes a fixed count).
 static inline int attn_ksplit(int b, int l) {
-  const char *e = getenv("BDM_ATTN_KSPLIT");
-  if (e != nullptr && e[0] >= '1' && e[0] <= '8') return e[0] - '0';
   const long long items = (long long)b * ((l + 127) / 128);
   // measured at l = 4096, 64 channels (us per call, 1 / 2 / 4 / 8 ranges): 1 shape 131 / 82 / 60 / 59, 3 shapes 140 / 96 / 87 / 90, 8 shapes 165 / 149 / 158 / 174
   return l < 1024 ? 1 : (items < 128 ? 4 : (items < 512 ? 2 : 1));
@@ -363,10 +363,10 @@ extern "C" int bdm_attention_h2_key_slices(int b, int l) { return attn_ksplit(b,
 static inline int attn_cp(int c) { return c <= 32 ? 32 : 64; }
 static inline int attn_lp(int l) { return (l + 7) / 8 * 8; }
 
-extern "C" size_t bdm_attention_h2_workspace_bytes(int b, int c, int l) {
+extern "C" size_t bdm_attention_h2_workspace_bytes(int b, int c, int l, int key_slices) {
   if (l <= 64 || c > 64) return 0;
   const size_t cp = attn_cp(c), qk = (size_t)(cp / 8) * 2 * l * 16, v = 2 * cp * (size_t)attn_lp(l) * 2;
-  const int ks = attn_ksplit(b, l);   // + the partial results of the key ranges (none for one range)
+  const int ks = key_slices < 1 ? 1 : key_slices;   // + the partial results of the key ranges (none for one range)
   return (size_t)b * (2 * qk + v) + 64 + (ks > 1 ? (size_t)ks * b * (cp + 2) * l * sizeof(float) + 64 : 0);
 }
 
@@ -374,8 +374,12 @@ extern "C" size_t bdm_attention_h2_workspace_bytes(int b, int c, int l) {
 // shape s (bit patterns of non-negative floats, e.g. from bdm_pointwise_conv_gn's amax output).  64 < l, c <= 64.
 extern "C" int bdm_attention_core_h2(int b, int c, int l, const float *q, const float *k, const float *v, long long bs_qkv,
                                      int ld_qkv, const float *amax, float *out, long long bs_o, int ld_o, void *workspace,
-                                     void *stream) {
+                                     size_t workspace_bytes, int key_slices, void *stream) {
   BDM_REQUIRE(b >= 0 && c >= 1 && c <= 64 && l > 64 && amax != nullptr && workspace != nullptr, "attention_core_h2: bad arguments");
+  BDM_REQUIRE(key_slices >= 1 && key_slices <= 8, "attention_core_h2: key_slices = %d (1 .. 8; bdm_attention_h2_key_slices recommends one)", key_slices);
+  BDM_REQUIRE(workspace_bytes >= bdm_attention_h2_workspace_bytes(b, c, l, key_slices),
+              "attention_core_h2: workspace of %zu bytes, %zu needed for %d key ranges", workspace_bytes,
+              bdm_attention_h2_workspace_bytes(b, c, l, key_slices), key_slices);
   if (b == 0) return BDM_OK;
   hipStream_t s = (hipStream_t)stream;
   const int cp = attn_cp(c), c8 = cp / 8, lp = attn_lp(l);
@@ -385,7 +389,7 @@ extern "C" int bdm_attention_core_h2(int b, int c, int l, const float *q, const 
   unsigned short *vt = reinterpret_cast<unsigned short *>(ks + qk_rec);
   hipLaunchKernelGGL(attn_split_qk_h2_kernel, dim3(cdiv(l, 128), c8, 2 * b), dim3(128), 0, s, c, l, q, k, bs_qkv, ld_qkv, amax, qs, ks);
   hipLaunchKernelGGL(attn_split_v_h2_kernel, dim3(cdiv(lp / 8, 64), cp, b), dim3(64), 0, s, c, cp, l, lp, v, bs_qkv, ld_qkv, amax, vt);
-  const int ksplit = attn_ksplit(b, l);
+  const int ksplit = key_slices;
   const long long total = (long long)cdiv(l, 128) * b * ksplit;
   BDM_REQUIRE(total < (1ll << 28), "attention_core_h2: too many workgroups");
   float *part_o = reinterpret_cast<float *>((reinterpret_cast<size_t>(vt + (size_t)b * 2 * cp * lp) + 63) & ~(size_t)63);

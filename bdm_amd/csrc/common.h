@@ -111,7 +111,18 @@ __device__ __forceinline__ float readlane_f32(float v, const int l) {
 __device__ __forceinline__ double readlane_f64(double v, const int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
+// CONTRACT of every helper below: called by a FULL wave in converged control flow -- all 64 lanes active (block sizes are
+// multiples of 64 and the call does not sit under a divergent branch).  The DPP steps run with bound_ctrl (an inactive source lane reads 0)
+// but the row totals are fetched with v_readlane from lanes 0 / 16 / 32 / 48, whose registers are STALE when those lanes are inactive;
+// debug builds (-DBDM_DEBUG_WAVES) trap on a partial wave.  wave_sum associates ((row0 + row1) + row2) + row3: it is NOT bit-compatible
+// with the xor butterfly of rounds 1 - 4 (wave_sum_bfly, row16_sum and half32_sum are).
+#ifdef BDM_DEBUG_WAVES
+#define BDM_FULL_WAVE() do { if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap(); } while (0)
+#else
+#define BDM_FULL_WAVE() do { } while (0)
+#endif
 __device__ __forceinline__ float wave_sum(float v) {
+  BDM_FULL_WAVE();
   v += dpp_f32(v, BDM_DPP_QUAD_XOR1);
   v += dpp_f32(v, BDM_DPP_QUAD_XOR2);
   v += dpp_f32(v, BDM_DPP_ROW_HALF_MIRROR);

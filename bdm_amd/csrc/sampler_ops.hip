@@ -87,9 +87,10 @@ extern "C" int bdm_lincomb(long long n, int k, float c0, const float *x0, float 
 }
 
 // x0 = a*x - b*eps ; mean = c1*x0 + c2*x ; out = mean + sigma*z   (sigma = 0 at t == 0)
-__global__ void pvd_step_kernel(long long n, const float *__restrict__ x, const float *__restrict__ eps,
+// (x and out are NOT __restrict__: the replayed prior loop steps in place, out == x -- elementwise, each element read and written by one thread)
+__global__ void pvd_step_kernel(long long n, const float *x, const float *__restrict__ eps,
                                 const float *__restrict__ z, float a, float b, float c1, float c2, float sigma,
-                                float *__restrict__ out) {
+                                float *out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float xi = x[i];
     const float x0 = a * xi - b * eps[i];

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(1024) void vox_dilate_kernel(int r, int n_dil_max, 
   }
 }
 
-static bool half_tile_ok(int r, int tile) { return tile == 0 || ((r == 16 || r == 32) && (tile == 64 || tile == 128 || tile == 256)); }
+static bool half_tile_ok(int r, int tile) { return tile == 0 || ((r == 16 || r == 32) && (tile == 64 || tile == 128 || tile == 256)) || (r == 8 && (tile == 64 || tile == 128)); }
 
 extern "C" int bdm_voxel_dilate_slices(int r, int tile) {
   int tl, xcap, tiles_max;
@@ -342,7 +342,9 @@ extern "C" int bdm_voxel_dilate_again(int b, int r, int n_dil_max, const int *di
 #ifdef DIL_TIMING   // phase timestamps of every live workgroup (wall_clock64: 100 MHz), a debug build for tools/sparse_os_probe.py only
 __device__ long long *g_dil_ts = nullptr;
 extern "C" int bdm_debug_dil_timestamps(long long *buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_dil_ts), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; }
-#define DIL_STAMP(i) do { if (g_dil_ts && tid == 0) g_dil_ts[(size_t)item * 8 + (i)] = wall_clock64(); } while (0)
+// stamp 0 also leaves the CU the workgroup runs on in slot 7: HW_ID (wave / SIMD / CU / SH / SE) | XCC_ID << 32
+#define DIL_STAMP(i) do { if (g_dil_ts && tid == 0) { g_dil_ts[(size_t)item * 8 + (i)] = wall_clock64();                                  \
+    if ((i) == 0) g_dil_ts[(size_t)item * 8 + 7] = (long long)__builtin_amdgcn_s_getreg(63492) | ((long long)__builtin_amdgcn_s_getreg(63508) << 32); } } while (0)
 #else
 #define DIL_STAMP(i)
 #endif
@@ -715,15 +717,11 @@ __global__ __launch_bounds__(256, 2) void sconv_dilh_kernel(
   constexpr int NW = 4, NT_ = NW * 64;
   constexpr int BM = 16 * MT, TILE = NT * NW * 16;
   constexpr int R2 = R * R, R3 = R2 * R;
-  constexpr int NQ = OS_PAIRS / 2, QA = 4;           // tap quads; quads of weight phase A (phase B: the other NQ - QA)
-  constexpr int WA = QA * 8 * BM, WB = (NQ - QA) * 8 * BM;   // float4 records per phase
-  constexpr int WIA = WA / NT_, WIB = WB / NT_;
+  constexpr int NQ = OS_PAIRS / 2;                   // tap quads
   constexpr int PF = 3;                              // input rows per thread prefetched in registers one chunk ahead
   constexpr int NBLK = NT * NW, NB = MT * 4 * 2;
   constexpr int XCAP = DILH_XCAP, XS = XCAP + 128;   // records XCAP .. XCAP + 63 of each split: zero; XCAP + 64 .. + 127: the chunk's constant (H2IN)
-  static_assert(WA % NT_ == 0 && WB % NT_ == 0, "weight phases are whole records per thread");
-  float4 *Ws = smem4;                 // [QA][2 pairs][2 splits][2 halves][BM]
-  float4 *Xs = smem4 + WA;            // [2][XS]
+  float4 *Xs = smem4;                 // [2][XS]
   __shared__ int s_item;
   __shared__ float s_osc[64], s_obi[64];
 
@@ -767,7 +765,13 @@ __global__ __launch_bounds__(256, 2) void sconv_dilh_kernel(
       s_osc[tid] = inv_scale[m] * (1.0f / sx);
       s_obi[tid] = bias ? bias[m] : 0.f;
     }
-    const float4 *wbase = Ws + ((kg >> 1) * 4 + (kg & 1)) * BM + l16;
+    // A fragments (weights) come STRAIGHT FROM GLOBAL MEMORY in fragment order: record (chunk c8, quad Q, split s, channel tile mt) of
+    // this lane = wlane[((c8 * NQ + Q) * 8 + s * 2) * Cout + mt * 16] -- 16 lanes read 256 contiguous bytes.  The image is the same for
+    // every wave of the chip (L2-resident, 0.9 MB at 64 -> 64 channels) and the waves of a CU read it nearly in step (L1).
+    // Buffer loads: ONE lane offset (this lane's record inside a (quad, split) block) + a wave-uniform scalar offset per fragment --
+    // no 64-bit per-lane address arithmetic; reads past the image (channel tiles beyond Cout) return zeros and are never stored.
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(wq), 0, C8 * (OS_PAIRS * 4) * Cout * 16, 0x00020000);
+    const int wlane = (((kg >> 1) * 4 + (kg & 1)) * Cout + m0 + l16) * 16;
     f32x4a acc[MT][NT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(256, 2) void sconv_dilh_kernel(
       for (int q = 0; q < NT; ++q) acc[a][q] = f32x4a{0.f, 0.f, 0.f, 0.f};
     typedef f32x4v_t f32x4v;
     f32x4v cr = {0.f, 0.f, 0.f, 0.f};
-    f32x4v xa[PF][2], wr[WIA];
+    f32x4v xa[PF][2];
     const float4 *xb = xr + (size_t)bi * C8 * n_max * 2;
 
     auto load_x = [&](int c8) {
@@ -793,23 +797,6 @@ __global__ __launch_bounds__(256, 2) void sconv_dilh_kernel(
         }
       }
       if (H2IN && tid < 128) cr = *reinterpret_cast<const f32x4v *>(xconst + ((size_t)bi * C8 + c8) * 2 + (tid >> 6));
-    };
-    auto load_w = [&](int c8, int first, int count) {   // records [first, first + count * NT_) of the chunk's weight image
-#pragma unroll
-      for (int i = 0; i < WIA; ++i) {
-        if (i >= count) break;
-        const int e = first + tid + i * NT_;
-        const int m = e % BM, psh = e / BM;
-        const bool ok = m0 + m < Cout;
-        wr[i] = *reinterpret_cast<const f32x4v *>(&wq[ok ? (unsigned)((c8 * (OS_PAIRS * 4) + psh) * Cout + m0 + m) : 0u]);
-      }
-    };
-    auto store_w = [&](int count) {
-#pragma unroll
-      for (int i = 0; i < WIA; ++i) {
-        if (i >= count) break;
-        *reinterpret_cast<f32x4v *>(&Ws[tid + i * NT_]) = wr[i];
-      }
     };
     auto put = [&](int row, const float4 &p, const float4 &q) {
       if (H2IN) {
@@ -848,7 +835,7 @@ __global__ __launch_bounds__(256, 2) void sconv_dilh_kernel(
       if (H2IN && tid < 128) *reinterpret_cast<f32x4v *>(&Xs[(tid >> 6) * XS + XCAP + 64 + (tid & 63)]) = cr;
     };
 
-    if (!nothing) { load_x(0); load_w(0, 0, WIA); }   // chunk 0's operands are in flight while the neighbour records are looked up
+    if (!nothing) load_x(0);   // chunk 0's rows are in flight while the neighbour records are looked up
 
     // ---- tile set-up: per-lane neighbour records, skip mask ------------------------------------------------------------------
     // rec: LDS record of this lane's (voxel, tap) neighbour; XCAP + lane = this lane's zero record, XCAP + 64 + lane = its copy of the
@@ -901,54 +888,64 @@ __global__ __launch_bounds__(256, 2) void sconv_dilh_kernel(
     }
     DIL_STAMP(1);
 
-    auto quads = [&](int q_first, int q_count) {   // tap quads [q_first, q_first + q_count) from Ws slots 0 ..
-#pragma unroll
-      for (int qq = 0; qq < QA; ++qq) {
-        if (qq >= q_count) break;
-        const int Q = q_first + qq;
-        const unsigned qm = (amask >> (Q * NT)) & ((1u << NT) - 1u);
-        if (qm == 0u) continue;
-        f16x8 fa[MT][2];
+    if (!nothing) {
+      f32x4v fa[MT][2], fn[MT][2];                           // this step's weight fragments / the next live step's, in flight
+      auto load_a = [&](f32x4v (&dst)[MT][2], int c8, int Q) {
+        const int so = ((c8 * NQ + Q) * 8) * Cout * 16;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const float4 t = wbase[qq * 8 * BM + s * 2 * BM + mt * 16];
-            fa[mt][s] = *reinterpret_cast<const f16x8 *>(&t);
-          }
+          for (int mt = 0; mt < MT; ++mt)
+            dst[mt][s] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + mt * 256, so + s * 2 * Cout * 16, 0));
+      };
+      const unsigned live_q = [&] {                          // bit Q: some 16-voxel block of this wave has a neighbour under quad Q
+        unsigned m = 0u;
 #pragma unroll
-        for (int q = 0; q < NT; ++q) {
-          f16x8 fb[2];
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const float4 t = Xs[s * XS + rec[q][Q]];
-            fb[s] = *reinterpret_cast<const f16x8 *>(&t);
-          }
-#pragma unroll
-          for (int term = 0; term < 3; ++term)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-              acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[mt][term == 0 ? 1 : 0], fb[term == 1 ? 1 : 0], acc[mt][q], 0, 0, 0);
-        }
-      }
-    };
-    if (!nothing) {
+        for (int Q = 0; Q < NQ; ++Q)
+          if ((amask >> (Q * NT)) & ((1u << NT) - 1u)) m |= 1u << Q;
+        return m;
+      }();
+      int q_first = 0;
+      while (q_first < NQ && !((live_q >> q_first) & 1u)) ++q_first;
+      if (q_first < NQ) load_a(fa, 0, q_first);
       for (int c8 = 0; c8 < C8; ++c8) {
-        __syncthreads();                                   // (A) the previous chunk's operand reads are done; chunk c8's loads have landed
+        __syncthreads();                                   // (A) the previous chunk's row reads are done; chunk c8's rows have landed
         if (c8 == 0) DIL_STAMP(2);
         if (c8 == 0 && tid < 128) Xs[(tid >> 6) * XS + XCAP + (tid & 63)] = make_float4(0.f, 0.f, 0.f, 0.f);
         store_x(c8);
-        store_w(WIA);
         lds_barrier();                                     // (B)
         if (c8 == 0) DIL_STAMP(3);
-        load_w(c8, WA, WIB);                               // phase B's weights in flight under phase A's matrix work
-        quads(0, QA);
-        __syncthreads();                                   // (C) every wave is done with phase A's weights; phase B's have landed
-        store_w(WIB);
-        lds_barrier();                                     // (D)
-        if (c8 == 0) DIL_STAMP(4);
-        if (c8 + 1 < C8) { load_x(c8 + 1); load_w(c8 + 1, 0, WIA); }
-        quads(QA, NQ - QA);
+        if (c8 == 1) DIL_STAMP(4);
+        if (c8 + 1 < C8) load_x(c8 + 1);
+#pragma unroll
+        for (int Q = 0; Q < NQ; ++Q) {
+          if (!((live_q >> Q) & 1u)) continue;             // wave-uniform: no voxel of this wave has a present neighbour under this tap quad
+          {   // the next live quad's fragments (of this chunk, else the next chunk's first live quad)
+            int nq = Q + 1;
+            while (nq < NQ && !((live_q >> nq) & 1u)) ++nq;
+            if (nq < NQ) load_a(fn, c8, nq);
+            else if (c8 + 1 < C8) load_a(fn, c8 + 1, q_first);
+          }
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            f16x8 fb[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const float4 t = Xs[s * XS + rec[q][Q]];
+              fb[s] = *reinterpret_cast<const f16x8 *>(&t);
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+                acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[mt][term == 0 ? 1 : 0]), fb[term == 1 ? 1 : 0],
+                                                                    acc[mt][q], 0, 0, 0);
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fa[mt][s] = fn[mt][s];
+        }
       }
     }
 
@@ -1062,7 +1059,7 @@ static int sconv_dil_launch(bool h2in, int b, int cin, int cout, int r, int n_ma
   int tile, xcap, tiles;
   sconv_dil_geometry(r, half_tile, &tile, &xcap, &tiles);
   const int bm = 32 * mi, nblk = tile / 16, nb = (bm / 16) * 8, ncb = cdiv(cout, bm);
-  size_t smem = half_tile ? 16 * ((size_t)4 * 8 * bm + 2 * ((size_t)xcap + 128))       // weights of four tap quads + the row ranges
+  size_t smem = half_tile ? 16 * (2 * ((size_t)xcap + 128))                             // the row ranges (weights come from global memory)
                           : 16 * ((size_t)OS_PAIRS * 4 * bm + 2 * ((size_t)xcap + 128));
   const size_t smem_out = sizeof(float) * ((size_t)(nblk + 1) * nb + (compact ? 0 : (size_t)bm * tile));
   if (smem_out > smem) smem = smem_out;
@@ -1108,7 +1105,8 @@ static int sconv_dil_launch(bool h2in, int b, int cin, int cout, int r, int n_ma
   if (half_tile) {
     const int nt = half_tile / 64;
     if (r == 32) { if (nt == 4) DILH_PICK(4, 32); else if (nt == 2) DILH_PICK(2, 32); else DILH_PICK(1, 32); }
-    else { if (nt == 4) DILH_PICK(4, 16); else if (nt == 2) DILH_PICK(2, 16); else DILH_PICK(1, 16); }
+    else if (r == 16) { if (nt == 4) DILH_PICK(4, 16); else if (nt == 2) DILH_PICK(2, 16); else DILH_PICK(1, 16); }
+    else { if (nt == 2) DILH_PICK(2, 8); else DILH_PICK(1, 8); }
     return launch_status("sparse_conv_dil (half tiles)");
   }
   if (r == 32) { if (mi == 2) DIL_LAUNCH(4, 4, 8, 32); else DIL_LAUNCH(2, 4, 8, 32); }

@@ -465,6 +465,16 @@ def attention_h2_ok(C, l):
     return ATTENTION_IMPL == "fp16x3" and l > 64 and C <= 64 and C % 32 == 0
 
 
+# Key ranges of the fp16x3 attention (csrc/attention_h2.hip): None = the library's recommendation for the launch's (shapes, positions) -- 4 / 2 / 1
+# ranges at 4096 positions for < 4 / < 16 / more shapes, i.e. like the convolutions' tile forms a shape's bits depend on the per-launch batch
+# (tests pin the count where they compare batch sizes) -- or a fixed count 1 .. 8 from BDM_ATTN_KSPLIT, read ONCE here.
+ATTN_KSPLIT = int(os.environ["BDM_ATTN_KSPLIT"]) if os.environ.get("BDM_ATTN_KSPLIT", "") in tuple("12345678") else None
+
+
+def attention_key_slices(B, l):
+    return int(ATTN_KSPLIT) if ATTN_KSPLIT else int(L.lib().bdm_attention_h2_key_slices(B, l))
+
+
 def attention_core(qkv, C, impl=None, amax=None):
     """qkv (B, 3C, L): rows [0,C) = q, [C,2C) = k, [2C,3C) = v  ->  (B, C, L).  amax (3 floats per shape: max |q|, |k|, |v|,
     from pointwise_conv_gn) selects the fp16x3 kernel."""
@@ -473,9 +483,12 @@ def attention_core(qkv, C, impl=None, amax=None):
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     lib = L.lib()
     if amax is not None:
-        ws = workspace(lib.bdm_attention_h2_workspace_bytes(B, C, l), qkv.device, "attention_h2")
+        ks = attention_key_slices(B, l)
+        nbytes = lib.bdm_attention_h2_workspace_bytes(B, C, l, ks)
+        ws = workspace(nbytes, qkv.device, "attention_h2")
         L.check(lib.bdm_attention_core_h2(B, C, l, L.ptr(q), L.ptr(k), L.ptr(v), L.c_ll(qkv.stride(0)), qkv.stride(1), L.ptr(amax),
-                                          L.ptr(out), L.c_ll(C * l), l, L.ptr(ws), L.stream()), "attention_core_h2")
+                                          L.ptr(out), L.c_ll(C * l), l, L.ptr(ws), ctypes.c_size_t(ws.numel() * ws.element_size()), ks, L.stream()),
+                "attention_core_h2")
         return out
     nbytes = lib.bdm_attention_workspace_bytes(B, C, l) if (impl or ATTENTION_IMPL) in ("bf16x6", "fp16x3") else 0
     ws = workspace(nbytes, qkv.device, "attention") if nbytes else None
@@ -1006,28 +1019,22 @@ def has_voxel_plan(coords, r):
 
 
 TILE_REC = 16         # ints per tile record of a dilated plan (include/bdm_hip.h)
-# Tile form of the list convolutions (csrc/sparse_conv_os.hip): "auto" = the rule below, "0" = full tiles everywhere (round 4's kernel, one
-# workgroup per CU), "64" / "128" / "256" = that half-tile size wherever the form exists (r = 16, 32)
-DIL_TILE = os.environ.get("BDM_DIL_TILE", "auto")
-DIL_HALF_CUS = 256    # CUs the rule fills with two workgroups each
+# Tile form of the list convolutions (csrc/sparse_conv_os.hip): "0" (default) = FULL tiles, one eight-wave workgroup per CU (round 4's
+# kernel); "64" / "128" / "256" = HALF tiles of that many entries, two four-wave workgroups per CU, weights straight from L2 (round 6).
+# The half form was built to hide a tile's look-up chain / store burst behind a co-resident tile's matrix phase and
+# MEASURED: two workgroups do co-reside, give the full form's bits, and a 256-entry tile then lives exactly as long as a 512-entry one
+# (75 vs 78 us at 64 -> 64 channels, 32^3: the chunk loop is bound by the CU's matrix pipe, which the partners share, and with ~1 tile per
+# slot both run the same phase at the same time) -- kernel 94 vs 84 us, replayed C2 step 5.16 vs 4.95 ms; at 8^3 it loses to GEMM + gather
+# by 1.4 - 2.7x (profiles/r06_sparse_dil_half_tiles.txt).  Kept as an opt-in with its tests; never the default.
+DIL_TILE = os.environ.get("BDM_DIL_TILE", "0")
 
 
 def dil_tile(batch, n_points, r, second):
-    """Entries per tile of the (once- / twice-) dilated list of a level: 0 = the full-tile form.  The half-tile form runs TWO four-wave
-    workgroups per CU (each hides the other's look-up chain, barriers and store burst), so it wants >= ~2 items per CU: the largest of
-    256 / 128 / 64 entries that gives the batch that many tiles.  The dilated fractions are estimated from the sizes alone (as
-    sparse_dil_pays: a cloud of n points dilates to ~2 n voxels once, ~3 n twice, capped by the grid), so the choice depends on the
-    configuration, never on the data; one rule per (batch, points, resolution) -- not per channel count -- because the PVConvs of a
-    level share the plan."""
-    if r not in (16, 32):
+    """Entries per tile of the (once- / twice-) dilated list of a level: 0 = the full-tile form (the default, see DIL_TILE).  One value
+    per (batch, points, resolution) -- not per channel count -- because the PVConvs of a level share the plan."""
+    if r not in (8, 16, 32) or DIL_TILE in ("0", "", "auto"):
         return 0
-    if DIL_TILE != "auto":
-        return int(DIL_TILE)
-    listed = min((3 if second else 2) * n_points, (r ** 3 * 3) // 4) * batch
-    for tile in (256, 128):
-        if listed // tile >= 2 * DIL_HALF_CUS * 3 // 4:
-            return tile
-    return 64
+    return min(int(DIL_TILE), 128) if r == 8 else int(DIL_TILE)
 
 
 DILATED_PLAN = True   # voxel plans carry the once-dilated voxel list + tile table of the compact first convolution (sparse_conv_os.hip)

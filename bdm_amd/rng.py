@@ -69,8 +69,10 @@ class ShapeStreams:
         (may be `x` itself: the kernel is elementwise)."""
         x, eps = x.contiguous(), eps.contiguous()
         per = self._check(x.shape)
-        if out is None or not (out.is_contiguous() and out.shape == x.shape and out.dtype == x.dtype):
+        if out is None:
             out = torch.empty_like(x)
+        if not (out.is_contiguous() and out.shape == x.shape and out.dtype == x.dtype and out.device == x.device):
+            raise ValueError("ShapeStreams.ddpm_step: `out` must be a contiguous tensor of x's shape, dtype and device")
         sigma = c["sigma"] if c.get("noise", True) else 0.0
         draw = self._next(purpose) if sigma != 0.0 else 0
         L.check(L.lib().bdm_ddpm_step_philox(x.shape[0], per, L.ptr(x), L.ptr(eps), L.ptr(self.keys), draw, purpose,

@@ -102,7 +102,9 @@ class DDPMScheduler:
         eps = model_output.contiguous()
         assert x.shape == eps.shape and x.dtype == torch.float32
         if out is not None and not (out.is_contiguous() and out.shape == x.shape and out.dtype == x.dtype and out.device == x.device):
-            out = None
+            # (never a silent fresh tensor -- the in-place reverse loops discard the return value and would denoise the same x forever)
+            raise ValueError(f"DDPMScheduler.step: `out` must be a contiguous {tuple(x.shape)} {x.dtype} tensor on {x.device}, got "
+                             f"{tuple(out.shape)} {out.dtype} on {out.device}, contiguous={out.is_contiguous()}")
         if self.streams is not None and self.noise_source is None:
             out = self.streams.ddpm_step(x, eps, dict(c, noise=t > 0), purpose=self.stream_purpose, out=out)
             return SimpleNamespace(prev_sample=out) if return_dict else (out,)

@@ -283,13 +283,16 @@ int bdm_attention_core(int b, int c, int l, const float *q, const float *k, cons
 /* fp16x3 form (half the matrix work of the bf16x6 kernel behind bdm_attention_core): needs amax[3 s + 0..2] = max |q|, |k|, |v| of
  * shape s (the projection GEMM leaves them: bdm_pointwise_conv_gn amax with amax_rows = c) and a workspace of bdm_attention_h2_workspace_bytes;
  * 64 < l, c <= 64 */
-size_t bdm_attention_h2_workspace_bytes(int b, int c, int l);
-/* Key ranges per (shape, query tile) of bdm_attention_core_h2 for b shapes of l positions: 1 when the (shape, query tile) items fill the chip;
- * 2 or 4 for few shapes (each range leaves an unnormalised partial result, merged in ascending key order: deterministic, and a function of
- * (b, l) only -- but a shape's bits then depend on how many shapes share its launch; BDM_ATTN_KSPLIT=1..8 fixes the count). */
+size_t bdm_attention_h2_workspace_bytes(int b, int c, int l, int key_slices);
+/* key_slices = key ranges per (shape, query tile), 1 .. 8: each range leaves an unnormalised partial result, merged in ascending key order
+ * (deterministic).  The CALLER chooses the count and passes it to both functions (no environment look-up in the library: the workspace and
+ * the launch cannot disagree, and the launch checks workspace_bytes).  bdm_attention_h2_key_slices(b, l) is the library's recommendation
+ * for b shapes of l positions -- 1 when the (shape, query tile) items fill the chip, 2 or 4 for few shapes; a shape's bits depend on the
+ * count, so a caller that wants them independent of the launch's batch passes a fixed one (host side: BDM_ATTN_KSPLIT, read once). */
 int bdm_attention_h2_key_slices(int b, int l);
 int bdm_attention_core_h2(int b, int c, int l, const float *q, const float *k, const float *v, long long bs_qkv, int ld_qkv,
-                          const float *amax, float *out, long long bs_o, int ld_o, void *workspace, void *stream);
+                          const float *amax, float *out, long long bs_o, int ld_o, void *workspace, size_t workspace_bytes,
+                          int key_slices, void *stream);
 
 #ifdef BDM_EXPERIMENTAL  /* fp32-input MFMA convolution family (csrc/experimental/conv3d.hip): `make EXPERIMENTAL=1` */
 /* nn.Conv3d(cin, cout, 3, padding=1) on (b, cin, r, r, r), r in {8, 16, 32} (pvconv.py:75-85).
@@ -627,7 +630,7 @@ int bdm_lincomb(long long n, int k, float c0, const float *x0, float c1, const f
 
 /* PVD scheduler step: GaussianDiffusion.p_sample (experiments/pvd/__init__.py:136-224):
  *   x0 = sqrt_recip_abar * x - sqrt_recipm1_abar * eps;  mean = coef1 * x0 + coef2 * x;
- *   out = mean + sigma * noise      (sigma = 0 at t == 0; noise is always drawn, as the reference does) */
+ *   out = mean + sigma * noise      (sigma = 0 at t == 0; noise is always drawn, as the reference does).  `out` may be `x` (elementwise). */
 int bdm_pvd_step(long long n, const float *x, const float *eps, const float *noise,
                  float sqrt_recip_abar, float sqrt_recipm1_abar, float coef1, float coef2,
                  float sigma, float *out, void *stream);

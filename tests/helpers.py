@@ -70,3 +70,19 @@ def golden_trajectory(name):
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"traj_{name}.npz"))
     return {k: g[k] for k in g.files}
+
+
+def oracle_spread(name):
+    """Oracle-vs-oracle yardstick of a trajectory fixture: the relative L2 distance between the final clouds of the
+    fixture of record and of the SAME case run by the SAME oracle at another reduction order (`traj_<name>_alt*.npz`: another
+    `torch.set_num_threads`, oracle/gen_golden_traj.py --threads) -- the largest over the alternates present.  Owes nothing to the
+    product: both sides are oracle/.  None when the fixture has no alternate."""
+    import glob
+    import os
+    g = golden_trajectory(name)
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    alts = sorted(glob.glob(os.path.join(here, f"traj_{name}_alt*.npz")))
+    if not alts:
+        return None
+    ref = torch.from_numpy(g["final"])
+    return max(rel_l2(torch.from_numpy(np.load(a)["final"]), ref) for a in alts)

@@ -189,13 +189,13 @@ def test_attention_key_ranges_equal_the_single_range_form(ops, monkeypatch, B, C
     x = qkv.cuda()
     outs = {}
     for ks in (1, 2, 3, 4, 8):
-        monkeypatch.setenv("BDM_ATTN_KSPLIT", str(ks))
+        monkeypatch.setattr(ops, "ATTN_KSPLIT", ks)
         outs[ks] = ops.attention_core(x, C, amax=amax).cpu()
         assert rel(outs[ks], ref) < 5e-6, ks
         assert torch.equal(outs[ks], ops.attention_core(x, C, amax=amax).cpu()), ks   # deterministic
         if ks > 1:
             assert rel(outs[ks], outs[1]) < 2e-6 and not torch.equal(outs[ks], outs[1]), ks
-    monkeypatch.delenv("BDM_ATTN_KSPLIT")
+    monkeypatch.setattr(ops, "ATTN_KSPLIT", None)
     auto = L_.lib().bdm_attention_h2_key_slices(B, L)
     assert auto in (1, 2, 4) and torch.equal(ops.attention_core(x, C, amax=amax).cpu(), outs[auto])
 

@@ -12,7 +12,9 @@ for m in (1024, 256, 64):
     clouds[m] = F.furthest_point_sample(clouds[m * 4], m)
 lib = L.lib()
 lib.bdm_debug_dil_timestamps.argtypes = [ctypes.c_void_p]
-for name, cin, cout, r, n in [("SA0.1", 32, 32, 32, 4096), ("FP2.x", 128, 128, 16, 1024), ("FP3.x", 64, 64, 32, 4096)]:
+FORMS = sys.argv[1:] or ["0", "256"]
+for form, (name, cin, cout, r, n) in [(fm, l) for l in [("SA0.1", 32, 32, 32, 4096), ("FP2.x", 128, 128, 16, 1024), ("FP3.x", 64, 64, 32, 4096)] for fm in FORMS]:
+    ops.DIL_TILE = form
     ops.clear_plan_cache()
     plan = ops.voxel_plan(clouds[n], r, dilate=1)
     f = torch.randn(B, cin, n, generator=g).cuda()
@@ -35,6 +37,17 @@ for name, cin, cout, r, n in [("SA0.1", 32, 32, 32, 4096), ("FP2.x", 128, 128, 1
     us = (live - t0) / 100.0          # 100 MHz
     d = np.diff(us[:, :7], axis=1)
     lab = ["tile record -> neighbour records", "-> first barrier (W/X chunk 0 loaded)", "stage chunk 0", "chunk 0 MFMA (+ prefetch)", "chunks 1..", "epilogue"]
+    hw = live[:, 7].astype(np.int64)
+    cu = ((hw >> 32) & 15) * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 50 + ((hw >> 8) & 15)     # (XCC, SE, SH, CU)
+    conc = 0
+    for c in np.unique(cu):
+        iv = us[cu == c][:, [0, 6]]
+        ev = sorted([(a, 1) for a, _ in iv] + [(b, -1) for _, b in iv])
+        k = 0
+        for _, dlt in ev:
+            k += dlt
+            conc = max(conc, k)
+    print(f"tile form {form}: {len(np.unique(cu))} distinct CUs, at most {conc} workgroups resident on one CU at a time")
     print(f"{name} {cin}->{cout} r={r}: {len(live)} live workgroups; start spread {us[:, 0].max():.1f} us; kernel end {us[:, 6].max():.1f} us")
     for i, l in enumerate(lab):
         print(f"    {l:42s} mean {d[:, i].mean():7.2f} us   max {d[:, i].max():7.2f}")

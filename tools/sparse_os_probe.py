@@ -55,3 +55,37 @@ for name, cin, cout, r, n in LAYERS:
         tp1 = t(lambda: ops.plan_dilation.__wrapped__(plan) if hasattr(ops.plan_dilation, '__wrapped__') else None, 1)
         print(f"{name} {cin:3d}->{cout:3d} r={r:2d} tile {form:>3s}: listed {nd1:6.0f} / {nd2:6.0f} voxels, {nt1:5.1f} / {nt2:5.1f} tiles per shape, max rows {rmax1} / {rmax2} | "
               f"first {t(first):6.1f} us  second {t(second):6.1f} us{same}", flush=True)
+
+# ---- 8^3 levels: the list kernel in its half-tile form against the route the product takes there (fp16x3 GEMM over the occupied rows +
+# gather with GroupNorm-1 + Swish + operand split in its epilogue)
+print("8^3 levels: first convolution -> second convolution's fp16 operand", flush=True)
+for name, cin, cout, n in [("FP1.x", 256, 256, 256), ("FP0.x", 256, 256, 64), ("SA2.0", 192, 128, 256), ("SA3->", 128, 256, 64)]:
+    r = 8
+    pts = clouds[n]
+    f = torch.randn(B, cin, n, generator=g).cuda()
+    w1 = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).cuda()
+    b1 = torch.randn(cout, generator=g).cuda()
+    gn1 = nn.GroupNorm(8, cout).cuda()
+    pk1, pkg = ops.conv3d_h2_pack(w1), ops.sparse_conv_pack_h2(w1)
+    ops.DIL_TILE = "0"
+    ops.clear_plan_cache()
+    plan = ops.voxel_plan(pts, r)
+    def gemm():
+        v, st = ops.sparse_first_conv_planned(f, plan, pkg, b1, cout, gn_groups=8)
+        return ops.to_h2(v, gn1, swish=True, stats=st)
+    ref = gemm()
+    t_gemm = t(gemm)
+    line = f"{name} {cin:3d}->{cout:3d} n={n:4d}: features + split + GEMM + gather(stats) + operand split {t_gemm:6.1f} us |"
+    for form in ("0", "64", "128"):
+        ops.DIL_TILE = form
+        ops.clear_plan_cache()
+        plan = ops.voxel_plan(pts, r, dilate=1)
+
+        def lst():
+            v, st = ops.sparse_first_conv_os(f, plan, pk1, b1, cout, gn_groups=8, compact=False)
+            return ops.to_h2(v, gn1, swish=True, stats=st)
+        got = lst()
+        conv_only = t(lambda: ops.sparse_first_conv_os(f, plan, pk1, b1, cout, gn_groups=8, compact=False))
+        d = float((got[0].float() - ref[0].float()).abs().max())
+        line += f" list tile {form:>3s}: {t(lst):6.1f} us (conv + features {conv_only:6.1f}) max|d hi| {d:.1e} |"
+    print(line, flush=True)
