@@ -1101,6 +1101,68 @@ __global__ __launch_bounds__(256) void sa_group_pm_kernel(int c, int n, int m, i
   }
 }
 
+// --- LDS-staged path (round 6) ---------------------------------------------------------------------
+// The levels that materialise the grouped tensor are small (1024 / 256 / 64 points): a channel row of ALL the shape's points is 4 KB or
+// less.  A workgroup owns SAG_R channel rows of one shape: it brings them into LDS with LDS-DMA (global_load_lds_dwordx4: a
+// wave-instruction moves 64 x 16 bytes from per-lane addresses straight into 1 KB of LDS, no VGPR in between; all of a wave's pieces in
+// flight, one wait), then every (centre, neighbour) element of its block reads its SAG_R values from LDS -- 64 random dwords in two
+// cycles, where a scattered 4-byte load from global memory costs the address unit a line per lane (~4 B / clk / CU: what bounds
+// sa_group_kernel) -- and the stores out[ch][e] are coalesced across lanes as before.  17.3 -> 11.7 us at level 1 of the denoisers, B = 16
+// (35 MB written at 3 TB/s: the write stream is what is left; profiles/r06_g1_query_and_gather.txt).
+constexpr int SAG_R = 3;        // channel rows per workgroup (the three coordinate rows are workgroup 0's)
+constexpr int SAG_EB = 4096;    // (centre, neighbour) elements per workgroup
+__global__ __launch_bounds__(256) void sa_group_lds_kernel(int c, int n, int m, int u, int dma, const float *__restrict__ coords,
+                                                           const float *__restrict__ centers, const float *__restrict__ feat,
+                                                           long long bs_f, int ld_f, const int *__restrict__ idx, float *__restrict__ out) {
+  extern __shared__ __align__(16) float sag_tile[];   // [SAG_R][n] (+ 1 KB of slack)
+  const int bi = blockIdx.z, ch0 = blockIdx.x * SAG_R, rows = c + 3, nr = min(SAG_R, rows - ch0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t mu = (size_t)m * u;
+  auto row_of = [&](int ch) { return ch < 3 ? coords + ((size_t)bi * 3 + ch) * n : feat + (size_t)bi * bs_f + (size_t)(ch - 3) * ld_f; };
+  if (dma) {                                          // n % 256 == 0, rows 16-byte aligned: whole 1-KB pieces
+    const int ppr = n >> 8;                           // pieces per row
+    for (int pc = wave; pc < nr * ppr; pc += 4) {
+      const int r = pc / ppr, p = pc - r * ppr;
+      const float *g = row_of(ch0 + r) + p * 256 + lane * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                       (__attribute__((address_space(3))) void *)(sag_tile + (size_t)r * n + p * 256), 16, 0, 0);
+    }
+  } else {
+    for (int r = 0; r < nr; ++r) {
+      const float *row = row_of(ch0 + r);
+      for (int k = threadIdx.x; k < n; k += 256) sag_tile[(size_t)r * n + k] = row[k];
+    }
+  }
+  const int e0 = blockIdx.y * SAG_EB, e1 = (int)min((size_t)e0 + SAG_EB, mu);
+  const int *ib = idx + (size_t)bi * mu;
+  int src[SAG_EB / 256];
+#pragma unroll
+  for (int k = 0; k < SAG_EB / 256; ++k) {            // the indices are in flight with the rows
+    const int e = e0 + threadIdx.x + k * 256;
+    src[k] = e < e1 ? ib[e] : 0;
+  }
+  __syncthreads();                                    // (drains the DMA: vmcnt(0))
+  float *ob = out + ((size_t)bi * rows + ch0) * mu;
+  const float *cc = centers + (size_t)bi * 3 * m;
+#pragma unroll
+  for (int k = 0; k < SAG_EB / 256; ++k) {
+    const int e = e0 + threadIdx.x + k * 256;
+    if (e < e1) {
+      float v[SAG_R];
+#pragma unroll
+      for (int r = 0; r < SAG_R; ++r) v[r] = r < nr ? sag_tile[(size_t)r * n + src[k]] : 0.f;
+      if (ch0 == 0) {                                 // group(coords) - centre (ball_query.py:27); SAG_R >= 3: all three rows are here
+        const int j = e / u;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) v[r] = v[r] - cc[(size_t)r * m + j];
+      }
+#pragma unroll
+      for (int r = 0; r < SAG_R; ++r)
+        if (r < nr) ob[(size_t)r * mu + e] = v[r];
+    }
+  }
+}
+
 static inline int sa_row_floats(int c) { return ((c + 3 + 3) / 4) * 4; }
 
 extern "C" size_t bdm_sa_group_workspace_bytes(int b, int c, int n) {
@@ -1119,6 +1181,17 @@ extern "C" int bdm_sa_group(int b, int c, int n, int m, int u, const float *coor
                        coords, features, bs_f, ld_f, (float *)workspace);
     hipLaunchKernelGGL(sa_group_pm_kernel, dim3(cdiv(m * u, 256), cdiv(p / 4, SAQ), b), dim3(256), 0, (hipStream_t)stream, c,
                        n, m, u, p, (const float *)workspace, centers, indices, out);
+    return launch_status("sa_group");
+  }
+  // SAG_R rows of the shape's points fit LDS (96 KB at 8192 points); below 256 points a row is a fraction of a DMA piece and the whole
+  // level is launch-bound either way (measured at B = 16, kernel trace: 1024 points 17.3 -> 11.7 us, 256 points 8.9 -> 7.8, 64 points 6.0 -> 6.5)
+  if (n >= 256 && n <= 8192 && (long long)m * u <= (1ll << 24)) {
+    const int dma = (n % 256 == 0) && (ld_f % 4 == 0) && (bs_f % 4 == 0) && ((reinterpret_cast<size_t>(coords) & 15) == 0) &&
+                    (c == 0 || (reinterpret_cast<size_t>(features) & 15) == 0);
+    const size_t smem = sizeof(float) * SAG_R * (size_t)n + 1024;
+    BDM_ALLOW_LDS(sa_group_lds_kernel, smem);
+    hipLaunchKernelGGL(sa_group_lds_kernel, dim3(cdiv(c + 3, SAG_R), cdiv(m * u, SAG_EB), b), dim3(256), smem, (hipStream_t)stream, c, n, m, u,
+                       dma, coords, centers, features, bs_f, ld_f, indices, out);
     return launch_status("sa_group");
   }
   int gy = c < 32 ? (c < 1 ? 1 : c) : 32;
