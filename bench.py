@@ -426,6 +426,22 @@ def main():
                     "pair_hbm_frac": round((gather_bytes + query_bytes - 4.0 * b_ * m_ * u_) / (sg["avg_us"] + bq["avg_us"]) / 1e3 / profiling.HBM_PEAK_GBS, 3),
                     "note": "the query is bound by VALU issue (6.7 instructions per distance test), not by its 3 MB of traffic; the gather meets "
                             "the 40 % target on its own, the pair cannot by memory tuning (DESIGN.md 7.6)"}
+                # the pair that DOES run inside the timed region: set-abstraction level 1 (n / 4 points -> n / 16 centres), ball query on the
+                # sampler's stream + the grouping gather from LDS-staged channel rows (round 6: sa_group_lds_kernel) on the main stream
+                bq1 = _row("bdm_ball_query", lambda sh: sh[1] == args.points // 4 and sh[2] == args.points // 16)
+                sg1 = _row("bdm_sa_group", lambda sh: sh[2] == args.points // 4 and sh[3] == args.points // 16)
+                if bq1 and sg1:
+                    b1_, c1_, n1_, m1_, u1_ = sg1["shape"][:5]
+                    pair_bytes = 4.0 * b1_ * (3 * n1_ + 3 * m1_ + c1_ * n1_ + m1_ * u1_ + (c1_ + 3) * m1_ * u1_)
+                    gather1 = 4.0 * b1_ * ((3 + c1_) * n1_ + m1_ * u1_ + (c1_ + 3) * m1_ * u1_)
+                    line["g1_ball_query_and_grouping"]["in_path_pair_level1"] = {
+                        "level": f"SA1: {b1_} x {n1_} points -> {m1_} centres x {u1_} neighbours, {c1_} feature channels", "in_timed_path": True,
+                        "ball_query_us": round(bq1["avg_us"], 2), "grouping_gather_us": round(sg1["avg_us"], 2),
+                        "algorithmic_mb": round(pair_bytes / 2 ** 20, 1),
+                        "gather_hbm_frac": round(gather1 / sg1["avg_us"] / 1e3 / profiling.HBM_PEAK_GBS, 3),
+                        "pair_hbm_frac": round(pair_bytes / (bq1["avg_us"] + sg1["avg_us"]) / 1e3 / profiling.HBM_PEAK_GBS, 3),
+                        "note": "both kernels timed by the in-run events of the timed region; why the pair stays below 0.40 at every level: "
+                                "profiles/r06_g1_query_and_gather.txt (the gather alone is write-bound at 0.41 - 0.49)"}
                 if fused is not None:
                     fb_, fc_, fn_, fm_, fu_, f1_, f2_ = fused["shape"][:7]
                     flops_ = 2.0 * fb_ * fm_ * fu_ * ((3 + fc_) * f1_ + f1_ * f2_)

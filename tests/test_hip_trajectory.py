@@ -25,28 +25,36 @@ def _c1_fixture(name):
     return {k: g[k] for k in g.files}, {k: alt[k] for k in alt.files}
 
 
-def test_c1_free_running_final_cloud_vs_oracle_fixture(hip):
+@pytest.mark.parametrize("name", ["c1_n1024_h03", "c1_n1024_h01"])
+def test_c1_free_running_final_cloud_vs_oracle_fixture(hip, name):
     """C1 as the reference runs it (model/model.py:182-201): vanilla PC^2, ONE shape, N = 1024, 100 FREE-RUNNING steps, projection
-    conditioning at every step -- final cloud against the oracle's (tests/golden/traj_c1_n1024_h03.npz, oracle/gen_golden_traj.py) at
-    the literal 1e-3.  Head scale 0.3 = the largest of {1, 0.3, 0.1, 0.03} at which the oracle's own 1-ulp self-sensitivity over these
-    100 steps stays below 1e-4 (7.1e-3 / 8.2e-6 / 2.6e-7 / 2.0e-7: the rule of tests/test_hip_full_trajectory.py applied to this
-    configuration).  The oracle's self-sensitivity and its distance from itself at another reduction order travel
-    with the fixture and go on the record beside the figure."""
+    conditioning at every step -- final cloud against the oracle's (tests/golden/traj_<name>.npz, oracle/gen_golden_traj.py) at the
+    LITERAL 1e-3.  Head scale 0.3 = the largest of {1, 0.3, 0.1, 0.03} at which the oracle's own 1-ulp
+    self-sensitivity over these 100 steps stays below 1e-4 (7.1e-3 / 8.2e-6 / 2.6e-7 / 2.0e-7: the rule of
+    tests/test_hip_full_trajectory.py applied to this configuration).  The oracle at ANOTHER reduction order (the `_alt` fixture: 1
+    thread against 2) says more than that single probe: at 0.3 it ends 1.05e-3 from the fixture of record -- one discrete decision
+    (pixel ownership / ball membership) flips between steps 30 and 40 -- at 0.1 it stays at the fp32 floor.  Both head scales are
+    held to the literal bound; the 1e-4 early-warning line is asserted where the oracle agrees with itself (0.1).  Both oracle
+    yardsticks travel with the fixtures and go on the record beside the figure."""
     import trajectory_case as case
     from helpers import parity
-    g, alt = _c1_fixture("c1_n1024_h03")
-    c = case.build_c1(float(g["head_scale"]), num_points=int(g["N"]), steps=int(g["steps"]))
+    g, alt = _c1_fixture(name)
+    h = float(g["head_scale"])
+    c = case.build_c1(h, num_points=int(g["N"]), steps=int(g["steps"]))
     final, snaps = case.run_hip_c1(c)
     assert bool(torch.isfinite(final).all())
     curve = [rel_l2(x, torch.from_numpy(g[f"snap_{i}"])) for i, x in enumerate(snaps)]
-    err = parity("traj_c1_n1024_h03 final cloud (C1: vanilla PC^2, 100 free-running steps, head 0.3)", rel_l2(final, torch.from_numpy(g["final"])), 1e-3,
-                 note="margin line 1e-4")
-    parity("traj_c1_n1024_h03 oracle 1-ulp self-sensitivity (context)", float(g["self_sensitivity"]), 1e-4)
-    parity("traj_c1_n1024_h03 oracle vs oracle at another reduction order (context)", rel_l2(torch.from_numpy(alt["final"]), torch.from_numpy(g["final"])), 1.0)
-    print("C1 free-running, head 0.3: every 10th step", " ".join(f"{e:.1e}" for e in curve), f"final {err:.3e}")
+    d_oo = rel_l2(torch.from_numpy(alt["final"]), torch.from_numpy(g["final"]))
+    calm = d_oo < 1e-4
+    err = parity(f"traj_{name} final cloud (C1: vanilla PC^2, 100 free-running steps, head {h:g})", rel_l2(final, torch.from_numpy(g["final"])), 1e-3,
+                 note="margin line 1e-4" if calm else f"oracle vs oracle {d_oo:.1e}: no margin line")
+    parity(f"traj_{name} oracle 1-ulp self-sensitivity (context)", float(g["self_sensitivity"]), 1e-4)
+    parity(f"traj_{name} oracle vs oracle at another reduction order (context)", d_oo, 1.0)
+    print(f"C1 free-running, head {h:g}: every 10th step", " ".join(f"{e:.1e}" for e in curve), f"final {err:.3e}; oracle vs oracle {d_oo:.3e}")
     assert float(g["self_sensitivity"]) < 1e-4
     assert err <= 1e-3, f"final rel-L2 {err:.3e}; every 10th step {['%.1e' % e for e in curve]}"
-    assert err <= 1e-4, f"margin gone: {err:.3e} is inside 1e-3 but past the 1e-4 early-warning line"
+    if calm:
+        assert err <= 1e-4, f"margin gone: {err:.3e} is inside 1e-3 but past the 1e-4 early-warning line"
 
 
 def test_c1_chaos_monitor_divergence_no_faster_than_the_oracles_own(hip):

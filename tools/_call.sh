@@ -1,16 +1,5 @@
-mkdir -p $GRAFT_REPO_ROOT/gpurun_out/r6
-cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sg -o sg -- python3 $GRAFT_REPO_ROOT/tools/sa_group_bench.py 16 > /dev/null 2>&1
-python3 - <<'P' > $GRAFT_REPO_ROOT/gpurun_out/r6/c09_sa_group_kernels.txt
-import csv, glob, collections
-f = glob.glob('/tmp/sg/**/*kernel_trace.csv', recursive=True)[0]
-d = collections.defaultdict(list)
-for r in csv.DictReader(open(f)):
-    k = r['Kernel_Name'].split('(')[0]
-    if any(s in k for s in ('sa_group', 'sa_pack', 'ball_query')):
-        d[(k, r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-for k, v in sorted(d.items()):
-    v = sorted(v)
-    print(f"{k[0][:40]:40s} grid=({k[1]},{k[2]},{k[3]}) n={len(v):3d} median {v[len(v)//2]:7.2f} us  min {v[0]:7.2f}")
-P
-cat $GRAFT_REPO_ROOT/gpurun_out/r6/c09_sa_group_kernels.txt
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6
+timeout 900 python -m pytest tests/test_hip_dense.py tests/test_hip_net.py -m gpu -q -x -k "conv3d or golden or forced" 2>&1 | grep -v PARITY | tail -6 > gpurun_out/r6/c11_tests.txt
+for pp in 0 1 0 1; do echo "== PINGPONG=$pp"; BDM_CONV_PINGPONG=$pp BENCH_S3=0 python tools/conv_h2_bench.py 16 2>&1 | grep -v amdgpu; done > gpurun_out/r6/c11_conv.txt 2>&1
+for pp in 0 1 0 1; do echo "PINGPONG=$pp $(BDM_CONV_PINGPONG=$pp python tools/replay_host_time.py 16 4096 2>&1 | tail -1)"; done > gpurun_out/r6/c11_step.txt 2>&1
+cat gpurun_out/r6/c11_tests.txt gpurun_out/r6/c11_conv.txt gpurun_out/r6/c11_step.txt
