@@ -1527,7 +1527,7 @@ def sparse_dil_pays(batch, n_points, r, cout):
 
 def compact_tail_pays(batch, n_points, r, cout):
     """Does the voxel branch on voxel lists (second convolution on the twice-dilated list, no dense grids: pvconv_compact.hip) beat the
-    dense-grid path?  Measured at B = 16 (tools/conv2_compact_estimate.py): 64 channels at 32^3 187 vs 358 us, 32 channels 84 vs 117,
+    dense-grid path?  Measured at B = 16 (round 4's pricing tool, since replaced by tools/sparse_os_probe.py): 64 channels at 32^3 187 vs 358 us, 32 channels 84 vs 117,
     64 channels at 16^3 56 vs 75, 128 channels at 16^3 176 vs 157 (the list covers 72 % of that grid: no).  As sparse_dil_pays: decided
     from the sizes, never from the data."""
     if r == 32:
