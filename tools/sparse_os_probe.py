@@ -18,12 +18,13 @@ def t(fn, n=20):
 
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-spread = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+N0 = int(sys.argv[2]) if len(sys.argv) > 2 else 4096            # points of the cloud (C4: 8192)
 g = torch.Generator().manual_seed(0)
-clouds = {4096: (torch.randn(B, 3, 4096, generator=g) * spread).cuda()}
-for m in (1024, 256, 64):
+clouds = {N0: (torch.randn(B, 3, N0, generator=g) * 0.5).cuda()}
+for m in (N0 // 4, N0 // 16, N0 // 64):
     clouds[m] = F.furthest_point_sample(clouds[m * 4], m)
-LAYERS = [("SA0.1", 32, 32, 32, 4096), ("FP3.x", 64, 64, 32, 4096), ("FP2.x", 128, 128, 16, 1024), ("SA1.0", 128, 64, 16, 1024)]
+LAYERS = [("SA0.1", 32, 32, 32, N0), ("FP3.x", 64, 64, 32, N0), ("FP2.x", 128, 128, 16, N0 // 4), ("SA1.0", 128, 64, 16, N0 // 4)]
+ONLY_LIST = len(sys.argv) > 3
 for name, cin, cout, r, n in LAYERS:
     pts = clouds[n]
     f = torch.randn(B, cin, n, generator=g).cuda()
@@ -56,10 +57,12 @@ for name, cin, cout, r, n in LAYERS:
         print(f"{name} {cin:3d}->{cout:3d} r={r:2d} tile {form:>3s}: listed {nd1:6.0f} / {nd2:6.0f} voxels, {nt1:5.1f} / {nt2:5.1f} tiles per shape, max rows {rmax1} / {rmax2} | "
               f"first {t(first):6.1f} us  second {t(second):6.1f} us{same}", flush=True)
 
+if ONLY_LIST:
+    sys.exit(0)
 # ---- 8^3 levels: the list kernel in its half-tile form against the route the product takes there (fp16x3 GEMM over the occupied rows +
 # gather with GroupNorm-1 + Swish + operand split in its epilogue)
 print("8^3 levels: first convolution -> second convolution's fp16 operand", flush=True)
-for name, cin, cout, n in [("FP1.x", 256, 256, 256), ("FP0.x", 256, 256, 64), ("SA2.0", 192, 128, 256), ("SA3->", 128, 256, 64)]:
+for name, cin, cout, n in [("FP1.x", 256, 256, N0 // 16), ("FP0.x", 256, 256, N0 // 64), ("SA2.0", 192, 128, N0 // 16), ("SA3->", 128, 256, N0 // 64)]:
     r = 8
     pts = clouds[n]
     f = torch.randn(B, cin, n, generator=g).cuda()
