@@ -300,7 +300,11 @@ __global__ __launch_bounds__(1024) void vox_dilate_kernel(int r, int n_dil_max, 
   }
 }
 
+#ifdef BDM_EXPERIMENTAL
 static bool half_tile_ok(int r, int tile) { return tile == 0 || ((r == 16 || r == 32) && (tile == 64 || tile == 128 || tile == 256)) || (r == 8 && (tile == 64 || tile == 128)); }
+#else
+static bool half_tile_ok(int, int tile) { return tile == 0; }   // the half-tile convolution is part of the EXPERIMENTAL=1 build
+#endif
 
 extern "C" int bdm_voxel_dilate_slices(int r, int tile) {
   int tl, xcap, tiles_max;
@@ -312,7 +316,7 @@ static int voxel_dilate_launch(int b, int r, int n_dil_max, const int *src, int 
                                int *tile_start, int *class_count, int half_tile, void *stream) {
   BDM_REQUIRE(b >= 0 && (r == 8 || r == 16 || r == 32) && n_dil_max >= 1 && src && dil_list && dil_index && plane_start && tile_start,
               "voxel_dilate: bad arguments (r in {8, 16, 32})");
-  BDM_REQUIRE(half_tile_ok(r, half_tile), "voxel_dilate: tile %d unsupported (0 = full tiles; 64 / 128 / 256 at r = 16, 32)", half_tile);
+  BDM_REQUIRE(half_tile_ok(r, half_tile), "voxel_dilate: tile %d unsupported (0 = full tiles; 64 / 128 / 256: EXPERIMENTAL=1 builds)", half_tile);
   if (b == 0) return BDM_OK;
   int tile, xcap, tiles_max;
   sconv_dil_geometry(r, half_tile, &tile, &xcap, &tiles_max);
@@ -688,6 +692,7 @@ __global__ __launch_bounds__(NW * 64) void sconv_dil_kernel(
 }
 
 
+#ifdef BDM_EXPERIMENTAL   // measured NOT faster than the full-tile kernel (profiles/r06_sparse_dil_half_tiles.txt): EXPERIMENTAL=1 builds only
 // ---------------------------------------------------------------------------------------------------------------------
 // the convolution, half-tile form (round 6): TWO workgroups per CU
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1040,6 +1045,8 @@ __global__ __launch_bounds__(256, 2) void sconv_dilh_kernel(
   }   // work items
 }
 
+#endif   // BDM_EXPERIMENTAL
+
 static int sconv_dil_launch(bool h2in, int b, int cin, int cout, int r, int n_max, int n_dil_max, const void *xr, const float *amax,
                             const void *xconst, float x_inv_scale, const int *in_index, const int *dil_list, const int *dil_index,
                             const int *tile_start, const void *packed_w, const float *inv_scale, const float *bias, float *y,
@@ -1052,7 +1059,7 @@ static int sconv_dil_launch(bool h2in, int b, int cin, int cout, int r, int n_ma
     set_error("sparse_conv_dil: resolution %d unsupported (8, 16, 32)", r);
     return BDM_ERR_UNSUPPORTED;
   }
-  BDM_REQUIRE(half_tile_ok(r, half_tile), "sparse_conv_dil: tile %d unsupported (0 = full tiles; 64 / 128 / 256 at r = 16, 32)", half_tile);
+  BDM_REQUIRE(half_tile_ok(r, half_tile), "sparse_conv_dil: tile %d unsupported (0 = full tiles; 64 / 128 / 256: EXPERIMENTAL=1 builds)", half_tile);
   if (b == 0) return BDM_OK;
   const int c8 = (cin + 7) / 8;
   const int mi = cout > 32 ? 2 : 1;                     // 64 or 32 output channels per workgroup
@@ -1102,6 +1109,7 @@ static int sconv_dil_launch(bool h2in, int b, int cin, int cout, int r, int n_ma
   } while (0)
 #define DILH_LAUNCH(MT, NT, R) do { if (h2in) DILH_LAUNCH_(MT, NT, R, true); else DILH_LAUNCH_(MT, NT, R, false); } while (0)
 #define DILH_PICK(NT, R) do { if (mi == 2) DILH_LAUNCH(4, NT, R); else DILH_LAUNCH(2, NT, R); } while (0)
+#ifdef BDM_EXPERIMENTAL
   if (half_tile) {
     const int nt = half_tile / 64;
     if (r == 32) { if (nt == 4) DILH_PICK(4, 32); else if (nt == 2) DILH_PICK(2, 32); else DILH_PICK(1, 32); }
@@ -1109,6 +1117,7 @@ static int sconv_dil_launch(bool h2in, int b, int cin, int cout, int r, int n_ma
     else { if (nt == 2) DILH_PICK(2, 8); else DILH_PICK(1, 8); }
     return launch_status("sparse_conv_dil (half tiles)");
   }
+#endif
   if (r == 32) { if (mi == 2) DIL_LAUNCH(4, 4, 8, 32); else DIL_LAUNCH(2, 4, 8, 32); }
   else if (r == 16) { if (mi == 2) DIL_LAUNCH(4, 2, 8, 16); else DIL_LAUNCH(2, 2, 8, 16); }
   else { if (mi == 2) DIL_LAUNCH(4, 1, 8, 8); else DIL_LAUNCH(2, 1, 8, 8); }

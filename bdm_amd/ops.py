@@ -1025,7 +1025,8 @@ TILE_REC = 16         # ints per tile record of a dilated plan (include/bdm_hip.
 # MEASURED: two workgroups do co-reside, give the full form's bits, and a 256-entry tile then lives exactly as long as a 512-entry one
 # (75 vs 78 us at 64 -> 64 channels, 32^3: the chunk loop is bound by the CU's matrix pipe, which the partners share, and with ~1 tile per
 # slot both run the same phase at the same time) -- kernel 94 vs 84 us, replayed C2 step 5.16 vs 4.95 ms; at 8^3 it loses to GEMM + gather
-# by 1.4 - 2.7x (profiles/r06_sparse_dil_half_tiles.txt).  Kept as an opt-in with its tests; never the default.
+# by 1.4 - 2.7x (profiles/r06_sparse_dil_half_tiles.txt).  Kept with its tests in the EXPERIMENTAL=1 build (as the other negative-result kernel
+# families: csrc/experimental/); the default library refuses a non-zero tile.
 DIL_TILE = os.environ.get("BDM_DIL_TILE", "0")
 
 
@@ -1034,6 +1035,9 @@ def dil_tile(batch, n_points, r, second):
     per (batch, points, resolution) -- not per channel count -- because the PVConvs of a level share the plan."""
     if r not in (8, 16, 32) or DIL_TILE in ("0", "", "auto"):
         return 0
+    if not L.has_experimental():
+        raise L.BdmHipError(f"BDM_DIL_TILE={DIL_TILE}: the half-tile list convolution belongs to the experimental kernel families; "
+                            "rebuild with `make -C bdm_amd/csrc EXPERIMENTAL=1`")
     return min(int(DIL_TILE), 128) if r == 8 else int(DIL_TILE)
 
 

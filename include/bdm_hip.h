@@ -529,7 +529,8 @@ int bdm_sparse_conv_gemm_h2_cb(int b, int n_max, int cin, int cout, const void *
  *                           (b, groups, tiles, 2 doubles), *slices_out = tiles = bdm_voxel_dilate_slices(r, tile).
  * `tile` (round 6) selects the tile form of a plan and of the convolutions that run on it (the two must agree):
  *   0            FULL tiles (<= 512 / 256 / 128 entries at r = 32 / 16 / 8, one row range of <= 3 r^2 rows, one workgroup per CU);
- *   64/128/256   HALF tiles (r = 16, 32): that many entries, four waves and 80 KB of LDS per workgroup, TWO workgroups per CU; a tile
+ *   64/128/256   HALF tiles (EXPERIMENTAL=1 builds only: measured not faster, profiles/r06_sparse_dil_half_tiles.txt; the default library
+ *                refuses them): that many entries, four waves and 80 KB of LDS per workgroup, TWO workgroups per CU; a tile
  *                inside one x-plane lists three row ranges ((x-1, x, x+1) x y-rows y0-1 .. y1+1), a tile across planes one range of
  *                whole planes; never more than 1376 rows (<= 3 tile + 12 r inside a plane; across planes only when they fit).
  * A tile record is 16 ints: [first entry, end entry, first voxel of the owned linear range, its end, range 0 first row, range 0 rows,
