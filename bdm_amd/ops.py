@@ -1013,13 +1013,6 @@ def voxel_plan(coords, r, eps=0.0, dilate=False):
     return p
 
 
-def adopt_plan(plan, coords):
-    """Enter a plan made from ANOTHER tensor holding the same coordinate values (pvcnn.early_first_sampler: the transposed copy of the
-    step's cloud) under `coords`: the consumer that asks voxel_plan(coords, plan.r) waits for plan.ready and takes it."""
-    _plan_cache[(coords.data_ptr(), coords._version, tuple(coords.shape), int(plan.r))] = plan
-    return plan
-
-
 def has_voxel_plan(coords, r):
     """Is the plan of (this very coordinate tensor, r) in the pass's cache?"""
     return (coords.data_ptr(), coords._version, tuple(coords.shape), int(r)) in _plan_cache

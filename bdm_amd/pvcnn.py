@@ -138,20 +138,6 @@ NN_PLANS = {}       # (points ptr, centres ptr) -> (points, centres, idx, w, eve
 
 
 EARLY_SAMPLER = os.environ.get("BDM_EARLY_SAMPLER", "1") == "1"
-# round 6: the first level's VOXEL PLAN (voxel coordinates, point lists, occupied / dilated cell lists, tile tables: five launches of one
-# workgroup per shape, ~80 us at B = 16) needs the step's cloud only, like its sampler: enqueued on a third stream before the projection
-# conditioning, so the main stream finds it ready when the first PVConv asks (it used to open the denoiser on the main stream)
-EARLY_PLAN = os.environ.get("BDM_EARLY_PLAN", "1") == "1"
-_plan_streams = {}
-
-
-def _plan_stream(device):
-    cur = torch.cuda.current_stream(device)
-    key = (device, cur.cuda_stream)
-    ps = _plan_streams.get(key)
-    if ps is None:
-        ps = _plan_streams[key] = torch.cuda.Stream(device=device, priority=SIDE_STREAM_PRIORITY)
-    return ps
 
 
 def _side_stream(device):
@@ -174,27 +160,12 @@ def early_first_sampler(net, x_t):
             and x_t.shape[0] * x_t.shape[1] >= SIDE_STREAM_MIN_POINTS):
         return None
     first = sa_layers[0][-1] if isinstance(sa_layers[0], nn.Sequential) else sa_layers[0]
-    pv = sa_layers[0][0] if isinstance(sa_layers[0], nn.Sequential) and hasattr(sa_layers[0][0], "voxel_plan_args") else None
-    args = pv.voxel_plan_args() if (pv is not None and EARLY_PLAN and SIDE_PLAN) else None
     cur, side = _side_stream(x_t.device)
-    plan_stream = _plan_stream(x_t.device) if args is not None else None   # (looked up while the main stream is current: one per main stream)
     tape.wait_stream(side, cur)
-    ev_c0 = None
     with torch.cuda.stream(side):
         c0 = ops.transpose12(x_t) if x_t.is_contiguous() else x_t.transpose(1, 2).contiguous()   # the values of the denoiser's coordinate rows (model.get_input_with_conditioning); one library launch
-        if args is not None:
-            ev_c0 = torch.cuda.Event()
-            tape.record_event(ev_c0, side)
         centers0 = first.sample(c0)
-    plan0 = None
-    if args is not None:
-        with torch.cuda.stream(plan_stream):
-            tape.wait_event(ev_c0)   # the coordinate rows are written (the sampler behind them on `side` is not waited for)
-            B, n = c0.shape[0], c0.shape[2]
-            plan0 = ops.voxel_plan(c0, *args, dilate=2 if pv.wants_compact_tail(B, n) else (1 if pv.wants_dilated_plan(B, n) else 0))
-            plan0.ready = torch.cuda.Event()
-            tape.record_event(plan0.ready, plan_stream)
-    return (c0, centers0, side, plan0)
+    return (c0, centers0, side)
 
 
 def plan_sampling_chain(sa_layers, coords, early=None, fp_layers=None):
@@ -294,8 +265,6 @@ def encode(sa_layers, global_att, inputs, t_emb, early=None, fp_layers=None):
     """Down path (pvcnn.py:90-110)."""
     coords = ops.xyz_rows(inputs)
     ops.clear_plan_cache()  # voxel plans are valid within one encoder/decoder pass
-    if early is not None and len(early) > 3 and early[3] is not None and tuple(early[0].shape) == tuple(coords.shape) and coords.is_cuda:
-        ops.adopt_plan(early[3], coords)   # the first level's plan, made from the same coordinate VALUES ahead of the conditioning (early_first_sampler)
     NN_PLANS.clear()
     for blocks in sa_layers:  # sampler plans too: never inherit one from an aborted or foreign forward
         (blocks[-1] if isinstance(blocks, nn.Sequential) else blocks)._planned = None
