@@ -3,7 +3,7 @@ so that the `-m gpu` parity tests do not spend minutes of host time per run re-d
 
     python -m oracle.gen_golden_traj [--threads T] [blending_n1024] [merging_n1024] [c2_b16_shape11] ...     (no name: every case)
 
-`--threads T` (round 6): run the SAME case with `torch.set_num_threads(T)` and write `traj_<name>_alt.npz` (final + segment
+`--threads T` / `--threads alt` (round 6): run the SAME case with `torch.set_num_threads(T)` and write `traj_<name>_alt.npz` (final + segment
 clouds only) next to the fixture of record.  The CPU kernels of torch split their reductions by thread, so the two files are the oracle at two
 summation orders: their distance d_oo is an oracle-vs-oracle yardstick for the chaos of a case that owes nothing to the product
 (measured on one PC^2 forward at N = 4096: 8 vs 4 / 2 / 1 threads = 5.4e-7 / 6.2e-7 / 8.0e-7 relative L2, i.e. the fp32 noise floor).
@@ -50,15 +50,21 @@ CASES = {
     "merging_n1024_h003": dict(N=1024, B=1, merging=True, philox_seed=None, row=0, head_scale=0.03),
     # round 6: C3's own per-GPU shape -- BDM-Merging, B = 16, N = 4096, per-shape Philox streams, FULL length
     # (995 PC^2 + 75 PVD + 5 fused forwards), one sampled shape; head per the rule at this size (0.03) + the 0.1 chaos monitor
-    "c3_b16_shape5_h003": dict(N=4096, B=16, merging=True, philox_seed=42, row=5, head_scale=0.03),
-    "c3_b16_shape5": dict(N=4096, B=16, merging=True, philox_seed=42, row=5),
+    "c3_b16_shape5_h003": dict(N=4096, B=16, merging=True, philox_seed=42, row=5, head_scale=0.03, threads=1, alt_threads=2),
+    "c3_b16_shape5": dict(N=4096, B=16, merging=True, philox_seed=42, row=5, threads=1, alt_threads=2),
 }
+# Reduction order of the fixtures of record: torch's CPU kernels split their sums by thread, so a fixture is reproduced BIT FOR BIT only at the
+# thread count it was made with (stored in the file as `threads`).  The generator therefore SETS it: 8 for the fixtures of rounds 3 - 5, 1 for
+# the C3 cases and 2 for the C1 cases of round 6 (made while other oracle jobs shared the container's 8 cores); `alt_threads` = the count of the
+# committed `_alt` files (c2_b16_shape11: `_alt` at 1 thread, `_alt2` at 2).
+DEFAULT_THREADS, DEFAULT_ALT_THREADS = 8, 1
 
 # round 6: C1 = vanilla PC^2, ONE shape, N = 1024, 100 free-running steps (reference model/model.py:182-201) at the
 # largest head scale of {1, 0.3, 0.1, 0.03} the rule allows (oracle 1-ulp self-sensitivity < 1e-4: 7.1e-3 / 8.2e-6 / 2.6e-7 / 2.0e-7 -> 0.3)
 # (the 0.1 twin: at 0.3 the oracle at ANOTHER reduction order ends 1.05e-3 from the fixture of record -- one discrete decision flips between steps
 # 30 and 40 -- although a 1-ulp move of the initial cloud stays at 8e-6: the rule's single probe missed it; 0.1 is calm under both)
-C1_CASES = {"c1_n1024_h03": dict(head_scale=0.3), "c1_n1024_h01": dict(head_scale=0.1), "c1_n1024_h1": dict(head_scale=1.0)}
+C1_CASES = {"c1_n1024_h03": dict(head_scale=0.3, threads=2, alt_threads=1), "c1_n1024_h01": dict(head_scale=0.1, threads=2, alt_threads=1),
+            "c1_n1024_h1": dict(head_scale=1.0, threads=2, alt_threads=1)}
 
 
 def oracle_case(name):
@@ -127,9 +133,11 @@ def generate(name, alt=False):
 
 
 if __name__ == "__main__":
-    args, alt = sys.argv[1:], False
-    if args[:1] == ["--threads"]:
-        torch.set_num_threads(int(args[1]))
+    args, alt, forced = sys.argv[1:], False, None
+    if args[:1] == ["--threads"]:       # --threads T: the `_alt` file at T threads;  --threads alt: at the case's recorded alt_threads
+        forced = None if args[1] == "alt" else int(args[1])
         args, alt = args[2:], True
     for nm in (args or list(CASES) + list(C1_CASES)):
+        d = CASES.get(nm) or C1_CASES[nm]
+        torch.set_num_threads(forced if forced is not None else (d.get("alt_threads", DEFAULT_ALT_THREADS) if alt else d.get("threads", DEFAULT_THREADS)))
         generate(nm, alt)
