@@ -351,7 +351,7 @@ def main():
             head = top_rows[0]
             traffic, traffic_commit = None, None
             try:  # HBM bytes per launch of that kernel from the committed PMC pass (separate rocprofv3 --pmc runs)
-                pm_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(p))
+                pm_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(p))
                 pm = json.load(open(pm_path))
                 key = f"{head['function']}{tuple(head['shape'])}"
                 ent = (pm["kernels"].get(key) or pm["kernels"].get(key.replace("_h2_gn(", "_h2("))  # same kernels + GN epilogue
