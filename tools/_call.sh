@@ -1,8 +1,16 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6
-BDM_RECORD_DURATIONS=gpurun_out/r6/durations.json timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -170 > gpurun_out/r6/r06_gpu_suite.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 >> gpurun_out/r6/r06_gpu_suite.txt
-echo "== EXPERIMENTAL=1 build: the half-tile list convolution's cases (tests/test_hip_dense.py, tests/test_hip_compact_tail.py)" >> gpurun_out/r6/r06_gpu_suite.txt
-BDM_LIB_PATH=$GRAFT_REPO_ROOT/bdm_amd/libbdm_hip_experimental.so timeout 900 python -m pytest tests/test_hip_dense.py tests/test_hip_compact_tail.py -m gpu -q -k "dilated or output_stationary or compact or second_conv or se_gate or voxel_lists" 2>&1 | grep -v PARITY | tail -4 >> gpurun_out/r6/r06_gpu_suite.txt
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r6/r06_bench_driver_form.json 2> gpurun_out/r6/r06_bench_driver_form.err
-BDM_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r6/r06_bench_gpus2_shared.json 2> gpurun_out/r6/r06_bench_gpus2_shared.err
-tail -12 gpurun_out/r6/r06_gpu_suite.txt | cut -c1-200; python tools/bench_digest.py gpurun_out/r6/r06_bench_driver_form.json | head -3; python tools/bench_digest.py gpurun_out/r6/r06_bench_gpus2_shared.json | head -2
+cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/r6
+rm -rf /tmp/trs; timeout 250 rocprofv3 --kernel-trace --output-format csv -d /tmp/trs -o st -- python3 $R/tools/trace_step.py > /dev/null 2>&1
+F=$(find /tmp/trs -name "*kernel_trace.csv" | head -1); python3 $R/tools/trace_timeline.py $F > $R/gpurun_out/r6/c15_timeline.txt
+python3 $R/tools/trace_step_summary.py $R/gpurun_out/r6/c15_timeline.txt | cut -c1-300 | head -10
+python3 - <<'P'
+import re, os
+rows=[]
+for l in open(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/r6/c15_timeline.txt'):
+    m = re.match(r'q(\d+) t=\s*([\d.]+)\s+dur=\s*([\d.]+)\s+gap=\s*(-?[\d.]+)\s+grid=\(([^)]*)\)\s+(.*)', l)
+    if m: rows.append((int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4)), m.group(6).strip()))
+starts=[i for i,r in enumerate(rows) if 'time_embed' in r[4]]
+step=rows[starts[2]:starts[3]]
+t0=step[0][1]
+print("--- step 2: every launch (queue, start offset us, duration us, gap us, kernel)")
+for r in step: print(f"q{r[0]} {r[1]-t0:8.1f} {r[2]:7.1f} {r[3]:7.1f}  {r[4][:60]}")
+P
