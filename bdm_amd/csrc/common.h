@@ -130,6 +130,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   return ((readlane_f32(v, 0) + readlane_f32(v, 16)) + readlane_f32(v, 32)) + readlane_f32(v, 48);
 }
 __device__ __forceinline__ double wave_sum(double v) {
+  BDM_FULL_WAVE();
   v += dpp_f64(v, BDM_DPP_QUAD_XOR1);
   v += dpp_f64(v, BDM_DPP_QUAD_XOR2);
   v += dpp_f64(v, BDM_DPP_ROW_HALF_MIRROR);
@@ -154,21 +155,25 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 __device__ __forceinline__ float half32_sum(float v) {   // all 64 lanes active
+  BDM_FULL_WAVE();
   v = row16_sum(v);
   const float lo = readlane_f32(v, 0) + readlane_f32(v, 16), hi = readlane_f32(v, 32) + readlane_f32(v, 48);
   return (threadIdx.x & 32) ? hi : lo;
 }
 __device__ __forceinline__ double half32_sum(double v) {
+  BDM_FULL_WAVE();
   v = row16_sum(v);
   const double lo = readlane_f64(v, 0) + readlane_f64(v, 16), hi = readlane_f64(v, 32) + readlane_f64(v, 48);
   return (threadIdx.x & 32) ? hi : lo;
 }
 // ... and over all 64 lanes in the butterfly's association ((row 0 + row 1) + (row 2 + row 3)): bit-identical to xor 1 .. 32; wave-uniform
 __device__ __forceinline__ double wave_sum_bfly(double v) {
+  BDM_FULL_WAVE();
   v = row16_sum(v);
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
+  BDM_FULL_WAVE();
   v = fmaxf(v, dpp_f32(v, BDM_DPP_QUAD_XOR1));
   v = fmaxf(v, dpp_f32(v, BDM_DPP_QUAD_XOR2));
   v = fmaxf(v, dpp_f32(v, BDM_DPP_ROW_HALF_MIRROR));
