@@ -211,8 +211,10 @@ int bdm_max_over_neighbors(int b, int c, int m, int u, const float *x, float *y,
 
 /* BallQuery.forward's grouped tensor (modules/ball_query.py:16-30) in one launch:
  * out (b, 3+c, m, u) = cat[ grouping(coords, idx) - centers[..., None], grouping(features, idx) ].
- * workspace: NULL -> direct channel-first gather; else >= bdm_sa_group_workspace_bytes(b, c, n) bytes (16-byte aligned):
- * [coords ; features] are first repacked point-major so the gather reads 16-byte runs (same values). */
+ * workspace: NULL -> channel-first gather: for 256 <= n <= 8192 points a workgroup stages three channel rows of ALL the shape's points in
+ * LDS (LDS-DMA, global_load_lds_dwordx4, when n % 256 == 0 and the rows are 16-byte aligned) and gathers from there (round 6), otherwise
+ * one scattered load per element; else >= bdm_sa_group_workspace_bytes(b, c, n) bytes (16-byte aligned): [coords ; features] are first
+ * repacked point-major so the gather reads 16-byte runs.  Same values in every form (a gather). */
 size_t bdm_sa_group_workspace_bytes(int b, int c, int n);
 int bdm_sa_group(int b, int c, int n, int m, int u, const float *coords, const float *centers,
                  const float *features, long long bs_f, int ld_f, const int *indices, float *out,
